@@ -1,0 +1,338 @@
+"""ORACLE -- test infrastructure only (never imported by the product path).
+
+CPU restatement, in closed form, of the reference's emotion-conditioned Music
+Transformer hot path (serkansulun/midi-emotion).  Only `tests/`,
+`__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this
+file; the shipped path (`midi-emotion_amd/midiemo`) calls the HIP library and
+fails loudly without it.
+
+Parity pin: this restatement is checked against golden vectors captured from
+the imported reference (see `oracle/make_fixtures.py`, `tests/golden/*.npz`,
+`tests/test_oracle_golden.py`).
+
+Every function cites the reference lines it restates (paths relative to
+/root/reference/src).  The restatement is written functionally over a plain
+`dict[str, Tensor]` that uses the reference's `state_dict` key names
+(models/music_multi.py:57-71, models/music_continuous_token.py:49-64).
+
+The math deliberately avoids the reference's pad/reshape "skewing" and float
+mask tensors:  Srel[l, j] = q_l . E[M-1-(l-j)]  for j <= l  (closed form of
+music_multi.py:215-217,245-262), masks are predicates.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+MAX_SEQ = 2048          # models/build_model.py:22 (hard-coded)
+PAD_TOKEN = 0           # models/build_model.py:23
+
+
+# --------------------------------------------------------------------------
+# configuration
+# --------------------------------------------------------------------------
+class Cfg:
+    """Mirror of the kwargs build_model() derives (models/build_model.py:14-24)."""
+
+    def __init__(self, vocab_size, n_layer, n_head, d_model, d_inner,
+                 d_condition=-1, conditioning="none", max_seq=MAX_SEQ,
+                 pad_token=PAD_TOKEN):
+        assert conditioning in ("none", "discrete_token", "continuous_token",
+                                "continuous_concat")
+        self.vocab_size = vocab_size
+        self.n_layer = n_layer
+        self.n_head = n_head
+        self.d_model = d_model
+        self.d_inner = d_inner
+        self.conditioning = conditioning
+        # music_multi.py:53-54 : negative d_condition -> 0;  continuous_token
+        # has no d_condition at all (build_model.py:34-37)
+        if conditioning != "continuous_concat" or d_condition < 0:
+            d_condition = 0
+        self.d_condition = d_condition
+        self.max_seq = max_seq
+        self.pad_token = pad_token
+        self.dh = d_model // n_head
+
+    @property
+    def d_emb(self):
+        return self.d_model - self.d_condition
+
+
+def param_shapes(cfg: Cfg) -> "Dict[str, Tuple[int, ...]]":
+    """state_dict key -> shape, in the reference's registration order."""
+    d, di, V, M, dh = cfg.d_model, cfg.d_inner, cfg.vocab_size, cfg.max_seq, cfg.dh
+    s: Dict[str, Tuple[int, ...]] = {}
+    s["embedding.weight"] = (V, cfg.d_emb)
+    if cfg.conditioning == "continuous_concat" and cfg.d_condition > 0:
+        s["fc_condition.weight"] = (cfg.d_condition, 2)
+        s["fc_condition.bias"] = (cfg.d_condition,)
+    if cfg.conditioning == "continuous_token":
+        for i in range(2):
+            s[f"fc_condition.{i}.weight"] = (d, 1)
+            s[f"fc_condition.{i}.bias"] = (d,)
+    for i in range(cfg.n_layer):
+        p = f"enc_layers.{i}."
+        s[p + "rga.E"] = (M, dh)
+        for w in ("Wq", "Wk", "Wv", "fc"):
+            s[p + f"rga.{w}.weight"] = (d, d)
+            s[p + f"rga.{w}.bias"] = (d,)
+        s[p + "FFN_pre.weight"] = (di, d)
+        s[p + "FFN_pre.bias"] = (di,)
+        s[p + "FFN_suf.weight"] = (d, di)
+        s[p + "FFN_suf.bias"] = (d,)
+        for ln in ("layernorm1", "layernorm2"):
+            s[p + ln + ".weight"] = (d,)
+            s[p + ln + ".bias"] = (d,)
+    s["fc.weight"] = (V, d)
+    s["fc.bias"] = (V,)
+    return s
+
+
+def seeded_params(cfg: Cfg, seed: int, dtype=torch.float32) -> Dict[str, Tensor]:
+    """Stream-stable synthetic weights (np.random.RandomState), drawn in
+    param_shapes() order.  Scales follow the reference initialisers loosely
+    (music_multi.py:75-82, torch Linear default, randn E) but every tensor is
+    non-trivial (biases and LayerNorm affine included) so that parity tests
+    exercise every term."""
+    rs = np.random.RandomState(seed)
+    out = {}
+    for k, shp in param_shapes(cfg).items():
+        if k.endswith("rga.E"):
+            a = rs.standard_normal(shp)
+        elif "layernorm" in k and k.endswith("weight"):
+            a = 1.0 + 0.1 * rs.standard_normal(shp)
+        elif "layernorm" in k or k.endswith("bias"):
+            a = 0.05 * rs.standard_normal(shp)
+        elif k in ("embedding.weight", "fc.weight") or k.startswith("fc_condition"):
+            a = rs.uniform(-0.1, 0.1, shp)
+        else:
+            fan_in = shp[-1]
+            a = rs.uniform(-1.0, 1.0, shp) / math.sqrt(fan_in)
+        out[k] = torch.from_numpy(np.ascontiguousarray(a)).to(dtype)
+    return out
+
+
+# --------------------------------------------------------------------------
+# forward
+# --------------------------------------------------------------------------
+def sinusoid_pe(max_seq: int, d: int) -> Tensor:
+    """models/music_multi.py:137-147 : PE[p, i] = sin(p * 10000^(-(i - i%2)/d) + (i%2) * pi/2)
+    evaluated in float64 (the reference evaluates it with Python floats)."""
+    p = np.arange(max_seq, dtype=np.float64)[:, None]
+    i = np.arange(d, dtype=np.float64)[None, :]
+    par = np.mod(i, 2.0)
+    ang = p * np.exp(-math.log(10000.0) * i / d) * np.exp(math.log(10000.0) / d * par) + 0.5 * math.pi * par
+    return torch.from_numpy(np.sin(ang))  # float64 [max_seq, d]
+
+
+def key_is_pad(cfg: Cfg, tokens: Tensor) -> Tensor:
+    """Per-key pad predicate [B, Lmodel] (True = masked key).
+    music_multi.py:25-38 ; for continuous_token the two prepended condition
+    slots are never pad (music_continuous_token.py:86-87 pads tokens with -1)."""
+    pad = tokens == cfg.pad_token
+    if cfg.conditioning == "continuous_token":
+        pad = F.pad(pad, (2, 0), value=False)
+    return pad
+
+
+def embed(cfg: Cfg, P: Dict[str, Tensor], tokens: Tensor, cond: Tensor) -> Tensor:
+    """Prologue.  music_multi.py:89-102 / music_continuous_token.py:77-100 (dropout off)."""
+    dt = P["embedding.weight"].dtype
+    x = P["embedding.weight"][tokens] * math.sqrt(cfg.d_emb)           # :91-92
+    if cfg.conditioning == "continuous_concat" and cfg.d_condition > 0:
+        c = cond.to(dt) @ P["fc_condition.weight"].t() + P["fc_condition.bias"]   # :96
+        x = torch.cat([x, c[:, None, :].expand(-1, x.shape[1], -1)], dim=-1)      # :98-99
+    elif cfg.conditioning == "continuous_token":
+        cs = [cond[:, i:i + 1].to(dt) @ P[f"fc_condition.{i}.weight"].t() + P[f"fc_condition.{i}.bias"]
+              for i in range(2)]                                        # cont_token:92-94
+        x = torch.cat([torch.stack(cs, dim=1), x], dim=1)               # :97
+    L = x.shape[1]
+    assert L <= cfg.max_seq
+    pe = sinusoid_pe(cfg.max_seq, cfg.d_model)[:L].to(dt)              # :160-164
+    return x + pe[None]
+
+
+def rga_scores_rel(q: Tensor, E: Tensor) -> Tensor:
+    """Srel[b,h,l,j] = q[b,h,l,:] . E[M-1-(l-j), :] for j <= l, 0 elsewhere.
+    Closed form of einsum+_qe_masking+_skewing (music_multi.py:215-217,245-262)."""
+    L = q.shape[2]
+    M = E.shape[0]
+    QE = q @ E[M - L:].t()                                # [B,H,L,L], column m <-> E[M-L+m]
+    l = torch.arange(L)[:, None]
+    j = torch.arange(L)[None, :]
+    m = (L - 1) - (l - j)                                 # E row M-1-(l-j) == column L-1-(l-j)
+    valid = j <= l
+    m = torch.where(valid, m, torch.zeros_like(m))
+    srel = torch.gather(QE, 3, m.expand(QE.shape[0], QE.shape[1], L, L))
+    return srel * valid.to(srel.dtype)
+
+
+def rga_attention_core(q: Tensor, k: Tensor, v: Tensor, E: Tensor,
+                       pad: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
+    """Relative global attention on head-major q,k,v [B,H,L,dh].
+    music_multi.py:213-232.  Returns (O [B,H,L,dh], LSE [B,H,L])."""
+    L = q.shape[2]
+    dh = q.shape[3]
+    s = (q @ k.transpose(2, 3) + rga_scores_rel(q, E)) / math.sqrt(dh)     # :219-222
+    l = torch.arange(L)[:, None]
+    j = torch.arange(L)[None, :]
+    masked = (j > l)[None, None]                                           # causal
+    if pad is not None:
+        masked = masked | pad[:, None, None, :]                            # key padding
+    s = s.masked_fill(masked, float("-inf"))                               # :224-229
+    lse = torch.logsumexp(s, dim=-1)
+    p = torch.softmax(s, dim=-1)                                           # :231
+    return p @ v, lse                                                      # :232
+
+
+def layer_norm(x: Tensor, w: Tensor, b: Tensor, eps: float = 1e-6) -> Tensor:
+    """torch.nn.LayerNorm(d, eps=1e-6), music_multi.py:120-121 (biased variance)."""
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * w + b
+
+
+def encoder_layer(cfg: Cfg, P: Dict[str, Tensor], i: int, x: Tensor, pad: Optional[Tensor]) -> Tensor:
+    """music_multi.py:126-135 (post-LN, ReLU FFN, dropout off)."""
+    p = f"enc_layers.{i}."
+    B, L, d = x.shape
+    H, dh = cfg.n_head, cfg.dh
+
+    def proj(name):
+        y = x @ P[p + f"rga.{name}.weight"].t() + P[p + f"rga.{name}.bias"]
+        return y.view(B, L, H, dh).permute(0, 2, 1, 3)                     # :196-209
+    o, _ = rga_attention_core(proj("Wq"), proj("Wk"), proj("Wv"), P[p + "rga.E"], pad)
+    o = o.permute(0, 2, 1, 3).reshape(B, L, d)                             # :234-235
+    a = o @ P[p + "rga.fc.weight"].t() + P[p + "rga.fc.bias"]              # :237
+    o1 = layer_norm(a + x, P[p + "layernorm1.weight"], P[p + "layernorm1.bias"])   # :129
+    f = torch.relu(o1 @ P[p + "FFN_pre.weight"].t() + P[p + "FFN_pre.bias"])       # :131
+    f = f @ P[p + "FFN_suf.weight"].t() + P[p + "FFN_suf.bias"]                    # :132
+    return layer_norm(o1 + f, P[p + "layernorm2.weight"], P[p + "layernorm2.bias"])  # :134
+
+
+def forward(cfg: Cfg, P: Dict[str, Tensor], tokens: Tensor, cond: Tensor,
+            return_hidden: bool = False):
+    """model(x, condition) -> logits [B, L(+2), V].  music_multi.py:84-108."""
+    x = embed(cfg, P, tokens, cond)
+    pad = key_is_pad(cfg, tokens)
+    hs = [x]
+    for i in range(cfg.n_layer):
+        x = encoder_layer(cfg, P, i, x, pad)
+        hs.append(x)
+    logits = x @ P["fc.weight"].t() + P["fc.bias"]                         # :106
+    return (logits, hs) if return_hidden else logits
+
+
+def ce_loss(cfg: Cfg, logits: Tensor, target: Tensor) -> Tensor:
+    """CrossEntropyLoss(ignore_index=pad) on (B*L, V); train.py:124,288-290."""
+    lg = logits.reshape(-1, logits.shape[-1])
+    t = target.reshape(-1)
+    lse = torch.logsumexp(lg, dim=-1)
+    picked = lg.gather(1, t[:, None]).squeeze(1)
+    valid = t != cfg.pad_token
+    return ((lse - picked) * valid.to(lg.dtype)).sum() / valid.sum().to(lg.dtype)
+
+
+# --------------------------------------------------------------------------
+# optimiser step: clip_grad_norm_(1.0) + Adam   (train.py:182,319-325)
+# --------------------------------------------------------------------------
+def clip_coef(grads: List[Tensor], max_norm: float) -> Tensor:
+    """torch.nn.utils.clip_grad_norm_: coef = min(1, max_norm / (||g||_2 + 1e-6))."""
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads))
+    return torch.clamp(max_norm / (total + 1e-6), max=1.0), total
+
+
+def adam_step(P, G, M1, M2, step: int, lr=2e-5, b1=0.9, b2=0.999, eps=1e-8,
+              weight_decay=0.0, clip=1.0):
+    """One optimiser step in place on dicts of tensors.  step counts from 1.
+    torch.optim.Adam (weight_decay=0 == reference), preceded by global-norm clip.
+    AdamW-style decoupled decay is applied when weight_decay > 0."""
+    keys = list(P.keys())
+    coef, total = clip_coef([G[k] for k in keys], clip) if clip > 0 else (torch.tensor(1.0), None)
+    bc1 = 1.0 - b1 ** step
+    bc2 = 1.0 - b2 ** step
+    for k in keys:
+        g = G[k] * coef.to(G[k].dtype)
+        if weight_decay > 0:
+            P[k].mul_(1.0 - lr * weight_decay)
+        M1[k].mul_(b1).add_(g, alpha=1 - b1)
+        M2[k].mul_(b2).addcmul_(g, g, value=1 - b2)
+        denom = (M2[k].sqrt() / math.sqrt(bc2)).add_(eps)
+        P[k].addcdiv_(M1[k], denom, value=-lr / bc1)
+    return total
+
+
+def loss_and_grads(cfg: Cfg, P: Dict[str, Tensor], tokens, cond, target):
+    """Forward + CE + backward through the restatement (torch autograd on the
+    closed-form graph).  Embedding pad row receives no gradient
+    (padding_idx, music_multi.py:57-59)."""
+    Pg = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+    logits = forward(cfg, Pg, tokens, cond)
+    loss = ce_loss(cfg, logits, target)
+    loss.backward()
+    G = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in Pg.items()}
+    G["embedding.weight"][cfg.pad_token].zero_()
+    return loss.detach(), logits.detach(), G
+
+
+# --------------------------------------------------------------------------
+# synthetic batches and greedy decode (generate.py:92-189, top_k=1)
+# --------------------------------------------------------------------------
+def synthetic_batch(cfg: Cfg, B: int, L: int, seed: int):
+    """Tokens in [2, V) (no PAD/START); input = tok[:, :-1], target = tok[:, 1:].
+    L is the *model* sequence length (for continuous_token the token input is
+    L-2 long and the target is left-padded with PAD, data/loader.py:55-57,184-187)."""
+    g = torch.Generator().manual_seed(seed)
+    V = cfg.vocab_size
+    if cfg.conditioning == "continuous_token":
+        tok = torch.randint(2, V, (B, L - 1), generator=g)
+        inp, tgt = tok[:, :-1], F.pad(tok[:, 1:], (2, 0), value=cfg.pad_token)
+    else:
+        tok = torch.randint(2, V, (B, L + 1), generator=g)
+        if cfg.conditioning == "discrete_token" and V >= 1017:
+            tok[:, 0] = torch.randint(1007, 1012, (B,), generator=g)
+            tok[:, 1] = torch.randint(1012, 1017, (B,), generator=g)
+        inp, tgt = tok[:, :-1], tok[:, 1:]
+    if cfg.conditioning in ("continuous_token", "continuous_concat"):
+        cond = torch.rand(B, 2, generator=g) * 2 - 1
+    else:
+        cond = torch.full((B, 2), float("nan"))
+    return inp.contiguous(), cond, tgt.contiguous()
+
+
+def special_token_ids(vocab_size: int) -> List[int]:
+    """Indices whose symbol starts with '<' (generate.py:57): <PAD>=0, <START>=1
+    and, for discrete_token vocabularies, the appended bin tokens 1007..V-1
+    (data/loader.py:58-75)."""
+    return [0, 1] + list(range(1007, vocab_size))
+
+
+def greedy_decode(cfg: Cfg, P, conds: Tensor, gen_len: int, max_input_len: int,
+                  discrete_prefix: Optional[Tensor] = None, start_token: int = 1) -> Tensor:
+    """Reference decode loop with top_k=1 (generate.py:92-189): full-window
+    recompute every step, last position, NaN->0, specials -> -inf, argmax.
+    Returns generated stream [T, B] including the primer (gen_song_tensor)."""
+    B = conds.shape[0]
+    if cfg.conditioning == "continuous_token":
+        max_input_len -= 2                                   # generate.py:76
+    elif cfg.conditioning == "discrete_token":
+        max_input_len -= discrete_prefix.shape[0]            # generate.py:81
+    song = torch.zeros((0, B), dtype=torch.long)
+    cur = torch.full((1, B), start_token, dtype=torch.long)
+    specials = special_token_ids(cfg.vocab_size)
+    for _ in range(gen_len):
+        song = torch.cat([song, cur], 0)
+        inp = song[-max_input_len:]
+        if cfg.conditioning == "discrete_token":
+            inp = torch.cat([discrete_prefix, inp], 0)       # generate.py:105-107
+        out = forward(cfg, P, inp.t().contiguous(), conds)[:, -1, :].clone()
+        out[out != out] = 0
+        out[:, specials] = float("-inf")
+        cur = out.argmax(-1)[None, :]
+    return song

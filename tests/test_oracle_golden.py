@@ -1,0 +1,154 @@
+"""Pins the oracle (oracle/ref_model.py) to golden vectors captured from the
+imported reference (oracle/make_fixtures.py -> tests/golden/*.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_model as O
+
+MODES = ["none", "discrete_token", "continuous_token", "continuous_concat"]
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def sub(a):
+    f = np.asarray(a).reshape(-1)
+    return f[::7] if f.size > 4096 else f
+
+
+def f1_cfg(mode, z):
+    V, nl, nh, d, di, dc, M = [int(x) for x in z["cfg"]]
+    return O.Cfg(V, nl, nh, d, di, d_condition=dc if dc > 0 else -1, conditioning=mode, max_seq=M)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_f1_logits_loss(golden_dir, mode):
+    z = load(golden_dir, f"f1_{mode}.npz")
+    cfg = f1_cfg(mode, z)
+    P = O.seeded_params(cfg, int(z["weight_seed"]))
+    for L in (1, 7, 33, 64):
+        tok = torch.from_numpy(z[f"L{L}_tokens"])
+        cond = torch.from_numpy(z[f"L{L}_cond"])
+        tgt = torch.from_numpy(z[f"L{L}_target"])
+        lg = O.forward(cfg, P, tok, cond)
+        np.testing.assert_allclose(lg.numpy(), z[f"L{L}_logits"], rtol=2e-4, atol=2e-5)
+        loss = O.ce_loss(cfg, lg, tgt)
+        assert abs(loss.item() - float(z[f"L{L}_loss"])) < 2e-5 * max(1, abs(float(z[f"L{L}_loss"])))
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_f1_pad_at_position0_nan_pattern(golden_dir, mode):
+    z = load(golden_dir, f"f1_{mode}.npz")
+    cfg = f1_cfg(mode, z)
+    P = O.seeded_params(cfg, int(z["weight_seed"]))
+    lg = O.forward(cfg, P, torch.from_numpy(z["pad0_tokens"]), torch.from_numpy(z["pad0_cond"]))
+    assert np.array_equal(torch.isnan(lg).numpy(), z["pad0_isnan"])
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_f1_grads_and_adam(golden_dir, mode):
+    z = load(golden_dir, f"f1_{mode}.npz")
+    cfg = f1_cfg(mode, z)
+    P = {k: v.double() for k, v in O.seeded_params(cfg, int(z["weight_seed"])).items()}
+    P0 = {k: v.clone() for k, v in P.items()}
+    M1 = {k: torch.zeros_like(v) for k, v in P.items()}
+    M2 = {k: torch.zeros_like(v) for k, v in P.items()}
+    for step in (1, 2, 3):
+        tok = torch.from_numpy(z[f"opt{step}_tokens"])
+        cond = torch.from_numpy(z[f"opt{step}_cond"])
+        tgt = torch.from_numpy(z[f"opt{step}_target"])
+        loss, _, G = O.loss_and_grads(cfg, P, tok, cond, tgt)
+        assert abs(loss.item() - float(z[f"opt{step}_loss"])) < 3e-5
+        if step == 1:
+            for k in P:
+                g = G[k].numpy()
+                ref = z[f"grad/{k}"]
+                scale = max(float(z[f"gradnorm/{k}"]) / np.sqrt(max(g.size, 1)), 1e-8)
+                np.testing.assert_allclose(sub(g), ref, rtol=2e-3, atol=2e-3 * scale + 1e-8, err_msg=k)
+                assert abs(np.sqrt((g ** 2).sum()) - float(z[f"gradnorm/{k}"])) <= 2e-4 * float(z[f"gradnorm/{k}"]) + 1e-9
+        total = O.adam_step(P, G, M1, M2, step, lr=2e-5, clip=1.0)
+        assert abs(float(total) - float(z[f"opt{step}_gradnorm"])) < 2e-4 * float(z[f"opt{step}_gradnorm"])
+        if step in (1, 3):
+            for k in P:
+                if k.endswith("Wk.bias"):
+                    # d(loss)/d(Wk.bias) is exactly 0 (softmax is shift-invariant along keys); the
+                    # reference's fp32 autograd leaves ~1e-11 noise there which Adam normalises to
+                    # +-lr steps.  Not a property to match.
+                    continue
+                upd = ((P[k] - P0[k]) / 2e-5).numpy()
+                # reference ran in fp32: its update carries fp32 rounding of p (|p|*6e-8/2e-5 ~ 3e-3*|p|)
+                tol = 2e-2 + 6e-3 * float(P0[k].abs().max())
+                # Adam's first steps are ~sign(g): elements with |g| ~ eps=1e-8 amplify fp32 noise,
+                # so allow a 0.5 % outlier fraction (bounded by 0.2) on top of the tolerance.
+                err = np.abs(sub(upd) - z[f"upd{step}/{k}"])
+                assert (err > tol).mean() <= 5e-3 and err.max() < 0.2, (k, step, err.max(), (err > tol).mean())
+
+
+def test_f2_cfg1_logits_loss_and_trajectory(golden_dir):
+    z = load(golden_dir, "f2_cfg1.npz")
+    cfg = O.Cfg(1007, 2, 4, 256, 1024, conditioning="none")
+    P = O.seeded_params(cfg, int(z["weight_seed"]))
+    tok = torch.from_numpy(z["tokens"])
+    tgt = torch.from_numpy(z["target"])
+    cond = torch.full((2, 2), float("nan"))
+    lg = O.forward(cfg, P, tok, cond)
+    rows = z["rows"]
+    np.testing.assert_allclose(lg[:, rows].numpy(), z["logits_rows"], rtol=2e-4, atol=5e-5)
+    assert abs(O.ce_loss(cfg, lg, tgt).item() - float(z["loss"])) < 5e-5
+    # 20-step trajectory with the restated clip+Adam
+    M1 = {k: torch.zeros_like(v) for k, v in P.items()}
+    M2 = {k: torch.zeros_like(v) for k, v in P.items()}
+    traj = []
+    for step in range(20):
+        inp, cond, tgt = O.synthetic_batch(cfg, 2, 256, seed=5000 + step)
+        loss, _, G = O.loss_and_grads(cfg, P, inp, cond, tgt)
+        O.adam_step(P, G, M1, M2, step + 1, lr=float(z["traj_lr"]), clip=1.0)
+        traj.append(loss.item())
+    np.testing.assert_allclose(np.array(traj), z["traj_loss"], rtol=0, atol=2e-3)
+
+
+def test_f3_cfg2_headline_shape(golden_dir):
+    z = load(golden_dir, "f3_cfg2.npz")
+    cfg = O.Cfg(1007, 6, 8, 512, 2048, d_condition=128, conditioning="continuous_concat")
+    P = O.seeded_params(cfg, int(z["weight_seed"]))
+    inp, cond, tgt = O.synthetic_batch(cfg, 2, 1024, seed=int(z["batch_seed"]))
+    loss, lg, G = O.loss_and_grads(cfg, P, inp, cond, tgt)
+    ref = z["logits_rows"]
+    got = lg[:, z["rows"]].numpy()
+    rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+    assert rel < 2e-5, rel
+    assert abs(loss.item() - float(z["loss"])) < 5e-5
+    for k in P:
+        gn = float(torch.sqrt((G[k].double() ** 2).sum()))
+        assert abs(gn - float(z[f"gradnorm/{k}"])) <= 1e-3 * float(z[f"gradnorm/{k}"]) + 1e-9, k
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_f4_greedy_decode_ids(golden_dir, mode):
+    z = load(golden_dir, "f4_decode.npz")
+    V = 1017 if mode == "discrete_token" else 1007
+    cfg = O.Cfg(V, 2, 2, 64, 128, d_condition=16, conditioning=mode)
+    P = O.seeded_params(cfg, int(z["weight_seed"]))
+    conds = torch.from_numpy(z["conds"]) if mode.startswith("continuous") else torch.full((4, 2), float("nan"))
+    prefix = torch.from_numpy(z[f"{mode}_prefix"]) if mode == "discrete_token" else None
+    for tag in ("noslide", "slide"):
+        gen_len, mil = [int(x) for x in z[f"{mode}_{tag}_cfg"]]
+        ids = O.greedy_decode(cfg, P, conds, gen_len, mil, discrete_prefix=prefix)
+        assert np.array_equal(ids.numpy(), z[f"{mode}_{tag}_ids"]), (mode, tag)
+
+
+def test_f5_attention_core_fp64(golden_dir):
+    z = load(golden_dir, "f5_attn_core.npz")
+    q, k, v, E = (torch.tensor(z[n], requires_grad=True) for n in ("q", "k", "v", "E"))
+    pad = torch.from_numpy(z["pad"])
+    np.testing.assert_allclose(O.rga_scores_rel(q, E).detach().numpy(), z["srel"], rtol=1e-12, atol=1e-12)
+    o, lse = O.rga_attention_core(q, k, v, E, pad)
+    np.testing.assert_allclose(o.detach().numpy(), z["O"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(lse.detach().numpy(), z["lse"], rtol=1e-10, atol=1e-12)
+    (o * torch.from_numpy(z["dO"])).sum().backward()
+    for t, n in ((q, "dq"), (k, "dk"), (v, "dv"), (E, "dE")):
+        np.testing.assert_allclose(t.grad.numpy(), z[n], rtol=1e-9, atol=1e-11, err_msg=n)
