@@ -1,0 +1,192 @@
+/* midiemo.h -- C-ABI of libmidiemo_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the hot path of serkansulun/midi-emotion: the
+ * emotion-conditioned Music-Transformer block stack (train step + cached
+ * decode).  The reference has no native layer: its "FFI" for this path is the
+ * set of PyTorch op call sites inside src/models/music_multi.py,
+ * src/models/music_continuous_token.py and src/train.py.  Every entry point
+ * below names the reference call sites (file:line under /root/reference/src)
+ * it replaces.
+ *
+ * Conventions
+ *   - all pointers are DEVICE addresses owned by the caller (PyTorch tensors);
+ *     the library is stateless, never allocates, never retains a pointer;
+ *   - `stream` is a hipStream_t passed as void*; calls only enqueue work;
+ *   - `dtype` selects the activation/weight storage type T of the call:
+ *       ME_F32  : exact-f32 MFMA (v_mfma_f32_32x32x2_f32), parity tier
+ *       ME_BF16 : bf16 storage, f32 accumulate (v_mfma_f32_32x32x16_bf16)
+ *     master parameters, gradients, optimiser state, statistics are always f32;
+ *   - return value: ME_OK or a negative ME_ERR_* code; nothing throws/aborts.
+ */
+#ifndef MIDIEMO_H
+#define MIDIEMO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ME_ABI_VERSION 1
+
+enum { ME_F32 = 0, ME_BF16 = 1 };
+
+enum {
+    ME_OK = 0,
+    ME_ERR_BAD_DTYPE = -1,
+    ME_ERR_BAD_SHAPE = -2,   /* unsupported head dim, K not chunk-aligned, L > max_seq, ... */
+    ME_ERR_ALIGNMENT = -3,   /* pointer / leading dimension not 16-byte aligned */
+    ME_ERR_LAUNCH = -4,      /* hipGetLastError() after launch */
+    ME_ERR_NULL = -5
+};
+
+/* conditioning modes of the embedding prologue */
+enum { ME_COND_NONE = 0, ME_COND_CONCAT = 1, ME_COND_TOKEN = 2 };
+
+/* epilogue flags of me_gemm_nt */
+enum {
+    ME_EPI_RELU = 1,        /* y = max(y, 0) after bias             (F.relu, music_multi.py:131) */
+    ME_EPI_OUT_F32 = 2,     /* C is float regardless of dtype       (logits for the CE head)     */
+    ME_EPI_RELU_BWD = 4     /* y = (gate > 0) ? y : 0 ; gate is T   (autograd of F.relu)         */
+};
+
+int me_abi_version(void);
+
+/* ---- parameter preparation ------------------------------------------------
+ * f32 master [rows][cols] -> T copy (dst, ld_dst) and/or T transposed copy
+ * (dstT [cols][rows], ld_dstT).  Either destination may be NULL.
+ * Replaces: the implicit weight casts of torch.cuda.amp.autocast (train.py:281). */
+int me_cast_transpose(const float* src, int rows, int cols, void* dst, int ld_dst,
+                      void* dstT, int ld_dstT, int dtype, void* stream);
+
+/* ---- embedding prologue ---------------------------------------------------
+ * out[B, Lm, d] (T).  Lm = Ltok (+2 for ME_COND_TOKEN).
+ *   NONE  : out = emb[tok]*sqrt(d) + PE                       (music_multi.py:91-92,101)
+ *   CONCAT: out = cat(emb[tok]*sqrt(d-dc), Wc.cond+bc) + PE   (music_multi.py:94-101)
+ *   TOKEN : out = cat_seq([W0*v+b0, W1*a+b1], emb[tok]*sqrt(d)) + PE
+ *                                                  (music_continuous_token.py:80-100)
+ * followed by inverted dropout(p) with the counter-based mask (seed, site 0)
+ * (music_multi.py:102).  emb is the f32 master table [V][d-dc]; pe is f32 [>=Lm][d]. */
+int me_embed_fwd(void* out, int dtype, const int64_t* tokens, const float* cond,
+                 const float* emb, const float* cw0, const float* cb0,
+                 const float* cw1, const float* cb1, const float* pe,
+                 int mode, int B, int Ltok, int d_model, int d_cond,
+                 float p_drop, uint64_t seed, void* stream);
+
+/* Gradient of the prologue: accumulates (+=) into the f32 gradient tensors.
+ * Rows of g_emb for token == pad_token receive nothing (padding_idx,
+ * music_multi.py:57-59). */
+int me_embed_bwd(const void* dout, int dtype, const int64_t* tokens, const float* cond,
+                 float* g_emb, float* g_cw0, float* g_cb0, float* g_cw1, float* g_cb1,
+                 int mode, int B, int Ltok, int d_model, int d_cond, int pad_token,
+                 float p_drop, uint64_t seed, void* stream);
+
+/* ---- key padding mask -----------------------------------------------------
+ * key_pad[B, Lm] (uint8, 1 = masked key) from tokens == pad_token; the `shift`
+ * leading slots (2 for ME_COND_TOKEN) are never pad.
+ * Replaces generate_mask's pad part (music_multi.py:25-38); the causal part is a
+ * predicate inside the attention kernels and is never materialised. */
+int me_key_pad_mask(uint8_t* key_pad, const int64_t* tokens, int B, int Ltok, int shift,
+                    int pad_token, void* stream);
+
+/* ---- GEMM  C[M,N] = A[M,K] . B[N,K]^T  (+bias[N]) (+add[M,N]) ------------------
+ * A, B are T with the contraction dimension contiguous (lda, ldb in elements,
+ * multiples of 16 bytes).  C is T, or float with ME_EPI_OUT_F32.  bias is f32 or
+ * NULL; add (T, ld = ldadd) is added after bias or NULL; gate (T, ld = ldgate) is
+ * the ReLU-backward gate or NULL.
+ * Replaces nn.Linear forward (music_multi.py:106,131-132,196-209,237) and, with
+ * pre-transposed weights, the dX = dY.W products of its autograd. */
+int me_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+               const float* bias, const void* add, int ldadd, const void* gate, int ldgate,
+               int M, int N, int K, int flags, int dtype, void* stream);
+
+/* ---- GEMM  dW[N,K] += A[T,N]^T . B[T,K]   (f32 atomic accumulation) ----------
+ * A = dY (T, lda), B = X (T, ldb), dW f32 (lddw).  If dbias != NULL also
+ * dbias[N] += column sums of A.  Replaces the weight/bias gradients of nn.Linear. */
+int me_gemm_tn_acc(const void* A, int lda, const void* B, int ldb, float* dW, int lddw,
+                   float* dbias, int T, int N, int K, int dtype, void* stream);
+
+/* ---- relative global attention ---------------------------------------------
+ * qkv  : T [B, L, 3, H, dh]  (token-major output of the fused QKV projection)
+ * E    : T [M, dh] relative table of the layer (natural layout)
+ * key_pad : uint8 [B, L] or NULL
+ * out  : T [B, L, H, dh]   lse : f32 [B, H, L]
+ *   logits[l,j] = (q_l.k_j + q_l.E[M-1-(l-j)]) / sqrt(dh),  j<=l and key j not pad
+ * Replaces music_multi.py:211-235 (einsum QE, _qe_masking, _skewing, QK^T, mask,
+ * softmax, PV, head merge).  dh in {32, 64}; M % 32 == 0; L <= M. */
+int me_rga_fwd(const void* qkv, const void* E, const uint8_t* key_pad, void* out, float* lse,
+               int B, int L, int H, int dh, int M, int dtype, void* stream);
+
+/* Backward of me_rga_fwd.  dout: T [B,L,H,dh].  Writes dqkv (T, same layout as qkv),
+ * accumulates (+=) dE f32 [M, dh].  ET is the transposed table T [dh, M].
+ * Workspaces: delta f32 [B,H,L]; ds T [B,H,L,L] (scaled dS of the current layer). */
+int me_rga_bwd(const void* qkv, const void* E, const void* ET, const uint8_t* key_pad,
+               const void* out, const float* lse, const void* dout,
+               void* dqkv, float* dE, float* delta_ws, void* ds_ws,
+               int B, int L, int H, int dh, int M, int dtype, void* stream);
+
+/* ---- residual + dropout + LayerNorm (post-LN, eps) ---------------------------
+ *   s = x + dropout(a) ;  y = LN(s) * gamma + beta          (music_multi.py:128-129,133-134)
+ * x, a, y, s_out are T [rows, d]; s_out (pre-norm sum, needed by backward) and
+ * stats (f32 [rows][2] = mean, rstd) may be NULL for inference. */
+int me_resid_ln_fwd(const void* x, const void* a, const float* gamma, const float* beta,
+                    void* y, void* s_out, float* stats, int rows, int d, float eps,
+                    float p_drop, uint64_t seed, uint32_t site, int dtype, void* stream);
+
+/* Backward: given dy (T), s (T), stats, gamma:
+ *   ds = LN'(dy) ; dx = ds (T) ; da = dropout'(ds) (T) ; dgamma,dbeta += (f32). */
+int me_resid_ln_bwd(const void* dy, const void* s, const float* stats, const float* gamma,
+                    void* dx, void* da, float* dgamma, float* dbeta, int rows, int d,
+                    float p_drop, uint64_t seed, uint32_t site, int dtype, void* stream);
+
+/* ---- cross-entropy head ------------------------------------------------------
+ * logits f32 [rows, ld] (V valid columns), target int64 [rows].
+ * me_ce_fwd:  row_lse[r] = logsumexp(logits[r, :V]);
+ *             *loss_sum += sum over target != ignore of (row_lse - logit[target]);
+ *             *n_valid  += count(target != ignore)          (both f32 device scalars)
+ * me_ce_bwd:  dlogits (T [rows, ld_d]) = (exp(logit - row_lse) - onehot) * (target != ignore)
+ *             * extra_scale / *n_valid ; columns V..ld_d-1 are written as 0.
+ * Replaces CrossEntropyLoss(ignore_index=pad) + its autograd (train.py:124,288-290). */
+int me_ce_fwd(const float* logits, int ld, const int64_t* target, float* row_lse,
+              float* loss_sum, float* n_valid, int rows, int V, int ignore_index, void* stream);
+int me_ce_bwd(const float* logits, int ld, const int64_t* target, const float* row_lse,
+              void* dlogits, int ld_d, const float* n_valid, float extra_scale,
+              int rows, int V, int ignore_index, int dtype, void* stream);
+
+/* ---- optimiser: global-norm clip + Adam(W) -----------------------------------
+ * me_sumsq: *out += sum g[i]^2   (zero *out first; multiple calls accumulate)
+ * me_adamw_step: coef = min(1, clip/(sqrt(*sumsq)+1e-6)) (clip <= 0: coef = 1);
+ *   g' = g*coef*grad_scale ; m = b1 m + (1-b1) g' ; v = b2 v + (1-b2) g'^2 ;
+ *   p = p*(1 - lr*wd) - (lr/bias_corr1) * m / (sqrt(v)/sqrt(bias_corr2) + eps)
+ * with bias_corr{1,2} = 1 - beta^step computed by the caller.  weight_decay = 0 is
+ * exactly torch.optim.Adam.  If zero_grad != 0 the gradient is zeroed in the same pass.
+ * Replaces clip_grad_norm_ + optim.Adam.step + zero_grad (train.py:320-325). */
+int me_sumsq(const float* g, int64_t n, float* out, void* stream);
+int me_adamw_step(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq,
+                  float clip, float grad_scale, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, float bias_corr1, float bias_corr2, int zero_grad,
+                  void* stream);
+
+/* ---- KV-cached decode (generate.py:92-122 with the model call made incremental) ---
+ * One new position `t` per sequence.  qkv_new: T [B, 3, H, dh] for the new token;
+ * kcache/vcache: T [B, H, Mc, dh] (position-major); writes k,v at position t, then
+ *   out[b,h,:] = softmax_j<=t( (q.k_j + q.E[M-1-(t-j)])/sqrt(dh) ) . v_j   (pad keys masked)
+ * out: T [B, H, dh]. */
+int me_rga_decode_step(const void* qkv_new, void* kcache, void* vcache, const void* E,
+                       const uint8_t* key_pad, int ld_pad, void* out, int B, int H, int dh,
+                       int M, int Mc, int t, int dtype, void* stream);
+
+/* Small-M projection y[Mr,N] = x[Mr,K].W[N,K]^T + bias (Mr <= 8), optional ReLU;
+ * weight-streaming kernel for the decode step (HBM-bound). */
+int me_gemv_small(const void* x, int ldx, const void* W, int ldw, const float* bias,
+                  void* y, int ldy, int Mr, int N, int K, int flags, int dtype, void* stream);
+
+/* Greedy pick for generate(top_k=1): logits f32 [B, ld]; NaN -> 0, ids in
+ * special[0..n_special) -> -inf, argmax -> out_ids[B] (generate.py:122-136,166-183). */
+int me_greedy_pick(const float* logits, int ld, int V, const int32_t* special, int n_special,
+                   int64_t* out_ids, int B, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIDIEMO_H */

@@ -1,0 +1,147 @@
+// Shared device-side helpers for the midiemo gfx950 (CDNA4 / MI355X) kernels.
+// wave = 64 lanes; every MFMA tile below is the 32x32 "macro-atom":
+//     acc[32x32] += sum_{h in {0,1}, e in 0..7} a(i,h)[e] * b(j,h)[e]
+// where lane = (i | h<<5) supplies 8 contraction elements of row i of A and
+// lane = (j | h<<5) supplies 8 contraction elements of column j of B.
+//   bf16 : one v_mfma_f32_32x32x16_bf16            (8 bf16 per lane, 16 B)
+//   f32  : eight v_mfma_f32_32x32x2_f32 (exact f32) (8 floats per lane, 32 B)
+// Because A and B always use the same (h,e)->k map, the hardware's own k
+// ordering never matters; only the C/D map does:
+//   col = lane & 31,  row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/midiemo.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+#define ME_WAVE 64
+#define ME_DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------------------
+// C/D layout of the 32x32 accumulator
+// ---------------------------------------------------------------------------
+ME_DEV int c_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+ME_DEV int c_col(int lane) { return lane & 31; }
+
+// ---------------------------------------------------------------------------
+// element traits
+// ---------------------------------------------------------------------------
+template <typename T> struct ET;
+template <> struct ET<bf16_t> {
+    static constexpr int CH = 8;  // elements per 16-byte chunk
+    ME_DEV static float to_f(bf16_t x) { return (float)x; }
+    ME_DEV static bf16_t from_f(float x) { return (bf16_t)x; }
+    ME_DEV static float fexp(float x) { return __expf(x); }
+};
+template <> struct ET<float> {
+    static constexpr int CH = 4;
+    ME_DEV static float to_f(float x) { return x; }
+    ME_DEV static float from_f(float x) { return x; }
+    ME_DEV static float fexp(float x) { return expf(x); }
+};
+
+// 16-byte chunk moved as one unit between global memory, registers and LDS
+struct __attribute__((aligned(16))) chunk16 { u32x4_t v; };
+ME_DEV chunk16 zero_chunk() { chunk16 c; c.v = (u32x4_t){0u, 0u, 0u, 0u}; return c; }
+ME_DEV chunk16 ld_chunk(const void* p) { return *reinterpret_cast<const chunk16*>(p); }
+ME_DEV void st_chunk(void* p, const chunk16& c) { *reinterpret_cast<chunk16*>(p) = c; }
+
+// ---------------------------------------------------------------------------
+// MFMA operand fragment: 8 contraction elements for one row/column
+// ---------------------------------------------------------------------------
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> { bf16x8_t v; };
+template <> struct Frag<float> { f32x4_t lo, hi; };
+
+// 8 contiguous elements (16-byte aligned for bf16, 16-byte aligned halves for f32)
+ME_DEV void frag_load(Frag<bf16_t>& f, const bf16_t* p) { f.v = *reinterpret_cast<const bf16x8_t*>(p); }
+ME_DEV void frag_load(Frag<float>& f, const float* p) {
+    f.lo = *reinterpret_cast<const f32x4_t*>(p);
+    f.hi = *reinterpret_cast<const f32x4_t*>(p + 4);
+}
+// two groups of 4 contiguous elements (used with the accumulator-as-operand k map)
+ME_DEV void frag_load_4x2(Frag<bf16_t>& f, const bf16_t* p0, const bf16_t* p1) {
+    bf16x4_t a = *reinterpret_cast<const bf16x4_t*>(p0);
+    bf16x4_t b = *reinterpret_cast<const bf16x4_t*>(p1);
+    f.v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+ME_DEV void frag_load_4x2(Frag<float>& f, const float* p0, const float* p1) {
+    f.lo = *reinterpret_cast<const f32x4_t*>(p0);
+    f.hi = *reinterpret_cast<const f32x4_t*>(p1);
+}
+ME_DEV void frag_zero(Frag<bf16_t>& f) { f.v = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0}; }
+ME_DEV void frag_zero(Frag<float>& f) { f.lo = (f32x4_t){0, 0, 0, 0}; f.hi = f.lo; }
+ME_DEV void frag_set(Frag<bf16_t>& f, int e, float x) { f.v[e] = (bf16_t)x; }
+ME_DEV void frag_set(Frag<float>& f, int e, float x) { if (e < 4) f.lo[e] = x; else f.hi[e - 4] = x; }
+
+// accumulator registers [8*t .. 8*t+7] -> operand fragment (k map = c_row of those registers)
+ME_DEV void frag_from_acc(Frag<bf16_t>& f, const f32x16_t& a, int t) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f.v[e] = (bf16_t)a[8 * t + e];
+}
+ME_DEV void frag_from_acc(Frag<float>& f, const f32x16_t& a, int t) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f.lo[e] = a[8 * t + e]; f.hi[e] = a[8 * t + 4 + e]; }
+}
+
+ME_DEV void mma32(f32x16_t& acc, const Frag<bf16_t>& a, const Frag<bf16_t>& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+ME_DEV void mma32(f32x16_t& acc, const Frag<float>& a, const Frag<float>& b) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo[e], b.lo[e], acc, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi[e], b.hi[e], acc, 0, 0, 0);
+}
+ME_DEV void acc_zero(f32x16_t& a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+}
+
+// ---------------------------------------------------------------------------
+// wave reductions (64 lanes)
+// ---------------------------------------------------------------------------
+ME_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+ME_DEV float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// counter-based dropout RNG: 32-bit avalanche hash of (seed, site, element).
+// One hash yields two 16-bit uniforms (two neighbouring elements).
+// keep  <=>  u16 >= thr16  with thr16 = round(p * 65536)
+// ---------------------------------------------------------------------------
+ME_DEV uint32_t me_hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+ME_DEV uint32_t me_rng_pair(uint64_t seed, uint32_t site, uint64_t pair_index) {
+    uint32_t lo = (uint32_t)pair_index, hi = (uint32_t)(pair_index >> 32);
+    uint32_t s = me_hash32((uint32_t)seed ^ (site * 0x9E3779B9U) ^ (hi * 0x85EBCA6BU));
+    return me_hash32(lo ^ s ^ (uint32_t)(seed >> 32));
+}
+// keep-flag of element idx (consistent with the pair generator)
+ME_DEV bool me_keep(uint64_t seed, uint32_t site, uint64_t idx, uint32_t thr16) {
+    uint32_t r = me_rng_pair(seed, site, idx >> 1);
+    uint32_t u = (idx & 1) ? (r >> 16) : (r & 0xFFFFu);
+    return u >= thr16;
+}
+
+// status helper for the C-ABI launchers
+static inline int me_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ME_OK : ME_ERR_LAUNCH;
+}

@@ -1,0 +1,580 @@
+// HBM-bound kernels of the midiemo hot path (gfx950): embedding prologue,
+// residual+dropout+LayerNorm, cross-entropy head, global-norm clip + AdamW,
+// key-pad mask, greedy pick.  One wavefront (64 lanes) owns one row; every lane
+// moves 16-byte chunks; row statistics are wave shuffles, no LDS.
+#include "me_common.h"
+
+namespace {
+
+constexpr int MAXC = 4;   // chunks per lane per row  =>  d <= 64*4*CH  (2048 bf16 / 1024 f32)
+
+template <typename T> ME_DEV void chunk_to_f(const chunk16& c, float* f) {
+    const T* e = reinterpret_cast<const T*>(&c);
+#pragma unroll
+    for (int i = 0; i < ET<T>::CH; ++i) f[i] = ET<T>::to_f(e[i]);
+}
+template <typename T> ME_DEV chunk16 f_to_chunk(const float* f) {
+    chunk16 c;
+    T* e = reinterpret_cast<T*>(&c);
+#pragma unroll
+    for (int i = 0; i < ET<T>::CH; ++i) e[i] = ET<T>::from_f(f[i]);
+    return c;
+}
+
+// dropout multipliers (0 or 1/(1-p)) for CH consecutive elements starting at even index idx0
+template <int CH> ME_DEV void drop_mult(float* mult, uint64_t seed, uint32_t site, uint64_t idx0, uint32_t thr16, float inv_keep) {
+#pragma unroll
+    for (int i = 0; i < CH; i += 2) {
+        const uint32_t r = me_rng_pair(seed, site, (idx0 + i) >> 1);
+        mult[i] = ((r & 0xFFFFu) >= thr16) ? inv_keep : 0.f;
+        mult[i + 1] = ((r >> 16) >= thr16) ? inv_keep : 0.f;
+    }
+}
+inline uint32_t thr_of(float p) {
+    if (p <= 0.f) return 0u;
+    float t = p * 65536.f + 0.5f;
+    return t > 65535.f ? 65535u : (uint32_t)t;
+}
+
+// ------------------------------------------------------------------ embedding prologue
+template <typename T>
+__global__ __launch_bounds__(256) void embed_fwd_kernel(T* __restrict__ out, const int64_t* __restrict__ tokens,
+                                                        const float* __restrict__ cond, const float* __restrict__ emb,
+                                                        const float* __restrict__ cw0, const float* __restrict__ cb0,
+                                                        const float* __restrict__ cw1, const float* __restrict__ cb1,
+                                                        const float* __restrict__ pe, int mode, int B, int Ltok, int d,
+                                                        int dc, uint32_t thr16, float inv_keep, uint64_t seed) {
+    constexpr int CH = ET<T>::CH;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int shift = mode == ME_COND_TOKEN ? 2 : 0;
+    const int Lm = Ltok + shift;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wid;
+    if (row >= (int64_t)B * Lm) return;
+    const int b = (int)(row / Lm), l = (int)(row % Lm);
+    const int de = d - dc;
+    const float sq = sqrtf((float)de);
+    const float c0 = cond ? cond[b * 2] : 0.f, c1 = cond ? cond[b * 2 + 1] : 0.f;
+    int64_t tok = 0;
+    if (l >= shift) tok = tokens[(int64_t)b * Ltok + (l - shift)];
+    for (int col = lane * CH; col < d; col += 64 * CH) {
+        float v[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int j = col + i;
+            float x;
+            if (l < shift) {
+                x = l == 0 ? cw0[j] * c0 + cb0[j] : cw1[j] * c1 + cb1[j];
+            } else if (j < de) {
+                x = emb[tok * de + j] * sq;
+            } else {
+                const int jc = j - de;
+                x = cw0[jc * 2] * c0 + cw0[jc * 2 + 1] * c1 + cb0[jc];
+            }
+            v[i] = x + pe[(int64_t)l * d + j];
+        }
+        if (thr16) {
+            float mult[CH];
+            drop_mult<CH>(mult, seed, 0u, (uint64_t)row * d + col, thr16, inv_keep);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) v[i] *= mult[i];
+        }
+        st_chunk(out + row * d + col, f_to_chunk<T>(v));
+    }
+}
+
+// grid (nslab, B); block loops over the rows of its slab, per-lane column partials for
+// the condition projection are reduced across the 4 waves in LDS -> one atomic per column
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const T* __restrict__ dout, const int64_t* __restrict__ tokens,
+                                                        const float* __restrict__ cond, float* __restrict__ g_emb,
+                                                        float* __restrict__ g_cw0, float* __restrict__ g_cb0,
+                                                        float* __restrict__ g_cw1, float* __restrict__ g_cb1, int mode,
+                                                        int B, int Ltok, int d, int dc, int pad_token, uint32_t thr16,
+                                                        float inv_keep, uint64_t seed) {
+    constexpr int CH = ET<T>::CH;
+    __shared__ float red[4][MAXC * 64 * 8];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int shift = mode == ME_COND_TOKEN ? 2 : 0;
+    const int Lm = Ltok + shift;
+    const int b = blockIdx.y;
+    const int de = d - dc;
+    const float sq = sqrtf((float)de);
+    const int rows_per = (Lm + gridDim.x - 1) / gridDim.x;
+    const int l_begin = blockIdx.x * rows_per, l_end = min(Lm, l_begin + rows_per);
+    float part[MAXC][CH];   // column partial sums of the concat-condition part
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+        for (int i = 0; i < CH; ++i) part[c][i] = 0.f;
+
+    for (int l = l_begin + wid; l < l_end; l += 4) {
+        const int64_t row = (int64_t)b * Lm + l;
+        int64_t tok = 0;
+        if (l >= shift) tok = tokens[(int64_t)b * Ltok + (l - shift)];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int col = (lane + c * 64) * CH;
+            if (col >= d) break;
+            float g[CH];
+            chunk_to_f<T>(ld_chunk(dout + row * d + col), g);
+            if (thr16) {
+                float mult[CH];
+                drop_mult<CH>(mult, seed, 0u, (uint64_t)row * d + col, thr16, inv_keep);
+#pragma unroll
+                for (int i = 0; i < CH; ++i) g[i] *= mult[i];
+            }
+            if (l < shift) {
+                // continuous_token prefix rows: d W_l[j] += g*cond[b][l], d b_l[j] += g
+                const float cv = cond[b * 2 + l];
+                float* gw = l == 0 ? g_cw0 : g_cw1;
+                float* gb = l == 0 ? g_cb0 : g_cb1;
+#pragma unroll
+                for (int i = 0; i < CH; ++i) { atomicAdd(&gw[col + i], g[i] * cv); atomicAdd(&gb[col + i], g[i]); }
+            } else {
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    const int j = col + i;
+                    if (j < de) { if (tok != pad_token) atomicAdd(&g_emb[tok * de + j], g[i] * sq); }
+                    else part[c][i] += g[i];
+                }
+            }
+        }
+    }
+    if (mode != ME_COND_CONCAT || dc <= 0) return;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+        for (int i = 0; i < CH; ++i) red[wid][(c * 64 + lane) * CH + i] = part[c][i];
+    __syncthreads();
+    const float c0 = cond[b * 2], c1 = cond[b * 2 + 1];
+    for (int j = threadIdx.x; j < d; j += 256) {
+        if (j < de) continue;
+        const float s = red[0][j] + red[1][j] + red[2][j] + red[3][j];
+        const int jc = j - de;
+        atomicAdd(&g_cw0[jc * 2], s * c0);
+        atomicAdd(&g_cw0[jc * 2 + 1], s * c1);
+        atomicAdd(&g_cb0[jc], s);
+    }
+}
+
+__global__ void key_pad_kernel(uint8_t* __restrict__ kp, const int64_t* __restrict__ tokens, int B, int Ltok, int shift,
+                               int pad_token) {
+    const int Lm = Ltok + shift;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * Lm) return;
+    const int b = (int)(i / Lm), l = (int)(i % Lm);
+    kp[i] = (l >= shift && tokens[(int64_t)b * Ltok + (l - shift)] == pad_token) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ residual + dropout + LayerNorm
+template <typename T>
+__global__ __launch_bounds__(256) void resid_ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ a,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           T* __restrict__ y, T* __restrict__ s_out, float* __restrict__ stats,
+                                                           int rows, int d, float eps, uint32_t thr16, float inv_keep,
+                                                           uint64_t seed, uint32_t site) {
+    constexpr int CH = ET<T>::CH;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wid; row < rows; row += (int64_t)gridDim.x * 4) {
+        float s[MAXC][CH];
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int col = (lane + c * 64) * CH;
+            if (col < d) {
+                float xv[CH], av[CH];
+                chunk_to_f<T>(ld_chunk(x + row * d + col), xv);
+                chunk_to_f<T>(ld_chunk(a + row * d + col), av);
+                if (thr16) {
+                    float mult[CH];
+                    drop_mult<CH>(mult, seed, site, (uint64_t)row * d + col, thr16, inv_keep);
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) av[i] *= mult[i];
+                }
+#pragma unroll
+                for (int i = 0; i < CH; ++i) { s[c][i] = xv[i] + av[i]; sum += s[c][i]; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < CH; ++i) s[c][i] = 0.f;
+            }
+        }
+        const float mean = wave_sum(sum) / d;
+        float vs = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int col = (lane + c * 64) * CH;
+            if (col < d) {
+#pragma unroll
+                for (int i = 0; i < CH; ++i) { const float t = s[c][i] - mean; vs += t * t; }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(vs) / d + eps);
+        if (stats && lane == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int col = (lane + c * 64) * CH;
+            if (col < d) {
+                float o[CH];
+#pragma unroll
+                for (int i = 0; i < CH; ++i) o[i] = (s[c][i] - mean) * rstd * gamma[col + i] + beta[col + i];
+                st_chunk(y + row * d + col, f_to_chunk<T>(o));
+                if (s_out) st_chunk(s_out + row * d + col, f_to_chunk<T>(s[c]));
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void resid_ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ s,
+                                                           const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                           T* __restrict__ dx, T* __restrict__ da, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int rows, int d, uint32_t thr16,
+                                                           float inv_keep, uint64_t seed, uint32_t site) {
+    constexpr int CH = ET<T>::CH;
+    __shared__ float red[2][4][MAXC * 64 * 8];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float pg[MAXC][CH], pb[MAXC][CH];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+        for (int i = 0; i < CH; ++i) { pg[c][i] = 0.f; pb[c][i] = 0.f; }
+
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wid; row < rows; row += (int64_t)gridDim.x * 4) {
+        const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+        float g[MAXC][CH], xh[MAXC][CH];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int col = (lane + c * 64) * CH;
+            if (col < d) {
+                float dyv[CH], sv[CH];
+                chunk_to_f<T>(ld_chunk(dy + row * d + col), dyv);
+                chunk_to_f<T>(ld_chunk(s + row * d + col), sv);
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    xh[c][i] = (sv[i] - mean) * rstd;
+                    g[c][i] = dyv[i] * gamma[col + i];
+                    s1 += g[c][i];
+                    s2 += g[c][i] * xh[c][i];
+                    pg[c][i] += dyv[i] * xh[c][i];
+                    pb[c][i] += dyv[i];
+                }
+            }
+        }
+        const float c1 = wave_sum(s1) / d, c2 = wave_sum(s2) / d;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int col = (lane + c * 64) * CH;
+            if (col < d) {
+                float o[CH];
+#pragma unroll
+                for (int i = 0; i < CH; ++i) o[i] = rstd * (g[c][i] - c1 - xh[c][i] * c2);
+                st_chunk(dx + row * d + col, f_to_chunk<T>(o));
+                if (thr16) {
+                    float mult[CH];
+                    drop_mult<CH>(mult, seed, site, (uint64_t)row * d + col, thr16, inv_keep);
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) o[i] *= mult[i];
+                }
+                st_chunk(da + row * d + col, f_to_chunk<T>(o));
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            red[0][wid][(c * 64 + lane) * CH + i] = pg[c][i];
+            red[1][wid][(c * 64 + lane) * CH + i] = pb[c][i];
+        }
+    __syncthreads();
+    for (int j = threadIdx.x; j < d; j += 256) {
+        atomicAdd(&dgamma[j], red[0][0][j] + red[0][1][j] + red[0][2][j] + red[0][3][j]);
+        atomicAdd(&dbeta[j], red[1][0][j] + red[1][1][j] + red[1][2][j] + red[1][3][j]);
+    }
+}
+
+// ------------------------------------------------------------------ cross-entropy head
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, int ld,
+                                                     const int64_t* __restrict__ target, float* __restrict__ row_lse,
+                                                     float* __restrict__ loss_sum, float* __restrict__ n_valid, int rows,
+                                                     int V, int ignore_index) {
+    __shared__ float red[2][4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float bl = 0.f, bn = 0.f;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wid; row < rows; row += (int64_t)gridDim.x * 4) {
+        const float* lg = logits + row * ld;
+        float mx = -INFINITY;
+        for (int j = lane; j < V; j += 64) mx = fmaxf(mx, lg[j]);
+        mx = wave_max(mx);
+        float se = 0.f;
+        for (int j = lane; j < V; j += 64) se += expf(lg[j] - mx);
+        se = wave_sum(se);
+        const float lse = mx + logf(se);
+        if (lane == 0) {
+            if (row_lse) row_lse[row] = lse;
+            const int64_t t = target[row];
+            if (t != ignore_index) { bl += lse - lg[t]; bn += 1.f; }
+        }
+    }
+    if (lane == 0) { red[0][wid] = bl; red[1][wid] = bn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(loss_sum, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(n_valid, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, int ld,
+                                                     const int64_t* __restrict__ target, const float* __restrict__ row_lse,
+                                                     T* __restrict__ dlogits, int ld_d, const float* __restrict__ n_valid,
+                                                     float extra_scale, int rows, int V, int ignore_index) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const float scale = extra_scale / fmaxf(*n_valid, 0.f);   // n_valid == 0 -> inf/nan like torch's 0/0 mean
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wid; row < rows; row += (int64_t)gridDim.x * 4) {
+        const float* lg = logits + row * ld;
+        const int64_t t = target[row];
+        const float lse = row_lse[row];
+        const bool valid = t != ignore_index;
+        for (int j = lane; j < ld_d; j += 64) {
+            float g = 0.f;
+            if (valid && j < V) g = (expf(lg[j] - lse) - (j == t ? 1.f : 0.f)) * scale;
+            dlogits[row * ld_d + j] = ET<T>::from_f(g);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ clip + AdamW
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float s = 0.f;
+    const int64_t n4 = n >> 2;
+    const f32x4_t* g4 = reinterpret_cast<const f32x4_t*>(g);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4_t v = g4[i];
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[(n4 << 2) + threadIdx.x]; s += v * v; }
+    s = wave_sum(s);
+    if (lane == 0) red[wid] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, int64_t n, const float* __restrict__ sumsq,
+                                                    float clip, float grad_scale, float lr, float b1, float b2, float eps,
+                                                    float wd, float bc1, float bc2, int zero_grad) {
+    float coef = grad_scale;
+    if (clip > 0.f && sumsq) {
+        const float total = sqrtf(*sumsq) * fabsf(grad_scale);
+        coef *= fminf(1.f, clip / (total + 1e-6f));
+    }
+    const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2), decay = 1.f - lr * wd;
+    auto upd = [&](float& pp, float gg, float& mm, float& vv) {
+        gg *= coef;
+        mm = b1 * mm + (1.f - b1) * gg;
+        vv = b2 * vv + (1.f - b2) * gg * gg;
+        const float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
+        pp = pp * decay - step_size * (mm / denom);
+    };
+    const int64_t n4 = n >> 2;
+    f32x4_t* p4 = reinterpret_cast<f32x4_t*>(p);
+    f32x4_t* g4 = reinterpret_cast<f32x4_t*>(g);
+    f32x4_t* m4 = reinterpret_cast<f32x4_t*>(m);
+    f32x4_t* v4 = reinterpret_cast<f32x4_t*>(v);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4_t pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float pe_ = pp[e], me_ = mm[e], ve_ = vv[e];
+            upd(pe_, gg[e], me_, ve_);
+            pp[e] = pe_; mm[e] = me_; vv[e] = ve_;
+        }
+        p4[i] = pp; m4[i] = mm; v4[i] = vv;
+        if (zero_grad) g4[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        upd(p[i], g[i], m[i], v[i]);
+        if (zero_grad) g[i] = 0.f;
+    }
+}
+
+// ------------------------------------------------------------------ greedy pick (generate top_k=1)
+__global__ __launch_bounds__(256) void greedy_pick_kernel(const float* __restrict__ logits, int ld, int V,
+                                                          const int32_t* __restrict__ special, int n_special,
+                                                          int64_t* __restrict__ out_ids) {
+    __shared__ float bv[256];
+    __shared__ int bi[256];
+    const float* lg = logits + (int64_t)blockIdx.x * ld;
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    for (int j = threadIdx.x; j < V; j += 256) {
+        float v = lg[j];
+        if (v != v) v = 0.f;                                  // generate.py:123 (NaN -> 0)
+        for (int s = 0; s < n_special; ++s) if (special[s] == j) v = -INFINITY;   // generate.py:131-136
+        if (v > best || (v == best && j < besti)) { best = v; besti = j; }
+    }
+    bv[threadIdx.x] = best; bi[threadIdx.x] = besti;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            const float ov = bv[threadIdx.x + o]; const int oi = bi[threadIdx.x + o];
+            if (ov > bv[threadIdx.x] || (ov == bv[threadIdx.x] && oi < bi[threadIdx.x])) { bv[threadIdx.x] = ov; bi[threadIdx.x] = oi; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out_ids[blockIdx.x] = bi[0] == 0x7fffffff ? 0 : bi[0];
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline int row_grid(int64_t rows, int cap) { int64_t g = (rows + 3) / 4; return (int)(g < 1 ? 1 : (g > cap ? cap : g)); }
+
+}  // namespace
+
+#define ME_DISPATCH(dtype, CALL)                         \
+    if ((dtype) == ME_F32) { typedef float T; CALL; }    \
+    else if ((dtype) == ME_BF16) { typedef bf16_t T; CALL; } \
+    else return ME_ERR_BAD_DTYPE;
+
+extern "C" {
+
+int me_embed_fwd(void* out, int dtype, const int64_t* tokens, const float* cond, const float* emb, const float* cw0,
+                 const float* cb0, const float* cw1, const float* cb1, const float* pe, int mode, int B, int Ltok,
+                 int d, int dc, float p, uint64_t seed, void* stream) {
+    if (!out || !tokens || !emb || !pe) return ME_ERR_NULL;
+    if (mode == ME_COND_CONCAT && (!cond || !cw0 || !cb0 || dc <= 0 || dc >= d)) return ME_ERR_NULL;
+    if (mode == ME_COND_TOKEN && (!cond || !cw0 || !cb0 || !cw1 || !cb1)) return ME_ERR_NULL;
+    if (mode != ME_COND_CONCAT) dc = 0;
+    if (B <= 0 || Ltok < 0 || d <= 0 || d % 8) return ME_ERR_BAD_SHAPE;
+    if (!aligned16(out)) return ME_ERR_ALIGNMENT;
+    const int Lm = Ltok + (mode == ME_COND_TOKEN ? 2 : 0);
+    const int64_t rows = (int64_t)B * Lm;
+    if (rows == 0) return ME_OK;
+    const uint32_t thr = thr_of(p);
+    const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    hipStream_t st = (hipStream_t)stream;
+    ME_DISPATCH(dtype, (embed_fwd_kernel<T><<<(unsigned)((rows + 3) / 4), 256, 0, st>>>(
+                           (T*)out, tokens, cond, emb, cw0, cb0, cw1, cb1, pe, mode, B, Ltok, d, dc, thr, inv_keep, seed)));
+    return me_launch_status();
+}
+
+int me_embed_bwd(const void* dout, int dtype, const int64_t* tokens, const float* cond, float* g_emb, float* g_cw0,
+                 float* g_cb0, float* g_cw1, float* g_cb1, int mode, int B, int Ltok, int d, int dc, int pad_token,
+                 float p, uint64_t seed, void* stream) {
+    if (!dout || !tokens || !g_emb) return ME_ERR_NULL;
+    if (mode == ME_COND_CONCAT && (!cond || !g_cw0 || !g_cb0)) return ME_ERR_NULL;
+    if (mode == ME_COND_TOKEN && (!cond || !g_cw0 || !g_cb0 || !g_cw1 || !g_cb1)) return ME_ERR_NULL;
+    if (mode != ME_COND_CONCAT) dc = 0;
+    if (d % 8 || d > 64 * MAXC * 4) return ME_ERR_BAD_SHAPE;
+    const int Lm = Ltok + (mode == ME_COND_TOKEN ? 2 : 0);
+    if (B <= 0 || Lm <= 0) return ME_OK;
+    const uint32_t thr = thr_of(p);
+    const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    int nslab = (Lm + 63) / 64;
+    if (nslab > 32) nslab = 32;
+    dim3 grid(nslab, B);
+    hipStream_t st = (hipStream_t)stream;
+    ME_DISPATCH(dtype, (embed_bwd_kernel<T><<<grid, 256, 0, st>>>((const T*)dout, tokens, cond, g_emb, g_cw0, g_cb0, g_cw1,
+                                                                  g_cb1, mode, B, Ltok, d, dc, pad_token, thr, inv_keep, seed)));
+    return me_launch_status();
+}
+
+int me_key_pad_mask(uint8_t* key_pad, const int64_t* tokens, int B, int Ltok, int shift, int pad_token, void* stream) {
+    if (!key_pad || !tokens) return ME_ERR_NULL;
+    const int64_t n = (int64_t)B * (Ltok + shift);
+    if (n <= 0) return ME_OK;
+    key_pad_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(key_pad, tokens, B, Ltok, shift, pad_token);
+    return me_launch_status();
+}
+
+int me_resid_ln_fwd(const void* x, const void* a, const float* gamma, const float* beta, void* y, void* s_out,
+                    float* stats, int rows, int d, float eps, float p, uint64_t seed, uint32_t site, int dtype,
+                    void* stream) {
+    if (!x || !a || !gamma || !beta || !y) return ME_ERR_NULL;
+    if (rows <= 0) return ME_OK;
+    const int ch = dtype == ME_F32 ? 4 : 8;
+    if (d <= 0 || d % ch || d > 64 * MAXC * ch) return ME_ERR_BAD_SHAPE;
+    if (!aligned16(x) || !aligned16(a) || !aligned16(y) || (s_out && !aligned16(s_out))) return ME_ERR_ALIGNMENT;
+    const uint32_t thr = thr_of(p);
+    const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    hipStream_t st = (hipStream_t)stream;
+    ME_DISPATCH(dtype, (resid_ln_fwd_kernel<T><<<row_grid(rows, 8192), 256, 0, st>>>(
+                           (const T*)x, (const T*)a, gamma, beta, (T*)y, (T*)s_out, stats, rows, d, eps, thr, inv_keep, seed, site)));
+    return me_launch_status();
+}
+
+int me_resid_ln_bwd(const void* dy, const void* s, const float* stats, const float* gamma, void* dx, void* da,
+                    float* dgamma, float* dbeta, int rows, int d, float p, uint64_t seed, uint32_t site, int dtype,
+                    void* stream) {
+    if (!dy || !s || !stats || !gamma || !dx || !da || !dgamma || !dbeta) return ME_ERR_NULL;
+    if (rows <= 0) return ME_OK;
+    const int ch = dtype == ME_F32 ? 4 : 8;
+    if (d <= 0 || d % ch || d > 64 * MAXC * ch) return ME_ERR_BAD_SHAPE;
+    if (!aligned16(dy) || !aligned16(s) || !aligned16(dx) || !aligned16(da)) return ME_ERR_ALIGNMENT;
+    const uint32_t thr = thr_of(p);
+    const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    hipStream_t st = (hipStream_t)stream;
+    ME_DISPATCH(dtype, (resid_ln_bwd_kernel<T><<<row_grid(rows, 1024), 256, 0, st>>>(
+                           (const T*)dy, (const T*)s, stats, gamma, (T*)dx, (T*)da, dgamma, dbeta, rows, d, thr, inv_keep, seed, site)));
+    return me_launch_status();
+}
+
+int me_ce_fwd(const float* logits, int ld, const int64_t* target, float* row_lse, float* loss_sum, float* n_valid,
+              int rows, int V, int ignore_index, void* stream) {
+    if (!logits || !target || !loss_sum || !n_valid) return ME_ERR_NULL;
+    if (rows <= 0) return ME_OK;
+    if (V <= 0 || ld < V) return ME_ERR_BAD_SHAPE;
+    ce_fwd_kernel<<<row_grid(rows, 2048), 256, 0, (hipStream_t)stream>>>(logits, ld, target, row_lse, loss_sum, n_valid, rows, V, ignore_index);
+    return me_launch_status();
+}
+
+int me_ce_bwd(const float* logits, int ld, const int64_t* target, const float* row_lse, void* dlogits, int ld_d,
+              const float* n_valid, float extra_scale, int rows, int V, int ignore_index, int dtype, void* stream) {
+    if (!logits || !target || !row_lse || !dlogits || !n_valid) return ME_ERR_NULL;
+    if (rows <= 0) return ME_OK;
+    if (V <= 0 || ld < V || ld_d < V) return ME_ERR_BAD_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    ME_DISPATCH(dtype, (ce_bwd_kernel<T><<<row_grid(rows, 8192), 256, 0, st>>>(logits, ld, target, row_lse, (T*)dlogits, ld_d,
+                                                                             n_valid, extra_scale, rows, V, ignore_index)));
+    return me_launch_status();
+}
+
+int me_sumsq(const float* g, int64_t n, float* out, void* stream) {
+    if (!g || !out) return ME_ERR_NULL;
+    if (n <= 0) return ME_OK;
+    if (!aligned16(g)) return ME_ERR_ALIGNMENT;
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    sumsq_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(g, n, out);
+    return me_launch_status();
+}
+
+int me_adamw_step(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq, float clip, float grad_scale,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,
+                  int zero_grad, void* stream) {
+    if (!p || !g || !m || !v) return ME_ERR_NULL;
+    if (n <= 0) return ME_OK;
+    if (clip > 0.f && !sumsq) return ME_ERR_NULL;
+    if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v)) return ME_ERR_ALIGNMENT;
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    adamw_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, sumsq, clip, grad_scale, lr, beta1, beta2, eps,
+                                                                   weight_decay, bias_corr1, bias_corr2, zero_grad);
+    return me_launch_status();
+}
+
+int me_greedy_pick(const float* logits, int ld, int V, const int32_t* special, int n_special, int64_t* out_ids, int B,
+                   void* stream) {
+    if (!logits || !out_ids || (n_special > 0 && !special)) return ME_ERR_NULL;
+    if (B <= 0) return ME_OK;
+    greedy_pick_kernel<<<B, 256, 0, (hipStream_t)stream>>>(logits, ld, V, special, n_special, out_ids);
+    return me_launch_status();
+}
+
+}  // extern "C"

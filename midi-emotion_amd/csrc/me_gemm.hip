@@ -1,0 +1,366 @@
+// GEMM kernels of the midiemo hot path (gfx950).
+//   me_gemm_nt      C[M,N]  = A[M,K] . B[N,K]^T (+bias, relu, +add, relu-gate)
+//   me_gemm_tn_acc  dW[N,K] += A[T,N]^T . B[T,K]   (f32 atomics, split over T)
+//   me_cast_transpose, me_gemv_small
+// Block tile 128x128, 4 waves (2x2), each wave 64x64 = 2x2 macro-atoms of 32x32.
+// Operands are staged global -> registers -> LDS (register prefetch of the next
+// K-slab overlaps the MFMA work of the current one); LDS rows are padded by one
+// 16-byte chunk so that the ds_read_b128 fragment reads are bank-conflict free.
+#include "me_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32, NTHREADS = 256;
+
+template <typename T, bool OUT_F32>
+__global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(
+    const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc,
+    const float* __restrict__ bias, const T* __restrict__ add, int ldadd, const T* __restrict__ gate, int ldgate,
+    int M, int N, int K, int flags) {
+    constexpr int CH = ET<T>::CH;
+    constexpr int CPR = BK / CH;           // chunks per tile row
+    constexpr int LDK = BK + CH;           // padded LDS row (elements)
+    constexpr int NCH = BM * CPR / NTHREADS;
+    __shared__ __attribute__((aligned(16))) T As[BM * LDK];
+    __shared__ __attribute__((aligned(16))) T Bs[BN * LDK];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    chunk16 ra[NCH], rb[NCH];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + i * NTHREADS, row = c / CPR, k = k0 + (c % CPR) * CH;
+            ra[i] = (m0 + row < M && k < K) ? ld_chunk(A + (size_t)(m0 + row) * lda + k) : zero_chunk();
+            rb[i] = (n0 + row < N && k < K) ? ld_chunk(B + (size_t)(n0 + row) * ldb + k) : zero_chunk();
+        }
+    };
+    auto sstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + i * NTHREADS, row = c / CPR, cc = c % CPR;
+            st_chunk(&As[row * LDK + cc * CH], ra[i]);
+            st_chunk(&Bs[row * LDK + cc * CH], rb[i]);
+        }
+    };
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc_zero(acc[i][j]);
+
+    const int nk = (K + BK - 1) / BK;
+    const int frow = lane & 31, fk = (lane >> 5) * 8;
+    gload(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        sstore();
+        __syncthreads();
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            Frag<T> fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                frag_load(fa[i], &As[(wr * 64 + i * 32 + frow) * LDK + kk * 16 + fk]);
+                frag_load(fb[i], &Bs[(wc * 64 + i * 32 + frow) * LDK + kk * 16 + fk]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma32(acc[i][j], fa[i], fb[j]);
+        }
+        __syncthreads();
+    }
+
+    const bool relu = flags & ME_EPI_RELU;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wc * 64 + j * 32 + c_col(lane);
+            if (col >= N) continue;
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * 64 + i * 32 + c_row(r, lane);
+                if (row >= M) continue;
+                float v = acc[i][j][r] + bv;
+                if (relu) v = fmaxf(v, 0.f);
+                if (add) v += ET<T>::to_f(add[(size_t)row * ldadd + col]);
+                if (gate) v = ET<T>::to_f(gate[(size_t)row * ldgate + col]) > 0.f ? v : 0.f;
+                if (OUT_F32) reinterpret_cast<float*>(Cv)[(size_t)row * ldc + col] = v;
+                else reinterpret_cast<T*>(Cv)[(size_t)row * ldc + col] = ET<T>::from_f(v);
+            }
+        }
+}
+
+// dW[n][k] += sum_t A[t][n] * B[t][k].  Tiles are staged TRANSPOSED into LDS
+// ([n][t] / [k][t], contraction contiguous) so the fragment reads are the same
+// 16-byte reads as in the NT kernel.  Lanes walk t (consecutive LDS addresses)
+// during the transposing scatter, so the element writes are conflict free.
+constexpr int BT = 32;
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(
+    const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb, float* __restrict__ dW, int lddw,
+    float* __restrict__ dbias, int Tn, int N, int K, int t_per_block) {
+    constexpr int CH = ET<T>::CH;
+    constexpr int LDT = BT + CH;
+    constexpr int CPC = 128 / CH;                 // chunks per 128-wide tile row
+    constexpr int NCH = BT * CPC / NTHREADS;      // chunks per thread per operand
+    __shared__ __attribute__((aligned(16))) T As[128 * LDT];
+    __shared__ __attribute__((aligned(16))) T Bs[128 * LDT];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
+    const int t_begin = blockIdx.z * t_per_block;
+    const int t_end = min(Tn, t_begin + t_per_block);
+    if (t_begin >= t_end) return;
+
+    chunk16 ra[NCH], rb[NCH];
+    auto gload = [&](int t0) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + i * NTHREADS, t = c % BT, cc = (c / BT) * CH;
+            const bool tv = t0 + t < t_end;
+            ra[i] = (tv && n0 + cc < N) ? ld_chunk(A + (size_t)(t0 + t) * lda + n0 + cc) : zero_chunk();
+            rb[i] = (tv && k0 + cc < K) ? ld_chunk(B + (size_t)(t0 + t) * ldb + k0 + cc) : zero_chunk();
+        }
+    };
+    auto sstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + i * NTHREADS, t = c % BT, cc = (c / BT) * CH;
+            const T* ea = reinterpret_cast<const T*>(&ra[i]);
+            const T* eb = reinterpret_cast<const T*>(&rb[i]);
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+                As[(cc + e) * LDT + t] = ea[e];
+                Bs[(cc + e) * LDT + t] = eb[e];
+            }
+        }
+    };
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc_zero(acc[i][j]);
+    float bsum = 0.f;
+    const bool do_bias = dbias != nullptr && blockIdx.y == 0;
+    const int frow = lane & 31, fk = (lane >> 5) * 8;
+
+    gload(t_begin);
+    for (int t0 = t_begin; t0 < t_end; t0 += BT) {
+        sstore();
+        __syncthreads();
+        if (t0 + BT < t_end) gload(t0 + BT);
+        if (do_bias && tid < 128) {
+#pragma unroll 8
+            for (int t = 0; t < BT; ++t) bsum += ET<T>::to_f(As[tid * LDT + t]);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BT / 16; ++kk) {
+            Frag<T> fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                frag_load(fa[i], &As[(wr * 64 + i * 32 + frow) * LDT + kk * 16 + fk]);
+                frag_load(fb[i], &Bs[(wc * 64 + i * 32 + frow) * LDT + kk * 16 + fk]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma32(acc[i][j], fa[i], fb[j]);
+        }
+        __syncthreads();
+    }
+    if (do_bias && tid < 128 && n0 + tid < N) atomicAdd(&dbias[n0 + tid], bsum);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = k0 + wc * 64 + j * 32 + c_col(lane);
+            if (col >= K) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = n0 + wr * 64 + i * 32 + c_row(r, lane);
+                if (row < N) atomicAdd(&dW[(size_t)row * lddw + col], acc[i][j][r]);
+            }
+        }
+}
+
+// f32 master -> T copy and/or T transposed copy, 32x32 tiles through LDS
+template <typename T>
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, int rows, int cols,
+                                                             T* __restrict__ dst, int ld_dst, T* __restrict__ dstT,
+                                                             int ld_dstT) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + i * 8, c = c0 + tx;
+        float v = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.f;
+        tile[ty + i * 8][tx] = v;
+        if (dst && r < rows && c < cols) dst[(size_t)r * ld_dst + c] = ET<T>::from_f(v);
+    }
+    if (!dstT) return;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + i * 8, r = r0 + tx;    // dstT[c][r]
+        if (c < cols && r < rows) dstT[(size_t)c * ld_dstT + r] = ET<T>::from_f(tile[tx][ty + i * 8]);
+    }
+}
+
+// y[m][n] = sum_k x[m][k] W[n][k] + bias[n], m < MR (<= 8).  One wave per output
+// column n; the W row is streamed once with 16-byte loads, x rows come from L1/L2.
+template <typename T, int MR>
+__global__ __launch_bounds__(256) void gemv_small_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ W,
+                                                         int ldw, const float* __restrict__ bias, void* __restrict__ yv,
+                                                         int ldy, int N, int K, int flags) {
+    constexpr int CH = ET<T>::CH;
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float acc[MR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) acc[m] = 0.f;
+    for (int k = lane * CH; k < K; k += 64 * CH) {
+        chunk16 w = ld_chunk(W + (size_t)n * ldw + k);
+        const T* we = reinterpret_cast<const T*>(&w);
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            chunk16 xv = ld_chunk(x + (size_t)m * ldx + k);
+            const T* xe = reinterpret_cast<const T*>(&xv);
+#pragma unroll
+            for (int e = 0; e < CH; ++e) acc[m] = fmaf(ET<T>::to_f(we[e]), ET<T>::to_f(xe[e]), acc[m]);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MR; ++m) acc[m] = wave_sum(acc[m]);
+    if (lane == 0) {
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            float v = acc[m] + bv;
+            if (flags & ME_EPI_RELU) v = fmaxf(v, 0.f);
+            if (flags & ME_EPI_OUT_F32) reinterpret_cast<float*>(yv)[(size_t)m * ldy + n] = v;
+            else reinterpret_cast<T*>(yv)[(size_t)m * ldy + n] = ET<T>::from_f(v);
+        }
+    }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <typename T>
+int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
+                   const void* add, int ldadd, const void* gate, int ldgate, int M, int N, int K, int flags,
+                   hipStream_t st) {
+    constexpr int CH = ET<T>::CH;
+    if (M <= 0 || N <= 0 || K <= 0) return ME_ERR_BAD_SHAPE;
+    if (K % CH || lda % CH || ldb % CH) return ME_ERR_BAD_SHAPE;
+    if (!aligned16(A) || !aligned16(B)) return ME_ERR_ALIGNMENT;
+    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM);
+    if (flags & ME_EPI_OUT_F32)
+        gemm_nt_kernel<T, true><<<grid, NTHREADS, 0, st>>>((const T*)A, lda, (const T*)B, ldb, C, ldc, bias,
+                                                          (const T*)add, ldadd, (const T*)gate, ldgate, M, N, K, flags);
+    else
+        gemm_nt_kernel<T, false><<<grid, NTHREADS, 0, st>>>((const T*)A, lda, (const T*)B, ldb, C, ldc, bias,
+                                                           (const T*)add, ldadd, (const T*)gate, ldgate, M, N, K, flags);
+    return me_launch_status();
+}
+
+template <typename T>
+int gemm_tn_launch(const void* A, int lda, const void* B, int ldb, float* dW, int lddw, float* dbias, int Tn, int N,
+                   int K, hipStream_t st) {
+    constexpr int CH = ET<T>::CH;
+    if (Tn <= 0 || N <= 0 || K <= 0) return ME_ERR_BAD_SHAPE;
+    if (lda % CH || ldb % CH || K % CH) return ME_ERR_BAD_SHAPE;
+    if (lda < ((N + CH - 1) / CH) * CH) return ME_ERR_BAD_SHAPE;   // padded rows must be readable
+    if (!aligned16(A) || !aligned16(B)) return ME_ERR_ALIGNMENT;
+    const int tn = (N + 127) / 128, tk = (K + 127) / 128;
+    int nsplit = (1024 + tn * tk - 1) / (tn * tk);
+    const int max_split = (Tn + 4 * BT - 1) / (4 * BT);
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit < 1) nsplit = 1;
+    int t_per = (Tn + nsplit - 1) / nsplit;
+    t_per = ((t_per + BT - 1) / BT) * BT;
+    nsplit = (Tn + t_per - 1) / t_per;
+    dim3 grid(tn, tk, nsplit);
+    gemm_tn_kernel<T><<<grid, NTHREADS, 0, st>>>((const T*)A, lda, (const T*)B, ldb, dW, lddw, dbias, Tn, N, K, t_per);
+    return me_launch_status();
+}
+
+template <typename T>
+int gemv_launch(const void* x, int ldx, const void* W, int ldw, const float* bias, void* y, int ldy, int Mr, int N,
+                int K, int flags, hipStream_t st) {
+    constexpr int CH = ET<T>::CH;
+    if (Mr < 1 || Mr > 8 || K % CH || ldx % CH || ldw % CH) return ME_ERR_BAD_SHAPE;
+    if (!aligned16(x) || !aligned16(W)) return ME_ERR_ALIGNMENT;
+    dim3 grid((N + 3) / 4);
+#define ME_GEMV_CASE(MR)                                                                                         \
+    case MR:                                                                                                     \
+        gemv_small_kernel<T, MR><<<grid, 256, 0, st>>>((const T*)x, ldx, (const T*)W, ldw, bias, y, ldy, N, K, flags); \
+        break;
+    switch (Mr) {
+        ME_GEMV_CASE(1) ME_GEMV_CASE(2) ME_GEMV_CASE(3) ME_GEMV_CASE(4)
+        ME_GEMV_CASE(5) ME_GEMV_CASE(6) ME_GEMV_CASE(7) ME_GEMV_CASE(8)
+    }
+#undef ME_GEMV_CASE
+    return me_launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int me_abi_version(void) { return ME_ABI_VERSION; }
+
+int me_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias, const void* add,
+               int ldadd, const void* gate, int ldgate, int M, int N, int K, int flags, int dtype, void* stream) {
+    if (!A || !B || !C) return ME_ERR_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == ME_F32) return gemm_nt_launch<float>(A, lda, B, ldb, C, ldc, bias, add, ldadd, gate, ldgate, M, N, K, flags, st);
+    if (dtype == ME_BF16) return gemm_nt_launch<bf16_t>(A, lda, B, ldb, C, ldc, bias, add, ldadd, gate, ldgate, M, N, K, flags, st);
+    return ME_ERR_BAD_DTYPE;
+}
+
+int me_gemm_tn_acc(const void* A, int lda, const void* B, int ldb, float* dW, int lddw, float* dbias, int T, int N,
+                   int K, int dtype, void* stream) {
+    if (!A || !B || !dW) return ME_ERR_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == ME_F32) return gemm_tn_launch<float>(A, lda, B, ldb, dW, lddw, dbias, T, N, K, st);
+    if (dtype == ME_BF16) return gemm_tn_launch<bf16_t>(A, lda, B, ldb, dW, lddw, dbias, T, N, K, st);
+    return ME_ERR_BAD_DTYPE;
+}
+
+int me_cast_transpose(const float* src, int rows, int cols, void* dst, int ld_dst, void* dstT, int ld_dstT,
+                      int dtype, void* stream) {
+    if (!src || (!dst && !dstT)) return ME_ERR_NULL;
+    if (rows <= 0 || cols <= 0) return ME_ERR_BAD_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32);
+    if (dtype == ME_F32)
+        cast_transpose_kernel<float><<<grid, 256, 0, st>>>(src, rows, cols, (float*)dst, ld_dst, (float*)dstT, ld_dstT);
+    else if (dtype == ME_BF16)
+        cast_transpose_kernel<bf16_t><<<grid, 256, 0, st>>>(src, rows, cols, (bf16_t*)dst, ld_dst, (bf16_t*)dstT, ld_dstT);
+    else
+        return ME_ERR_BAD_DTYPE;
+    return me_launch_status();
+}
+
+int me_gemv_small(const void* x, int ldx, const void* W, int ldw, const float* bias, void* y, int ldy, int Mr, int N,
+                  int K, int flags, int dtype, void* stream) {
+    if (!x || !W || !y) return ME_ERR_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == ME_F32) return gemv_launch<float>(x, ldx, W, ldw, bias, y, ldy, Mr, N, K, flags, st);
+    if (dtype == ME_BF16) return gemv_launch<bf16_t>(x, ldx, W, ldw, bias, y, ldy, Mr, N, K, flags, st);
+    return ME_ERR_BAD_DTYPE;
+}
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+"""ctypes binding of libmidiemo_hip.so (C-ABI declared in include/midiemo.h).
+
+There is NO fallback: if the library is missing or a symbol is absent the
+import of the op layer raises, and every op raises RuntimeError on a non-zero
+status code."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmidiemo_hip.so")
+
+ME_F32, ME_BF16 = 0, 1
+ME_COND_NONE, ME_COND_CONCAT, ME_COND_TOKEN = 0, 1, 2
+ME_EPI_RELU, ME_EPI_OUT_F32, ME_EPI_RELU_BWD = 1, 2, 4
+ABI_VERSION = 1
+
+ERRORS = {0: "ME_OK", -1: "ME_ERR_BAD_DTYPE", -2: "ME_ERR_BAD_SHAPE", -3: "ME_ERR_ALIGNMENT",
+          -4: "ME_ERR_LAUNCH", -5: "ME_ERR_NULL"}
+
+_p, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+_i64, _u64, _u32 = ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint32
+
+# name -> argtypes, exactly the prototypes of include/midiemo.h
+SIGNATURES = {
+    "me_abi_version": [],
+    "me_cast_transpose": [_p, _i, _i, _p, _i, _p, _i, _i, _p],
+    "me_embed_fwd": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _u64, _p],
+    "me_embed_bwd": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _u64, _p],
+    "me_key_pad_mask": [_p, _p, _i, _i, _i, _i, _p],
+    "me_gemm_nt": [_p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
+    "me_gemm_tn_acc": [_p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p],
+    "me_rga_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "me_rga_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "me_resid_ln_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _f, _u64, _u32, _i, _p],
+    "me_resid_ln_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _u64, _u32, _i, _p],
+    "me_ce_fwd": [_p, _i, _p, _p, _p, _p, _i, _i, _i, _p],
+    "me_ce_bwd": [_p, _i, _p, _p, _p, _i, _p, _f, _i, _i, _i, _i, _p],
+    "me_sumsq": [_p, _i64, _p, _p],
+    "me_adamw_step": [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _p],
+    "me_rga_decode_step": [_p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "me_gemv_small": [_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "me_greedy_pick": [_p, _i, _i, _p, _i, _p, _i, _p],
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library and bind every declared symbol (raises if anything is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libmidiemo_hip.so not built (%s). Run `python __graft_entry__.py` or "
+            "`python midi-emotion_amd/midiemo/build.py`; there is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.argtypes = args
+        fn.restype = ctypes.c_int
+    v = lib.me_abi_version()
+    if v != ABI_VERSION:
+        raise RuntimeError("libmidiemo_hip.so ABI %d != binding ABI %d" % (v, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed: %s (%d)" % (what, ERRORS.get(rc, "unknown"), rc))

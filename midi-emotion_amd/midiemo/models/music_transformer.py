@@ -1,0 +1,548 @@
+"""Emotion-conditioned Music Transformer on the HIP engine.
+
+Mirrors the reference module contract (models/music_multi.py:41-108,
+models/music_continuous_token.py:32-105): same constructor kwargs, same
+state_dict keys/shapes, `forward(x, condition) -> logits [B, L(+2), V]`,
+`.train()/.eval()/.to()/.parameters()`; usable under autograd
+(`loss.backward()` fills `p.grad`).  Unlike the reference, the compute is not a
+graph of PyTorch ops: forward and backward are explicit kernel sequences over
+the C-ABI of libmidiemo_hip.so (see include/midiemo.h), activations live in
+preallocated workspaces, and all parameters/gradients live in two flat f32
+buffers (one fused optimiser pass, contiguous all-reduce buckets).
+
+Extras used by the build's own train.py / bench.py / generate.py:
+  * `loss_and_backward(...)`  fused forward + CE + backward into the flat grads
+  * `flat_params / flat_grads / bucket_ranges()`  for FusedAdamW and DDP
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+_DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}
+
+
+def _round_up(x, m):
+    return ((x + m - 1) // m) * m
+
+
+class _Lin(nn.Module):
+    """Parameter holder with nn.Linear's names/shapes/initialiser (compute happens in the engine)."""
+
+    def __init__(self, in_f, out_f):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(out_f, in_f))
+        self.bias = nn.Parameter(torch.empty(out_f))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1.0 / math.sqrt(in_f)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+
+class _LN(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(d))
+        self.bias = nn.Parameter(torch.zeros(d))
+
+
+class _Emb(nn.Module):
+    def __init__(self, n, d):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(n, d))
+
+
+class _RGA(nn.Module):
+    """RelativeGlobalAttention parameters (music_multi.py:180-185)."""
+
+    def __init__(self, d, h, max_seq):
+        super().__init__()
+        self.Wq = _Lin(d, d)
+        self.Wk = _Lin(d, d)
+        self.Wv = _Lin(d, d)
+        self.fc = _Lin(d, d)
+        self.E = nn.Parameter(torch.randn(max_seq, d // h))
+
+
+class _EncoderLayer(nn.Module):
+    """EncoderLayer parameters (music_multi.py:111-124)."""
+
+    def __init__(self, d, d_inner, h, max_seq):
+        super().__init__()
+        self.rga = _RGA(d, h, max_seq)
+        self.FFN_pre = _Lin(d, d_inner)
+        self.FFN_suf = _Lin(d_inner, d)
+        self.layernorm1 = _LN(d)
+        self.layernorm2 = _LN(d)
+
+
+def sinusoid_table(max_seq, d):
+    """music_multi.py:137-147, evaluated in float64 like the reference's Python floats."""
+    p = np.arange(max_seq, dtype=np.float64)[:, None]
+    i = np.arange(d, dtype=np.float64)[None, :]
+    par = np.mod(i, 2.0)
+    ang = p * np.exp(-math.log(10000.0) * i / d) * np.exp(math.log(10000.0) / d * par) + 0.5 * math.pi * par
+    return torch.from_numpy(np.sin(ang)).float()
+
+
+class _Workspace:
+    pass
+
+
+class MusicTransformerHIP(nn.Module):
+    LN_EPS = 1e-6
+
+    def __init__(self, embedding_dim=None, d_inner=None, d_condition=-1, vocab_size=None, num_layer=None,
+                 num_head=None, max_seq=2048, dropout=0.1, pad_token=0, token_conditioning=False,
+                 compute_dtype="bf16"):
+        super().__init__()
+        self.max_seq = max_seq
+        self.num_layer = num_layer
+        self.num_head = num_head
+        self.embedding_dim = embedding_dim
+        self.d_inner = d_inner
+        self.vocab_size = vocab_size
+        self.pad_token = pad_token
+        self.token_conditioning = bool(token_conditioning)
+        d_condition = 0 if (d_condition is None or d_condition < 0 or token_conditioning) else d_condition
+        self.d_condition = d_condition
+        self.dropout_p = float(dropout)
+        self.dh = embedding_dim // num_head
+        if embedding_dim % num_head or self.dh not in (32, 64):
+            raise ValueError("head dim %d unsupported by the HIP attention kernels (32 or 64)" % self.dh)
+        if max_seq % 32:
+            raise ValueError("max_seq must be a multiple of 32")
+        self.compute_dtype = _DTYPES[compute_dtype] if isinstance(compute_dtype, str) else compute_dtype
+
+        self.embedding = _Emb(vocab_size, embedding_dim - d_condition)
+        if self.token_conditioning:
+            self.fc_condition = nn.ModuleList([_Lin(1, embedding_dim) for _ in range(2)])
+        elif d_condition > 0:
+            self.fc_condition = _Lin(2, d_condition)
+        self.enc_layers = nn.ModuleList([_EncoderLayer(embedding_dim, d_inner, num_head, max_seq)
+                                         for _ in range(num_layer)])
+        self.fc = _Lin(embedding_dim, vocab_size)
+        self.init_weights()
+
+        self._step_seed = 0x5EED
+        self._fwd_count = 0
+        self._ws = {}
+        self._prep = None
+        self._prep_version = None
+        self._dirty = True
+        self._pe = None
+        self._packing = False
+        self._pack()
+
+    # ------------------------------------------------------------------ init / packing
+    def init_weights(self):
+        """music_multi.py:75-82 / music_continuous_token.py:68-75."""
+        r = 0.1
+        with torch.no_grad():
+            self.embedding.weight.uniform_(-r, r)
+            self.fc.bias.zero_()
+            self.fc.weight.uniform_(-r, r)
+            if self.token_conditioning:
+                for m in self.fc_condition:
+                    m.weight.uniform_(-r, r)
+                    m.bias.zero_()
+            elif self.d_condition > 0:
+                self.fc_condition.bias.zero_()
+                self.fc_condition.weight.uniform_(-r, r)
+
+    def _param_order(self):
+        """(name, param) in flat-buffer order; Wq/Wk/Wv weights (and biases) are adjacent so the
+        fused QKV projection reads one [3d, d] matrix.  Groups = DDP buckets."""
+        groups = []
+        g = [("embedding.weight", self.embedding.weight)]
+        if self.token_conditioning:
+            for i, m in enumerate(self.fc_condition):
+                g += [(f"fc_condition.{i}.weight", m.weight), (f"fc_condition.{i}.bias", m.bias)]
+        elif self.d_condition > 0:
+            g += [("fc_condition.weight", self.fc_condition.weight), ("fc_condition.bias", self.fc_condition.bias)]
+        groups.append(g)
+        for i, l in enumerate(self.enc_layers):
+            p = f"enc_layers.{i}."
+            groups.append([
+                (p + "rga.E", l.rga.E),
+                (p + "rga.Wq.weight", l.rga.Wq.weight), (p + "rga.Wk.weight", l.rga.Wk.weight),
+                (p + "rga.Wv.weight", l.rga.Wv.weight),
+                (p + "rga.Wq.bias", l.rga.Wq.bias), (p + "rga.Wk.bias", l.rga.Wk.bias), (p + "rga.Wv.bias", l.rga.Wv.bias),
+                (p + "rga.fc.weight", l.rga.fc.weight), (p + "rga.fc.bias", l.rga.fc.bias),
+                (p + "FFN_pre.weight", l.FFN_pre.weight), (p + "FFN_pre.bias", l.FFN_pre.bias),
+                (p + "FFN_suf.weight", l.FFN_suf.weight), (p + "FFN_suf.bias", l.FFN_suf.bias),
+                (p + "layernorm1.weight", l.layernorm1.weight), (p + "layernorm1.bias", l.layernorm1.bias),
+                (p + "layernorm2.weight", l.layernorm2.weight), (p + "layernorm2.bias", l.layernorm2.bias),
+            ])
+        groups.append([("fc.weight", self.fc.weight), ("fc.bias", self.fc.bias)])
+        return groups
+
+    def _pack(self):
+        """(Re)build the flat f32 parameter/gradient buffers on the parameters' current device and
+        turn every nn.Parameter into a view of the flat buffer."""
+        groups = self._param_order()
+        dev = groups[0][0][1].device
+        off = 0
+        slices, buckets = {}, []
+        for g in groups:
+            start = off
+            for name, p in g:
+                n = p.numel()
+                slices[name] = (off, n, tuple(p.shape))
+                off = _round_up(off + n, 4)
+            buckets.append((start, off))
+        flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        gflat = torch.zeros(off, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for g in groups:
+                for name, p in g:
+                    o, n, shp = slices[name]
+                    flat[o:o + n].copy_(p.detach().reshape(-1).to(torch.float32))
+                    p.data = flat[o:o + n].view(shp)
+                    p.grad = None
+        self._flat, self._gflat, self._slices, self._buckets = flat, gflat, slices, buckets
+        self._ws = {}
+        self._prep = None
+        self._dirty = True
+        self._pe = sinusoid_table(self.max_seq, self.embedding_dim).to(dev)
+
+    def _apply(self, fn, recurse=True):
+        super()._apply(fn, recurse)
+        if not self._packing:
+            self._packing = True
+            try:
+                self._pack()
+            finally:
+                self._packing = False
+        return self
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._dirty = True
+        return r
+
+    # ------------------------------------------------------------------ flat views for optimiser / DDP
+    @property
+    def flat_params(self):
+        return self._flat
+
+    @property
+    def flat_grads(self):
+        return self._gflat
+
+    def bucket_ranges(self):
+        """[(lo, hi)] element ranges of the flat buffers: embedding(+cond), layer 0..N-1, head."""
+        return list(self._buckets)
+
+    def _pview(self, buf, name):
+        o, n, shp = self._slices[name]
+        return buf[o:o + n].view(shp)
+
+    def link_grads(self):
+        """Make every p.grad a view of the flat gradient buffer (used by tests / external optimisers)."""
+        for g in self._param_order():
+            for name, p in g:
+                p.grad = self._pview(self._gflat, name)
+
+    def mark_params_changed(self):
+        self._dirty = True
+
+    # ------------------------------------------------------------------ prepared (cast / transposed) weights
+    def _refresh_weights(self):
+        ver = self._flat._version
+        if self._prep is not None and not self._dirty and ver == self._prep_version:
+            return
+        dt = self.compute_dtype
+        dev = self._flat.device
+        d, di, V, dh, M = self.embedding_dim, self.d_inner, self.vocab_size, self.dh, self.max_seq
+        if self._prep is None:
+            def buf(r, c, ld=None):
+                return torch.zeros(r, ld or c, dtype=dt, device=dev)
+            layers = []
+            for _ in range(self.num_layer):
+                L = {}
+                if dt != torch.float32:
+                    L.update(Wqkv=buf(3 * d, d), Wo=buf(d, d), W1=buf(di, d), W2=buf(d, di), E=buf(M, dh))
+                L.update(WqkvT=buf(d, 3 * d), WoT=buf(d, d), W1T=buf(d, di), W2T=buf(di, d), ET=buf(dh, M))
+                layers.append(L)
+            head = {"WfT": buf(d, V, _round_up(V, 16))}
+            if dt != torch.float32:
+                head["Wf"] = buf(V, d)
+            self._prep = {"layers": layers, "head": head}
+        f = self._flat
+        for i, L in enumerate(self._prep["layers"]):
+            p = f"enc_layers.{i}."
+            o, _, _ = self._slices[p + "rga.Wq.weight"]
+            wqkv = f[o:o + 3 * d * d].view(3 * d, d)
+            srcs = {"Wqkv": wqkv, "Wo": self._pview(f, p + "rga.fc.weight"), "W1": self._pview(f, p + "FFN_pre.weight"),
+                    "W2": self._pview(f, p + "FFN_suf.weight"), "E": self._pview(f, p + "rga.E")}
+            for k, src in srcs.items():
+                nat = L.get(k) if dt != torch.float32 else None
+                ops.cast_transpose(src, nat, L[k + "T"], dt)
+                if dt == torch.float32:
+                    L[k] = src
+            ob, _, _ = self._slices[p + "rga.Wq.bias"]
+            L["bqkv"] = f[ob:ob + 3 * d]
+        H = self._prep["head"]
+        src = self._pview(f, "fc.weight")
+        ops.cast_transpose(src, H.get("Wf") if dt != torch.float32 else None, H["WfT"], dt)
+        if dt == torch.float32:
+            H["Wf"] = src
+        self._prep_version = ver
+        self._dirty = False
+
+    # ------------------------------------------------------------------ workspaces
+    def _workspace(self, B, Lm, save):
+        key = (B, Lm, bool(save))
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        if len(self._ws) > 6:
+            self._ws.clear()
+        dt, dev = self.compute_dtype, self._flat.device
+        d, di, H, V, N = self.embedding_dim, self.d_inner, self.num_head, self.vocab_size, self.num_layer
+        T = B * Lm
+        e = lambda *s, dtype=dt: torch.empty(*s, dtype=dtype, device=dev)
+        ws = _Workspace()
+        ws.key_pad = e(B, Lm, dtype=torch.uint8)
+        nl = N if save else 1
+        ws.h = [e(T, d) for _ in range(N + 1 if save else 2)]
+        ws.layers = []
+        for _ in range(nl):
+            L = _Workspace()
+            L.qkv, L.att, L.o1, L.hid = e(T, 3 * d), e(T, d), e(T, d), e(T, di)
+            L.lse = e(B, H, Lm, dtype=torch.float32)
+            if save:
+                L.s1, L.s2 = e(T, d), e(T, d)
+                L.st1, L.st2 = e(T, 2, dtype=torch.float32), e(T, 2, dtype=torch.float32)
+            else:
+                L.s1 = L.s2 = L.st1 = L.st2 = None
+            ws.layers.append(L)
+        ws.tmp = e(T, d)
+        if save:
+            ldv = _round_up(V, 16)
+            ws.logits = e(T, ldv, dtype=torch.float32)
+            ws.row_lse = e(T, dtype=torch.float32)
+            ws.dlogits = torch.zeros(T, ldv, dtype=dt, device=dev)
+            ws.acc = torch.zeros(2, dtype=torch.float32, device=dev)      # loss_sum, n_valid
+            ws.dA, ws.dB, ws.dC = e(T, d), e(T, d), e(T, d)
+            ws.dhid, ws.dqkv = e(T, di), e(T, 3 * d)
+            ws.delta = e(B, H, Lm, dtype=torch.float32)
+            ws.ds = torch.zeros(B, H, Lm, Lm, dtype=dt, device=dev)
+        self._ws[key] = ws
+        return ws
+
+    # ------------------------------------------------------------------ engine: forward
+    def _mode(self):
+        if self.token_conditioning:
+            return ops.ME_COND_TOKEN
+        return ops.ME_COND_CONCAT if self.d_condition > 0 else ops.ME_COND_NONE
+
+    def _cond_params(self, buf):
+        if self.token_conditioning:
+            return (self._pview(buf, "fc_condition.0.weight"), self._pview(buf, "fc_condition.0.bias"),
+                    self._pview(buf, "fc_condition.1.weight"), self._pview(buf, "fc_condition.1.bias"))
+        if self.d_condition > 0:
+            return (self._pview(buf, "fc_condition.weight"), self._pview(buf, "fc_condition.bias"), None, None)
+        return (None, None, None, None)
+
+    def _check_inputs(self, tokens, cond):
+        if not self._flat.is_cuda:
+            raise RuntimeError("MusicTransformerHIP runs only on a HIP device (model.to('cuda')); "
+                               "there is no CPU fallback")
+        if tokens.dim() != 2:
+            raise ValueError("tokens must be [batch, seq]")
+        tokens = tokens.to(device=self._flat.device, dtype=torch.int64).contiguous()
+        B, Ltok = tokens.shape
+        shift = 2 if self.token_conditioning else 0
+        if Ltok + shift > self.max_seq:
+            raise RuntimeError("sequence length %d exceeds max_seq %d" % (Ltok + shift, self.max_seq))
+        if cond is None:
+            cond = torch.full((B, 2), float("nan"))
+        cond = cond.to(device=self._flat.device, dtype=torch.float32).contiguous()
+        return tokens, cond, B, Ltok, Ltok + shift
+
+    def _forward_impl(self, tokens, cond, B, Ltok, Lm, save, p_drop, seed, logits_out):
+        dt = self.compute_dtype
+        d, di, H, dh, V, N, M = (self.embedding_dim, self.d_inner, self.num_head, self.dh, self.vocab_size,
+                                 self.num_layer, self.max_seq)
+        T = B * Lm
+        ws = self._workspace(B, Lm, save)
+        self._refresh_weights()
+        f = self._flat
+        shift = Lm - Ltok
+        ops.key_pad_mask(ws.key_pad, tokens, B, Ltok, shift, self.pad_token)
+        cw0, cb0, cw1, cb1 = self._cond_params(f)
+        ops.embed_fwd(ws.h[0], tokens, cond, self._pview(f, "embedding.weight"), cw0, cb0, cw1, cb1, self._pe,
+                      self._mode(), B, Ltok, d, self.d_condition, p_drop, seed)
+        nh = len(ws.h)
+        for i in range(N):
+            W = self._prep["layers"][i]
+            Lw = ws.layers[i if save else 0]
+            x = ws.h[i % nh if not save else i]
+            y = ws.h[(i + 1) % nh if not save else i + 1]
+            p = f"enc_layers.{i}."
+            ops.gemm_nt(x, W["Wqkv"], Lw.qkv, bias=W["bqkv"], M=T, N=3 * d, K=d, dtype=dt)
+            ops.rga_fwd(Lw.qkv, W["E"], ws.key_pad, Lw.att, Lw.lse, B, Lm, H, dh, M)
+            ops.gemm_nt(Lw.att, W["Wo"], ws.tmp, bias=self._pview(f, p + "rga.fc.bias"), M=T, N=d, K=d, dtype=dt)
+            ops.resid_ln_fwd(x, ws.tmp, self._pview(f, p + "layernorm1.weight"), self._pview(f, p + "layernorm1.bias"),
+                             Lw.o1, Lw.s1, Lw.st1, T, d, self.LN_EPS, p_drop, seed, 1 + 2 * i)
+            ops.gemm_nt(Lw.o1, W["W1"], Lw.hid, bias=self._pview(f, p + "FFN_pre.bias"), M=T, N=di, K=d,
+                        flags=ops.ME_EPI_RELU, dtype=dt)
+            ops.gemm_nt(Lw.hid, W["W2"], ws.tmp, bias=self._pview(f, p + "FFN_suf.bias"), M=T, N=d, K=di, dtype=dt)
+            ops.resid_ln_fwd(Lw.o1, ws.tmp, self._pview(f, p + "layernorm2.weight"), self._pview(f, p + "layernorm2.bias"),
+                             y, Lw.s2, Lw.st2, T, d, self.LN_EPS, p_drop, seed, 2 + 2 * i)
+        hN = ws.h[N % nh if not save else N]
+        out = logits_out if logits_out is not None else ws.logits
+        ops.gemm_nt(hN, self._prep["head"]["Wf"], out, bias=self._pview(f, "fc.bias"), M=T, N=V, K=d,
+                    flags=ops.ME_EPI_OUT_F32, dtype=dt)
+        return ws
+
+    # ------------------------------------------------------------------ engine: backward
+    def _backward_impl(self, ws, tokens, cond, B, Ltok, Lm, p_drop, seed, gflat, bucket_hook=None):
+        """dlogits in ws.dlogits (T, padded ld) -> accumulates every parameter gradient into gflat."""
+        dt = self.compute_dtype
+        d, di, H, dh, V, N, M = (self.embedding_dim, self.d_inner, self.num_head, self.dh, self.vocab_size,
+                                 self.num_layer, self.max_seq)
+        T = B * Lm
+        f = self._flat
+        ldv = ws.dlogits.shape[1]
+        head = self._prep["head"]
+        gv = lambda name: self._pview(gflat, name)
+        hN = ws.h[N]
+        ops.gemm_tn_acc(ws.dlogits, hN, gv("fc.weight"), gv("fc.bias"), T=T, N=V, K=d, dtype=dt)
+        ops.gemm_nt(ws.dlogits, head["WfT"], ws.dA, M=T, N=d, K=ldv, dtype=dt)
+        if bucket_hook:
+            bucket_hook(N + 1)
+        dy = ws.dA
+        for i in reversed(range(N)):
+            W = self._prep["layers"][i]
+            Lw = ws.layers[i]
+            p = f"enc_layers.{i}."
+            x = ws.h[i]
+            # LN2 + FFN
+            ops.resid_ln_bwd(dy, Lw.s2, Lw.st2, self._pview(f, p + "layernorm2.weight"), ws.dB, ws.dC,
+                             gv(p + "layernorm2.weight"), gv(p + "layernorm2.bias"), T, d, p_drop, seed, 2 + 2 * i)
+            ops.gemm_tn_acc(ws.dC, Lw.hid, gv(p + "FFN_suf.weight"), gv(p + "FFN_suf.bias"), T=T, N=d, K=di, dtype=dt)
+            ops.gemm_nt(ws.dC, W["W2T"], ws.dhid, gate=Lw.hid, M=T, N=di, K=d, flags=ops.ME_EPI_RELU_BWD, dtype=dt)
+            ops.gemm_tn_acc(ws.dhid, Lw.o1, gv(p + "FFN_pre.weight"), gv(p + "FFN_pre.bias"), T=T, N=di, K=d, dtype=dt)
+            ops.gemm_nt(ws.dhid, W["W1T"], ws.dA, add=ws.dB, M=T, N=d, K=di, dtype=dt)          # d(o1) total
+            # LN1 + attention
+            ops.resid_ln_bwd(ws.dA, Lw.s1, Lw.st1, self._pview(f, p + "layernorm1.weight"), ws.dB, ws.dC,
+                             gv(p + "layernorm1.weight"), gv(p + "layernorm1.bias"), T, d, p_drop, seed, 1 + 2 * i)
+            ops.gemm_tn_acc(ws.dC, Lw.att, gv(p + "rga.fc.weight"), gv(p + "rga.fc.bias"), T=T, N=d, K=d, dtype=dt)
+            ops.gemm_nt(ws.dC, W["WoT"], ws.dA, M=T, N=d, K=d, dtype=dt)                         # d(att)
+            ops.rga_bwd(Lw.qkv, W["E"], W["ET"], ws.key_pad, Lw.att, Lw.lse, ws.dA, ws.dqkv, gv(p + "rga.E"),
+                        ws.delta, ws.ds, B, Lm, H, dh, M)
+            o, _, _ = self._slices[p + "rga.Wq.weight"]
+            ob, _, _ = self._slices[p + "rga.Wq.bias"]
+            ops.gemm_tn_acc(ws.dqkv, x, gflat[o:o + 3 * d * d].view(3 * d, d), gflat[ob:ob + 3 * d], T=T, N=3 * d, K=d,
+                            dtype=dt)
+            ops.gemm_nt(ws.dqkv, W["WqkvT"], ws.dA, add=ws.dB, M=T, N=d, K=3 * d, dtype=dt)     # d(x) total
+            dy = ws.dA
+            if bucket_hook:
+                bucket_hook(i + 1)
+        g = self._cond_params(gflat)
+        ops.embed_bwd(dy, tokens, cond, gv("embedding.weight"), g[0], g[1], g[2], g[3], self._mode(), B, Ltok, d,
+                      self.d_condition, self.pad_token, p_drop, seed)
+        if bucket_hook:
+            bucket_hook(0)
+
+    # ------------------------------------------------------------------ public API
+    def _next_seed(self):
+        self._fwd_count += 1
+        return (self._step_seed * 0x9E3779B97F4A7C15 + self._fwd_count * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+    def seed_dropout(self, seed):
+        self._step_seed = int(seed) & 0xFFFFFFFF
+        self._fwd_count = 0
+
+    def forward(self, x, condition=None):
+        """model(x, condition) -> logits f32 [B, L(+2), V]   (music_multi.py:84-108)."""
+        tokens, cond, B, Ltok, Lm = self._check_inputs(x, condition)
+        V = self.vocab_size
+        p_drop = self.dropout_p if self.training else 0.0
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if not need_grad:
+            out = torch.empty(B * Lm, V, dtype=torch.float32, device=self._flat.device)
+            self._forward_impl(tokens, cond, B, Ltok, Lm, False, p_drop, self._next_seed(), out)
+            return out.view(B, Lm, V)
+        params = [p for g in self._param_order() for _, p in g]
+        return _EngineFn.apply(self, tokens, cond, (B, Ltok, Lm), p_drop, self._next_seed(), *params)
+
+    def loss_and_backward(self, x, condition, target, grad_scale=1.0, bucket_hook=None, backward=True):
+        """Fused train-step front half: forward, CrossEntropyLoss(ignore_index=pad) (mean over
+        non-pad targets), backward into `flat_grads` (+=).  Returns the loss as a device scalar
+        (no host sync).  Replaces Runner.forward_pass + loss.backward() (train.py:276-292,317)."""
+        tokens, cond, B, Ltok, Lm = self._check_inputs(x, condition)
+        target = target.to(device=self._flat.device, dtype=torch.int64).contiguous().view(-1)
+        T, V = B * Lm, self.vocab_size
+        if target.numel() != T:
+            raise ValueError("target has %d elements, model output has %d positions" % (target.numel(), T))
+        p_drop = self.dropout_p if self.training else 0.0
+        seed = self._next_seed()
+        ws = self._forward_impl(tokens, cond, B, Ltok, Lm, True, p_drop, seed, None)
+        ws.acc.zero_()
+        ops.ce_fwd(ws.logits, target, ws.row_lse, ws.acc[0:1], ws.acc[1:2], T, V, self.pad_token)
+        loss = ws.acc[0] / ws.acc[1]
+        if backward:
+            ops.ce_bwd(ws.logits, target, ws.row_lse, ws.dlogits, ws.acc[1:2], grad_scale, T, V, self.pad_token)
+            self._backward_impl(ws, tokens, cond, B, Ltok, Lm, p_drop, seed, self._gflat, bucket_hook)
+        return loss
+
+
+class _EngineFn(torch.autograd.Function):
+    """Bridges the explicit engine into autograd so the reference's
+    `loss = CE(model(x, c)); loss.backward()` pattern works unchanged (train.py:288-317)."""
+
+    @staticmethod
+    def forward(ctx, model, tokens, cond, dims, p_drop, seed, *params):
+        B, Ltok, Lm = dims
+        V = model.vocab_size
+        out = torch.empty(B * Lm, V, dtype=torch.float32, device=model._flat.device)
+        ws = model._forward_impl(tokens, cond, B, Ltok, Lm, True, p_drop, seed, out)
+        ctx.model, ctx.ws, ctx.args = model, ws, (tokens, cond, B, Ltok, Lm, p_drop, seed)
+        ctx.stamp = model._fwd_count
+        return out.view(B, Lm, V)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        model, ws = ctx.model, ctx.ws
+        tokens, cond, B, Ltok, Lm, p_drop, seed = ctx.args
+        if ctx.stamp != model._fwd_count:
+            raise RuntimeError("backward() after another forward() of the same shape: activations of the "
+                               "HIP engine live in a shared workspace (one forward in flight per shape)")
+        V = model.vocab_size
+        ws.dlogits[:, :V].copy_(dlogits.reshape(B * Lm, V))
+        gbuf = torch.zeros_like(model._gflat)
+        model._backward_impl(ws, tokens, cond, B, Ltok, Lm, p_drop, seed, gbuf)
+        grads = [model._pview(gbuf, name) for g in model._param_order() for name, _ in g]
+        return (None, None, None, None, None, None) + tuple(grads)
+
+
+class MusicTransformerMulti(MusicTransformerHIP):
+    """none / discrete_token / continuous_concat  (models/music_multi.py:41-73 kwargs)."""
+
+    def __init__(self, embedding_dim=None, d_inner=None, d_condition=None, vocab_size=None, num_layer=None,
+                 num_head=None, max_seq=None, dropout=None, pad_token=None, compute_dtype="bf16"):
+        super().__init__(embedding_dim=embedding_dim, d_inner=d_inner, d_condition=d_condition,
+                         vocab_size=vocab_size, num_layer=num_layer, num_head=num_head, max_seq=max_seq,
+                         dropout=dropout, pad_token=pad_token, token_conditioning=False,
+                         compute_dtype=compute_dtype)
+
+
+class MusicTransformerContinuousToken(MusicTransformerHIP):
+    """continuous_token  (models/music_continuous_token.py:32-66 kwargs)."""
+
+    def __init__(self, embedding_dim=None, d_inner=None, vocab_size=None, num_layer=None, num_head=None,
+                 max_seq=None, dropout=None, pad_token=None, has_start_token=True, n_conditions=2,
+                 compute_dtype="bf16"):
+        if n_conditions != 2:
+            raise ValueError("n_conditions must be 2 (valence, arousal)")
+        super().__init__(embedding_dim=embedding_dim, d_inner=d_inner, d_condition=-1, vocab_size=vocab_size,
+                         num_layer=num_layer, num_head=num_head, max_seq=max_seq, dropout=dropout,
+                         pad_token=pad_token, token_conditioning=True, compute_dtype=compute_dtype)
+        self.has_start_token = has_start_token
+        self.n_conditions = n_conditions

@@ -1,0 +1,143 @@
+"""Tensor-level wrappers over the C-ABI (one Python function per entry point).
+
+Every wrapper takes torch CUDA tensors, passes raw device pointers and the
+current HIP stream, and raises RuntimeError on any non-zero status.  Nothing
+here computes on the host."""
+import torch
+
+from . import _lib
+from ._lib import (ME_BF16, ME_COND_CONCAT, ME_COND_NONE, ME_COND_TOKEN, ME_EPI_OUT_F32, ME_EPI_RELU,
+                   ME_EPI_RELU_BWD, ME_F32, check)
+
+DTYPE_CODE = {torch.float32: ME_F32, torch.bfloat16: ME_BF16}
+
+
+def lib():
+    return _lib.load()
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("midiemo ops need device (HIP) tensors; got a %s tensor -- there is no CPU path" % t.device)
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _code(dtype):
+    try:
+        return DTYPE_CODE[dtype]
+    except KeyError:
+        raise RuntimeError("unsupported compute dtype %s (float32 or bfloat16)" % dtype)
+
+
+def cast_transpose(src, dst, dstT, dtype):
+    rows, cols = src.shape
+    check(lib().me_cast_transpose(_ptr(src), rows, cols, _ptr(dst), dst.stride(0) if dst is not None else 0,
+                                  _ptr(dstT), dstT.stride(0) if dstT is not None else 0, _code(dtype), _stream()),
+          "me_cast_transpose")
+
+
+def embed_fwd(out, tokens, cond, emb, cw0, cb0, cw1, cb1, pe, mode, B, Ltok, d, dc, p, seed):
+    check(lib().me_embed_fwd(_ptr(out), _code(out.dtype), _ptr(tokens), _ptr(cond), _ptr(emb), _ptr(cw0), _ptr(cb0),
+                             _ptr(cw1), _ptr(cb1), _ptr(pe), mode, B, Ltok, d, dc, float(p), int(seed), _stream()),
+          "me_embed_fwd")
+
+
+def embed_bwd(dout, tokens, cond, g_emb, g_cw0, g_cb0, g_cw1, g_cb1, mode, B, Ltok, d, dc, pad_token, p, seed):
+    check(lib().me_embed_bwd(_ptr(dout), _code(dout.dtype), _ptr(tokens), _ptr(cond), _ptr(g_emb), _ptr(g_cw0),
+                             _ptr(g_cb0), _ptr(g_cw1), _ptr(g_cb1), mode, B, Ltok, d, dc, pad_token, float(p),
+                             int(seed), _stream()), "me_embed_bwd")
+
+
+def key_pad_mask(key_pad, tokens, B, Ltok, shift, pad_token):
+    check(lib().me_key_pad_mask(_ptr(key_pad), _ptr(tokens), B, Ltok, shift, pad_token, _stream()), "me_key_pad_mask")
+
+
+def gemm_nt(A, B, C, bias=None, add=None, gate=None, M=None, N=None, K=None, flags=0, dtype=None):
+    """C[M,N] = A[M,K] . B[N,K]^T (+bias)(relu)(+add)(relu-gate).  2-D row-major views (stride(1) == 1)."""
+    dtype = dtype or A.dtype
+    M = A.shape[0] if M is None else M
+    K = A.shape[1] if K is None else K
+    N = B.shape[0] if N is None else N
+    check(lib().me_gemm_nt(_ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(C), C.stride(0), _ptr(bias),
+                           _ptr(add), add.stride(0) if add is not None else 0,
+                           _ptr(gate), gate.stride(0) if gate is not None else 0,
+                           M, N, K, flags, _code(dtype), _stream()), "me_gemm_nt")
+
+
+def gemm_tn_acc(A, B, dW, dbias=None, T=None, N=None, K=None, dtype=None):
+    """dW[N,K] += A[T,N]^T . B[T,K] ; dbias[N] += colsum(A)."""
+    dtype = dtype or A.dtype
+    T = A.shape[0] if T is None else T
+    N = A.shape[1] if N is None else N
+    K = B.shape[1] if K is None else K
+    check(lib().me_gemm_tn_acc(_ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(dW), dW.stride(0), _ptr(dbias),
+                               T, N, K, _code(dtype), _stream()), "me_gemm_tn_acc")
+
+
+def rga_fwd(qkv, E, key_pad, out, lse, B, L, H, dh, M):
+    check(lib().me_rga_fwd(_ptr(qkv), _ptr(E), _ptr(key_pad), _ptr(out), _ptr(lse), B, L, H, dh, M,
+                           _code(qkv.dtype), _stream()), "me_rga_fwd")
+
+
+def rga_bwd(qkv, E, ET, key_pad, out, lse, dout, dqkv, dE, delta_ws, ds_ws, B, L, H, dh, M):
+    check(lib().me_rga_bwd(_ptr(qkv), _ptr(E), _ptr(ET), _ptr(key_pad), _ptr(out), _ptr(lse), _ptr(dout), _ptr(dqkv),
+                           _ptr(dE), _ptr(delta_ws), _ptr(ds_ws), B, L, H, dh, M, _code(qkv.dtype), _stream()),
+          "me_rga_bwd")
+
+
+def resid_ln_fwd(x, a, gamma, beta, y, s_out, stats, rows, d, eps, p, seed, site):
+    check(lib().me_resid_ln_fwd(_ptr(x), _ptr(a), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(s_out), _ptr(stats), rows, d,
+                                float(eps), float(p), int(seed), int(site), _code(x.dtype), _stream()), "me_resid_ln_fwd")
+
+
+def resid_ln_bwd(dy, s, stats, gamma, dx, da, dgamma, dbeta, rows, d, p, seed, site):
+    check(lib().me_resid_ln_bwd(_ptr(dy), _ptr(s), _ptr(stats), _ptr(gamma), _ptr(dx), _ptr(da), _ptr(dgamma),
+                                _ptr(dbeta), rows, d, float(p), int(seed), int(site), _code(dy.dtype), _stream()),
+          "me_resid_ln_bwd")
+
+
+def ce_fwd(logits, target, row_lse, loss_sum, n_valid, rows, V, ignore_index):
+    check(lib().me_ce_fwd(_ptr(logits), logits.stride(0), _ptr(target), _ptr(row_lse), _ptr(loss_sum), _ptr(n_valid),
+                          rows, V, ignore_index, _stream()), "me_ce_fwd")
+
+
+def ce_bwd(logits, target, row_lse, dlogits, n_valid, extra_scale, rows, V, ignore_index):
+    check(lib().me_ce_bwd(_ptr(logits), logits.stride(0), _ptr(target), _ptr(row_lse), _ptr(dlogits),
+                          dlogits.stride(0), _ptr(n_valid), float(extra_scale), rows, V, ignore_index,
+                          _code(dlogits.dtype), _stream()), "me_ce_bwd")
+
+
+def sumsq(g, out):
+    check(lib().me_sumsq(_ptr(g), g.numel(), _ptr(out), _stream()), "me_sumsq")
+
+
+def adamw_step(p, g, m, v, sumsq_t, clip, grad_scale, lr, beta1, beta2, eps, weight_decay, step, zero_grad):
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    check(lib().me_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(sumsq_t), float(clip),
+                              float(grad_scale), float(lr), float(beta1), float(beta2), float(eps),
+                              float(weight_decay), float(bc1), float(bc2), int(bool(zero_grad)), _stream()),
+          "me_adamw_step")
+
+
+def rga_decode_step(qkv_new, kcache, vcache, E, key_pad, ld_pad, out, B, H, dh, M, Mc, t):
+    check(lib().me_rga_decode_step(_ptr(qkv_new), _ptr(kcache), _ptr(vcache), _ptr(E), _ptr(key_pad), ld_pad,
+                                   _ptr(out), B, H, dh, M, Mc, t, _code(qkv_new.dtype), _stream()), "me_rga_decode_step")
+
+
+def gemv_small(x, W, bias, y, Mr, N, K, flags=0, dtype=None):
+    dtype = dtype or x.dtype
+    check(lib().me_gemv_small(_ptr(x), x.stride(0), _ptr(W), W.stride(0), _ptr(bias), _ptr(y), y.stride(0), Mr, N, K,
+                              flags, _code(dtype), _stream()), "me_gemv_small")
+
+
+def greedy_pick(logits, V, special, out_ids, B):
+    check(lib().me_greedy_pick(_ptr(logits), logits.stride(0), V, _ptr(special),
+                               special.numel() if special is not None else 0, _ptr(out_ids), B, _stream()),
+          "me_greedy_pick")

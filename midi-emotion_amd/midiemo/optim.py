@@ -1,0 +1,57 @@
+"""FusedAdamW: global-norm clip + Adam(W) over the model's flat f32 buffers in two
+kernel launches (me_sumsq, me_adamw_step), no host sync.
+
+Semantics = reference train step tail (train.py:319-325): clip_grad_norm_(params,
+clip) ; optim.Adam(lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0).step() ;
+zero_grad().  weight_decay > 0 gives decoupled (AdamW) decay."""
+import torch
+
+from . import ops
+
+
+class FusedAdamW:
+    def __init__(self, model, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip=1.0):
+        self.model = model
+        self.lr, self.betas, self.eps, self.weight_decay, self.clip = lr, betas, eps, weight_decay, clip
+        self.step_count = 0
+        self._alloc()
+        # mirrors torch.optim's param_groups just enough for the reference's LR warm-up code
+        # (train.py:329-331 writes optimizer.param_groups[0]['lr'])
+        self.param_groups = [{"lr": lr}]
+
+    def _alloc(self):
+        f = self.model.flat_params
+        self.m = torch.zeros_like(f)
+        self.v = torch.zeros_like(f)
+        self.sumsq = torch.zeros(1, dtype=torch.float32, device=f.device)
+
+    def grad_norm(self):
+        """Device scalar: global L2 norm of the (already all-reduced) flat gradient."""
+        self.sumsq.zero_()
+        ops.sumsq(self.model.flat_grads, self.sumsq)
+        return self.sumsq.sqrt()
+
+    def step(self, grad_scale=1.0, zero_grad=True):
+        m = self.model
+        if self.m.device != m.flat_params.device or self.m.numel() != m.flat_params.numel():
+            self._alloc()
+        self.step_count += 1
+        lr = self.param_groups[0]["lr"]
+        self.sumsq.zero_()
+        if self.clip and self.clip > 0:
+            ops.sumsq(m.flat_grads, self.sumsq)
+        ops.adamw_step(m.flat_params, m.flat_grads, self.m, self.v, self.sumsq, self.clip or 0.0, grad_scale, lr,
+                       self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count, zero_grad)
+        m.mark_params_changed()
+
+    def zero_grad(self):
+        self.model.flat_grads.zero_()
+
+    def state_dict(self):
+        return {"m": self.m, "v": self.v, "step": self.step_count, "lr": self.param_groups[0]["lr"]}
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd["m"])
+        self.v.copy_(sd["v"])
+        self.step_count = int(sd["step"])
+        self.param_groups[0]["lr"] = sd.get("lr", self.lr)

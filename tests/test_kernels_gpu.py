@@ -1,0 +1,408 @@
+"""Kernel-level parity tests (GPU): every C-ABI entry point against the oracle /
+plain fp64 torch math on the same seeded inputs.  f32 tier: tight tolerances;
+bf16 tier: error relative to the fp64 result bounded by bf16 rounding of the
+inputs (stated per test)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_model as O  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from midiemo import ops as _ops
+    _ops.lib()
+    return _ops
+
+
+DEV = "cuda"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype, f32=2e-5, bf16=2e-2):
+    return f32 if dtype == torch.float32 else bf16
+
+
+def relerr(got, ref):
+    """||got-ref|| / ||ref||; an exactly-zero reference is compared on an absolute 1e-4 scale."""
+    got = got.double().cpu()
+    ref = ref.double().cpu()
+    n = float(ref.norm())
+    if n < 1e-12:
+        return float((got - ref).abs().max()) / 1e-4 * 1e-6
+    return float((got - ref).norm() / n)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=torch.float64) * scale
+
+
+# ------------------------------------------------------------------ GEMMs
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (256, 384, 64), (77, 1007, 512), (3, 40, 8), (300, 130, 2048)])
+def test_gemm_nt_plain_and_bias(ops, dtype, M, N, K):
+    A = rnd(M, K, seed=1).to(dtype)
+    B = rnd(N, K, seed=2).to(dtype)
+    bias = rnd(N, seed=3).float()
+    ref = A.double() @ B.double().t() + bias.double()
+    Ad, Bd, bd = A.to(DEV), B.to(DEV), bias.to(DEV)
+    C = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    ops.gemm_nt(Ad, Bd, C, bias=bd)
+    assert relerr(C, ref) < tol(dtype, 1e-5, 6e-3), (relerr(C, ref))
+    C32 = torch.full((M, N + 3), float("nan"), dtype=torch.float32, device=DEV)
+    ops.gemm_nt(Ad, Bd, C32, bias=bd, flags=ops.ME_EPI_OUT_F32)
+    assert relerr(C32[:, :N], ref) < 1e-5 * (1 if dtype == torch.float32 else 1), relerr(C32[:, :N], ref)
+    assert torch.isnan(C32[:, N:]).all()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_nt_epilogues(ops, dtype):
+    M, N, K = 200, 136, 96
+    A = rnd(M, K, seed=4).to(dtype)
+    B = rnd(N, K, seed=5).to(dtype)
+    bias = rnd(N, seed=6).float()
+    add = rnd(M, N, seed=7).to(dtype)
+    gate = rnd(M, N, seed=8).to(dtype)
+    base = A.double() @ B.double().t()
+    Ad, Bd = A.to(DEV), B.to(DEV)
+    C = torch.empty(M, N, dtype=dtype, device=DEV)
+    ops.gemm_nt(Ad, Bd, C, bias=bias.to(DEV), flags=ops.ME_EPI_RELU)
+    assert relerr(C, torch.relu(base + bias.double())) < tol(dtype, 1e-5, 6e-3)
+    ops.gemm_nt(Ad, Bd, C, add=add.to(DEV))
+    assert relerr(C, base + add.double()) < tol(dtype, 1e-5, 6e-3)
+    ops.gemm_nt(Ad, Bd, C, gate=gate.to(DEV), flags=ops.ME_EPI_RELU_BWD)
+    assert relerr(C, base * (gate.double() > 0)) < tol(dtype, 1e-5, 6e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T,N,K", [(256, 128, 128), (1000, 136, 72), (21, 1007, 64), (4096, 96, 256)])
+def test_gemm_tn_acc(ops, dtype, T, N, K):
+    ch = 4 if dtype == torch.float32 else 8
+    ldA = ((N + ch - 1) // ch) * ch + ch
+    A = torch.zeros(T, ldA, dtype=dtype)
+    A[:, :N] = rnd(T, N, seed=9).to(dtype)
+    B = rnd(T, K, seed=10).to(dtype)
+    dW0 = rnd(N, K, seed=11).float()
+    db0 = rnd(N, seed=12).float()
+    ref = dW0.double() + A[:, :N].double().t() @ B.double()
+    refb = db0.double() + A[:, :N].double().sum(0)
+    dW = dW0.clone().to(DEV)
+    db = db0.clone().to(DEV)
+    ops.gemm_tn_acc(A.to(DEV), B.to(DEV), dW, db, T=T, N=N, K=K)
+    assert relerr(dW, ref) < tol(dtype, 2e-5, 2e-5), relerr(dW, ref)   # inputs already rounded -> f32 accumulate
+    assert relerr(db, refb) < 2e-5, relerr(db, refb)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_cast_transpose(ops, dtype):
+    src = rnd(70, 1007, seed=13).float().to(DEV)
+    dst = torch.zeros(70, 1008, dtype=dtype, device=DEV)
+    dstT = torch.zeros(1007, 72, dtype=dtype, device=DEV)
+    ops.cast_transpose(src, dst, dstT, dtype)
+    assert torch.equal(dst[:, :1007], src.to(dtype))
+    assert torch.equal(dstT[:, :70], src.to(dtype).t())
+    assert (dst[:, 1007:] == 0).all() and (dstT[:, 70:] == 0).all()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Mr", [1, 4, 7])
+def test_gemv_small(ops, dtype, Mr):
+    N, K = 1007, 512
+    x = rnd(Mr, K, seed=14).to(dtype)
+    W = rnd(N, K, seed=15).to(dtype)
+    bias = rnd(N, seed=16).float()
+    ref = x.double() @ W.double().t() + bias.double()
+    y = torch.empty(Mr, N, dtype=torch.float32, device=DEV)
+    ops.gemv_small(x.to(DEV), W.to(DEV), bias.to(DEV), y, Mr, N, K, flags=ops.ME_EPI_OUT_F32)
+    assert relerr(y, ref) < 1e-5
+
+
+# ------------------------------------------------------------------ residual + LayerNorm
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,d", [(37, 64), (256, 512), (5, 256)])
+def test_resid_ln_fwd_bwd(ops, dtype, rows, d):
+    x = rnd(rows, d, seed=17).to(dtype)
+    a = rnd(rows, d, seed=18).to(dtype)
+    gamma = (1 + 0.1 * rnd(d, seed=19)).float()
+    beta = (0.1 * rnd(d, seed=20)).float()
+    dy = rnd(rows, d, seed=21).to(dtype)
+    xs = x.double().requires_grad_(True)
+    as_ = a.double().requires_grad_(True)
+    g64 = gamma.double().requires_grad_(True)
+    b64 = beta.double().requires_grad_(True)
+    yref = O.layer_norm(xs + as_, g64, b64, 1e-6)
+    (yref * dy.double()).sum().backward()
+
+    y = torch.empty(rows, d, dtype=dtype, device=DEV)
+    s = torch.empty_like(y)
+    stats = torch.empty(rows, 2, dtype=torch.float32, device=DEV)
+    ops.resid_ln_fwd(x.to(DEV), a.to(DEV), gamma.to(DEV), beta.to(DEV), y, s, stats, rows, d, 1e-6, 0.0, 0, 1)
+    assert relerr(y, yref.detach()) < tol(dtype, 2e-6, 4e-3)
+    assert relerr(s, (x.double() + a.double())) < tol(dtype, 1e-7, 4e-3)
+    dx = torch.empty_like(y)
+    da = torch.empty_like(y)
+    dg = torch.zeros(d, dtype=torch.float32, device=DEV)
+    db = torch.zeros(d, dtype=torch.float32, device=DEV)
+    ops.resid_ln_bwd(dy.to(DEV), s, stats, gamma.to(DEV), dx, da, dg, db, rows, d, 0.0, 0, 1)
+    assert relerr(dx, xs.grad) < tol(dtype, 1e-5, 1e-2)
+    assert torch.equal(dx, da)
+    assert relerr(dg, g64.grad) < tol(dtype, 1e-5, 1e-2)
+    assert relerr(db, b64.grad) < tol(dtype, 1e-5, 1e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_dropout_mask_consistency(ops, dtype):
+    """Dropout: keep-rate ~ 1-p, forward mask == backward mask, inverted scaling."""
+    rows, d, p = 512, 512, 0.1
+    x = torch.zeros(rows, d, dtype=dtype, device=DEV)
+    a = torch.ones(rows, d, dtype=dtype, device=DEV)
+    gamma = torch.ones(d, device=DEV)
+    beta = torch.zeros(d, device=DEV)
+    y = torch.empty_like(x)
+    s = torch.empty_like(x)
+    stats = torch.empty(rows, 2, device=DEV)
+    ops.resid_ln_fwd(x, a, gamma, beta, y, s, stats, rows, d, 1e-6, p, 1234, 3)
+    keep = (s.float() != 0)
+    rate = keep.float().mean().item()
+    assert abs(rate - 0.9) < 0.005, rate
+    assert torch.allclose(s.float()[keep], torch.tensor(1 / 0.9, device=DEV), rtol=1e-2)
+    s2 = torch.empty_like(x)
+    ops.resid_ln_fwd(x, a, gamma, beta, y, s2, stats, rows, d, 1e-6, p, 1234, 4)
+    assert (s2 != s).any()                          # different site -> different mask
+    ops.resid_ln_fwd(x, a, gamma, beta, y, s2, stats, rows, d, 1e-6, p, 1234, 3)
+    assert torch.equal(s2, s)                       # same (seed, site) -> same mask
+    dx = torch.empty_like(x)
+    da = torch.empty_like(x)
+    dg = torch.zeros(d, device=DEV)
+    db = torch.zeros(d, device=DEV)
+    dy = torch.randn(rows, d, device=DEV).to(dtype)
+    ops.resid_ln_bwd(dy, s, stats, gamma, dx, da, dg, db, rows, d, p, 1234, 3)
+    assert torch.equal(da.float() != 0, keep & (dx.float() != 0))
+    sel = keep & (dx.float().abs() > 1e-3)
+    assert torch.allclose(da.float()[sel], dx.float()[sel] / 0.9, rtol=2e-2)
+
+
+# ------------------------------------------------------------------ cross entropy
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_ce_fwd_bwd(ops, dtype):
+    rows, V, ld = 97, 1007, 1008
+    lg = rnd(rows, V, seed=22, scale=3.0).float()
+    tgt = torch.randint(0, V, (rows,), generator=torch.Generator().manual_seed(23))
+    tgt[::5] = 0
+    l64 = lg.double().requires_grad_(True)
+    loss = torch.nn.functional.cross_entropy(l64, tgt, ignore_index=0)
+    loss.backward()
+    lgd = torch.zeros(rows, ld, device=DEV)
+    lgd[:, :V] = lg.to(DEV)
+    row_lse = torch.empty(rows, device=DEV)
+    acc = torch.zeros(2, device=DEV)
+    ops.ce_fwd(lgd, tgt.to(DEV), row_lse, acc[0:1], acc[1:2], rows, V, 0)
+    nvalid = int((tgt != 0).sum())
+    assert abs(acc[1].item() - nvalid) < 1e-3
+    assert abs(acc[0].item() / nvalid - loss.item()) < 2e-5 * abs(loss.item())
+    assert relerr(row_lse, torch.logsumexp(lg.double(), -1)) < 1e-6
+    dl = torch.full((rows, ld), float("nan"), dtype=dtype, device=DEV)
+    ops.ce_bwd(lgd, tgt.to(DEV), row_lse, dl, acc[1:2], 1.0, rows, V, 0)
+    assert relerr(dl[:, :V], l64.grad) < tol(dtype, 1e-5, 4e-3)
+    assert (dl[:, V:] == 0).all()
+
+
+# ------------------------------------------------------------------ optimiser
+def test_sumsq_and_adamw(ops):
+    n = 100003
+    rs = np.random.RandomState(5)
+    P = {"w": torch.from_numpy(rs.standard_normal(n)).double()}
+    G = {"w": torch.from_numpy(rs.standard_normal(n) * 0.01).double()}
+    M1 = {"w": torch.zeros(n, dtype=torch.float64)}
+    M2 = {"w": torch.zeros(n, dtype=torch.float64)}
+    p = P["w"].float().to(DEV)
+    m = torch.zeros(n, device=DEV)
+    v = torch.zeros(n, device=DEV)
+    for step in (1, 2, 3):
+        G["w"] = torch.from_numpy(rs.standard_normal(n) * (2.0 if step == 2 else 0.001)).double()
+        g = G["w"].float().to(DEV)
+        ss = torch.zeros(1, device=DEV)
+        ops.sumsq(g, ss)
+        assert abs(ss.item() - float((G["w"] ** 2).sum())) < 1e-4 * float((G["w"] ** 2).sum())
+        O.adam_step(P, G, M1, M2, step, lr=1e-3, clip=1.0)
+        ops.adamw_step(p, g, m, v, ss, 1.0, 1.0, 1e-3, 0.9, 0.999, 1e-8, 0.0, step, True)
+        assert (g == 0).all()
+        assert float((p.double().cpu() - P["w"]).abs().max()) < 2e-6, step
+
+
+# ------------------------------------------------------------------ embedding prologue
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("mode", ["none", "continuous_concat", "continuous_token"])
+def test_embed_fwd_bwd(ops, dtype, mode):
+    V, d, dc, B, L = 97, 64, 16, 3, 21
+    cfg = O.Cfg(V, 1, 2, d, 128, d_condition=dc, conditioning=mode, max_seq=64)
+    P = {k: v.double() for k, v in O.seeded_params(cfg, 3).items()}
+    tok, cond, _ = O.synthetic_batch(cfg, B, L, 7)
+    tok[1, -3:] = 0
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    ref = O.embed(cfg, Pg, tok, cond.double())
+    dy = rnd(*ref.shape, seed=24)
+    (ref * dy).sum().backward()
+    Ltok = tok.shape[1]
+    Lm = ref.shape[1]
+    code = {"none": ops.ME_COND_NONE, "continuous_concat": ops.ME_COND_CONCAT, "continuous_token": ops.ME_COND_TOKEN}[mode]
+    f = lambda k: P[k].float().contiguous().to(DEV) if k in P else None
+    pe = O.sinusoid_pe(64, d).float().to(DEV)
+    cw0 = f("fc_condition.weight") if mode == "continuous_concat" else f("fc_condition.0.weight")
+    cb0 = f("fc_condition.bias") if mode == "continuous_concat" else f("fc_condition.0.bias")
+    cw1, cb1 = f("fc_condition.1.weight"), f("fc_condition.1.bias")
+    out = torch.empty(B, Lm, d, dtype=dtype, device=DEV)
+    ops.embed_fwd(out, tok.to(DEV), cond.to(DEV), f("embedding.weight"), cw0, cb0, cw1, cb1, pe, code, B, Ltok, d,
+                  cfg.d_condition, 0.0, 0)
+    assert relerr(out, ref.detach()) < tol(dtype, 1e-6, 4e-3)
+    zl = lambda t: torch.zeros_like(t) if t is not None else None
+    g_emb, g_cw0, g_cb0, g_cw1, g_cb1 = zl(f("embedding.weight")), zl(cw0), zl(cb0), zl(cw1), zl(cb1)
+    ops.embed_bwd(dy.to(dtype).to(DEV), tok.to(DEV), cond.to(DEV), g_emb, g_cw0, g_cb0, g_cw1, g_cb1, code, B, Ltok, d,
+                  cfg.d_condition, 0, 0.0, 0)
+    gref = Pg["embedding.weight"].grad.clone()
+    gref[0] = 0
+    assert relerr(g_emb, gref) < tol(dtype, 1e-5, 6e-3)
+    assert (g_emb[0] == 0).all()
+    if mode == "continuous_concat":
+        assert relerr(g_cw0, Pg["fc_condition.weight"].grad) < tol(dtype, 1e-5, 6e-3)
+        assert relerr(g_cb0, Pg["fc_condition.bias"].grad) < tol(dtype, 1e-5, 6e-3)
+    if mode == "continuous_token":
+        for i, (gw, gb) in enumerate(((g_cw0, g_cb0), (g_cw1, g_cb1))):
+            assert relerr(gw, Pg[f"fc_condition.{i}.weight"].grad) < tol(dtype, 1e-5, 6e-3)
+            assert relerr(gb, Pg[f"fc_condition.{i}.bias"].grad) < tol(dtype, 1e-5, 6e-3)
+
+
+def test_key_pad_mask(ops):
+    tok = torch.tensor([[5, 0, 7, 0], [0, 1, 2, 3]])
+    kp = torch.empty(2, 6, dtype=torch.uint8, device=DEV)
+    ops.key_pad_mask(kp, tok.to(DEV), 2, 4, 2, 0)
+    assert kp.cpu().tolist() == [[0, 0, 0, 1, 0, 1], [0, 0, 1, 0, 0, 0]]
+
+
+# ------------------------------------------------------------------ relative global attention
+def attn_case(B, H, L, dh, M, seed, pad_rows=True):
+    q = rnd(B, H, L, dh, seed=seed)
+    k = rnd(B, H, L, dh, seed=seed + 1)
+    v = rnd(B, H, L, dh, seed=seed + 2)
+    E = rnd(M, dh, seed=seed + 3)
+    dO = rnd(B, H, L, dh, seed=seed + 4)
+    pad = torch.zeros(B, L, dtype=torch.bool)
+    if pad_rows and L > 8:
+        pad[-1, -(L // 5):] = True
+        if B > 1:
+            pad[0, 3] = True
+    return q, k, v, E, dO, pad
+
+
+def run_attn(ops, dtype, q, k, v, E, dO, pad, backward=True):
+    B, H, L, dh = q.shape
+    M = E.shape[0]
+    to_tok = lambda t: t.permute(0, 2, 1, 3)          # [B,L,H,dh]
+    qkv = torch.stack([to_tok(q), to_tok(k), to_tok(v)], dim=2).contiguous().to(dtype).to(DEV)   # [B,L,3,H,dh]
+    Ed = E.to(dtype).to(DEV).contiguous()
+    kp = pad.to(torch.uint8).to(DEV) if pad is not None else None
+    out = torch.full((B, L, H, dh), float("nan"), dtype=dtype, device=DEV)
+    lse = torch.empty(B, H, L, dtype=torch.float32, device=DEV)
+    ops.rga_fwd(qkv, Ed, kp, out, lse, B, L, H, dh, M)
+    res = {"O": out.permute(0, 2, 1, 3).float().cpu(), "lse": lse.cpu()}
+    if backward:
+        dout = to_tok(dO).contiguous().to(dtype).to(DEV)
+        dqkv = torch.full_like(qkv, float("nan"))
+        dE = torch.zeros(M, dh, dtype=torch.float32, device=DEV)
+        ET = Ed.t().contiguous()
+        delta = torch.empty(B, H, L, dtype=torch.float32, device=DEV)
+        ds = torch.zeros(B, H, L, L, dtype=dtype, device=DEV)
+        ops.rga_bwd(qkv, Ed, ET, kp, out, lse, dout, dqkv, dE, delta, ds, B, L, H, dh, M)
+        g = dqkv.float().cpu().permute(2, 0, 3, 1, 4)   # [3,B,H,L,dh]
+        res.update(dq=g[0], dk=g[1], dv=g[2], dE=dE.cpu())
+    return res
+
+
+def ref_attn(q, k, v, E, dO, pad, dtype):
+    """fp64 oracle on inputs rounded to the storage dtype."""
+    r = lambda t: t.to(dtype).double().requires_grad_(True)
+    q, k, v, E = r(q), r(k), r(v), r(E)
+    o, lse = O.rga_attention_core(q, k, v, E, pad)
+    (o * dO.to(dtype).double()).sum().backward()
+    return {"O": o.detach(), "lse": lse.detach(), "dq": q.grad, "dk": k.grad, "dv": v.grad, "dE": E.grad}
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_rga_golden_f5(ops, dtype, golden_dir):
+    z = np.load(os.path.join(golden_dir, "f5_attn_core.npz"))
+    q, k, v, E, dO = (torch.from_numpy(z[n]) for n in ("q", "k", "v", "E", "dO"))
+    pad = torch.from_numpy(z["pad"])
+    got = run_attn(ops, dtype, q, k, v, E, dO, pad)
+    if dtype == torch.float32:
+        errs = {n: relerr(got[n], torch.from_numpy(z[n])) for n in ("O", "lse", "dq", "dk", "dv", "dE")}
+        assert all(e < 2e-5 for e in errs.values()), errs
+    else:
+        ref = ref_attn(q, k, v, E, dO, pad, dtype)
+        errs = {n: relerr(got[n], ref[n]) for n in ("O", "lse", "dq", "dk", "dv", "dE")}
+        assert all(e < 1.5e-2 for e in errs.values()), errs
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,L,dh,M", [(2, 2, 1, 32, 64), (1, 3, 7, 64, 64), (2, 2, 33, 32, 64), (2, 4, 64, 64, 64),
+                                         (1, 2, 130, 64, 256), (2, 2, 256, 64, 2048), (1, 1, 300, 32, 512)])
+def test_rga_fwd_bwd_shapes(ops, dtype, B, H, L, dh, M):
+    q, k, v, E, dO, pad = attn_case(B, H, L, dh, M, seed=100 + L)
+    got = run_attn(ops, dtype, q, k, v, E, dO, pad)
+    ref = ref_attn(q, k, v, E, dO, pad, dtype)
+    errs = {n: relerr(got[n], ref[n]) for n in ("O", "lse", "dq", "dk", "dv", "dE")}
+    assert all(e < tol(dtype, 3e-5, 1.5e-2) for e in errs.values()), errs
+    # rows of E that can never be reached (relative distance >= L) get exactly zero gradient
+    if M > L:
+        assert (got["dE"][: M - L] == 0).all()
+
+
+def test_rga_fully_masked_row_is_nan(ops):
+    """PAD at key 0: query 0 has no valid key -> NaN (reference behaviour, SURVEY hard part 6);
+    later queries with leading masked keys must stay finite."""
+    q, k, v, E, dO, _ = attn_case(1, 1, 40, 32, 64, seed=5, pad_rows=False)
+    pad = torch.zeros(1, 40, dtype=torch.bool)
+    pad[0, 0] = True
+    got = run_attn(ops, torch.float32, q, k, v, E, dO, pad, backward=False)
+    ref, _ = O.rga_attention_core(q, k, v, E, pad)
+    assert torch.isnan(got["O"][0, 0, 0]).all()
+    assert relerr(got["O"][0, 0, 1:], ref[0, 0, 1:]) < 2e-5
+    # whole first key tile masked, later keys valid
+    pad = torch.zeros(1, 40, dtype=torch.bool)
+    pad[0, :34] = True
+    got = run_attn(ops, torch.float32, q, k, v, E, dO, pad, backward=False)
+    ref, _ = O.rga_attention_core(q, k, v, E, pad)
+    assert torch.isnan(got["O"][0, 0, :34]).all()
+    assert relerr(got["O"][0, 0, 34:], ref[0, 0, 34:]) < 2e-5
+
+
+def test_rga_prefix_invariance(ops):
+    """logits at position t do not depend on later tokens nor on L."""
+    q, k, v, E, dO, _ = attn_case(1, 2, 96, 64, 2048, seed=9, pad_rows=False)
+    full = run_attn(ops, torch.float32, q, k, v, E, dO, None, backward=False)["O"]
+    part = run_attn(ops, torch.float32, q[:, :, :50], k[:, :, :50], v[:, :, :50], E, dO[:, :, :50], None, backward=False)["O"]
+    assert relerr(full[:, :, :50], part) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_rga_decode_step_matches_full(ops, dtype):
+    B, H, L, dh, M = 3, 2, 45, 64, 2048
+    q, k, v, E, dO, pad = attn_case(B, H, L, dh, M, seed=77, pad_rows=False)
+    ref = ref_attn(q, k, v, E, dO, None, dtype)["O"]            # [B,H,L,dh]
+    Ed = E.to(dtype).to(DEV).contiguous()
+    Mc = 64
+    kc = torch.zeros(B, H, Mc, dh, dtype=dtype, device=DEV)
+    vc = torch.zeros_like(kc)
+    out = torch.empty(B, H, dh, dtype=dtype, device=DEV)
+    for t in range(L):
+        qkv_new = torch.stack([q[:, :, t], k[:, :, t], v[:, :, t]], dim=1).contiguous().to(dtype).to(DEV)  # [B,3,H,dh]
+        ops.rga_decode_step(qkv_new, kc, vc, Ed, None, 0, out, B, H, dh, M, Mc, t)
+        e = relerr(out, ref[:, :, t])
+        assert e < tol(dtype, 2e-5, 1.5e-2), (t, e)

@@ -1,0 +1,255 @@
+"""Model-level parity (GPU): the HIP engine behind build_model()/nn.Module against
+the oracle and the golden fixtures captured from the reference.
+
+Tolerances: f32 tier -- logits rel-L2 <= 1e-4 (north_star gate is 1e-3), grads rel-L2 <= 2e-4;
+bf16 tier -- logits rel-L2 <= 1.2e-2 on the tiny random models, <= 8e-3 on the headline model
+(the reference's own bf16-autocast error on the headline model is 3.8e-3)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_model as O  # noqa: E402
+
+MODES = ["none", "discrete_token", "continuous_token", "continuous_concat"]
+DEV = "cuda"
+
+
+def relerr(got, ref):
+    got = torch.as_tensor(got).double().cpu()
+    ref = torch.as_tensor(ref).double().cpu()
+    n = float(ref.norm())
+    if n < 1e-12:
+        return float((got - ref).abs().max())
+    return float((got - ref).norm() / n)
+
+
+def make_model(cfg, params, compute_dtype, dropout=0.0):
+    from midiemo.models.build_model import build_model
+    from midiemo.models.music_transformer import MusicTransformerContinuousToken, MusicTransformerMulti
+    if cfg.max_seq == 2048:
+        args = dict(vocab_size=cfg.vocab_size, n_layer=cfg.n_layer, n_head=cfg.n_head, d_model=cfg.d_model,
+                    d_inner=cfg.d_inner, dropout=dropout, d_condition=cfg.d_condition if cfg.d_condition > 0 else -1,
+                    conditioning=cfg.conditioning, compute_dtype=compute_dtype)
+        model, _ = build_model(args)
+    else:
+        kw = dict(embedding_dim=cfg.d_model, d_inner=cfg.d_inner, vocab_size=cfg.vocab_size, num_layer=cfg.n_layer,
+                  num_head=cfg.n_head, max_seq=cfg.max_seq, dropout=dropout, pad_token=0, compute_dtype=compute_dtype)
+        if cfg.conditioning == "continuous_token":
+            model = MusicTransformerContinuousToken(**kw)
+        else:
+            model = MusicTransformerMulti(d_condition=cfg.d_condition if cfg.d_condition > 0 else -1, **kw)
+    missing = model.load_state_dict(params, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return model.to(DEV)
+
+
+def report(line):
+    """Measured parity numbers, kept for DESIGN.md (gpurun_out/ is merged back from the GPU box)."""
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "parity_report.txt"), "a") as f:
+            f.write(line + "\n")
+
+
+def f1_cfg(mode, z):
+    V, nl, nh, d, di, dc, M = [int(x) for x in z["cfg"]]
+    return O.Cfg(V, nl, nh, d, di, d_condition=dc if dc > 0 else -1, conditioning=mode, max_seq=M)
+
+
+def sub(a):
+    f = np.asarray(a).reshape(-1)
+    return f[::7] if f.size > 4096 else f
+
+
+def test_state_dict_keys_match_reference_abi():
+    cfg = O.Cfg(1007, 2, 2, 64, 128, d_condition=16, conditioning="continuous_concat")
+    m = make_model(cfg, O.seeded_params(cfg, 1), "fp32")
+    assert list(m.state_dict().keys()) == list(O.param_shapes(cfg).keys())
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == O.param_shapes(cfg)[k]
+    n = sum(p.numel() for p in m.parameters())
+    assert n == sum(int(np.prod(s)) for s in O.param_shapes(cfg).values())
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("cd", ["fp32", "bf16"])
+def test_f1_logits_vs_golden(golden_dir, mode, cd):
+    z = np.load(os.path.join(golden_dir, f"f1_{mode}.npz"))
+    cfg = f1_cfg(mode, z)
+    model = make_model(cfg, O.seeded_params(cfg, int(z["weight_seed"])), cd).eval()
+    errs = {}
+    for L in (1, 7, 33, 64):
+        tok = torch.from_numpy(z[f"L{L}_tokens"]).to(DEV)
+        cond = torch.from_numpy(z[f"L{L}_cond"]).to(DEV)
+        with torch.no_grad():
+            lg = model(tok, cond)
+        errs[L] = relerr(lg, z[f"L{L}_logits"])
+    report("f1 %s logits rel-L2 vs reference, compute=%s: %s" % (mode, cd, {k: "%.2e" % v for k, v in errs.items()}))
+    assert all(e < (1e-4 if cd == "fp32" else 1.2e-2) for e in errs.values()), errs
+    # PAD at position 0 -> the reference's NaN pattern
+    with torch.no_grad():
+        lg = model(torch.from_numpy(z["pad0_tokens"]).to(DEV), torch.from_numpy(z["pad0_cond"]).to(DEV))
+    assert np.array_equal(torch.isnan(lg).cpu().numpy(), z["pad0_isnan"])
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_f1_autograd_grads_and_fused_adam_vs_golden(golden_dir, mode):
+    """Reference usage pattern (train.py:288-325) through autograd, then the fused path; f32 tier."""
+    z = np.load(os.path.join(golden_dir, f"f1_{mode}.npz"))
+    cfg = f1_cfg(mode, z)
+    P0 = O.seeded_params(cfg, int(z["weight_seed"]))
+    model = make_model(cfg, P0, "fp32").train()
+    V = cfg.vocab_size
+
+    # --- autograd path, step-1 batch: p.grad vs golden grads
+    tok = torch.from_numpy(z["opt1_tokens"]).to(DEV)
+    cond = torch.from_numpy(z["opt1_cond"]).to(DEV)
+    tgt = torch.from_numpy(z["opt1_target"]).to(DEV)
+    lg = model(tok, cond)
+    loss = torch.nn.functional.cross_entropy(lg.reshape(-1, V), tgt.reshape(-1), ignore_index=0)
+    loss.backward()
+    assert abs(loss.item() - float(z["opt1_loss"])) < 2e-5
+    bad = {}
+    for k, p in model.named_parameters():
+        gn = float(z[f"gradnorm/{k}"])
+        g = p.grad.detach().cpu().numpy()
+        err = np.abs(sub(g) - z[f"grad/{k}"]).max()
+        rms = gn / np.sqrt(max(g.size, 1))
+        if err > 1e-2 * rms + 1e-7 or abs(np.sqrt((g.astype(np.float64) ** 2).sum()) - gn) > 3e-4 * gn + 1e-8:
+            bad[k] = (float(err), rms)
+    assert not bad, bad
+    model.zero_grad(set_to_none=True)
+
+    # --- fused path: 3 steps of loss_and_backward + FusedAdamW vs golden normalised updates
+    from midiemo.optim import FusedAdamW
+    opt = FusedAdamW(model, lr=2e-5, clip=1.0)
+    for step in (1, 2, 3):
+        tok = torch.from_numpy(z[f"opt{step}_tokens"]).to(DEV)
+        cond = torch.from_numpy(z[f"opt{step}_cond"]).to(DEV)
+        tgt = torch.from_numpy(z[f"opt{step}_target"]).to(DEV)
+        loss = model.loss_and_backward(tok, cond, tgt)
+        assert abs(loss.item() - float(z[f"opt{step}_loss"])) < 3e-5, (step, loss.item())
+        gn = opt.grad_norm().item()
+        assert abs(gn - float(z[f"opt{step}_gradnorm"])) < 3e-4 * float(z[f"opt{step}_gradnorm"]), step
+        opt.step()
+        assert float(model.flat_grads.abs().max()) == 0.0
+        if step in (1, 3):
+            for k, p in model.named_parameters():
+                if k.endswith("Wk.bias"):
+                    continue        # exactly-zero gradient (softmax shift invariance); reference steps on fp noise
+                upd = (p.detach().cpu().double() - P0[k].double()) / 2e-5
+                err = np.abs(sub(upd.numpy()) - z[f"upd{step}/{k}"])
+                tol = 3e-2 + 6e-3 * float(P0[k].abs().max())
+                assert (err > tol).mean() <= 3e-2 and err.max() < 0.5, (k, step, err.max(), (err > tol).mean())
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("cd", ["fp32", "bf16"])
+def test_grads_vs_oracle_random_batch(mode, cd):
+    """Every parameter gradient against the oracle's autograd (rel-L2 per tensor)."""
+    V = 1017 if mode == "discrete_token" else 1007
+    cfg = O.Cfg(V, 2, 2, 128, 256, d_condition=32, conditioning=mode)
+    P = O.seeded_params(cfg, 5)
+    model = make_model(cfg, P, cd).train()
+    tok, cond, tgt = O.synthetic_batch(cfg, 3, 70, seed=9)
+    tok[-1, -9:] = 0
+    tgt[-1, -10:] = 0
+    loss_ref, lg_ref, G = O.loss_and_grads(cfg, {k: v.double() for k, v in P.items()}, tok, cond.double(), tgt)
+    loss = model.loss_and_backward(tok.to(DEV), cond.to(DEV), tgt.to(DEV))
+    tl = 1e-5 if cd == "fp32" else 5e-3
+    assert abs(loss.item() - loss_ref.item()) < tl * 10, (loss.item(), loss_ref.item())
+    model.link_grads()
+    bad = {}
+    for k, p in model.named_parameters():
+        if k.endswith("Wk.bias"):
+            assert float(p.grad.abs().max()) < (1e-6 if cd == "fp32" else 1e-3)
+            continue
+        e = relerr(p.grad, G[k])
+        # bf16: ReLU gates computed from bf16-rounded pre-activations flip for |x| ~ 1e-3, which
+        # dominates the FFN_pre gradient error (measured 4-6 %); everything else is < 4 %.
+        lim = 2e-4 if cd == "fp32" else (8e-2 if "FFN_pre" in k else 4e-2)
+        if e > lim:
+            bad[k] = e
+    assert not bad, bad
+
+
+def test_f2_cfg1_logits_and_trajectory(golden_dir):
+    """BASELINE config 1 (none, 2L d256 h4 di1024 L256 B2) through the HIP engine, f32 tier."""
+    z = np.load(os.path.join(golden_dir, "f2_cfg1.npz"))
+    cfg = O.Cfg(1007, 2, 4, 256, 1024, conditioning="none")
+    model = make_model(cfg, O.seeded_params(cfg, int(z["weight_seed"])), "fp32")
+    tok = torch.from_numpy(z["tokens"]).to(DEV)
+    with torch.no_grad():
+        lg = model.eval()(tok, None)
+    e = relerr(lg[:, z["rows"]], z["logits_rows"])
+    assert e < 1e-4, e
+    from midiemo.optim import FusedAdamW
+    model.train()
+    opt = FusedAdamW(model, lr=float(z["traj_lr"]), clip=1.0)
+    traj = []
+    for step in range(20):
+        inp, cond, tgt = O.synthetic_batch(cfg, 2, 256, seed=5000 + step)
+        traj.append(model.loss_and_backward(inp.to(DEV), cond.to(DEV), tgt.to(DEV)).item())
+        opt.step()
+    np.testing.assert_allclose(np.array(traj), z["traj_loss"], rtol=0, atol=3e-3)
+
+
+@pytest.mark.parametrize("cd", ["fp32", "bf16"])
+def test_f3_headline_model_logits(golden_dir, cd):
+    """cfg2 model (6L d512 h8 di2048 dc128), B=2, L=1024: logits + loss + per-tensor grad norms."""
+    z = np.load(os.path.join(golden_dir, "f3_cfg2.npz"))
+    cfg = O.Cfg(1007, 6, 8, 512, 2048, d_condition=128, conditioning="continuous_concat")
+    model = make_model(cfg, O.seeded_params(cfg, int(z["weight_seed"])), cd).train()
+    inp, cond, tgt = O.synthetic_batch(cfg, 2, 1024, seed=int(z["batch_seed"]))
+    with torch.no_grad():
+        lg = model(inp.to(DEV), cond.to(DEV))
+    e = relerr(lg[:, z["rows"]], z["logits_rows"])
+    report("cfg2 (6L d512 h8 L1024 B2) logits rel-L2 vs reference fp32, compute=%s: %.3e" % (cd, e))
+    assert e < (1e-4 if cd == "fp32" else 8e-3), e
+    loss = model.loss_and_backward(inp.to(DEV), cond.to(DEV), tgt.to(DEV))
+    assert abs(loss.item() - float(z["loss"])) < (5e-5 if cd == "fp32" else 5e-3)
+    model.link_grads()
+    bad = {}
+    for k, p in model.named_parameters():
+        if k.endswith("Wk.bias"):
+            continue
+        gn = float(p.grad.double().norm())
+        ref = float(z[f"gradnorm/{k}"])
+        if abs(gn - ref) > (1e-3 if cd == "fp32" else 5e-2) * ref + 1e-9:
+            bad[k] = (gn, ref)
+    assert not bad, bad
+
+
+def test_dropout_training_runs_and_is_seeded():
+    cfg = O.Cfg(1007, 2, 2, 128, 256, d_condition=32, conditioning="continuous_concat")
+    model = make_model(cfg, O.seeded_params(cfg, 5), "bf16", dropout=0.1).train()
+    tok, cond, tgt = O.synthetic_batch(cfg, 4, 64, seed=1)
+    tok, cond, tgt = tok.to(DEV), cond.to(DEV), tgt.to(DEV)
+    model.seed_dropout(7)
+    l1 = model.loss_and_backward(tok, cond, tgt).item()
+    g1 = model.flat_grads.clone()
+    model.flat_grads.zero_()
+    l2 = model.loss_and_backward(tok, cond, tgt).item()       # next dropout draw
+    model.flat_grads.zero_()
+    model.seed_dropout(7)
+    l3 = model.loss_and_backward(tok, cond, tgt).item()
+    # same (seed, counter) -> same masks; the loss sum uses float atomics, so allow 1e-5
+    assert abs(l1 - l2) > 1e-4 and abs(l1 - l3) < 1e-5, (l1, l2, l3)
+    assert torch.isfinite(g1).all()
+    model.eval()
+    with torch.no_grad():
+        a = model(tok, cond)
+        b = model(tok, cond)
+    assert torch.equal(a, b)
+
+
+def test_cpu_model_fails_loudly():
+    from midiemo.models.music_transformer import MusicTransformerMulti
+    m = MusicTransformerMulti(embedding_dim=64, d_inner=128, d_condition=-1, vocab_size=97, num_layer=1, num_head=2,
+                              max_seq=64, dropout=0.0, pad_token=0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.randint(2, 97, (1, 8)), None)
