@@ -1,0 +1,234 @@
+"""bench.py -- headline benchmark: MIDI tokens/s of one full training step
+(forward + CE + backward + gradient all-reduce + global-norm clip + AdamW, dropout on)
+of the emotion-conditioned Music Transformer on MI355X.
+
+Workload (BASELINE.json configs[1]): continuous_concat, 6 layers, d_model 512,
+8 heads, d_inner 2048, d_condition 128, V 1007, seq 1024, batch 32 per GPU, bf16 storage /
+f32 accumulate, synthetic tokens in [2, V), weights random-init.  Weak scaling: 32 seq/GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  `roofline` is the dominant kernel family
+(gemm_nt_kernel<bf16>, ~2/3 of the step's FLOPs): algorithmic FLOPs of its launches /
+their HIP-event durations, measured on the launch stream in instrumented steps after the
+timed region.  `cpu_baseline` is the oracle (oracle/ref_model.py, a port) timed on the
+host cores on a bounded sample (B=1..2, same model/seq), rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "midi-emotion_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+CFG = dict(vocab_size=1007, n_layer=6, n_head=8, d_model=512, d_inner=2048, d_condition=128,
+           conditioning="continuous_concat", dropout=0.1)
+SEQ, BATCH = 1024, 32
+PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def train_flop_per_token(c, L):
+    """SURVEY 8d official figure: causal-discounted, 2*MAC, train = 3 x fwd."""
+    d, di, V = c["d_model"], c["d_inner"], c["vocab_size"]
+    per_layer = 8 * d * d + 4 * d * di + 3 * (2 * d * (L + 1) // 2)
+    fwd = c["n_layer"] * per_layer + 2 * d * V
+    return 3 * fwd
+
+
+def synthetic_batch(c, B, L, seed, device):
+    """tokens randint(2, V, (B, L+1)), input = tok[:, :-1], target = tok[:, 1:], cond U(-1,1)."""
+    g = torch.Generator().manual_seed(seed)
+    tok = torch.randint(2, c["vocab_size"], (B, L + 1), generator=g)
+    cond = torch.rand(B, 2, generator=g) * 2 - 1
+    return tok[:, :-1].contiguous().to(device), cond.to(device), tok[:, 1:].contiguous().to(device)
+
+
+def cpu_baseline(c, L, budget_s=25.0):
+    """The oracle's full train step (fwd + CE + autograd bwd + clip + Adam, f32) on the host cores."""
+    from oracle import ref_model as O
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    ncores = max(1, min(avail, 32))          # beyond ~32 threads the small-op-bound oracle slows down
+    torch.set_num_threads(ncores)
+    cfg = O.Cfg(c["vocab_size"], c["n_layer"], c["n_head"], c["d_model"], c["d_inner"],
+                d_condition=c["d_condition"], conditioning=c["conditioning"])
+    P = O.seeded_params(cfg, 0)
+    M1 = {k: torch.zeros_like(v) for k, v in P.items()}
+    M2 = {k: torch.zeros_like(v) for k, v in P.items()}
+    B = 1
+    inp, cond, tgt = O.synthetic_batch(cfg, B, L, seed=1234)
+    times = []
+    t_start = time.perf_counter()
+    step = 0
+    while True:
+        t0 = time.perf_counter()
+        _, _, G = O.loss_and_grads(cfg, P, inp, cond, tgt)
+        O.adam_step(P, G, M1, M2, step + 1, lr=2e-5, clip=1.0)
+        times.append(time.perf_counter() - t0)
+        step += 1
+        if step >= 4 or (step >= 2 and time.perf_counter() - t_start > budget_s):
+            break
+    best = min(times[1:]) if len(times) > 1 else times[0]
+    return {"value": round(B * L / best, 1), "unit": "tokens/s", "cores": ncores, "kind": "port",
+            "sample": "oracle train step (fwd+CE+bwd+clip+Adam, f32, dropout off), B=%d L=%d, %d steps, best of last %d"
+                      % (B, L, len(times), max(1, len(times) - 1))}
+
+
+class GemmProbe:
+    """HIP-event timing of every me_gemm_nt launch (events recorded on the launch stream)."""
+
+    def __init__(self, ops):
+        self.ops, self.orig, self.rec = ops, ops.gemm_nt, []
+
+    def __enter__(self):
+        def timed(A, B, C, bias=None, add=None, gate=None, M=None, N=None, K=None, flags=0, dtype=None):
+            m = A.shape[0] if M is None else M
+            k = A.shape[1] if K is None else K
+            n = B.shape[0] if N is None else N
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.orig(A, B, C, bias=bias, add=add, gate=gate, M=M, N=N, K=K, flags=flags, dtype=dtype)
+            e1.record()
+            self.rec.append((2.0 * m * n * k, e0, e1))
+        self.ops.gemm_nt = timed
+        return self
+
+    def __exit__(self, *a):
+        self.ops.gemm_nt = self.orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        flops = sum(r[0] for r in self.rec)
+        ms = sum(r[1].elapsed_time(r[2]) for r in self.rec)
+        return flops, ms, len(self.rec)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH, help="sequences per GPU (weak scaling)")
+    ap.add_argument("--seq", type=int, default=SEQ)
+    ap.add_argument("--compute_dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_probe", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
+                             % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from midiemo import ops
+    from midiemo.ddp import GradAllReducer, broadcast_params
+    from midiemo.models.build_model import build_model
+    from midiemo.optim import FusedAdamW
+
+    torch.manual_seed(0)                                   # identical random-init weights on every rank
+    margs = dict(CFG, compute_dtype=args.compute_dtype)
+    model, _ = build_model(margs)
+    model = model.to(dev).train()
+    broadcast_params(model.flat_params)
+    model.seed_dropout(1000 + rank)
+    opt = FusedAdamW(model, lr=2e-5, clip=1.0)             # == Adam(lr) + clip_grad_norm_(1.0), train.py:182,321
+    reducer = GradAllReducer(lambda: model.flat_grads, model.bucket_ranges())
+    B, L = args.batch, args.seq
+    batches = [synthetic_batch(CFG, B, L, 1234 + rank + 7919 * i, dev) for i in range(4)]
+
+    def step(i):
+        tok, cond, tgt = batches[i % len(batches)]
+        loss = model.loss_and_backward(tok, cond, tgt, bucket_hook=reducer.hook if world > 1 else None)
+        reducer.finish()
+        opt.step(grad_scale=reducer.grad_scale)
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    loss = None
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    e1.record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    final_loss = float(loss.item())
+
+    probe = None
+    if rank == 0 and not args.no_probe:
+        with GemmProbe(ops) as gp:
+            for i in range(3):
+                step(i)
+            probe = gp.summary()
+    fence()
+
+    if rank == 0:
+        tokens = world * B * L * args.steps
+        tps = tokens / elapsed
+        fpt = train_flop_per_token(CFG, L)
+        out = {
+            "metric": "MIDI tokens/sec training (B32 seq1024 d512 6L)", "value": round(tps, 1), "unit": "tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.compute_dtype, "data": "synthetic",
+            "config": {"workload": "continuous_concat 6L d512 8H d_inner2048 d_cond128 V1007, seq %d, batch %d/GPU, "
+                                   "fwd+CE+bwd+clip+AdamW, dropout 0.1" % (L, B),
+                       "global_batch": world * B, "seq_len": L, "parallelism": "dp%d" % world,
+                       "final_loss": round(final_loss, 4), "gpu_event_ms_per_step": round(e0.elapsed_time(e1) / args.steps, 3)},
+            "step_tflops_algorithmic": round(tps * fpt / 1e12 / world, 2),
+        }
+        if probe is not None:
+            flops, ms, n = probe
+            ach = flops / (ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel<%s>" % args.compute_dtype,
+                               "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS if args.compute_dtype == "bf16" else 157.3,
+                               "unit": "TFLOP/s",
+                               "frac": round(ach / (PEAK_BF16_TFLOPS if args.compute_dtype == "bf16" else 157.3), 4),
+                               "traffic": None, "launches_per_step": n // 3,
+                               "avg_launch_us": round(1000.0 * ms / n, 2),
+                               "gemm_nt_ms_per_step": round(ms / 3, 3),
+                               "step_frac_of_peak": round(tps * fpt / 1e12 / world / PEAK_BF16_TFLOPS, 4)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(CFG, L)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -784,6 +784,7 @@ extern "C" {
 
 int me_rga_fwd(const void* qkv, const void* E, const uint8_t* key_pad, void* out, float* lse, int B, int L, int H, int dh,
                int M, int dtype, void* stream) {
+    me_clear_error();
     if (!qkv || !E || !out || !lse) return ME_ERR_NULL;
     if (B <= 0 || L <= 0 || H <= 0 || L > M || (M & 31)) return ME_ERR_BAD_SHAPE;
     if (!aligned16(qkv) || !aligned16(E) || !aligned16(out)) return ME_ERR_ALIGNMENT;
@@ -794,6 +795,7 @@ int me_rga_fwd(const void* qkv, const void* E, const uint8_t* key_pad, void* out
 int me_rga_bwd(const void* qkv, const void* E, const void* ET_, const uint8_t* key_pad, const void* out, const float* lse,
                const void* dout, void* dqkv, float* dE, float* delta_ws, void* ds_ws, int B, int L, int H, int dh, int M,
                int dtype, void* stream) {
+    me_clear_error();
     if (!qkv || !E || !ET_ || !out || !lse || !dout || !dqkv || !dE || !delta_ws || !ds_ws) return ME_ERR_NULL;
     if (B <= 0 || L <= 0 || H <= 0 || L > M || (M & 31)) return ME_ERR_BAD_SHAPE;
     if (!aligned16(qkv) || !aligned16(E) || !aligned16(ET_) || !aligned16(out) || !aligned16(dout) || !aligned16(dqkv) ||
@@ -805,6 +807,7 @@ int me_rga_bwd(const void* qkv, const void* E, const void* ET_, const uint8_t* k
 
 int me_rga_decode_step(const void* qkv_new, void* kcache, void* vcache, const void* E, const uint8_t* key_pad, int ld_pad,
                        void* out, int B, int H, int dh, int M, int Mc, int t, int dtype, void* stream) {
+    me_clear_error();
     if (!qkv_new || !kcache || !vcache || !E || !out) return ME_ERR_NULL;
     if (B <= 0 || H <= 0 || t < 0 || t >= Mc || t >= M || t >= 2048) return ME_ERR_BAD_SHAPE;
     hipStream_t st = (hipStream_t)stream;

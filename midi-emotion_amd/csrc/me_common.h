@@ -140,7 +140,10 @@ ME_DEV bool me_keep(uint64_t seed, uint32_t site, uint64_t idx, uint32_t thr16) 
     return u >= thr16;
 }
 
-// status helper for the C-ABI launchers
+// status helpers for the C-ABI launchers.  hipGetLastError() is sticky per thread: other users
+// of the runtime (PyTorch) routinely leave benign non-success codes behind, so every entry point
+// clears the state first and only reports errors raised by its own launches.
+static inline void me_clear_error() { (void)hipGetLastError(); }
 static inline int me_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? ME_OK : ME_ERR_LAUNCH;

@@ -445,6 +445,7 @@ extern "C" {
 int me_embed_fwd(void* out, int dtype, const int64_t* tokens, const float* cond, const float* emb, const float* cw0,
                  const float* cb0, const float* cw1, const float* cb1, const float* pe, int mode, int B, int Ltok,
                  int d, int dc, float p, uint64_t seed, void* stream) {
+    me_clear_error();
     if (!out || !tokens || !emb || !pe) return ME_ERR_NULL;
     if (mode == ME_COND_CONCAT && (!cond || !cw0 || !cb0 || dc <= 0 || dc >= d)) return ME_ERR_NULL;
     if (mode == ME_COND_TOKEN && (!cond || !cw0 || !cb0 || !cw1 || !cb1)) return ME_ERR_NULL;
@@ -465,6 +466,7 @@ int me_embed_fwd(void* out, int dtype, const int64_t* tokens, const float* cond,
 int me_embed_bwd(const void* dout, int dtype, const int64_t* tokens, const float* cond, float* g_emb, float* g_cw0,
                  float* g_cb0, float* g_cw1, float* g_cb1, int mode, int B, int Ltok, int d, int dc, int pad_token,
                  float p, uint64_t seed, void* stream) {
+    me_clear_error();
     if (!dout || !tokens || !g_emb) return ME_ERR_NULL;
     if (mode == ME_COND_CONCAT && (!cond || !g_cw0 || !g_cb0)) return ME_ERR_NULL;
     if (mode == ME_COND_TOKEN && (!cond || !g_cw0 || !g_cb0 || !g_cw1 || !g_cb1)) return ME_ERR_NULL;
@@ -484,6 +486,7 @@ int me_embed_bwd(const void* dout, int dtype, const int64_t* tokens, const float
 }
 
 int me_key_pad_mask(uint8_t* key_pad, const int64_t* tokens, int B, int Ltok, int shift, int pad_token, void* stream) {
+    me_clear_error();
     if (!key_pad || !tokens) return ME_ERR_NULL;
     const int64_t n = (int64_t)B * (Ltok + shift);
     if (n <= 0) return ME_OK;
@@ -494,6 +497,7 @@ int me_key_pad_mask(uint8_t* key_pad, const int64_t* tokens, int B, int Ltok, in
 int me_resid_ln_fwd(const void* x, const void* a, const float* gamma, const float* beta, void* y, void* s_out,
                     float* stats, int rows, int d, float eps, float p, uint64_t seed, uint32_t site, int dtype,
                     void* stream) {
+    me_clear_error();
     if (!x || !a || !gamma || !beta || !y) return ME_ERR_NULL;
     if (rows <= 0) return ME_OK;
     const int ch = dtype == ME_F32 ? 4 : 8;
@@ -510,6 +514,7 @@ int me_resid_ln_fwd(const void* x, const void* a, const float* gamma, const floa
 int me_resid_ln_bwd(const void* dy, const void* s, const float* stats, const float* gamma, void* dx, void* da,
                     float* dgamma, float* dbeta, int rows, int d, float p, uint64_t seed, uint32_t site, int dtype,
                     void* stream) {
+    me_clear_error();
     if (!dy || !s || !stats || !gamma || !dx || !da || !dgamma || !dbeta) return ME_ERR_NULL;
     if (rows <= 0) return ME_OK;
     const int ch = dtype == ME_F32 ? 4 : 8;
@@ -525,6 +530,7 @@ int me_resid_ln_bwd(const void* dy, const void* s, const float* stats, const flo
 
 int me_ce_fwd(const float* logits, int ld, const int64_t* target, float* row_lse, float* loss_sum, float* n_valid,
               int rows, int V, int ignore_index, void* stream) {
+    me_clear_error();
     if (!logits || !target || !loss_sum || !n_valid) return ME_ERR_NULL;
     if (rows <= 0) return ME_OK;
     if (V <= 0 || ld < V) return ME_ERR_BAD_SHAPE;
@@ -534,6 +540,7 @@ int me_ce_fwd(const float* logits, int ld, const int64_t* target, float* row_lse
 
 int me_ce_bwd(const float* logits, int ld, const int64_t* target, const float* row_lse, void* dlogits, int ld_d,
               const float* n_valid, float extra_scale, int rows, int V, int ignore_index, int dtype, void* stream) {
+    me_clear_error();
     if (!logits || !target || !row_lse || !dlogits || !n_valid) return ME_ERR_NULL;
     if (rows <= 0) return ME_OK;
     if (V <= 0 || ld < V || ld_d < V) return ME_ERR_BAD_SHAPE;
@@ -544,6 +551,7 @@ int me_ce_bwd(const float* logits, int ld, const int64_t* target, const float* r
 }
 
 int me_sumsq(const float* g, int64_t n, float* out, void* stream) {
+    me_clear_error();
     if (!g || !out) return ME_ERR_NULL;
     if (n <= 0) return ME_OK;
     if (!aligned16(g)) return ME_ERR_ALIGNMENT;
@@ -557,6 +565,7 @@ int me_sumsq(const float* g, int64_t n, float* out, void* stream) {
 int me_adamw_step(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq, float clip, float grad_scale,
                   float lr, float beta1, float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,
                   int zero_grad, void* stream) {
+    me_clear_error();
     if (!p || !g || !m || !v) return ME_ERR_NULL;
     if (n <= 0) return ME_OK;
     if (clip > 0.f && !sumsq) return ME_ERR_NULL;
@@ -571,6 +580,7 @@ int me_adamw_step(float* p, float* g, float* m, float* v, int64_t n, const float
 
 int me_greedy_pick(const float* logits, int ld, int V, const int32_t* special, int n_special, int64_t* out_ids, int B,
                    void* stream) {
+    me_clear_error();
     if (!logits || !out_ids || (n_special > 0 && !special)) return ME_ERR_NULL;
     if (B <= 0) return ME_OK;
     greedy_pick_kernel<<<B, 256, 0, (hipStream_t)stream>>>(logits, ld, V, special, n_special, out_ids);

@@ -323,6 +323,7 @@ int me_abi_version(void) { return ME_ABI_VERSION; }
 
 int me_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias, const void* add,
                int ldadd, const void* gate, int ldgate, int M, int N, int K, int flags, int dtype, void* stream) {
+    me_clear_error();
     if (!A || !B || !C) return ME_ERR_NULL;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == ME_F32) return gemm_nt_launch<float>(A, lda, B, ldb, C, ldc, bias, add, ldadd, gate, ldgate, M, N, K, flags, st);
@@ -332,6 +333,7 @@ int me_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
 
 int me_gemm_tn_acc(const void* A, int lda, const void* B, int ldb, float* dW, int lddw, float* dbias, int T, int N,
                    int K, int dtype, void* stream) {
+    me_clear_error();
     if (!A || !B || !dW) return ME_ERR_NULL;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == ME_F32) return gemm_tn_launch<float>(A, lda, B, ldb, dW, lddw, dbias, T, N, K, st);
@@ -341,6 +343,7 @@ int me_gemm_tn_acc(const void* A, int lda, const void* B, int ldb, float* dW, in
 
 int me_cast_transpose(const float* src, int rows, int cols, void* dst, int ld_dst, void* dstT, int ld_dstT,
                       int dtype, void* stream) {
+    me_clear_error();
     if (!src || (!dst && !dstT)) return ME_ERR_NULL;
     if (rows <= 0 || cols <= 0) return ME_ERR_BAD_SHAPE;
     hipStream_t st = (hipStream_t)stream;
@@ -356,6 +359,7 @@ int me_cast_transpose(const float* src, int rows, int cols, void* dst, int ld_ds
 
 int me_gemv_small(const void* x, int ldx, const void* W, int ldw, const float* bias, void* y, int ldy, int Mr, int N,
                   int K, int flags, int dtype, void* stream) {
+    me_clear_error();
     if (!x || !W || !y) return ME_ERR_NULL;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == ME_F32) return gemv_launch<float>(x, ldx, W, ldw, bias, y, ldy, Mr, N, K, flags, st);
