@@ -23,6 +23,10 @@
 // untransposed tile for the same reason with key as the lane-owned index.
 #include "me_common.h"
 
+#ifndef ME_ABL
+#define ME_ABL 0
+#endif
+
 namespace {
 
 constexpr int LDG = 36;   // G ring row (floats): 32 + 4 -> conflict-free b128 writes, b32 skew reads
@@ -130,14 +134,21 @@ template <> ME_DEV void st4<float>(float* p, float a, float b, float c, float d)
 // =====================================================================================
 // forward
 // =====================================================================================
+// Per key tile and wave: 4 (K.Q) + 4 (new E block . Q) + 4 (V^T.P^T) macro-atoms.  K / V^T tiles
+// are double buffered in LDS (one barrier per step; the next tile's global loads are in
+// flight during the whole step), the E fragments of the NEXT step's new block are fetched
+// into registers right after the current block's MFMAs were issued, the pad flags travel
+// with the tile, and tiles that need no masking (not diagonal, no pad, not the ragged tail)
+// skip all per-element predicates.  Softmax runs in the exp2 domain.
 template <typename T, int DH>
 __global__ __launch_bounds__(256) void rga_fwd_kernel(const T* __restrict__ qkv, const T* __restrict__ E,
                                                       const uint8_t* __restrict__ key_pad, T* __restrict__ out,
                                                       float* __restrict__ lse, int B, int L, int H, int M, float scale) {
     using C = ACfg<T, DH>;
-    __shared__ __attribute__((aligned(16))) T Ks[32 * C::LDN];
-    __shared__ __attribute__((aligned(16))) T Vt[DH * LDT];
+    __shared__ __attribute__((aligned(16))) T Ks[2][32 * C::LDN];
+    __shared__ __attribute__((aligned(16))) T Vt[2][DH * LDT];
     __shared__ __attribute__((aligned(16))) float Gs[4][2][32 * LDG];
+    __shared__ uint32_t Ps[2][32];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, a = lane & 31, h = lane >> 5;
     const int nqb = (L + 127) / 128;
@@ -153,6 +164,7 @@ __global__ __launch_bounds__(256) void rga_fwd_kernel(const T* __restrict__ qkv,
     const bool wave_on = q0 < L;
     const int nkt = min((L + 31) / 32, qb * 4 + 4);
     const int my_last_kt = qb * 4 + wid;            // diagonal tile of this wave
+    const float c2 = scale * 1.4426950408889634f;   // logits are kept in log2 units
 
     Frag<T> qf[C::KA];
     row_frags<T, DH>(qf, qb_ + (size_t)q * ldq, wave_on && q < L, h);
@@ -163,88 +175,138 @@ __global__ __launch_bounds__(256) void rga_fwd_kernel(const T* __restrict__ qkv,
     float m_run = -INFINITY, l_run = 0.f;
 
     chunk16 rk[C::NPT], rv[C::NPT];
-    tile_gload_co<T, DH>(rk, kb_, ldq, 0, L, tid);
-    tile_gload_rw<T, DH>(rv, vb_, ldq, 0, L, tid);
+    uint32_t rp = 0;
+    auto gload = [&](int kt) {
+        tile_gload_co<T, DH>(rk, kb_, ldq, kt * 32, L, tid);
+        tile_gload_rw<T, DH>(rv, vb_, ldq, kt * 32, L, tid);
+        if (key_pad && tid < 32) { const int key = kt * 32 + tid; rp = key < L ? key_pad[(size_t)b * L + key] : 0; }
+    };
+    auto sstore = [&](int buf) {
+        tile_sstore_nat_co<T, DH>(rk, Ks[buf], tid);
+        tile_sstore_tr_rw<T, DH>(rv, Vt[buf], tid);
+        if (key_pad && tid < 32) Ps[buf][tid] = rp;
+    };
+    auto g_block = [&](const Frag<T>* ef, int eb) {     // G^T[m][q] = E[eb*32+m] . Q[q] -> ring slot eb&1
+        f32x16_t g; acc_zero(g);
+#pragma unroll
+        for (int kk = 0; kk < C::KA; ++kk) mma32(g, ef[kk], qf[kk]);
+        float* gs = &Gs[wid][eb & 1][a * LDG];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+            *reinterpret_cast<f32x4_t*>(gs + 8 * gq + 4 * h) = (f32x4_t){g[4 * gq], g[4 * gq + 1], g[4 * gq + 2], g[4 * gq + 3]};
+    };
+
+    gload(0);
+    // E blocks of step 0: lo now, hi prefetched (not needed if step 0 is already the diagonal)
+    const int eb0 = (M - 32 - q0) >> 5;
+    Frag<T> ef[C::KA];
+    if (wave_on) {
+        row_frags<T, DH>(ef, E + (size_t)(eb0 * 32 + a) * DH, true, h);
+        g_block(ef, eb0);
+        if (my_last_kt > 0) row_frags<T, DH>(ef, E + (size_t)((eb0 + 1) * 32 + a) * DH, true, h);
+    }
+    sstore(0);
+    if (nkt > 1) gload(1);
+    __syncthreads();
 
     for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();
-        tile_sstore_nat_co<T, DH>(rk, Ks, tid);
-        tile_sstore_tr_rw<T, DH>(rv, Vt, tid);
-        __syncthreads();
-        if (kt + 1 < nkt) {
-            tile_gload_co<T, DH>(rk, kb_, ldq, (kt + 1) * 32, L, tid);
-            tile_gload_rw<T, DH>(rv, vb_, ldq, (kt + 1) * 32, L, tid);
-        }
-        if (!wave_on || kt > my_last_kt) continue;
-
-        const int k0 = kt * 32;
-        const bool diag = kt == my_last_kt;
-        const int eb_lo = (M - 32 - q0 + k0) >> 5;
-        // ---- new block(s) of G^T[m][q] = E[eb*32+m] . Q[q]  -> LDS ring slot (eb & 1)
-        for (int w = (kt == 0 ? 0 : 1); w < (diag ? 1 : 2); ++w) {
-            const int eb = eb_lo + w;
-            f32x16_t g; acc_zero(g);
-            const T* erow = E + (size_t)(eb * 32 + a) * DH;
+        const int buf = kt & 1;
+        if (wave_on && kt <= my_last_kt) {
+            const int k0 = kt * 32;
+            const bool diag = kt == my_last_kt;
+            const int eb_lo = eb0 + kt;
+#if ME_ABL != 1
+            if (!diag) {
+                g_block(ef, eb_lo + 1);
+                if (kt + 1 < my_last_kt) row_frags<T, DH>(ef, E + (size_t)((eb_lo + 2) * 32 + a) * DH, true, h);
+            }
+#endif
+            // ---- S^T[key][q] = K[key] . Q[q]
+            f32x16_t s; acc_zero(s);
 #pragma unroll
             for (int kk = 0; kk < C::KA; ++kk) {
-                Frag<T> ef; frag_load(ef, erow + kk * 16 + h * 8);
-                mma32(g, ef, qf[kk]);
+                Frag<T> kf; frag_load(kf, &Ks[buf][a * C::LDN + kk * 16 + h * 8]);
+                mma32(s, kf, qf[kk]);
             }
-            float* gs = &Gs[wid][eb & 1][a * LDG];
+            // ---- + Srel (skewed read), log2-scale, mask, online softmax (lane owns query q)
+            uint32_t pbits = 0;
+            if (key_pad) pbits = __builtin_amdgcn_readfirstlane((uint32_t)__ballot(lane < 32 && Ps[buf][a] != 0));
+            const float* glo = &Gs[wid][eb_lo & 1][a * LDG];
+            const float* ghi = &Gs[wid][(eb_lo + 1) & 1][a * LDG];
+            const int mbase = 31 - a + 4 * h;
+            float mt = -INFINITY;
+            if (!diag && pbits == 0u && k0 + 32 <= L) {
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq)
-                *reinterpret_cast<f32x4_t*>(gs + 8 * gq + 4 * h) = (f32x4_t){g[4 * gq], g[4 * gq + 1], g[4 * gq + 2], g[4 * gq + 3]};
-        }
-        // ---- S^T[key][q] = K[key] . Q[q]
-        f32x16_t s; acc_zero(s);
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);
+#if ME_ABL == 1 || ME_ABL == 6
+                    const float g = 0.f;
+#else
+                    const float g = m < 32 ? glo[m] : ghi[m - 32];
+#endif
+                    s[r] = (s[r] + g) * c2;
+                    mt = fmaxf(mt, s[r]);
+                }
+            } else {
 #pragma unroll
-        for (int kk = 0; kk < C::KA; ++kk) {
-            Frag<T> kf; frag_load(kf, &Ks[a * C::LDN + kk * 16 + h * 8]);
-            mma32(s, kf, qf[kk]);
-        }
-        // ---- + Srel (skewed read), scale, mask, online softmax (lane owns query q)
-        const uint32_t pbits = pad_bits(key_pad, b, L, k0, lane);
-        float mt = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int bk = c_row(r, lane), key = k0 + bk;
-            const int m = 31 - a + bk;
-            const bool masked = key > q || key >= L || ((pbits >> bk) & 1u);
-            float v = -INFINITY;
-            if (!masked) v = (s[r] + Gs[wid][(eb_lo + (m >> 5)) & 1][a * LDG + (m & 31)]) * scale;
-            s[r] = v;
-            mt = fmaxf(mt, v);
-        }
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        const float m_new = fmaxf(m_run, mt);
-        const float m_safe = m_new == -INFINITY ? 0.f : m_new;
-        const float alpha = ET<T>::fexp(m_run - m_safe);
-        float rs = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = ET<T>::fexp(s[r] - m_safe); rs += s[r]; }
-        l_run = l_run * alpha + rs;
-        m_run = m_new;
-#pragma unroll
-        for (int i = 0; i < C::DB; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-        // ---- O^T[d][q] += V^T[d][key] . P^T[key][q]
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            Frag<T> pf; frag_from_acc(pf, s, t);
-#pragma unroll
-            for (int i = 0; i < C::DB; ++i) {
-                Frag<T> vf;
-                const T* vp = &Vt[(i * 32 + a) * LDT + 16 * t + 4 * h];
-                frag_load_4x2(vf, vp, vp + 8);
-                mma32(o[i], vf, pf);
+                for (int r = 0; r < 16; ++r) {
+                    const int bk = (r & 3) + 8 * (r >> 2) + 4 * h, key = k0 + bk;
+                    const int m = 31 - a + bk;
+                    const bool masked = key > q || key >= L || ((pbits >> bk) & 1u);
+                    float v = -INFINITY;
+                    if (!masked) v = (s[r] + (m < 32 ? glo[m] : ghi[m - 32])) * c2;
+                    s[r] = v;
+                    mt = fmaxf(mt, v);
+                }
             }
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+            const float m_new = fmaxf(m_run, mt);
+            const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+            const float alpha = exp2f(m_run - m_safe);
+            float rs = 0.f;
+#pragma unroll
+#if ME_ABL == 2
+            for (int r = 0; r < 16; ++r) { s[r] = (s[r] - m_safe); rs += s[r]; }
+#else
+            for (int r = 0; r < 16; ++r) { s[r] = exp2f(s[r] - m_safe); rs += s[r]; }
+#endif
+            l_run = l_run * alpha + rs;
+            m_run = m_new;
+#pragma unroll
+            for (int i = 0; i < C::DB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+            // ---- O^T[d][q] += V^T[d][key] . P^T[key][q]
+#if ME_ABL == 3
+            o[0][0] += s[0] + s[15];
+#else
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                Frag<T> pf; frag_from_acc(pf, s, t);
+#pragma unroll
+                for (int i = 0; i < C::DB; ++i) {
+                    Frag<T> vf;
+                    const T* vp = &Vt[buf][(i * 32 + a) * LDT + 16 * t + 4 * h];
+                    frag_load_4x2(vf, vp, vp + 8);
+                    mma32(o[i], vf, pf);
+                }
+            }
+#endif
         }
+#if ME_ABL != 4
+        if (kt + 1 < nkt) {
+            sstore(buf ^ 1);                      // buf^1 was last read in step kt-1 (barrier since)
+            if (kt + 2 < nkt) gload(kt + 2);
+        }
+#endif
+#if ME_ABL != 5
+        __syncthreads();
+#endif
     }
     if (!wave_on || q >= L) return;
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.f / l_tot;
-    if (h == 0) lse[((size_t)b * H + head) * L + q] = m_run + logf(l_tot);
+    if (h == 0) lse[((size_t)b * H + head) * L + q] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
     T* op = out + ((size_t)b * L + q) * dm + head * DH;
 #pragma unroll
     for (int i = 0; i < C::DB; ++i)

@@ -7,7 +7,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmidiemo_hip.so")
+LIB_PATH = os.environ.get("MIDIEMO_LIB") or os.path.join(HERE, "libmidiemo_hip.so")
 
 ME_F32, ME_BF16 = 0, 1
 ME_COND_NONE, ME_COND_CONCAT, ME_COND_TOKEN = 0, 1, 2

@@ -1,0 +1,228 @@
+"""train.py -- training driver for the emotion-conditioned Music Transformer on MI355X.
+
+Keeps the reference's CLI surface (src/config.py flag names/defaults) and train-loop
+semantics (src/train.py:294-333: CrossEntropyLoss(ignore_index=pad), gradient
+accumulation, global-norm clip, Adam(lr), LR warm-up, periodic log/checkpoint/eval) and
+checkpoint files (model.pt / optimizer.pt / stats.pt / model_config.pt / mappings.pt,
+train.py:180,397-407) -- but the step itself runs on the HIP engine:
+
+    loss = model.loss_and_backward(x, cond, y)      # fwd + CE + bwd, flat f32 grads
+    reducer.finish()                                # RCCL all-reduce buckets (overlapped with bwd)
+    opt.step()                                      # fused clip + AdamW (weight_decay 0 == Adam)
+
+Data: the Lakh/Spotify pipeline (src/data, src/create_dataset) is outside the accelerated
+path and its dataset is not shipped; `--synthetic` (default) draws the synthetic batches
+defined in SURVEY 8d.  One process per GPU: launch with
+    python -m torch.distributed.run --nproc-per-node N train.py ...
+Deviations from the reference, on purpose: bf16 (no GradScaler) instead of fp16 autocast;
+`loss.item()` is only read every --log_step (the reference syncs every step, train.py:308);
+schedulers `cosine`/`inv_sqrt` are implemented (the reference never constructs them,
+train.py:129 tests for '--').
+"""
+import argparse
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "midi-emotion_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description="Generates emotion-based symbolic music (MI355X engine)")
+    # ---- reference flags (config.py:7-113), same names and defaults
+    p.add_argument("--conditioning", type=str, default="continuous_concat",
+                   choices=["none", "discrete_token", "continuous_token", "continuous_concat"])
+    p.add_argument("--n_layer", type=int, default=20)
+    p.add_argument("--n_head", type=int, default=16)
+    p.add_argument("--d_model", type=int, default=768)
+    p.add_argument("--d_condition", type=int, default=192)
+    p.add_argument("--d_inner", type=int, default=768 * 4)
+    p.add_argument("--tgt_len", type=int, default=1216)
+    p.add_argument("--dropout", type=float, default=0.1)
+    p.add_argument("--lr", type=float, default=2e-5)
+    p.add_argument("--scheduler", default="constant", choices=["cosine", "inv_sqrt", "constant"])
+    p.add_argument("--warmup_step", type=int, default=0)
+    p.add_argument("--clip", type=float, default=1.0)
+    p.add_argument("--batch_size", type=int, default=4, help="sequences per GPU")
+    p.add_argument("--accumulate_step", type=int, default=1)
+    p.add_argument("--seed", type=int, default=-1)
+    p.add_argument("--log_step", type=int, default=1000)
+    p.add_argument("--eval_step", type=int, default=8000)
+    p.add_argument("--max_eval_step", type=int, default=1000)
+    p.add_argument("--work_dir", default="../output", type=str)
+    p.add_argument("--restart_dir", type=str, default=None)
+    p.add_argument("--debug", action="store_true", help="do not write files")
+    p.add_argument("--max_step", type=int, default=1000000000)
+    p.add_argument("--n_emotion_bins", type=int, default=5)
+    p.add_argument("--no_amp", action="store_true", help="exact-f32 engine tier instead of bf16")
+    p.add_argument("--overwrite_lr", action="store_true")
+    p.add_argument("--regression", action="store_true")
+    # ---- additions
+    p.add_argument("--synthetic", action="store_true", default=True, help="synthetic token batches (SURVEY 8d)")
+    p.add_argument("--weight_decay", type=float, default=0.0, help="decoupled decay; 0 == reference Adam")
+    args = p.parse_args(argv)
+    if args.conditioning != "continuous_concat":
+        args.d_condition = -1                                  # config.py:120-121
+    if args.regression:
+        raise SystemExit("--regression (evaluation-only model) is outside this build's hot path")
+    return args
+
+
+def synthetic_batch(args, V, B, L, seed, device):
+    """SURVEY 8d synthetic inputs for every conditioning mode."""
+    g = torch.Generator().manual_seed(seed)
+    if args.conditioning == "continuous_token":
+        tok = torch.randint(2, V, (B, L - 1), generator=g)
+        inp, tgt = tok[:, :-1], torch.nn.functional.pad(tok[:, 1:], (2, 0), value=0)   # loader.py:55-57,184-187
+    else:
+        tok = torch.randint(2, V, (B, L + 1), generator=g)
+        if args.conditioning == "discrete_token":
+            tok[:, 0] = torch.randint(1007, 1007 + args.n_emotion_bins, (B,), generator=g)
+            tok[:, 1] = torch.randint(1007 + args.n_emotion_bins, 1007 + 2 * args.n_emotion_bins, (B,), generator=g)
+        inp, tgt = tok[:, :-1], tok[:, 1:]
+    if args.conditioning in ("continuous_token", "continuous_concat"):
+        cond = torch.rand(B, 2, generator=g) * 2 - 1
+    else:
+        cond = torch.full((B, 2), float("nan"))
+    return inp.contiguous().to(device), cond.to(device), tgt.contiguous().to(device)
+
+
+def lr_at(args, step):
+    """Warm-up (train.py:327-331) then the schedule."""
+    if args.scheduler == "constant":
+        return args.lr
+    if args.warmup_step > 0 and step <= args.warmup_step:
+        return args.lr * step / args.warmup_step
+    if args.scheduler == "cosine":
+        return 0.5 * args.lr * (1 + math.cos(math.pi * min(1.0, step / max(1, args.max_step))))
+    return args.lr / math.sqrt(max(1.0, step / max(1, args.warmup_step)))      # inv_sqrt
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("train.py: the MI355X engine needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from midiemo.ddp import GradAllReducer, broadcast_params
+    from midiemo.models.build_model import build_model
+    from midiemo.optim import FusedAdamW
+    from midiemo.vocab import get_maps
+
+    torch.manual_seed(args.seed if args.seed > 0 else 0)
+    maps = get_maps(n_emotion_bins=args.n_emotion_bins if args.conditioning == "discrete_token" else 0)
+    V = len(maps["tuple2idx"])
+    pad_idx = maps["tuple2idx"]["<PAD>"]
+    config = dict(vars(args), vocab_size=V, compute_dtype="fp32" if args.no_amp else "bf16")
+    work_dir = os.path.join(args.work_dir, ("DEBUG_" if args.debug else "") + time.strftime("%Y%m%d-%H%M%S"))
+    restart = os.path.join(args.work_dir, args.restart_dir) if args.restart_dir else None
+    if restart:
+        config = torch.load(os.path.join(restart, "model_config.pt"))
+        model, _ = build_model(None, load_config_dict=config)
+        model.load_state_dict(torch.load(os.path.join(restart, "model.pt"), map_location="cpu"))
+        work_dir = restart
+    else:
+        model, config = build_model(config)
+    model = model.to(device).train()
+    broadcast_params(model.flat_params)
+    model.mark_params_changed()
+    model.seed_dropout((args.seed if args.seed > 0 else 0) * 1000 + rank)
+    opt = FusedAdamW(model, lr=args.lr, clip=args.clip, weight_decay=args.weight_decay)
+    stats = {"step": 0, "hour": 0.0, "epoch": 0, "sample": 0}
+    if restart:
+        try:
+            opt.load_state_dict(torch.load(os.path.join(restart, "optimizer.pt"), map_location=device))
+            stats = torch.load(os.path.join(restart, "stats.pt"))
+        except Exception as e:                                  # reference tolerates missing files (train.py:187-211)
+            print("optimizer/stats not restored:", e)
+        if args.overwrite_lr:
+            opt.param_groups[0]["lr"] = args.lr
+    reducer = GradAllReducer(lambda: model.flat_grads, model.bucket_ranges())
+    if rank == 0 and not args.debug:
+        os.makedirs(work_dir, exist_ok=True)
+        torch.save(config, os.path.join(work_dir, "model_config.pt"))      # train.py:180
+        torch.save(maps, os.path.join(work_dir, "mappings.pt"))            # train.py:114
+    n_params = sum(p.numel() for p in model.parameters())
+    if rank == 0:
+        print(f"#params = {n_params}  world = {world}  dtype = {config['compute_dtype']}  work_dir = {work_dir}")
+
+    B, L = args.batch_size, args.tgt_len
+    step = stats["step"]
+    micro = 0
+    loss_acc = torch.zeros((), device=device)
+    n_acc = 0
+    t0 = time.time()
+    tok_per_micro = world * B * L
+
+    def evaluate():
+        model.eval()
+        tot = torch.zeros((), device=device)
+        n = min(args.max_eval_step, 8)
+        with torch.no_grad():
+            for i in range(n):
+                x, c, y = synthetic_batch(args, V, B, L, 10_000_019 + i * 31 + rank, device)
+                tot += model.loss_and_backward(x, c, y, backward=False)
+        model.train()
+        if world > 1:
+            dist.all_reduce(tot)
+            tot /= world
+        return float(tot.item()) / n
+
+    try:
+        while step < args.max_step:
+            x, c, y = synthetic_batch(args, V, B, L, 1234 + rank + 7919 * (step * args.accumulate_step + micro), device)
+            last = (micro + 1) % args.accumulate_step == 0
+            # every micro-batch contributes grad/accumulate_step (train.py:309); buckets are exchanged on the last one
+            loss = model.loss_and_backward(x, c, y, grad_scale=1.0 / args.accumulate_step,
+                                           bucket_hook=reducer.hook if (last and world > 1) else None)
+            loss_acc += loss.detach()
+            n_acc += 1
+            micro += 1
+            if not last:
+                continue
+            micro = 0
+            reducer.finish()
+            step += 1
+            opt.param_groups[0]["lr"] = lr_at(args, step)
+            opt.step(grad_scale=reducer.grad_scale)
+            if step % args.log_step == 0 or step == args.max_step:
+                cur = float(loss_acc.item()) / max(n_acc, 1)                 # the only host sync
+                el = time.time() - t0
+                if rank == 0:
+                    print("| step {:>8d} | lr {:.3e} | ms/batch {:7.2f} | tok/s {:10.0f} | loss {:7.4f} | ppl {:9.3f}".format(
+                        step, opt.param_groups[0]["lr"], 1000 * el / max(n_acc, 1), n_acc * tok_per_micro / el, cur,
+                        math.exp(min(cur, 20))))
+                    if not args.debug:
+                        stats.update(step=step, hour=stats["hour"] + el / 3600)
+                        torch.save(model.state_dict(), os.path.join(work_dir, "model.pt"))
+                        torch.save(opt.state_dict(), os.path.join(work_dir, "optimizer.pt"))
+                        torch.save(stats, os.path.join(work_dir, "stats.pt"))
+                loss_acc.zero_()
+                n_acc = 0
+                t0 = time.time()
+            if step % args.eval_step == 0:
+                v = evaluate()
+                if rank == 0:
+                    print("| eval at step {:>8d} | valid loss {:7.4f} | ppl {:9.3f}".format(step, v, math.exp(min(v, 20))))
+    except KeyboardInterrupt:
+        print("Exiting from training early")
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
