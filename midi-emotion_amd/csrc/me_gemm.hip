@@ -12,11 +12,29 @@ namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32, NTHREADS = 256;
 
+// Optional second output of gemm_nt: a head-major TRANSPOSED copy of C,
+//   CT[s][b][head][dd][l]  for  column n = s*(H*dh) + head*dh + dd,  row t = b*L + l,
+// leading dimension Lp (>= L, multiple of 32; the padding is never written).  In the MFMA
+// accumulator layout a lane owns one column and 4 consecutive rows per register quad, so
+// this store is the natural one (8/16 bytes per lane).  It feeds the attention kernels
+// their contraction-contiguous K^T / V^T / Q^T / dO^T operands without any LDS transpose.
+template <typename T> ME_DEV void st4_t(T* p, float a, float b, float c, float d);
+template <> ME_DEV void st4_t<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+    bf16x4_t v; v[0] = (bf16_t)a; v[1] = (bf16_t)b; v[2] = (bf16_t)c; v[3] = (bf16_t)d;
+    *reinterpret_cast<bf16x4_t*>(p) = v;
+}
+template <> ME_DEV void st4_t<float>(float* p, float a, float b, float c, float d) { *reinterpret_cast<f32x4_t*>(p) = (f32x4_t){a, b, c, d}; }
+
+struct HeadT {
+    void* ptr;
+    int Bn, L, H, dh, Lp;
+};
+
 template <typename T, bool OUT_F32>
 __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(
     const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc,
     const float* __restrict__ bias, const T* __restrict__ add, int ldadd, const T* __restrict__ gate, int ldgate,
-    int M, int N, int K, int flags) {
+    int M, int N, int K, int flags, HeadT ht) {
     constexpr int CH = ET<T>::CH;
     constexpr int CPR = BK / CH;           // chunks per tile row
     constexpr int LDK = BK + CH;           // padded LDS row (elements)
@@ -83,6 +101,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(
             const int col = n0 + wc * 64 + j * 32 + c_col(lane);
             if (col >= N) continue;
             const float bv = bias ? bias[col] : 0.f;
+            float vals[16];
+            size_t tcol = 0;                 // offset of this column inside one batch of CT (without s,b terms)
+            int sec = 0;
+            if (ht.ptr) {
+                const int dm = ht.H * ht.dh;
+                sec = col / dm;
+                tcol = (size_t)(col - sec * dm) * ht.Lp;       // (head*dh + dd) * Lp
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wr * 64 + i * 32 + c_row(r, lane);
@@ -93,6 +119,26 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(
                 if (gate) v = ET<T>::to_f(gate[(size_t)row * ldgate + col]) > 0.f ? v : 0.f;
                 if (OUT_F32) reinterpret_cast<float*>(Cv)[(size_t)row * ldc + col] = v;
                 else reinterpret_cast<T*>(Cv)[(size_t)row * ldc + col] = ET<T>::from_f(v);
+                vals[r] = v;
+            }
+            if (ht.ptr) {
+                const size_t per_b = (size_t)ht.H * ht.dh * ht.Lp;
+                T* base = reinterpret_cast<T*>(ht.ptr) + (size_t)sec * ht.Bn * per_b + tcol;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int row0 = m0 + wr * 64 + i * 32 + 8 * g + 4 * (lane >> 5);   // 4 consecutive tokens
+                    if (row0 >= M) continue;
+                    const int b0 = row0 / ht.L, l0 = row0 - b0 * ht.L;
+                    if (row0 + 3 < M && l0 + 3 < ht.L && (l0 & 3) == 0) {
+                        st4_t<T>(base + (size_t)b0 * per_b + l0, vals[4 * g], vals[4 * g + 1], vals[4 * g + 2], vals[4 * g + 3]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int rr = row0 + e;
+                            if (rr < M) { const int bb = rr / ht.L; base[(size_t)bb * per_b + (rr - bb * ht.L)] = ET<T>::from_f(vals[4 * g + e]); }
+                        }
+                    }
+                }
             }
         }
 }
@@ -260,7 +306,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 template <typename T>
 int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
                    const void* add, int ldadd, const void* gate, int ldgate, int M, int N, int K, int flags,
-                   hipStream_t st) {
+                   hipStream_t st, HeadT ht = HeadT{nullptr, 0, 1, 1, 1, 0}) {
     constexpr int CH = ET<T>::CH;
     if (M <= 0 || N <= 0 || K <= 0) return ME_ERR_BAD_SHAPE;
     if (K % CH || lda % CH || ldb % CH) return ME_ERR_BAD_SHAPE;
@@ -268,10 +314,10 @@ int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int 
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM);
     if (flags & ME_EPI_OUT_F32)
         gemm_nt_kernel<T, true><<<grid, NTHREADS, 0, st>>>((const T*)A, lda, (const T*)B, ldb, C, ldc, bias,
-                                                          (const T*)add, ldadd, (const T*)gate, ldgate, M, N, K, flags);
+                                                          (const T*)add, ldadd, (const T*)gate, ldgate, M, N, K, flags, ht);
     else
         gemm_nt_kernel<T, false><<<grid, NTHREADS, 0, st>>>((const T*)A, lda, (const T*)B, ldb, C, ldc, bias,
-                                                           (const T*)add, ldadd, (const T*)gate, ldgate, M, N, K, flags);
+                                                           (const T*)add, ldadd, (const T*)gate, ldgate, M, N, K, flags, ht);
     return me_launch_status();
 }
 
@@ -328,6 +374,20 @@ int me_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
     hipStream_t st = (hipStream_t)stream;
     if (dtype == ME_F32) return gemm_nt_launch<float>(A, lda, B, ldb, C, ldc, bias, add, ldadd, gate, ldgate, M, N, K, flags, st);
     if (dtype == ME_BF16) return gemm_nt_launch<bf16_t>(A, lda, B, ldb, C, ldc, bias, add, ldadd, gate, ldgate, M, N, K, flags, st);
+    return ME_ERR_BAD_DTYPE;
+}
+
+int me_gemm_nt_headT(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias, const void* add,
+                     int ldadd, void* CT, int Bn, int L, int H, int dh, int Lp, int M, int N, int K, int flags, int dtype,
+                     void* stream) {
+    me_clear_error();
+    if (!A || !B || !C || !CT) return ME_ERR_NULL;
+    if (Bn <= 0 || L <= 0 || H <= 0 || dh <= 0 || Lp < L || M != Bn * L || N % (H * dh) || (flags & ME_EPI_OUT_F32))
+        return ME_ERR_BAD_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    HeadT ht{CT, Bn, L, H, dh, Lp};
+    if (dtype == ME_F32) return gemm_nt_launch<float>(A, lda, B, ldb, C, ldc, bias, add, ldadd, nullptr, 0, M, N, K, flags, st, ht);
+    if (dtype == ME_BF16) return gemm_nt_launch<bf16_t>(A, lda, B, ldb, C, ldc, bias, add, ldadd, nullptr, 0, M, N, K, flags, st, ht);
     return ME_ERR_BAD_DTYPE;
 }
 
