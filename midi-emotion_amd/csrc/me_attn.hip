@@ -32,6 +32,10 @@
 // zero-initialised once (rows q >= L and the unreachable corner stay zero).
 #include "me_common.h"
 
+#ifndef ME_ABL
+#define ME_ABL 0
+#endif
+
 namespace {
 
 constexpr int LDG = 36;   // G ring row (floats): 32 + 4 -> conflict-free b128 writes, b32 skew reads
@@ -267,19 +271,19 @@ __global__ __launch_bounds__(256) void rga_fwd_kernel(const T* __restrict__ qkv,
 // backward 1/3 (query-owned): delta, dQ, and the materialised P^T, dS^T, dG^T
 // =====================================================================================
 template <typename T, int DH>
-__global__ __launch_bounds__(256) void rga_bwd_q_kernel(
+__global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
     const T* __restrict__ qkv, const T* __restrict__ kT, const T* __restrict__ E, const T* __restrict__ ET_,
     const uint8_t* __restrict__ key_pad, const T* __restrict__ out, const float* __restrict__ lse,
     const T* __restrict__ dout, T* __restrict__ dqkv, float* __restrict__ delta_ws, T* __restrict__ PT,
     T* __restrict__ dST, T* __restrict__ dGT, int B, int L, int Lp, int H, int M, float scale) {
     using C = ACfg<T, DH>;
     constexpr int LDR = 40;                         // dG ring row (elements of T)
-    __shared__ __attribute__((aligned(16))) T Ks[2][32 * C::LDN];
-    __shared__ __attribute__((aligned(16))) T Vs[2][32 * C::LDN];
-    __shared__ __attribute__((aligned(16))) T Kt[2][DH * LDT];
+    __shared__ __attribute__((aligned(16))) T Ks[1][32 * C::LDN];
+    __shared__ __attribute__((aligned(16))) T Vs[1][32 * C::LDN];
+    __shared__ __attribute__((aligned(16))) T Kt[1][DH * LDT];
     __shared__ __attribute__((aligned(16))) float Gs[4][2][32 * LDG];
     __shared__ __attribute__((aligned(16))) T Ds[4][2][32 * LDR];
-    __shared__ uint32_t Ps[2][32];
+    __shared__ uint32_t Ps[1][32];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, a = lane & 31, h = lane >> 5;
     const int nqb = (L + 127) / 128;
@@ -364,15 +368,16 @@ __global__ __launch_bounds__(256) void rga_bwd_q_kernel(
         row_frags<T, DH>(ef, E + (size_t)(eb0 * 32 + a) * DH, true, h);
         g_block(ef, eb0);
         if (my_last_kt > 0) row_frags<T, DH>(ef, E + (size_t)((eb0 + 1) * 32 + a) * DH, true, h);
-        et_frags(etf, eb0);
     }
-    sstore(0);
-    if (nkt > 1) gload(1);
-    __syncthreads();
-
     const size_t ws_bh = (size_t)bh * Lp * Lp;
+    // single LDS tile set (two barriers per step) keeps the block under 80 KB -> 2 blocks per CU;
+    // the next tile's global loads are still in flight during the whole compute phase
     for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
+        const int buf = 0;
+        __syncthreads();
+        sstore(0);
+        __syncthreads();
+        if (kt + 1 < nkt) gload(kt + 1);
         if (wave_on && kt <= my_last_kt) {
             const int k0 = kt * 32;
             const bool diag = kt == my_last_kt;
@@ -409,10 +414,10 @@ __global__ __launch_bounds__(256) void rga_bwd_q_kernel(
                 }
                 s[r] = ds;
                 dp[r] = p;
-                if (m < 32) dlo[m] = ET<T>::from_f(ds); else dhi[m - 32] = ET<T>::from_f(ds);
+                if (ME_ABL != 4) { if (m < 32) dlo[m] = ET<T>::from_f(ds); else dhi[m - 32] = ET<T>::from_f(ds); }
             }
             // ---- materialise P^T, dS^T rows [key][q] (32 lanes = 64/128 contiguous bytes per key row)
-            if (row_on) {
+            if (row_on && ME_ABL != 1) {
                 T* pt = PT + ws_bh + (size_t)k0 * Lp + q;
                 T* st = dST + ws_bh + (size_t)k0 * Lp + q;
 #pragma unroll
@@ -437,26 +442,21 @@ __global__ __launch_bounds__(256) void rga_bwd_q_kernel(
                 }
             }
             // ---- the lo block of dG is complete now: relative part of dQ and flush of dG^T
+            if (ME_ABL != 3) et_frags(etf, eb_lo);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 Frag<T> dgf;
                 frag_load_4x2(dgf, dlo + 16 * t + 4 * h, dlo + 16 * t + 8 + 4 * h);
 #pragma unroll
-                for (int i = 0; i < C::DB; ++i) mma32(dq[i], etf[i][t], dgf);
-                if (row_on) {
+                for (int i = 0; i < C::DB; ++i) { if (ME_ABL != 3) mma32(dq[i], etf[i][t], dgf); }
+                if (row_on && ME_ABL != 2) {
                     T* gt = dGT + ws_bh + (size_t)((cb0 + kt) * 32 + 16 * t + 4 * h) * Lp + q;
                     const T* ge = reinterpret_cast<const T*>(&dgf);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) gt[(size_t)((e & 3) + 8 * (e >> 2)) * Lp] = ge[e];
                 }
             }
-            if (!diag) et_frags(etf, eb_lo + 1);           // next step's lo block
         }
-        if (kt + 1 < nkt) {
-            sstore(buf ^ 1);
-            if (kt + 2 < nkt) gload(kt + 2);
-        }
-        __syncthreads();
     }
     if (!row_on) return;
     T* dqp = dqkv + ((size_t)b * L + q) * ldq + head * DH;
