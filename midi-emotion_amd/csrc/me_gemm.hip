@@ -6,11 +6,17 @@
 // Operands are staged global -> registers -> LDS (register prefetch of the next
 // K-slab overlaps the MFMA work of the current one); LDS rows are padded by one
 // 16-byte chunk so that the ds_read_b128 fragment reads are bank-conflict free.
+#include <stdlib.h>
+
 #include "me_common.h"
+
+#ifndef ME_GABL
+#define ME_GABL 0
+#endif
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32, NTHREADS = 256;
+constexpr int BM = 128, BN = 128, NTHREADS = 256;
 
 // Optional second output of gemm_nt: a head-major TRANSPOSED copy of C,
 //   CT[s][b][head][dd][l]  for  column n = s*(H*dh) + head*dh + dd,  row t = b*L + l,
@@ -30,21 +36,279 @@ struct HeadT {
     int Bn, L, H, dh, Lp;
 };
 
+ME_DEV void acc_zero_quad(f32x16_t& a, int g) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[4 * g + e] = 0.f;
+}
+
+// Epilogue of one TRANSPOSED 32x32 accumulator block (mfma(B, A)): lane = row of C, register
+// quad = 4 consecutive columns -> 8/16-byte row-contiguous stores and add/gate loads.
 template <typename T, bool OUT_F32>
+ME_DEV void epi_block_swapped(const f32x16_t& acc, int row_base, int col_base, int lane, void* Cv, int ldc,
+                              const float* bias, const T* add, int ldadd, const T* gate, int ldgate, int M, int N,
+                              bool relu) {
+    const int row = row_base + (lane & 31);
+    if (row >= M) return;
+    const bool vec_c = (ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(Cv) & 15) == 0;
+    const bool vec_add = add && (ldadd & 3) == 0 && (reinterpret_cast<uintptr_t>(add) & 15) == 0;
+    const bool vec_gate = gate && (ldgate & 3) == 0 && (reinterpret_cast<uintptr_t>(gate) & 15) == 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int col = col_base + 8 * g + 4 * (lane >> 5);
+        if (col >= N) continue;
+        float v[4];
+        const bool full = col + 3 < N;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = acc[4 * g + e] + ((bias && col + e < N) ? bias[col + e] : 0.f);
+            if (relu) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (add) {
+            const T* ap = add + (size_t)row * ldadd + col;
+            if (full && vec_add) {
+                T t4[4];
+                if constexpr (sizeof(T) == 2) *reinterpret_cast<uint64_t*>(t4) = *reinterpret_cast<const uint64_t*>(ap);
+                else *reinterpret_cast<f32x4_t*>(t4) = *reinterpret_cast<const f32x4_t*>(ap);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += ET<T>::to_f(t4[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (col + e < N) v[e] += ET<T>::to_f(ap[e]);
+            }
+        }
+        if (gate) {
+            const T* gp = gate + (size_t)row * ldgate + col;
+            if (full && vec_gate) {
+                T t4[4];
+                if constexpr (sizeof(T) == 2) *reinterpret_cast<uint64_t*>(t4) = *reinterpret_cast<const uint64_t*>(gp);
+                else *reinterpret_cast<f32x4_t*>(t4) = *reinterpret_cast<const f32x4_t*>(gp);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = ET<T>::to_f(t4[e]) > 0.f ? v[e] : 0.f;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (col + e < N) v[e] = ET<T>::to_f(gp[e]) > 0.f ? v[e] : 0.f;
+            }
+        }
+        if (OUT_F32) {
+            float* cp = reinterpret_cast<float*>(Cv) + (size_t)row * ldc + col;
+            if (full && vec_c) *reinterpret_cast<f32x4_t*>(cp) = (f32x4_t){v[0], v[1], v[2], v[3]};
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (col + e < N) cp[e] = v[e];
+            }
+        } else {
+            T* cp = reinterpret_cast<T*>(Cv) + (size_t)row * ldc + col;
+            if (full && vec_c) st4_t<T>(cp, v[0], v[1], v[2], v[3]);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (col + e < N) cp[e] = ET<T>::from_f(v[e]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 256x256 tile, 8 waves (2 x 4, each 128 x 64 = 4 x 2 macro-atoms), bf16, K % 64 == 0.
+// Operands go global -> LDS directly (global_load_lds, 16 B per lane, no VGPR staging, no
+// ds_write): each wave instruction fills 8 rows x 128 B of a LINEAR [256][64] slab image.  Bank
+// conflicts of the ds_read_b128 fragment reads are avoided by permuting the SOURCE chunk of
+// every lane (slot c of row r holds chunk c ^ (r & 7)) and applying the same XOR on the read.
+// Two 64 KB slab buffers: the next slab streams in while the current one is multiplied.
+// Rows beyond M / N are clamped on the load side (their results are never stored).
+// ---------------------------------------------------------------------------------------------
+template <bool OUT_F32>
+__global__ __launch_bounds__(512) void gemm_nt256_kernel(
+    const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc,
+    const float* __restrict__ bias, const bf16_t* __restrict__ add, int ldadd, const bf16_t* __restrict__ gate,
+    int ldgate, int M, int N, int K, int flags) {
+    typedef bf16_t T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // [2 buffers][A 32 KB | B 32 KB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int ntn = (N + 255) / 256, ntiles = ntn * ((M + 255) / 256);
+    const int nk = K / 64;
+    // persistent over tiles: block b handles tiles b, b+grid, ...; the (tile, slab) sequence is
+    // one pipeline, so the first slab of the next tile streams in during this tile's epilogue
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nsteps = my_tiles * nk;
+    auto tile_origin = [&](int it, int& m0, int& n0) {
+        int t = it * gridDim.x + blockIdx.x;
+        if ((ntiles & 7) == 0) t = (t & 7) * (ntiles >> 3) + (t >> 3);      // contiguous tile range per XCD
+        m0 = (t / ntn) * 256;
+        n0 = (t % ntn) * 256;
+    };
+
+    const int lrow = lane >> 3;
+    auto issue = [&](int step) {
+        int m0, n0;
+        tile_origin(step / nk, m0, n0);
+        const int k0 = (step % nk) * 64;
+        char* base = smem + (step & 1) * 65536 + (wid * 4) * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = (wid * 4 + i) * 8 + lrow;
+            const int lchunk = (lane & 7) ^ ((lrow ^ (wid * 4 + i)) & 7);       // slot c of row r holds chunk c ^ swz(r)
+            const bf16_t* sa = A + (size_t)min(m0 + r, M - 1) * lda + lchunk * 8 + k0;
+            const bf16_t* sb = B + (size_t)min(n0 + r, N - 1) * ldb + lchunk * 8 + k0;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
+                                             (__attribute__((address_space(3))) void*)(base + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb,
+                                             (__attribute__((address_space(3))) void*)(base + 32768 + i * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc_zero(acc[i][j]);
+
+    const int frow = lane & 31, h = lane >> 5;
+    const bool relu = flags & ME_EPI_RELU;
+    const bool vec_c = (ldc % (OUT_F32 ? 4 : 8)) == 0 && (reinterpret_cast<uintptr_t>(Cv) & 15) == 0;
+    if (nsteps <= 0) return;
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int step = 0; step < nsteps; ++step) {
+#if ME_GABL != 2
+        if (step + 1 < nsteps) issue(step + 1);
+#endif
+        const char* as = smem + (step & 1) * 65536;
+        const char* bs = as + 32768;
+        // swz(r) = (r ^ (r >> 3)) & 7 makes every 16-lane group of a ds_read_b128 hit 16 distinct
+        // 16-byte slots of the 256-byte bank row (conflict free); fragments of k-step kk+1 are
+        // fetched before the MFMAs of kk so the LDS latency hides under the matrix pipe
+        Frag<T> fa[2][4], fb[2][2];
+        auto lfrag = [&](int set, int kk) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = wr * 128 + i * 32 + frow;
+                frag_load(fa[set][i], reinterpret_cast<const T*>(as + r * 128 + (((kk * 2 + h) ^ ((r ^ (r >> 3)) & 7)) << 4)));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = wc * 64 + j * 32 + frow;
+                frag_load(fb[set][j], reinterpret_cast<const T*>(bs + r * 128 + (((kk * 2 + h) ^ ((r ^ (r >> 3)) & 7)) << 4)));
+            }
+        };
+        lfrag(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kk < 3) lfrag((kk + 1) & 1, kk + 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { if (ME_GABL != 1) mma32(acc[i][j], fb[kk & 1][j], fa[kk & 1][i]); else acc[i][j][0] += (float)fa[kk & 1][i].v[0] * (float)fb[kk & 1][j].v[1]; }
+        }
+        if ((step + 1) % nk == 0) {
+            // ---- tile finished.  The slab buffer just consumed is free (the other one is receiving the
+            // next tile's first slab): stage the tile through it so that every store instruction writes
+            // 8 full rows of 128 B (per-lane 8-byte pieces across 32 rows are L2-transaction bound).
+            int m0, n0;
+            tile_origin(step / nk, m0, n0);
+            __syncthreads();                                   // all waves are done reading this buffer
+            char* stg = smem + (step & 1) * 65536 + wid * 8192;        // 8 KB per wave
+            constexpr int PASS_ROWS = OUT_F32 ? 32 : 64;              // rows of the wave's 128 x 64 sub-tile per pass
+            constexpr int ROWB = OUT_F32 ? 256 : 128;                  // bytes per staged row (64 columns)
+#pragma unroll
+            for (int ps = 0; ps < 128 / PASS_ROWS; ++ps) {
+#pragma unroll
+                for (int ib = 0; ib < PASS_ROWS / 32; ++ib) {
+                    const int i = ps * (PASS_ROWS / 32) + ib;
+                    const int lr = ib * 32 + (lane & 31);              // row inside the pass
+                    const int row = m0 + wr * 128 + i * 32 + (lane & 31);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int cl = j * 32 + 8 * g + 4 * h;     // column inside the wave's 64
+                            const int col = n0 + wc * 64 + cl;
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                v[e] = acc[i][j][4 * g + e] + ((bias && col + e < N) ? bias[col + e] : 0.f);
+                                if (relu) v[e] = fmaxf(v[e], 0.f);
+                            }
+                            if (add && row < M) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) if (col + e < N) v[e] += (float)add[(size_t)row * ldadd + col + e];
+                            }
+                            if (gate && row < M) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) if (col + e < N) v[e] = (float)gate[(size_t)row * ldgate + col + e] > 0.f ? v[e] : 0.f;
+                            }
+                            // 16-byte slot index XOR (row & 7): spreads the 32 rows of a store over the banks
+                            if constexpr (OUT_F32) {
+                                const int slot = ((cl * 4) >> 4) ^ (lr & 7);
+                                *reinterpret_cast<f32x4_t*>(stg + lr * ROWB + (slot << 4)) = (f32x4_t){v[0], v[1], v[2], v[3]};
+                            } else {
+                                const int slot = ((cl * 2) >> 4) ^ (lr & 7);
+                                st4_t<T>(reinterpret_cast<T*>(stg + lr * ROWB + (slot << 4) + ((cl * 2) & 15)), v[0], v[1], v[2], v[3]);
+                            }
+                            acc_zero_quad(acc[i][j], g);
+                        }
+                }
+                // read back: lane -> (row = it*R + lane / CPRW, 16-byte chunk lane % CPRW): full-row coalesced stores
+                constexpr int CPRW = ROWB / 16;                        // chunks per row (8 / 16)
+                constexpr int RPI = 64 / CPRW;                         // rows per store instruction (8 / 4)
+#pragma unroll
+                for (int it = 0; it < PASS_ROWS / RPI; ++it) {
+                    const int lr = it * RPI + lane / CPRW, ch = lane % CPRW;
+                    const chunk16 v = ld_chunk(stg + lr * ROWB + ((ch ^ (lr & 7)) << 4));
+                    const int row = m0 + wr * 128 + ps * PASS_ROWS + lr;
+                    const int col = n0 + wc * 64 + ch * (OUT_F32 ? 4 : 8);
+                    if (row < M && col < N) {
+                        constexpr int EPC = OUT_F32 ? 4 : 8;           // elements per chunk
+                        if (col + EPC <= N && vec_c) {
+                            if constexpr (OUT_F32) st_chunk(reinterpret_cast<float*>(Cv) + (size_t)row * ldc + col, v);
+                            else st_chunk(reinterpret_cast<T*>(Cv) + (size_t)row * ldc + col, v);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < EPC; ++e)
+                                if (col + e < N) {
+                                    if constexpr (OUT_F32) (reinterpret_cast<float*>(Cv))[(size_t)row * ldc + col + e] = reinterpret_cast<const float*>(&v)[e];
+                                    else (reinterpret_cast<T*>(Cv))[(size_t)row * ldc + col + e] = reinterpret_cast<const T*>(&v)[e];
+                                }
+                        }
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+}
+
+// C = A.B^T.  128x128 block tile, 4 waves (2x2) x 64x64.  K-slab BKT (64 bf16 / 32 f32) is
+// double buffered in LDS: one barrier per slab, the slab after next is in flight in registers
+// while the current one is multiplied.  SWAP = true accumulates the TRANSPOSED 32x32 blocks
+// (mfma(B, A)): a lane then owns one row of C and 4 consecutive columns per register quad, so
+// the epilogue is 8/16-byte row-contiguous stores (and loads of add/gate) instead of 2-byte
+// ones.  SWAP = false (only for the head-major transposed copy) keeps lane = column.
+// Blocks are renumbered so that each XCD (private L2) works on a contiguous range of tiles.
+template <typename T> struct GemmK { static constexpr int BKT = sizeof(T) == 2 ? 64 : 32; };
+
+template <typename T, bool OUT_F32, bool SWAP>
 __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(
     const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc,
     const float* __restrict__ bias, const T* __restrict__ add, int ldadd, const T* __restrict__ gate, int ldgate,
     int M, int N, int K, int flags, HeadT ht) {
     constexpr int CH = ET<T>::CH;
-    constexpr int CPR = BK / CH;           // chunks per tile row
-    constexpr int LDK = BK + CH;           // padded LDS row (elements)
+    constexpr int BKT = GemmK<T>::BKT;
+    constexpr int CPR = BKT / CH;          // chunks per tile row
+    constexpr int LDK = BKT + CH;          // padded LDS row (elements)
     constexpr int NCH = BM * CPR / NTHREADS;
-    __shared__ __attribute__((aligned(16))) T As[BM * LDK];
-    __shared__ __attribute__((aligned(16))) T Bs[BN * LDK];
+    __shared__ __attribute__((aligned(16))) T As[2][BM * LDK];
+    __shared__ __attribute__((aligned(16))) T Bs[2][BN * LDK];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int ntn = (N + BN - 1) / BN, ntiles = ntn * ((M + BM - 1) / BM);
+    int tile = blockIdx.x;
+    if ((ntiles & 7) == 0) tile = (blockIdx.x & 7) * (ntiles >> 3) + (blockIdx.x >> 3);
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
 
     chunk16 ra[NCH], rb[NCH];
     auto gload = [&](int k0) {
@@ -55,12 +319,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(
             rb[i] = (n0 + row < N && k < K) ? ld_chunk(B + (size_t)(n0 + row) * ldb + k) : zero_chunk();
         }
     };
-    auto sstore = [&]() {
+    auto sstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = tid + i * NTHREADS, row = c / CPR, cc = c % CPR;
-            st_chunk(&As[row * LDK + cc * CH], ra[i]);
-            st_chunk(&Bs[row * LDK + cc * CH], rb[i]);
+            st_chunk(&As[buf][row * LDK + cc * CH], ra[i]);
+            st_chunk(&Bs[buf][row * LDK + cc * CH], rb[i]);
         }
     };
 
@@ -70,30 +334,47 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc_zero(acc[i][j]);
 
-    const int nk = (K + BK - 1) / BK;
+    const int nk = (K + BKT - 1) / BKT;
     const int frow = lane & 31, fk = (lane >> 5) * 8;
     gload(0);
+    sstore(0);
+    if (nk > 1) gload(BKT);
+    __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-        sstore();
-        __syncthreads();
-        if (kt + 1 < nk) gload((kt + 1) * BK);
+        const int buf = kt & 1;
 #pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
+        for (int kk = 0; kk < BKT / 16; ++kk) {
             Frag<T> fa[2], fb[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                frag_load(fa[i], &As[(wr * 64 + i * 32 + frow) * LDK + kk * 16 + fk]);
-                frag_load(fb[i], &Bs[(wc * 64 + i * 32 + frow) * LDK + kk * 16 + fk]);
+                frag_load(fa[i], &As[buf][(wr * 64 + i * 32 + frow) * LDK + kk * 16 + fk]);
+                frag_load(fb[i], &Bs[buf][(wc * 64 + i * 32 + frow) * LDK + kk * 16 + fk]);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) mma32(acc[i][j], fa[i], fb[j]);
+                for (int j = 0; j < 2; ++j) {
+                    if (SWAP) mma32(acc[i][j], fb[j], fa[i]);
+                    else mma32(acc[i][j], fa[i], fb[j]);
+                }
+        }
+        if (kt + 1 < nk) {
+            sstore(buf ^ 1);                       // buf^1 was last read in slab kt-1 (barrier since)
+            if (kt + 2 < nk) gload((kt + 2) * BKT);
         }
         __syncthreads();
     }
 
     const bool relu = flags & ME_EPI_RELU;
+    if constexpr (SWAP) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                epi_block_swapped<T, OUT_F32>(acc[i][j], m0 + wr * 64 + i * 32, n0 + wc * 64 + j * 32, lane, Cv, ldc, bias, add,
+                                              ldadd, gate, ldgate, M, N, relu);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -302,6 +583,7 @@ __global__ __launch_bounds__(256) void gemv_small_kernel(const T* __restrict__ x
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static const bool g_disable_nt256 = getenv("MIDIEMO_NO_NT256") != nullptr;
 
 template <typename T>
 int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
@@ -311,13 +593,33 @@ int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int 
     if (M <= 0 || N <= 0 || K <= 0) return ME_ERR_BAD_SHAPE;
     if (K % CH || lda % CH || ldb % CH) return ME_ERR_BAD_SHAPE;
     if (!aligned16(A) || !aligned16(B)) return ME_ERR_ALIGNMENT;
-    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM);
-    if (flags & ME_EPI_OUT_F32)
-        gemm_nt_kernel<T, true><<<grid, NTHREADS, 0, st>>>((const T*)A, lda, (const T*)B, ldb, C, ldc, bias,
-                                                          (const T*)add, ldadd, (const T*)gate, ldgate, M, N, K, flags, ht);
-    else
-        gemm_nt_kernel<T, false><<<grid, NTHREADS, 0, st>>>((const T*)A, lda, (const T*)B, ldb, C, ldc, bias,
-                                                           (const T*)add, ldadd, (const T*)gate, ldgate, M, N, K, flags, ht);
+    if constexpr (sizeof(T) == 2) {
+        if (!ht.ptr && K % 64 == 0 && M >= 256 && N >= 192 && !g_disable_nt256) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+                attr_set = true;
+            }
+            unsigned g256 = (unsigned)(((N + 255) / 256) * ((M + 255) / 256));
+            if (g256 > 256u) g256 = 256u;            // persistent: one block per CU
+            if (flags & ME_EPI_OUT_F32)
+                gemm_nt256_kernel<true><<<g256, 512, 131072, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias,
+                                                                   (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags);
+            else
+                gemm_nt256_kernel<false><<<g256, 512, 131072, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias,
+                                                                    (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags);
+            return me_launch_status();
+        }
+    }
+    const unsigned grid = (unsigned)(((N + BN - 1) / BN) * ((M + BM - 1) / BM));
+#define ME_NT_LAUNCH(F32, SW)                                                                                              \
+    gemm_nt_kernel<T, F32, SW><<<grid, NTHREADS, 0, st>>>((const T*)A, lda, (const T*)B, ldb, C, ldc, bias, (const T*)add,     \
+                                                          ldadd, (const T*)gate, ldgate, M, N, K, flags, ht)
+    if (ht.ptr) ME_NT_LAUNCH(false, false);
+    else if (flags & ME_EPI_OUT_F32) ME_NT_LAUNCH(true, true);
+    else ME_NT_LAUNCH(false, true);
+#undef ME_NT_LAUNCH
     return me_launch_status();
 }
 

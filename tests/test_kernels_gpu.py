@@ -63,6 +63,35 @@ def test_gemm_nt_plain_and_bias(ops, dtype, M, N, K):
     assert torch.isnan(C32[:, N:]).all()
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 1536, 512), (700, 1007, 512), (1024, 512, 2048), (260, 200, 128)])
+def test_gemm_nt_256_tile_path(ops, M, N, K):
+    """bf16 shapes that take the 256x256 direct-to-LDS kernel (K % 64 == 0), incl. ragged M/N and all epilogues."""
+    dtype = torch.bfloat16
+    A = rnd(M, K, seed=31).to(dtype)
+    B = rnd(N, K, seed=32).to(dtype)
+    bias = rnd(N, seed=33).float()
+    add = rnd(M, N, seed=34).to(dtype)
+    gate = rnd(M, N, seed=35).to(dtype)
+    base = A.double() @ B.double().t()
+    Ad, Bd = A.to(DEV), B.to(DEV)
+    ld = ((N + 15) // 16) * 16
+    C = torch.full((M, ld), float("nan"), dtype=dtype, device=DEV)
+    ops.gemm_nt(Ad, Bd, C, bias=bias.to(DEV), flags=ops.ME_EPI_RELU, N=N)
+    assert relerr(C[:, :N], torch.relu(base + bias.double())) < 6e-3
+    assert torch.isnan(C[:, N:]).all()
+    addp = torch.zeros(M, ld, dtype=dtype, device=DEV)
+    addp[:, :N] = add.to(DEV)
+    ops.gemm_nt(Ad, Bd, C, add=addp, N=N)
+    assert relerr(C[:, :N], base + add.double()) < 6e-3
+    gatep = torch.zeros(M, ld, dtype=dtype, device=DEV)
+    gatep[:, :N] = gate.to(DEV)
+    ops.gemm_nt(Ad, Bd, C, gate=gatep, flags=ops.ME_EPI_RELU_BWD, N=N)
+    assert relerr(C[:, :N], base * (gate.double() > 0)) < 6e-3
+    C32 = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+    ops.gemm_nt(Ad, Bd, C32, bias=bias.to(DEV), flags=ops.ME_EPI_OUT_F32)
+    assert relerr(C32, base + bias.double()) < 1e-5
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_nt_epilogues(ops, dtype):
     M, N, K = 200, 136, 96
