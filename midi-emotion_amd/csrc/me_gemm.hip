@@ -520,6 +520,112 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(
         }
 }
 
+// bf16 TN kernel, v2.  Tiles keep their NATURAL layout in LDS ([t][n], 16-byte chunk writes) and the
+// contraction-contiguous MFMA fragments are produced by the hardware transpose read
+// ds_read_b64_tr_b16: inside each 16-lane group lane l supplies the address of 4 contiguous
+// elements and lane i receives element i%4 of the chunks of lanes i/4 + 4j (measured on gfx950).
+// With lane l pointing at row k0 + l/4, columns 4*(l%4).., lane i gets column i for 4 consecutive
+// k: a free 4 x 16 transpose.  Row stride 160 elements (320 B) puts the 8 row segments of a
+// 32-lane half on distinct banks.  Double-buffered, BT = 32 tokens per step.
+ME_DEV bf16x4_t lds_tr4(const bf16_t* p) {
+    typedef short v4s __attribute__((ext_vector_type(4)));
+    v4s r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p));
+    return __builtin_bit_cast(bf16x4_t, r);
+}
+
+__global__ __launch_bounds__(NTHREADS) void gemm_tn_bf16_kernel(
+    const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, float* __restrict__ dW, int lddw,
+    float* __restrict__ dbias, int Tn, int N, int K, int t_per_block) {
+    typedef bf16_t T;
+    constexpr int LDN_ = 160;                      // LDS row stride (elements)
+    constexpr int NCH = BT * 16 / NTHREADS;        // 16-byte chunks per thread per operand (2)
+    __shared__ __attribute__((aligned(16))) T As[2][BT * LDN_];
+    __shared__ __attribute__((aligned(16))) T Bs[2][BT * LDN_];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
+    const int t_begin = blockIdx.z * t_per_block;
+    const int t_end = min(Tn, t_begin + t_per_block);
+    if (t_begin >= t_end) return;
+
+    chunk16 ra[NCH], rb[NCH];
+    auto gload = [&](int t0) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + i * NTHREADS, t = c >> 4, cc = (c & 15) * 8;
+            const bool tv = t0 + t < t_end;
+            ra[i] = (tv && n0 + cc < N) ? ld_chunk(A + (size_t)(t0 + t) * lda + n0 + cc) : zero_chunk();
+            rb[i] = (tv && k0 + cc < K) ? ld_chunk(B + (size_t)(t0 + t) * ldb + k0 + cc) : zero_chunk();
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + i * NTHREADS, t = c >> 4, cc = (c & 15) * 8;
+            st_chunk(&As[buf][t * LDN_ + cc], ra[i]);
+            st_chunk(&Bs[buf][t * LDN_ + cc], rb[i]);
+        }
+    };
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc_zero(acc[i][j]);
+    float bsum = 0.f;
+    const bool do_bias = dbias != nullptr && blockIdx.y == 0;
+    // transpose-read lane geometry
+    const int l16 = lane & 15, rbase = ((lane >> 4) & 1) * 16, h = lane >> 5;
+    const int trow = l16 >> 2, tcol = rbase + 4 * (l16 & 3);
+
+    const int nsteps = (t_end - t_begin + BT - 1) / BT;
+    gload(t_begin);
+    sstore(0);
+    if (nsteps > 1) gload(t_begin + BT);
+    __syncthreads();
+    for (int st = 0; st < nsteps; ++st) {
+        const int buf = st & 1;
+        if (do_bias && tid < 128) {
+#pragma unroll 8
+            for (int t = 0; t < BT; ++t) bsum += (float)As[buf][t * LDN_ + tid];
+        }
+#pragma unroll
+        for (int kk = 0; kk < BT / 16; ++kk) {
+            Frag<T> fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const T* pa = &As[buf][(kk * 16 + 8 * h + trow) * LDN_ + wr * 64 + i * 32 + tcol];
+                const T* pb = &Bs[buf][(kk * 16 + 8 * h + trow) * LDN_ + wc * 64 + i * 32 + tcol];
+                fa[i].v = __builtin_shufflevector(lds_tr4(pa), lds_tr4(pa + 4 * LDN_), 0, 1, 2, 3, 4, 5, 6, 7);
+                fb[i].v = __builtin_shufflevector(lds_tr4(pb), lds_tr4(pb + 4 * LDN_), 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma32(acc[i][j], fa[i], fb[j]);
+        }
+        if (st + 1 < nsteps) {
+            sstore(buf ^ 1);
+            if (st + 2 < nsteps) gload(t_begin + (st + 2) * BT);
+        }
+        __syncthreads();
+    }
+    if (do_bias && tid < 128 && n0 + tid < N) atomicAdd(&dbias[n0 + tid], bsum);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = k0 + wc * 64 + j * 32 + c_col(lane);
+            if (col >= K) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = n0 + wr * 64 + i * 32 + c_row(r, lane);
+                if (row < N) atomicAdd(&dW[(size_t)row * lddw + col], acc[i][j][r]);
+            }
+        }
+}
+
 // f32 master -> T copy and/or T transposed copy, 32x32 tiles through LDS
 template <typename T>
 __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, int rows, int cols,
@@ -640,7 +746,10 @@ int gemm_tn_launch(const void* A, int lda, const void* B, int ldb, float* dW, in
     t_per = ((t_per + BT - 1) / BT) * BT;
     nsplit = (Tn + t_per - 1) / t_per;
     dim3 grid(tn, tk, nsplit);
-    gemm_tn_kernel<T><<<grid, NTHREADS, 0, st>>>((const T*)A, lda, (const T*)B, ldb, dW, lddw, dbias, Tn, N, K, t_per);
+    if constexpr (sizeof(T) == 2)
+        gemm_tn_bf16_kernel<<<grid, NTHREADS, 0, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, dW, lddw, dbias, Tn, N, K, t_per);
+    else
+        gemm_tn_kernel<T><<<grid, NTHREADS, 0, st>>>((const T*)A, lda, (const T*)B, ldb, dW, lddw, dbias, Tn, N, K, t_per);
     return me_launch_status();
 }
 
