@@ -75,10 +75,11 @@ int me_embed_fwd(void* out, int dtype, const int64_t* tokens, const float* cond,
 
 /* Gradient of the prologue: accumulates (+=) into the f32 gradient tensors.
  * Rows of g_emb for token == pad_token receive nothing (padding_idx,
- * music_multi.py:57-59). */
+ * music_multi.py:57-59).  vocab = number of rows of the table (sizes the LDS-privatised
+ * accumulation; 0 selects plain global atomics). */
 int me_embed_bwd(const void* dout, int dtype, const int64_t* tokens, const float* cond,
                  float* g_emb, float* g_cw0, float* g_cb0, float* g_cw1, float* g_cb1,
-                 int mode, int B, int Ltok, int d_model, int d_cond, int pad_token,
+                 int mode, int B, int Ltok, int d_model, int d_cond, int vocab, int pad_token,
                  float p_drop, uint64_t seed, void* stream);
 
 /* ---- key padding mask -----------------------------------------------------

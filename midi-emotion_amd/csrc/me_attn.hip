@@ -416,18 +416,26 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
                 dp[r] = p;
                 if (ME_ABL != 4) { if (m < 32) dlo[m] = ET<T>::from_f(ds); else dhi[m - 32] = ET<T>::from_f(ds); }
             }
-            // ---- materialise P^T, dS^T rows [key][q] (32 lanes = 64/128 contiguous bytes per key row)
-            if (row_on && ME_ABL != 1) {
-                T* pt = PT + ws_bh + (size_t)k0 * Lp + q;
-                T* st = dST + ws_bh + (size_t)k0 * Lp + q;
+            // ---- materialise P^T, dS^T tiles [key][q]: transpose through the (now dead) lo slot of the G
+            //      ring so that the tiles leave as 16-byte row-contiguous stores.  Rows key >= L and
+            //      columns q >= L carry exact zeros (masked), consistent with the zero-initialised workspace.
+            T* stg = reinterpret_cast<T*>(&Gs[wid][eb_lo & 1][0]);
+            constexpr int LDX = sizeof(T) == 2 ? 40 : 36;          // staging row stride (16-byte aligned rows)
+            constexpr int CPRX = 32 / C::CH;                        // chunks per 32-wide row
+            auto flush_tile = [&](T* gdst) {                        // stg[32][LDX] -> gdst[32 rows][ld Lp]
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int bk = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (k0 + bk < L) {
-                        pt[(size_t)bk * Lp] = ET<T>::from_f(dp[r]);
-                        st[(size_t)bk * Lp] = ET<T>::from_f(s[r]);
-                    }
+                for (int it = 0; it < 32 * CPRX / 64; ++it) {
+                    const int c = it * 64 + lane, row = c / CPRX, cc = (c % CPRX) * C::CH;
+                    st_chunk(gdst + (size_t)row * Lp + cc, ld_chunk(&stg[row * LDX + cc]));
                 }
+            };
+            if (ME_ABL != 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * h) * LDX + a] = ET<T>::from_f(dp[r]);
+                flush_tile(PT + ws_bh + (size_t)k0 * Lp + q0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * h) * LDX + a] = ET<T>::from_f(s[r]);
+                flush_tile(dST + ws_bh + (size_t)k0 * Lp + q0);
             }
             // ---- dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
 #pragma unroll
@@ -449,13 +457,11 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
                 frag_load_4x2(dgf, dlo + 16 * t + 4 * h, dlo + 16 * t + 8 + 4 * h);
 #pragma unroll
                 for (int i = 0; i < C::DB; ++i) { if (ME_ABL != 3) mma32(dq[i], etf[i][t], dgf); }
-                if (row_on && ME_ABL != 2) {
-                    T* gt = dGT + ws_bh + (size_t)((cb0 + kt) * 32 + 16 * t + 4 * h) * Lp + q;
-                    const T* ge = reinterpret_cast<const T*>(&dgf);
+                const T* ge = reinterpret_cast<const T*>(&dgf);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) gt[(size_t)((e & 3) + 8 * (e >> 2)) * Lp] = ge[e];
-                }
+                for (int e = 0; e < 8; ++e) stg[(16 * t + 4 * h + (e & 3) + 8 * (e >> 2)) * LDX + a] = ge[e];
             }
+            if (ME_ABL != 2) flush_tile(dGT + ws_bh + (size_t)((cb0 + kt) * 32) * Lp + q0);
         }
     }
     if (!row_on) return;

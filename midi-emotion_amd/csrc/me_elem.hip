@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const T* __restrict__ do
                                                         float* __restrict__ g_cw0, float* __restrict__ g_cb0,
                                                         float* __restrict__ g_cw1, float* __restrict__ g_cb1, int mode,
                                                         int B, int Ltok, int d, int dc, int pad_token, uint32_t thr16,
-                                                        float inv_keep, uint64_t seed) {
+                                                        float inv_keep, uint64_t seed, int skip_emb) {
     constexpr int CH = ET<T>::CH;
     __shared__ float red[4][MAXC * 64 * 8];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const T* __restrict__ do
 #pragma unroll
                 for (int i = 0; i < CH; ++i) {
                     const int j = col + i;
-                    if (j < de) { if (tok != pad_token) atomicAdd(&g_emb[tok * de + j], g[i] * sq); }
+                    if (j < de) { if (!skip_emb && tok != pad_token) atomicAdd(&g_emb[tok * de + j], g[i] * sq); }
                     else part[c][i] += g[i];
                 }
             }
@@ -154,6 +154,52 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const T* __restrict__ do
         atomicAdd(&g_cw0[jc * 2], s * c0);
         atomicAdd(&g_cw0[jc * 2 + 1], s * c1);
         atomicAdd(&g_cb0[jc], s);
+    }
+}
+
+// Embedding-table gradient with LDS-privatised accumulation: a block owns an 8-column slice of the
+// table (V x 8 floats in LDS) and a slice of the tokens; gradients are scattered with LDS atomics
+// and flushed once, coalesced, with one global atomic per table element.  Replaces T x (d - dc)
+// contended global atomics (12.6 M per step at the headline config).
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_table_kernel(const T* __restrict__ dout, const int64_t* __restrict__ tokens,
+                                                              float* __restrict__ g_emb, int B, int Ltok, int shift, int d,
+                                                              int de, int V, int pad_token, uint32_t thr16, float inv_keep,
+                                                              uint64_t seed) {
+    extern __shared__ float tab[];                  // [V][8]
+    const int c0 = blockIdx.x * 8;
+    const int Lm = Ltok + shift;
+    const int64_t rows = (int64_t)B * Ltok;
+    const float sq = sqrtf((float)de);
+    for (int i = threadIdx.x; i < V * 8; i += 256) tab[i] = 0.f;
+    __syncthreads();
+    for (int64_t r = (int64_t)blockIdx.y * 256 + threadIdx.x; r < rows; r += (int64_t)gridDim.y * 256) {
+        const int b = (int)(r / Ltok), lt = (int)(r % Ltok);
+        const int64_t tok = tokens[r];
+        if (tok == pad_token) continue;
+        const int64_t row = (int64_t)b * Lm + lt + shift;
+        const T* src = dout + row * d + c0;
+        float g[8];
+        if constexpr (sizeof(T) == 2) {
+            chunk_to_f<T>(ld_chunk(src), g);
+        } else {
+            chunk_to_f<T>(ld_chunk(src), g);
+            chunk_to_f<T>(ld_chunk(src + 4), g + 4);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (c0 + e < de) {
+                float v = g[e] * sq;
+                if (thr16) v = me_keep(seed, 0u, (uint64_t)row * d + c0 + e, thr16) ? v * inv_keep : 0.f;
+                atomicAdd(&tab[tok * 8 + e], v);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < V * 8; i += 256) {
+        const int v = i >> 3, e = i & 7;
+        const float x = tab[i];
+        if (c0 + e < de && x != 0.f) atomicAdd(&g_emb[(size_t)v * de + c0 + e], x);
     }
 }
 
@@ -464,7 +510,7 @@ int me_embed_fwd(void* out, int dtype, const int64_t* tokens, const float* cond,
 }
 
 int me_embed_bwd(const void* dout, int dtype, const int64_t* tokens, const float* cond, float* g_emb, float* g_cw0,
-                 float* g_cb0, float* g_cw1, float* g_cb1, int mode, int B, int Ltok, int d, int dc, int pad_token,
+                 float* g_cb0, float* g_cw1, float* g_cb1, int mode, int B, int Ltok, int d, int dc, int vocab, int pad_token,
                  float p, uint64_t seed, void* stream) {
     me_clear_error();
     if (!dout || !tokens || !g_emb) return ME_ERR_NULL;
@@ -480,8 +526,24 @@ int me_embed_bwd(const void* dout, int dtype, const int64_t* tokens, const float
     if (nslab > 32) nslab = 32;
     dim3 grid(nslab, B);
     hipStream_t st = (hipStream_t)stream;
+    const int de = d - dc;
+    const bool table = vocab > 0 && (size_t)vocab * 32 <= 65536 && Ltok > 0 && (de & 7) == 0;
+    if (table) {
+        int ysplit = (int)(((int64_t)B * Ltok + 256 * 16 - 1) / (256 * 16));
+        if (ysplit < 1) ysplit = 1;
+        if (ysplit > 16) ysplit = 16;
+        dim3 g2(de / 8, ysplit);
+        const int shift = mode == ME_COND_TOKEN ? 2 : 0;
+        ME_DISPATCH(dtype, (embed_bwd_table_kernel<T><<<g2, 256, (size_t)vocab * 32, st>>>((const T*)dout, tokens, g_emb, B, Ltok,
+                                                                                           shift, d, de, vocab, pad_token, thr,
+                                                                                           inv_keep, seed)));
+        int rc = me_launch_status();
+        if (rc) return rc;
+        if (mode == ME_COND_NONE) return ME_OK;        // nothing but the table to differentiate
+    }
     ME_DISPATCH(dtype, (embed_bwd_kernel<T><<<grid, 256, 0, st>>>((const T*)dout, tokens, cond, g_emb, g_cw0, g_cb0, g_cw1,
-                                                                  g_cb1, mode, B, Ltok, d, dc, pad_token, thr, inv_keep, seed)));
+                                                                  g_cb1, mode, B, Ltok, d, dc, pad_token, thr, inv_keep, seed,
+                                                                  table ? 1 : 0)));
     return me_launch_status();
 }
 

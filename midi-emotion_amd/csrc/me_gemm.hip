@@ -116,11 +116,11 @@ ME_DEV void epi_block_swapped(const f32x16_t& acc, int row_base, int col_base, i
 // Two 64 KB slab buffers: the next slab streams in while the current one is multiplied.
 // Rows beyond M / N are clamped on the load side (their results are never stored).
 // ---------------------------------------------------------------------------------------------
-template <bool OUT_F32>
+template <bool OUT_F32, bool HT>
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(
     const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc,
     const float* __restrict__ bias, const bf16_t* __restrict__ add, int ldadd, const bf16_t* __restrict__ gate,
-    int ldgate, int M, int N, int K, int flags) {
+    int ldgate, int M, int N, int K, int flags, HeadT ht) {
     typedef bf16_t T;
     extern __shared__ __attribute__((aligned(16))) char smem[];          // [2 buffers][A 32 KB | B 32 KB]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -247,7 +247,6 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(
                                 const int slot = ((cl * 2) >> 4) ^ (lr & 7);
                                 st4_t<T>(reinterpret_cast<T*>(stg + lr * ROWB + (slot << 4) + ((cl * 2) & 15)), v[0], v[1], v[2], v[3]);
                             }
-                            acc_zero_quad(acc[i][j], g);
                         }
                 }
                 // read back: lane -> (row = it*R + lane / CPRW, 16-byte chunk lane % CPRW): full-row coalesced stores
@@ -274,6 +273,56 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(
                         }
                     }
                 }
+                if constexpr (HT && !OUT_F32) {
+                    // ---- head-major transposed copy CT[s][b][head][dd][l]: second trip through the staging
+                    //      area, this time [column][token] (64 x 64 per pass), read back as 16-byte token runs
+#pragma unroll
+                    for (int ib = 0; ib < PASS_ROWS / 32; ++ib) {
+                        const int i = ps * (PASS_ROWS / 32) + ib;
+                        const int lr = ib * 32 + (lane & 31);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const int cl = j * 32 + 8 * g + 4 * h + e;
+                                    const int col = n0 + wc * 64 + cl;
+                                    float v = acc[i][j][4 * g + e] + ((bias && col < N) ? bias[col] : 0.f);
+                                    if (relu) v = fmaxf(v, 0.f);
+                                    const int row = m0 + wr * 128 + i * 32 + (lane & 31);
+                                    if (add && row < M && col < N) v += (float)add[(size_t)row * ldadd + col];
+                                    reinterpret_cast<T*>(stg)[cl * 64 + lr] = (T)v;
+                                }
+                    }
+                    const size_t per_b = (size_t)ht.H * ht.dh * ht.Lp;
+                    const int dmh = ht.H * ht.dh;
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        const int cl = it * 8 + (lane >> 3), ch = lane & 7;
+                        const chunk16 v = ld_chunk(stg + cl * 128 + ch * 16);
+                        const int col = n0 + wc * 64 + cl;
+                        const int row0 = m0 + wr * 128 + ps * PASS_ROWS + ch * 8;        // 8 consecutive tokens
+                        if (col < N && row0 < M) {
+                            const int sec = col / dmh;
+                            T* base = reinterpret_cast<T*>(ht.ptr) + (size_t)sec * ht.Bn * per_b + (size_t)(col - sec * dmh) * ht.Lp;
+                            const int b0 = row0 / ht.L, l0 = row0 - b0 * ht.L;
+                            if (row0 + 7 < M && l0 + 7 < ht.L && (l0 & 7) == 0) {
+                                st_chunk(base + (size_t)b0 * per_b + l0, v);
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) {
+                                    const int rr = row0 + e;
+                                    if (rr < M) { const int bb = rr / ht.L; base[(size_t)bb * per_b + (rr - bb * ht.L)] = reinterpret_cast<const T*>(&v)[e]; }
+                                }
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int ib = 0; ib < PASS_ROWS / 32; ++ib)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc_zero(acc[ps * (PASS_ROWS / 32) + ib][j]);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -700,21 +749,23 @@ int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int 
     if (K % CH || lda % CH || ldb % CH) return ME_ERR_BAD_SHAPE;
     if (!aligned16(A) || !aligned16(B)) return ME_ERR_ALIGNMENT;
     if constexpr (sizeof(T) == 2) {
-        if (!ht.ptr && K % 64 == 0 && M >= 256 && N >= 192 && !g_disable_nt256) {
+        if (K % 64 == 0 && M >= 256 && N >= 192 && !g_disable_nt256 && !(ht.ptr && (flags & ME_EPI_OUT_F32))) {
             static bool attr_set = false;
             if (!attr_set) {
-                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
                 attr_set = true;
             }
             unsigned g256 = (unsigned)(((N + 255) / 256) * ((M + 255) / 256));
             if (g256 > 256u) g256 = 256u;            // persistent: one block per CU
-            if (flags & ME_EPI_OUT_F32)
-                gemm_nt256_kernel<true><<<g256, 512, 131072, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias,
-                                                                   (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags);
-            else
-                gemm_nt256_kernel<false><<<g256, 512, 131072, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias,
-                                                                    (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags);
+#define ME_NT256(F32, HTF)                                                                                                  \
+    gemm_nt256_kernel<F32, HTF><<<g256, 512, 131072, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias,     \
+                                                           (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags, ht)
+            if (ht.ptr) ME_NT256(false, true);
+            else if (flags & ME_EPI_OUT_F32) ME_NT256(true, false);
+            else ME_NT256(false, false);
+#undef ME_NT256
             return me_launch_status();
         }
     }

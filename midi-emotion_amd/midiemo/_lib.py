@@ -25,7 +25,7 @@ SIGNATURES = {
     "me_abi_version": [],
     "me_cast_transpose": [_p, _i, _i, _p, _i, _p, _i, _i, _p],
     "me_embed_fwd": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _u64, _p],
-    "me_embed_bwd": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _u64, _p],
+    "me_embed_bwd": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _p],
     "me_key_pad_mask": [_p, _p, _i, _i, _i, _i, _p],
     "me_gemm_nt": [_p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "me_gemm_tn_acc": [_p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p],

@@ -49,8 +49,9 @@ def embed_fwd(out, tokens, cond, emb, cw0, cb0, cw1, cb1, pe, mode, B, Ltok, d, 
 
 
 def embed_bwd(dout, tokens, cond, g_emb, g_cw0, g_cb0, g_cw1, g_cb1, mode, B, Ltok, d, dc, pad_token, p, seed):
+    vocab = g_emb.shape[0]
     check(lib().me_embed_bwd(_ptr(dout), _code(dout.dtype), _ptr(tokens), _ptr(cond), _ptr(g_emb), _ptr(g_cw0),
-                             _ptr(g_cb0), _ptr(g_cw1), _ptr(g_cb1), mode, B, Ltok, d, dc, pad_token, float(p),
+                             _ptr(g_cb0), _ptr(g_cw1), _ptr(g_cb1), mode, B, Ltok, d, dc, vocab, pad_token, float(p),
                              int(seed), _stream()), "me_embed_bwd")
 
 
