@@ -39,6 +39,7 @@
 namespace {
 
 constexpr int LDG = 36;   // G ring row (floats): 32 + 4 -> conflict-free b128 writes, b32 skew reads
+constexpr int LDG2 = 68;  // forward G ring row: 64-column ring + 4
 constexpr int LDT = 36;   // transposed-operand tile row (elements): 32 + 4 (72 B bf16 / 144 B f32)
 
 template <typename T, int DH> struct ACfg {
@@ -96,6 +97,9 @@ ME_DEV void row_frags(Frag<T>* f, const T* rowptr, bool valid, int h) {
     }
 }
 
+// v_exp_f32 without the denormal-range fix-up of exp2f (arguments here are <= 0: tiny results may flush to 0)
+ME_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 template <typename T> ME_DEV void st4(T* p, float a, float b, float c, float d);
 template <> ME_DEV void st4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
     bf16x4_t v; v[0] = (bf16_t)a; v[1] = (bf16_t)b; v[2] = (bf16_t)c; v[3] = (bf16_t)d;
@@ -114,14 +118,14 @@ template <> ME_DEV void st4<float>(float* p, float a, float b, float c, float d)
 // registers right after the current block's MFMAs were issued, the pad flags travel with the
 // tile, and tiles that need no masking skip all per-element predicates.  exp2-domain softmax.
 template <typename T, int DH>
-__global__ __launch_bounds__(256) void rga_fwd_kernel(const T* __restrict__ qkv, const T* __restrict__ vT,
+__global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ qkv, const T* __restrict__ vT,
                                                       const T* __restrict__ E, const uint8_t* __restrict__ key_pad,
                                                       T* __restrict__ out, float* __restrict__ lse, int B, int L, int Lp,
                                                       int H, int M, float scale) {
     using C = ACfg<T, DH>;
     __shared__ __attribute__((aligned(16))) T Ks[2][32 * C::LDN];
     __shared__ __attribute__((aligned(16))) T Vt[2][DH * LDT];
-    __shared__ __attribute__((aligned(16))) float Gs[4][2][32 * LDG];
+    __shared__ __attribute__((aligned(16))) float Gs[4][32 * LDG2];        // per wave: [q][64-column ring]
     __shared__ uint32_t Ps[2][32];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, a = lane & 31, h = lane >> 5;
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(256) void rga_fwd_kernel(const T* __restrict__ qkv,
         f32x16_t g; acc_zero(g);
 #pragma unroll
         for (int kk = 0; kk < C::KA; ++kk) mma32(g, ef[kk], qf[kk]);
-        float* gs = &Gs[wid][eb & 1][a * LDG];
+        float* gs = &Gs[wid][a * LDG2 + (eb & 1) * 32];
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq)
             *reinterpret_cast<f32x4_t*>(gs + 8 * gq + 4 * h) = (f32x4_t){g[4 * gq], g[4 * gq + 1], g[4 * gq + 2], g[4 * gq + 3]};
@@ -200,25 +204,23 @@ __global__ __launch_bounds__(256) void rga_fwd_kernel(const T* __restrict__ qkv,
             }
             uint32_t pbits = 0;
             if (key_pad) pbits = __builtin_amdgcn_readfirstlane((uint32_t)__ballot(lane < 32 && Ps[buf][a] != 0));
-            const float* glo = &Gs[wid][eb_lo & 1][a * LDG];
-            const float* ghi = &Gs[wid][(eb_lo + 1) & 1][a * LDG];
-            const int mbase = 31 - a + 4 * h;
+            // band element m (0..62) of this tile sits at ring column ((eb_lo & 1) * 32 + m) & 63
+            const float* grow = &Gs[wid][a * LDG2];
+            const int t0 = (eb_lo & 1) * 32 + 31 - a + 4 * h;
             float mt = -INFINITY;
             if (!diag && pbits == 0u && k0 + 32 <= L) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = mbase + (r & 3) + 8 * (r >> 2);
-                    s[r] = (s[r] + (m < 32 ? glo[m] : ghi[m - 32])) * c2;
+                    s[r] = (s[r] + grow[(t0 + (r & 3) + 8 * (r >> 2)) & 63]) * c2;
                     mt = fmaxf(mt, s[r]);
                 }
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int bk = (r & 3) + 8 * (r >> 2) + 4 * h, key = k0 + bk;
-                    const int m = 31 - a + bk;
                     const bool masked = key > q || key >= L || ((pbits >> bk) & 1u);
                     float v = -INFINITY;
-                    if (!masked) v = (s[r] + (m < 32 ? glo[m] : ghi[m - 32])) * c2;
+                    if (!masked) v = (s[r] + grow[(t0 + (r & 3) + 8 * (r >> 2)) & 63]) * c2;
                     s[r] = v;
                     mt = fmaxf(mt, v);
                 }
@@ -226,16 +228,18 @@ __global__ __launch_bounds__(256) void rga_fwd_kernel(const T* __restrict__ qkv,
             mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
             const float m_new = fmaxf(m_run, mt);
             const float m_safe = m_new == -INFINITY ? 0.f : m_new;
-            const float alpha = exp2f(m_run - m_safe);
+            const float alpha = fast_exp2(m_run - m_safe);
             float rs = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = exp2f(s[r] - m_safe); rs += s[r]; }
+            for (int r = 0; r < 16; ++r) { s[r] = fast_exp2(s[r] - m_safe); rs += s[r]; }
             l_run = l_run * alpha + rs;
+            if (__any(m_new != m_run)) {                 // running maxima settle quickly: most steps skip the rescale
+#pragma unroll
+                for (int i = 0; i < C::DB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+            }
             m_run = m_new;
-#pragma unroll
-            for (int i = 0; i < C::DB; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {                   // O^T[d][q] += V^T[d][key] . P^T[key][q]
                 Frag<T> pf; frag_from_acc(pf, s, t);
@@ -277,12 +281,12 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
     const T* __restrict__ dout, T* __restrict__ dqkv, float* __restrict__ delta_ws, T* __restrict__ PT,
     T* __restrict__ dST, T* __restrict__ dGT, int B, int L, int Lp, int H, int M, float scale) {
     using C = ACfg<T, DH>;
-    constexpr int LDR = 40;                         // dG ring row (elements of T)
+    constexpr int LDR = 72;                         // dG ring row (elements of T): 64-column ring + 8
     __shared__ __attribute__((aligned(16))) T Ks[1][32 * C::LDN];
     __shared__ __attribute__((aligned(16))) T Vs[1][32 * C::LDN];
     __shared__ __attribute__((aligned(16))) T Kt[1][DH * LDT];
-    __shared__ __attribute__((aligned(16))) float Gs[4][2][32 * LDG];
-    __shared__ __attribute__((aligned(16))) T Ds[4][2][32 * LDR];
+    __shared__ __attribute__((aligned(16))) float Gs[4][32 * LDG2];     // per wave: [q][64-column ring]
+    __shared__ __attribute__((aligned(16))) T Ds[4][32 * LDR];          // per wave: [q][64-column ring] of dG
     __shared__ uint32_t Ps[1][32];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, a = lane & 31, h = lane >> 5;
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
 #pragma unroll
     for (int i = 0; i < C::DB; ++i) acc_zero(dq[i]);
     // dG ring starts zeroed: the first lo block only receives its upper-right triangle
-    for (int i = lane; i < 2 * 32 * LDR; i += 64) (&Ds[wid][0][0])[i] = ET<T>::from_f(0.f);
+    for (int i = lane; i < 32 * LDR; i += 64) Ds[wid][i] = ET<T>::from_f(0.f);
 
     chunk16 rk[TileT<T, 32, DH>::NPT], rv[TileT<T, 32, DH>::NPT], rt[TileT<T, DH, 32>::NPT];
     uint32_t rp = 0;
@@ -343,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
         f32x16_t g; acc_zero(g);
 #pragma unroll
         for (int kk = 0; kk < C::KA; ++kk) mma32(g, ef[kk], qf[kk]);
-        float* gs = &Gs[wid][eb & 1][a * LDG];
+        float* gs = &Gs[wid][a * LDG2 + (eb & 1) * 32];
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq)
             *reinterpret_cast<f32x4_t*>(gs + 8 * gq + 4 * h) = (f32x4_t){g[4 * gq], g[4 * gq + 1], g[4 * gq + 2], g[4 * gq + 3]};
@@ -397,30 +401,31 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
             }
             uint32_t pbits = 0;
             if (key_pad) pbits = __builtin_amdgcn_readfirstlane((uint32_t)__ballot(lane < 32 && Ps[buf][a] != 0));
-            const float* glo = &Gs[wid][eb_lo & 1][a * LDG];
-            const float* ghi = &Gs[wid][(eb_lo + 1) & 1][a * LDG];
-            T* dlo = &Ds[wid][eb_lo & 1][a * LDR];
-            T* dhi = &Ds[wid][(eb_lo + 1) & 1][a * LDR];
+            // band element m (0..62) of this tile sits at ring column ((eb_lo & 1) * 32 + m) & 63 (G and dG rings)
+            const float* grow = &Gs[wid][a * LDG2];
+            T* drow = &Ds[wid][a * LDR];
+            const int t0 = (eb_lo & 1) * 32 + 31 - a + 4 * h;
             const bool plain = !diag && pbits == 0u && k0 + 32 <= L;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int bk = (r & 3) + 8 * (r >> 2) + 4 * h, key = k0 + bk;
-                const int m = 31 - a + bk;
+                const int col = (t0 + (r & 3) + 8 * (r >> 2)) & 63;
                 const bool masked = !row_on || (!plain && (key > q || key >= L || ((pbits >> bk) & 1u)));
                 float p = 0.f, ds = 0.f;
                 if (!masked) {
-                    p = exp2f((s[r] + (m < 32 ? glo[m] : ghi[m - 32])) * c2 - lse2);
+                    p = fast_exp2((s[r] + grow[col]) * c2 - lse2);
                     ds = p * (dp[r] - delta) * scale;
                 }
                 s[r] = ds;
                 dp[r] = p;
-                if (ME_ABL != 4) { if (m < 32) dlo[m] = ET<T>::from_f(ds); else dhi[m - 32] = ET<T>::from_f(ds); }
+                if (ME_ABL != 4) drow[col] = ET<T>::from_f(ds);
             }
             // ---- materialise P^T, dS^T tiles [key][q]: transpose through the (now dead) lo slot of the G
             //      ring so that the tiles leave as 16-byte row-contiguous stores.  Rows key >= L and
             //      columns q >= L carry exact zeros (masked), consistent with the zero-initialised workspace.
-            T* stg = reinterpret_cast<T*>(&Gs[wid][eb_lo & 1][0]);
-            constexpr int LDX = sizeof(T) == 2 ? 40 : 36;          // staging row stride (16-byte aligned rows)
+            // staging = the 32 dead lo columns of every ring row (row stride LDG2 floats)
+            T* stg = reinterpret_cast<T*>(&Gs[wid][(eb_lo & 1) * 32]);
+            constexpr int LDX = LDG2 * (int)(sizeof(float) / sizeof(T));   // staging row stride in elements of T
             constexpr int CPRX = 32 / C::CH;                        // chunks per 32-wide row
             auto flush_tile = [&](T* gdst) {                        // stg[32][LDX] -> gdst[32 rows][ld Lp]
 #pragma unroll
@@ -454,6 +459,7 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 Frag<T> dgf;
+                const T* dlo = drow + (eb_lo & 1) * 32;
                 frag_load_4x2(dgf, dlo + 16 * t + 4 * h, dlo + 16 * t + 8 + 4 * h);
 #pragma unroll
                 for (int i = 0; i < C::DB; ++i) { if (ME_ABL != 3) mma32(dq[i], etf[i][t], dgf); }
@@ -580,16 +586,32 @@ __global__ __launch_bounds__(256) void rga_bwd_e_kernel(const T* __restrict__ dG
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, a = lane & 31, h = lane >> 5;
     const int BH = B * H;
-    const int c0 = blockIdx.x * 128;
-    const int cbw = blockIdx.x * 4 + wid;
-    const bool wave_on = cbw * 32 < Lp;
     const int nqt = (L + 31) / 32;
     const int ncb = Lp / 32;
+    const int ngx = (Lp + 127) / 128;                   // groups of 4 column blocks (128 rows of dG^T)
+    // 1-D grid; group x needs nq(x) query slabs per (b, head) -> it gets blocks in proportion to nq(x)
+    // (the groups near column 0 only see the last few query tiles, the last group sees all of them)
+    int gx = 0, slot = 0, nslots = 1;
+    {
+        int total = 0;
+        for (int x = 0; x < ngx; ++x) total += nqt - max(0, ncb - 1 - min(ncb - 1, x * 4 + 3));
+        int first = 0;
+        for (int x = 0; x < ngx; ++x) {
+            const int nqx = nqt - max(0, ncb - 1 - min(ncb - 1, x * 4 + 3));
+            const int cnt = 1 + (int)(((long)((int)gridDim.x - ngx) * nqx) / total);     // sum <= gridDim.x
+            if ((int)blockIdx.x >= first && (int)blockIdx.x < first + cnt) { gx = x; slot = blockIdx.x - first; nslots = cnt; }
+            first += cnt;
+        }
+        if ((int)blockIdx.x >= first) return;             // rounding leftovers
+    }
+    const int c0 = gx * 128;
+    const int cbw = gx * 4 + wid;
+    const bool wave_on = cbw * 32 < Lp;
     const int my_qmin = max(0, ncb - 1 - cbw);
-    const int qs0 = max(0, ncb - 1 - min(ncb - 1, blockIdx.x * 4 + 3));       // earliest slab any wave needs
+    const int qs0 = max(0, ncb - 1 - min(ncb - 1, gx * 4 + 3));       // earliest slab any wave needs
     const int nq = nqt - qs0;
-    const int per = (BH + gridDim.y - 1) / gridDim.y;
-    const int bh_lo = blockIdx.y * per, bh_hi = min(BH, bh_lo + per);
+    const int per = (BH + nslots - 1) / nslots;
+    const int bh_lo = slot * per, bh_hi = min(BH, bh_lo + per);
     const int nsteps = (bh_hi - bh_lo) * nq;
     const int rows_valid = min(128, Lp - c0);
     if (nsteps <= 0 || nq <= 0) return;
@@ -742,9 +764,11 @@ int bwd_launch(const void* qkv, const void* qkvT, const void* E, const void* ET_
     rga_bwd_kv_kernel<T, DH><<<B * H * nqb, 256, 0, st>>>((const T*)PT, (const T*)dST, qT, (const T*)doutT, (T*)dqkv, B, L, Lp, H);
     rc = me_launch_status();
     if (rc) return rc;
-    int splits = B * H;
-    if (splits > 32) splits = 32;
-    rga_bwd_e_kernel<T, DH><<<dim3((Lp + 127) / 128, splits), 256, 0, st>>>((const T*)dGT, qT, dE, B, L, Lp, H, M);
+    const int ngx = (Lp + 127) / 128;
+    int eblocks = 512;                                   // ~2 per CU; every group gets at least one
+    if (eblocks > ngx * B * H) eblocks = ngx * B * H;
+    if (eblocks < ngx) eblocks = ngx;
+    rga_bwd_e_kernel<T, DH><<<eblocks, 256, 0, st>>>((const T*)dGT, qT, dE, B, L, Lp, H, M);
     return me_launch_status();
 }
 

@@ -576,6 +576,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(
 // With lane l pointing at row k0 + l/4, columns 4*(l%4).., lane i gets column i for 4 consecutive
 // k: a free 4 x 16 transpose.  Row stride 160 elements (320 B) puts the 8 row segments of a
 // 32-lane half on distinct banks.  Double-buffered, BT = 32 tokens per step.
+// (A 256x256 direct-to-LDS variant reaches 757 TF in its main loop but loses end to end: the split-K
+// flush costs blocks x tile-area f32 atomics either way, and only this 3-blocks-per-CU kernel overlaps
+// it with other blocks' MFMA work.  Measured: 173 vs 123 us on dW1.)
 ME_DEV bf16x4_t lds_tr4(const bf16_t* p) {
     typedef short v4s __attribute__((ext_vector_type(4)));
     v4s r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p));
