@@ -11,7 +11,7 @@ f32 accumulate, synthetic tokens in [2, V), weights random-init.  Weak scaling: 
            --master-port P bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0.  `roofline` is the dominant kernel family
-(gemm_nt_kernel<bf16>, ~2/3 of the step's FLOPs): algorithmic FLOPs of its launches /
+(the NT GEMM gemm_nt256_kernel<bf16>: every nn.Linear forward and dX product): algorithmic FLOPs of its launches /
 their HIP-event durations, measured on the launch stream in instrumented steps after the
 timed region.  `cpu_baseline` is the oracle (oracle/ref_model.py, a port) timed on the
 host cores on a bounded sample (B=1..2, same model/seq), rank 0, N=1 only.
@@ -87,26 +87,33 @@ def cpu_baseline(c, L, budget_s=25.0):
 
 
 class GemmProbe:
-    """HIP-event timing of every me_gemm_nt launch (events recorded on the launch stream)."""
+    """HIP-event timing of every NT-GEMM launch (me_gemm_nt and me_gemm_nt_headT; events recorded on
+    the launch stream).  At the bench shapes all of them run gemm_nt256_kernel<bf16>."""
 
     def __init__(self, ops):
-        self.ops, self.orig, self.rec = ops, ops.gemm_nt, []
+        self.ops, self.orig, self.orig_ht, self.rec = ops, ops.gemm_nt, ops.gemm_nt_headT, []
+
+    def _timed(self, fn, A, B, kw):
+        m = A.shape[0] if kw.get("M") is None else kw["M"]
+        k = A.shape[1] if kw.get("K") is None else kw["K"]
+        n = B.shape[0] if kw.get("N") is None else kw["N"]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        self.rec.append((2.0 * m * n * k, e0, e1))
 
     def __enter__(self):
-        def timed(A, B, C, bias=None, add=None, gate=None, M=None, N=None, K=None, flags=0, dtype=None):
-            m = A.shape[0] if M is None else M
-            k = A.shape[1] if K is None else K
-            n = B.shape[0] if N is None else N
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            self.orig(A, B, C, bias=bias, add=add, gate=gate, M=M, N=N, K=K, flags=flags, dtype=dtype)
-            e1.record()
-            self.rec.append((2.0 * m * n * k, e0, e1))
-        self.ops.gemm_nt = timed
+        def nt(A, B, C, **kw):
+            self._timed(lambda: self.orig(A, B, C, **kw), A, B, kw)
+
+        def nt_ht(A, B, C, CT, Bn, L, H, dh, Lp, **kw):
+            self._timed(lambda: self.orig_ht(A, B, C, CT, Bn, L, H, dh, Lp, **kw), A, B, kw)
+        self.ops.gemm_nt, self.ops.gemm_nt_headT = nt, nt_ht
         return self
 
     def __exit__(self, *a):
-        self.ops.gemm_nt = self.orig
+        self.ops.gemm_nt, self.ops.gemm_nt_headT = self.orig, self.orig_ht
 
     def summary(self):
         torch.cuda.synchronize()
@@ -215,7 +222,7 @@ def main():
         if probe is not None:
             flops, ms, n = probe
             ach = flops / (ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel<%s>" % args.compute_dtype,
+            out["roofline"] = {"bound": "mfma", "kernel": ("gemm_nt256_kernel<bf16>" if args.compute_dtype == "bf16" else "gemm_nt_kernel<float>"),
                                "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS if args.compute_dtype == "bf16" else 157.3,
                                "unit": "TFLOP/s",
                                "frac": round(ach / (PEAK_BF16_TFLOPS if args.compute_dtype == "bf16" else 157.3), 4),

@@ -390,6 +390,7 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
                 g_block(ef, eb_lo + 1);
                 if (kt + 1 < my_last_kt) row_frags<T, DH>(ef, E + (size_t)((eb_lo + 2) * 32 + a) * DH, true, h);
             }
+            if (ME_ABL != 3) et_frags(etf, eb_lo);      // E^T block of this step's lo block: in flight during S / dP / softmax
             f32x16_t s, dp; acc_zero(s); acc_zero(dp);
 #pragma unroll
             for (int kk = 0; kk < C::KA; ++kk) {
@@ -455,7 +456,6 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
                 }
             }
             // ---- the lo block of dG is complete now: relative part of dQ and flush of dG^T
-            if (ME_ABL != 3) et_frags(etf, eb_lo);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 Frag<T> dgf;
