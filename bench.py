@@ -87,33 +87,27 @@ def cpu_baseline(c, L, budget_s=25.0):
 
 
 class GemmProbe:
-    """HIP-event timing of every NT-GEMM launch (me_gemm_nt and me_gemm_nt_headT; events recorded on
-    the launch stream).  At the bench shapes all of them run gemm_nt256_kernel<bf16>."""
+    """HIP-event timing of every NT-GEMM launch (me_gemm_nt; events recorded on the launch stream).
+    At the bench shapes all of them run gemm_nt256_kernel<bf16>."""
 
     def __init__(self, ops):
-        self.ops, self.orig, self.orig_ht, self.rec = ops, ops.gemm_nt, ops.gemm_nt_headT, []
-
-    def _timed(self, fn, A, B, kw):
-        m = A.shape[0] if kw.get("M") is None else kw["M"]
-        k = A.shape[1] if kw.get("K") is None else kw["K"]
-        n = B.shape[0] if kw.get("N") is None else kw["N"]
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        fn()
-        e1.record()
-        self.rec.append((2.0 * m * n * k, e0, e1))
+        self.ops, self.orig, self.rec = ops, ops.gemm_nt, []
 
     def __enter__(self):
         def nt(A, B, C, **kw):
-            self._timed(lambda: self.orig(A, B, C, **kw), A, B, kw)
-
-        def nt_ht(A, B, C, CT, Bn, L, H, dh, Lp, **kw):
-            self._timed(lambda: self.orig_ht(A, B, C, CT, Bn, L, H, dh, Lp, **kw), A, B, kw)
-        self.ops.gemm_nt, self.ops.gemm_nt_headT = nt, nt_ht
+            m = A.shape[0] if kw.get("M") is None else kw["M"]
+            k = A.shape[1] if kw.get("K") is None else kw["K"]
+            n = B.shape[0] if kw.get("N") is None else kw["N"]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.orig(A, B, C, **kw)
+            e1.record()
+            self.rec.append((2.0 * m * n * k, e0, e1))
+        self.ops.gemm_nt = nt
         return self
 
     def __exit__(self, *a):
-        self.ops.gemm_nt, self.ops.gemm_nt_headT = self.orig, self.orig_ht
+        self.ops.gemm_nt = self.orig
 
     def summary(self):
         torch.cuda.synchronize()

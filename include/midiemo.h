@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 2
+#define ME_ABI_VERSION 3
 
 enum { ME_F32 = 0, ME_BF16 = 1 };
 
@@ -101,16 +101,6 @@ int me_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                const float* bias, const void* add, int ldadd, const void* gate, int ldgate,
                int M, int N, int K, int flags, int dtype, void* stream);
 
-/* me_gemm_nt plus a second, head-major TRANSPOSED copy of C (no gate, T output only):
- *   CT[s][b][head][dd][l] = C[b*L + l][s*H*dh + head*dh + dd],  leading dimension Lp >= L.
- * Used for the fused QKV projection (s = q,k,v) and for d(attention output): it hands the
- * attention kernels contraction-contiguous K^T/V^T/Q^T/dO^T (the permute(0,2,1,3) copies of
- * music_multi.py:196-209, produced for free by the MFMA accumulator layout).  M == Bn*L. */
-int me_gemm_nt_headT(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
-                     const float* bias, const void* add, int ldadd, void* CT,
-                     int Bn, int L, int H, int dh, int Lp, int M, int N, int K, int flags,
-                     int dtype, void* stream);
-
 /* ---- GEMM  dW[N,K] += A[T,N]^T . B[T,K]   (f32 atomic accumulation) ----------
  * A = dY (T, lda), B = X (T, ldb), dW f32 (lddw).  If dbias != NULL also
  * dbias[N] += column sums of A.  Replaces the weight/bias gradients of nn.Linear. */
@@ -118,24 +108,23 @@ int me_gemm_tn_acc(const void* A, int lda, const void* B, int ldb, float* dW, in
                    float* dbias, int T, int N, int K, int dtype, void* stream);
 
 /* ---- relative global attention ---------------------------------------------
- * qkv  : T [B, L, 3, H, dh]  (token-major output of the fused QKV projection)
- * qkvT : T [3][B][H][dh][Lp] head-major transposed copy written by me_gemm_nt_headT
- *        (Lp = L rounded up to 32; padding columns must be zero); vT = section 2
+ * qkv  : T [B, L, 3, H, dh]  (token-major output of the fused QKV projection; the kernels read
+ *        q / k / v tiles straight from it -- no head-major permute copies)
  * E    : T [M, dh] relative table of the layer;  ET : T [dh, M] its transpose
  * key_pad : uint8 [B, L] or NULL
  * out  : T [B, L, H, dh]   lse : f32 [B, H, L]
  *   logits[l,j] = (q_l.k_j + q_l.E[M-1-(l-j)]) / sqrt(dh),  j<=l and key j not pad
- * Replaces music_multi.py:211-235 (einsum QE, _qe_masking, _skewing, QK^T, mask,
- * softmax, PV, head merge).  dh in {32, 64}; M % 32 == 0; L <= Lp <= M. */
-int me_rga_fwd(const void* qkv, const void* vT, const void* E, const uint8_t* key_pad, void* out, float* lse,
-               int B, int L, int Lp, int H, int dh, int M, int dtype, void* stream);
+ * Replaces music_multi.py:196-235 (head split/permute, einsum QE, _qe_masking, _skewing, QK^T,
+ * mask, softmax, PV, head merge).  dh in {32, 64}; M % 32 == 0; L <= M. */
+int me_rga_fwd(const void* qkv, const void* E, const uint8_t* key_pad, void* out, float* lse,
+               int B, int L, int H, int dh, int M, int dtype, void* stream);
 
-/* Backward of me_rga_fwd.  dout: T [B,L,H,dh]; doutT: T [B][H][dh][Lp] (headT copy of dout).
- * Writes dqkv (T, same layout as qkv), accumulates (+=) dE f32 [M, dh].
- * Workspaces (caller-owned): delta f32 [B,H,L]; PT, dST, dGT: T [B*H][Lp][Lp] each, which
- * must be ZERO-INITIALISED once (only on/below-diagonal tiles are written and read). */
-int me_rga_bwd(const void* qkv, const void* qkvT, const void* E, const void* ET, const uint8_t* key_pad,
-               const void* out, const float* lse, const void* dout, const void* doutT,
+/* Backward of me_rga_fwd.  dout: T [B,L,H,dh].  Writes dqkv (T, same layout as qkv),
+ * accumulates (+=) dE f32 [M, dh].
+ * Workspaces (caller-owned): delta f32 [B,H,L]; PT, dST, dGT: T [B*H][Lp][Lp] each (Lp = L rounded
+ * up to 32), which must be ZERO-INITIALISED once (only on/below-diagonal tiles are written and read). */
+int me_rga_bwd(const void* qkv, const void* E, const void* ET, const uint8_t* key_pad,
+               const void* out, const float* lse, const void* dout,
                void* dqkv, float* dE, float* delta_ws, void* PT, void* dST, void* dGT,
                int B, int L, int Lp, int H, int dh, int M, int dtype, void* stream);
 

@@ -19,8 +19,9 @@
 // O^T[d][q] += V^T[d][key] P^T[key][q] (the V^T fragment is read with the accumulator's own
 // k-map), and the per-row rescale of O is a per-lane scalar.
 //
-// Contraction-contiguous operands (K^T, V^T, Q^T, dO^T: [b][head][d][l]) are produced by the
-// projection GEMMs' epilogues (me_gemm_nt_headT), so no kernel transposes through LDS.
+// Contraction-over-rows operands (V^T, K^T, Q^T, dO^T fragments) are read straight from NATURAL
+// LDS tiles with the hardware transpose read (frag_load_tr, me_common.h): no transposed copies in
+// memory, no LDS scatter.
 //
 // Backward.  The query-owned kernel recomputes P, forms dS, accumulates dQ (key part and
 // relative part) and MATERIALISES, for the current layer only, P^T, dS^T ([bh][key][q]) and
@@ -40,13 +41,15 @@ namespace {
 
 constexpr int LDG = 36;   // G ring row (floats): 32 + 4 -> conflict-free b128 writes, b32 skew reads
 constexpr int LDG2 = 68;  // forward G ring row: 64-column ring + 4
-constexpr int LDT = 36;   // transposed-operand tile row (elements): 32 + 4 (72 B bf16 / 144 B f32)
 
 template <typename T, int DH> struct ACfg {
     static constexpr int CH = ET<T>::CH;
     static constexpr int KA = DH / 16;       // contraction atoms over the head dim
     static constexpr int DB = DH / 32;       // 32-wide blocks of the head dim
-    static constexpr int LDN = DH + CH;      // natural [row][DH] tile row (elements)
+    static constexpr int LDN = DH + CH;      // natural [row][DH] tile row (elements), read with 16-byte fragment loads
+    // tile only read through transpose reads: a row stride of 192 B (mod 256) puts the 4 x 2 row segments of a
+    // 32-lane half on disjoint banks
+    static constexpr int LDV = sizeof(T) == 2 ? (DH == 64 ? 96 : 32) : DH + 4;
 };
 
 // ---- generic ROWS x COLS chunk tiles (16-byte chunks, lanes walk a row) ----------------
@@ -118,13 +121,12 @@ template <> ME_DEV void st4<float>(float* p, float a, float b, float c, float d)
 // registers right after the current block's MFMAs were issued, the pad flags travel with the
 // tile, and tiles that need no masking skip all per-element predicates.  exp2-domain softmax.
 template <typename T, int DH>
-__global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ qkv, const T* __restrict__ vT,
-                                                      const T* __restrict__ E, const uint8_t* __restrict__ key_pad,
-                                                      T* __restrict__ out, float* __restrict__ lse, int B, int L, int Lp,
-                                                      int H, int M, float scale) {
+__global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ qkv, const T* __restrict__ E, const uint8_t* __restrict__ key_pad,
+                                                      T* __restrict__ out, float* __restrict__ lse, int B, int L, int H, int M,
+                                                      float scale) {
     using C = ACfg<T, DH>;
     __shared__ __attribute__((aligned(16))) T Ks[2][32 * C::LDN];
-    __shared__ __attribute__((aligned(16))) T Vt[2][DH * LDT];
+    __shared__ __attribute__((aligned(16))) T Vs[2][32 * C::LDN];      // natural V tile, transpose-read (144-byte rows: 2-way conflicts, but 3 blocks/CU)
     __shared__ __attribute__((aligned(16))) float Gs[4][32 * LDG2];        // per wave: [q][64-column ring]
     __shared__ uint32_t Ps[2][32];
 
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ q
     const size_t ldq = (size_t)3 * dm;
     const T* qb_ = qkv + (size_t)b * L * ldq + head * DH;
     const T* kb_ = qb_ + dm;
-    const T* vt_ = vT + (size_t)bh * DH * Lp;
+    const T* vb_ = qb_ + 2 * dm;
     const int q0 = qb * 128 + wid * 32;
     const int q = q0 + a;
     const bool wave_on = q0 < L;
@@ -152,16 +154,16 @@ __global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ q
     for (int i = 0; i < C::DB; ++i) acc_zero(o[i]);
     float m_run = -INFINITY, l_run = 0.f;
 
-    chunk16 rk[TileT<T, 32, DH>::NPT], rv[TileT<T, DH, 32>::NPT];
+    chunk16 rk[TileT<T, 32, DH>::NPT], rv[TileT<T, 32, DH>::NPT];
     uint32_t rp = 0;
     auto gload = [&](int kt) {
         tile_gload<T, 32, DH>(rk, kb_ + (size_t)kt * 32 * ldq, ldq, L - kt * 32, tid);
-        tile_gload<T, DH, 32>(rv, vt_ + kt * 32, (size_t)Lp, DH, tid);
+        tile_gload<T, 32, DH>(rv, vb_ + (size_t)kt * 32 * ldq, ldq, L - kt * 32, tid);
         if (key_pad && tid < 32) { const int key = kt * 32 + tid; rp = key < L ? key_pad[(size_t)b * L + key] : 0; }
     };
     auto sstore = [&](int buf) {
         tile_sstore<T, 32, DH, C::LDN>(rk, Ks[buf], tid);
-        tile_sstore<T, DH, 32, LDT>(rv, Vt[buf], tid);
+        tile_sstore<T, 32, DH, C::LDN>(rv, Vs[buf], tid);
         if (key_pad && tid < 32) Ps[buf][tid] = rp;
     };
     auto g_block = [&](const Frag<T>* ef, int eb) {     // G^T[m][q] = E[eb*32+m] . Q[q] -> ring slot eb&1
@@ -245,9 +247,8 @@ __global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ q
                 Frag<T> pf; frag_from_acc(pf, s, t);
 #pragma unroll
                 for (int i = 0; i < C::DB; ++i) {
-                    Frag<T> vf;
-                    const T* vp = &Vt[buf][(i * 32 + a) * LDT + 16 * t + 4 * h];
-                    frag_load_4x2(vf, vp, vp + 8);
+                    Frag<T> vf;                              // V^T[d][key] for the accumulator's key map
+                    frag_load_tr(vf, Vs[buf], C::LDN, 16 * t + 4 * h, 16 * t + 8 + 4 * h, i * 32, lane);
                     mma32(o[i], vf, pf);
                 }
             }
@@ -276,18 +277,17 @@ __global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ q
 // =====================================================================================
 template <typename T, int DH>
 __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
-    const T* __restrict__ qkv, const T* __restrict__ kT, const T* __restrict__ E, const T* __restrict__ ET_,
+    const T* __restrict__ qkv, const T* __restrict__ E, const T* __restrict__ ET_,
     const uint8_t* __restrict__ key_pad, const T* __restrict__ out, const float* __restrict__ lse,
     const T* __restrict__ dout, T* __restrict__ dqkv, float* __restrict__ delta_ws, T* __restrict__ PT,
     T* __restrict__ dST, T* __restrict__ dGT, int B, int L, int Lp, int H, int M, float scale) {
     using C = ACfg<T, DH>;
     constexpr int LDR = 72;                         // dG ring row (elements of T): 64-column ring + 8
-    __shared__ __attribute__((aligned(16))) T Ks[1][32 * C::LDN];
-    __shared__ __attribute__((aligned(16))) T Vs[1][32 * C::LDN];
-    __shared__ __attribute__((aligned(16))) T Kt[1][DH * LDT];
+    __shared__ __attribute__((aligned(16))) T Ks[2][32 * C::LDN];      // natural K tile: 16-byte fragment reads (S) and transpose reads (dQ)
+    __shared__ __attribute__((aligned(16))) T Vs[2][32 * C::LDN];
     __shared__ __attribute__((aligned(16))) float Gs[4][32 * LDG2];     // per wave: [q][64-column ring]
     __shared__ __attribute__((aligned(16))) T Ds[4][32 * LDR];          // per wave: [q][64-column ring] of dG
-    __shared__ uint32_t Ps[1][32];
+    __shared__ uint32_t Ps[2][32];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, a = lane & 31, h = lane >> 5;
     const int nqb = (L + 127) / 128;
@@ -298,7 +298,6 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
     const T* qb_ = qkv + (size_t)b * L * ldq + head * DH;
     const T* kb_ = qb_ + dm;
     const T* vb_ = qb_ + 2 * dm;
-    const T* kt_ = kT + (size_t)bh * DH * Lp;
     const int q0 = qb * 128 + wid * 32;
     const int q = q0 + a;
     const bool wave_on = q0 < L;
@@ -329,18 +328,16 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
     // dG ring starts zeroed: the first lo block only receives its upper-right triangle
     for (int i = lane; i < 32 * LDR; i += 64) Ds[wid][i] = ET<T>::from_f(0.f);
 
-    chunk16 rk[TileT<T, 32, DH>::NPT], rv[TileT<T, 32, DH>::NPT], rt[TileT<T, DH, 32>::NPT];
+    chunk16 rk[TileT<T, 32, DH>::NPT], rv[TileT<T, 32, DH>::NPT];
     uint32_t rp = 0;
     auto gload = [&](int kt) {
         tile_gload<T, 32, DH>(rk, kb_ + (size_t)kt * 32 * ldq, ldq, L - kt * 32, tid);
         tile_gload<T, 32, DH>(rv, vb_ + (size_t)kt * 32 * ldq, ldq, L - kt * 32, tid);
-        tile_gload<T, DH, 32>(rt, kt_ + kt * 32, (size_t)Lp, DH, tid);
         if (key_pad && tid < 32) { const int key = kt * 32 + tid; rp = key < L ? key_pad[(size_t)b * L + key] : 0; }
     };
     auto sstore = [&](int buf) {
         tile_sstore<T, 32, DH, C::LDN>(rk, Ks[buf], tid);
         tile_sstore<T, 32, DH, C::LDN>(rv, Vs[buf], tid);
-        tile_sstore<T, DH, 32, LDT>(rt, Kt[buf], tid);
         if (key_pad && tid < 32) Ps[buf][tid] = rp;
     };
     auto g_block = [&](const Frag<T>* ef, int eb) {
@@ -374,14 +371,11 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
         if (my_last_kt > 0) row_frags<T, DH>(ef, E + (size_t)((eb0 + 1) * 32 + a) * DH, true, h);
     }
     const size_t ws_bh = (size_t)bh * Lp * Lp;
-    // single LDS tile set (two barriers per step) keeps the block under 80 KB -> 2 blocks per CU;
-    // the next tile's global loads are still in flight during the whole compute phase
+    sstore(0);
+    if (nkt > 1) gload(1);
+    __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = 0;
-        __syncthreads();
-        sstore(0);
-        __syncthreads();
-        if (kt + 1 < nkt) gload(kt + 1);
+        const int buf = kt & 1;
         if (wave_on && kt <= my_last_kt) {
             const int k0 = kt * 32;
             const bool diag = kt == my_last_kt;
@@ -449,9 +443,8 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
                 Frag<T> dsf; frag_from_acc(dsf, s, t);
 #pragma unroll
                 for (int i = 0; i < C::DB; ++i) {
-                    Frag<T> kf;
-                    const T* kp = &Kt[buf][(i * 32 + a) * LDT + 16 * t + 4 * h];
-                    frag_load_4x2(kf, kp, kp + 8);
+                    Frag<T> kf;                              // K^T[d][key] for the accumulator's key map
+                    frag_load_tr(kf, Ks[buf], C::LDN, 16 * t + 4 * h, 16 * t + 8 + 4 * h, i * 32, lane);
                     mma32(dq[i], kf, dsf);
                 }
             }
@@ -469,6 +462,11 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
             }
             if (ME_ABL != 2) flush_tile(dGT + ws_bh + (size_t)((cb0 + kt) * 32) * Lp + q0);
         }
+        if (kt + 1 < nkt) {
+            sstore(buf ^ 1);                      // buf^1 was last read in step kt-1 (barrier since)
+            if (kt + 2 < nkt) gload(kt + 2);
+        }
+        __syncthreads();
     }
     if (!row_on) return;
     T* dqp = dqkv + ((size_t)b * L + q) * ldq + head * DH;
@@ -488,13 +486,13 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
 // the kernel is HBM-bound (2 x Lp^2/2 elements per (b, head)).
 template <typename T, int DH>
 __global__ __launch_bounds__(256) void rga_bwd_kv_kernel(const T* __restrict__ PT, const T* __restrict__ dST,
-                                                         const T* __restrict__ qT, const T* __restrict__ doT,
+                                                         const T* __restrict__ qkv, const T* __restrict__ dout,
                                                          T* __restrict__ dqkv, int B, int L, int Lp, int H) {
-    constexpr int CH = ET<T>::CH, LDP = 32 + CH, DB = DH / 32;
+    constexpr int CH = ET<T>::CH, LDP = 32 + CH, DB = DH / 32, LDV = ACfg<T, DH>::LDV;
     __shared__ __attribute__((aligned(16))) T Pt[2][128 * LDP];
     __shared__ __attribute__((aligned(16))) T St[2][128 * LDP];
-    __shared__ __attribute__((aligned(16))) T Ot[2][DH * LDP];
-    __shared__ __attribute__((aligned(16))) T Qt[2][DH * LDP];
+    __shared__ __attribute__((aligned(16))) T Os[2][32 * LDV];         // natural dO / Q slabs [32 q][DH], transpose-read
+    __shared__ __attribute__((aligned(16))) T Qs[2][32 * LDV];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, a = lane & 31, h = lane >> 5;
     const int BH = B * H;
@@ -509,25 +507,25 @@ __global__ __launch_bounds__(256) void rga_bwd_kv_kernel(const T* __restrict__ P
     const int rows_valid = min(128, Lp - kb * 128);
     const T* pt_ = PT + (size_t)bh * Lp * Lp + (size_t)kb * 128 * Lp;
     const T* st_ = dST + (size_t)bh * Lp * Lp + (size_t)kb * 128 * Lp;
-    const T* qt_ = qT + (size_t)bh * DH * Lp;
-    const T* ot_ = doT + (size_t)bh * DH * Lp;
+    const T* q_ = qkv + (size_t)b * L * ldq + head * DH;
+    const T* o_ = dout + (size_t)b * L * dm + head * DH;
 
     f32x16_t dk[DB], dv[DB];
 #pragma unroll
     for (int i = 0; i < DB; ++i) { acc_zero(dk[i]); acc_zero(dv[i]); }
 
-    chunk16 rp[TileT<T, 128, 32>::NPT], rs[TileT<T, 128, 32>::NPT], ro[TileT<T, DH, 32>::NPT], rq[TileT<T, DH, 32>::NPT];
+    chunk16 rp[TileT<T, 128, 32>::NPT], rs[TileT<T, 128, 32>::NPT], ro[TileT<T, 32, DH>::NPT], rq[TileT<T, 32, DH>::NPT];
     auto gload = [&](int qs) {
         tile_gload<T, 128, 32>(rp, pt_ + qs * 32, (size_t)Lp, rows_valid, tid);
         tile_gload<T, 128, 32>(rs, st_ + qs * 32, (size_t)Lp, rows_valid, tid);
-        tile_gload<T, DH, 32>(ro, ot_ + qs * 32, (size_t)Lp, DH, tid);
-        tile_gload<T, DH, 32>(rq, qt_ + qs * 32, (size_t)Lp, DH, tid);
+        tile_gload<T, 32, DH>(ro, o_ + (size_t)qs * 32 * dm, (size_t)dm, L - qs * 32, tid);
+        tile_gload<T, 32, DH>(rq, q_ + (size_t)qs * 32 * ldq, ldq, L - qs * 32, tid);
     };
     auto sstore = [&](int buf) {
         tile_sstore<T, 128, 32, LDP>(rp, Pt[buf], tid);
         tile_sstore<T, 128, 32, LDP>(rs, St[buf], tid);
-        tile_sstore<T, DH, 32, LDP>(ro, Ot[buf], tid);
-        tile_sstore<T, DH, 32, LDP>(rq, Qt[buf], tid);
+        tile_sstore<T, 32, DH, LDV>(ro, Os[buf], tid);
+        tile_sstore<T, 32, DH, LDV>(rq, Qs[buf], tid);
     };
     gload(qs0);
     sstore(0);
@@ -544,8 +542,8 @@ __global__ __launch_bounds__(256) void rga_bwd_kv_kernel(const T* __restrict__ P
 #pragma unroll
                 for (int i = 0; i < DB; ++i) {
                     Frag<T> of, qf;
-                    frag_load(of, &Ot[buf][(i * 32 + a) * LDP + 16 * t + 8 * h]);
-                    frag_load(qf, &Qt[buf][(i * 32 + a) * LDP + 16 * t + 8 * h]);
+                    frag_load_tr(of, Os[buf], LDV, 16 * t + 8 * h, 16 * t + 8 * h + 4, i * 32, lane);     // dO^T[d][q]
+                    frag_load_tr(qf, Qs[buf], LDV, 16 * t + 8 * h, 16 * t + 8 * h + 4, i * 32, lane);     // Q^T[d][q]
                     mma32(dv[i], pf, of);
                     mma32(dk[i], sf, qf);
                 }
@@ -578,11 +576,11 @@ __global__ __launch_bounds__(256) void rga_bwd_kv_kernel(const T* __restrict__ P
 // accumulation over (bh, q) and one atomic flush per block.  Column block cb only receives
 // queries q >= 32*(Lp/32 - 1 - cb); earlier slabs are skipped.
 template <typename T, int DH>
-__global__ __launch_bounds__(256) void rga_bwd_e_kernel(const T* __restrict__ dGT, const T* __restrict__ qT,
+__global__ __launch_bounds__(256) void rga_bwd_e_kernel(const T* __restrict__ dGT, const T* __restrict__ qkv,
                                                         float* __restrict__ dE, int B, int L, int Lp, int H, int M) {
-    constexpr int CH = ET<T>::CH, LDP = 32 + CH, DB = DH / 32;
+    constexpr int CH = ET<T>::CH, LDP = 32 + CH, DB = DH / 32, LDV = ACfg<T, DH>::LDV;
     __shared__ __attribute__((aligned(16))) T Gt[2][128 * LDP];
-    __shared__ __attribute__((aligned(16))) T Qt[2][DH * LDP];
+    __shared__ __attribute__((aligned(16))) T Qs[2][32 * LDV];         // natural Q slab [32 q][DH], transpose-read
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, a = lane & 31, h = lane >> 5;
     const int BH = B * H;
@@ -620,15 +618,17 @@ __global__ __launch_bounds__(256) void rga_bwd_e_kernel(const T* __restrict__ dG
 #pragma unroll
     for (int i = 0; i < DB; ++i) acc_zero(acc[i]);
 
-    chunk16 rg[TileT<T, 128, 32>::NPT], rq[TileT<T, DH, 32>::NPT];
+    chunk16 rg[TileT<T, 128, 32>::NPT], rq[TileT<T, 32, DH>::NPT];
+    const int dm = H * DH;
+    const size_t ldq = (size_t)3 * dm;
     auto gload = [&](int s) {
         const int bh = bh_lo + s / nq, qs = qs0 + s % nq;
         tile_gload<T, 128, 32>(rg, dGT + (size_t)bh * Lp * Lp + (size_t)c0 * Lp + qs * 32, (size_t)Lp, rows_valid, tid);
-        tile_gload<T, DH, 32>(rq, qT + (size_t)bh * DH * Lp + qs * 32, (size_t)Lp, DH, tid);
+        tile_gload<T, 32, DH>(rq, qkv + ((size_t)(bh / H) * L + qs * 32) * ldq + (bh % H) * DH, ldq, L - qs * 32, tid);
     };
     auto sstore = [&](int buf) {
         tile_sstore<T, 128, 32, LDP>(rg, Gt[buf], tid);
-        tile_sstore<T, DH, 32, LDP>(rq, Qt[buf], tid);
+        tile_sstore<T, 32, DH, LDV>(rq, Qs[buf], tid);
     };
     gload(0);
     sstore(0);
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(256) void rga_bwd_e_kernel(const T* __restrict__ dG
 #pragma unroll
                 for (int i = 0; i < DB; ++i) {
                     Frag<T> qf;
-                    frag_load(qf, &Qt[buf][(i * 32 + a) * LDP + 16 * t + 8 * h]);
+                    frag_load_tr(qf, Qs[buf], LDV, 16 * t + 8 * h, 16 * t + 8 * h + 4, i * 32, lane);     // Q^T[d][q]
                     mma32(acc[i], gf, qf);
                 }
             }
@@ -738,37 +738,34 @@ __global__ __launch_bounds__(256) void rga_decode_kernel(const T* __restrict__ q
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <typename T, int DH>
-int fwd_launch(const void* qkv, const void* vT, const void* E, const uint8_t* key_pad, void* out, float* lse, int B, int L,
-               int Lp, int H, int M, hipStream_t st) {
+int fwd_launch(const void* qkv, const void* E, const uint8_t* key_pad, void* out, float* lse, int B, int L, int H, int M,
+               hipStream_t st) {
     const int nqb = (L + 127) / 128;
     const float scale = 1.f / sqrtf((float)DH);
-    rga_fwd_kernel<T, DH><<<B * H * nqb, 256, 0, st>>>((const T*)qkv, (const T*)vT, (const T*)E, key_pad, (T*)out, lse, B, L, Lp,
-                                                      H, M, scale);
+    rga_fwd_kernel<T, DH><<<B * H * nqb, 256, 0, st>>>((const T*)qkv, (const T*)E, key_pad, (T*)out, lse, B, L, H, M, scale);
     return me_launch_status();
 }
 
 template <typename T, int DH>
-int bwd_launch(const void* qkv, const void* qkvT, const void* E, const void* ET_, const uint8_t* key_pad, const void* out,
-               const float* lse, const void* dout, const void* doutT, void* dqkv, float* dE, float* delta_ws, void* PT,
-               void* dST, void* dGT, int B, int L, int Lp, int H, int M, hipStream_t st) {
+int bwd_launch(const void* qkv, const void* E, const void* ET_, const uint8_t* key_pad, const void* out, const float* lse,
+               const void* dout, void* dqkv, float* dE, float* delta_ws, void* PT, void* dST, void* dGT, int B, int L,
+               int Lp, int H, int M, hipStream_t st) {
     const int nqb = (L + 127) / 128;
     const float scale = 1.f / sqrtf((float)DH);
-    const size_t sec = (size_t)B * H * DH * Lp;
-    const T* qT = (const T*)qkvT;
-    const T* kT = qT + sec;
-    rga_bwd_q_kernel<T, DH><<<B * H * nqb, 256, 0, st>>>((const T*)qkv, kT, (const T*)E, (const T*)ET_, key_pad, (const T*)out, lse,
+    rga_bwd_q_kernel<T, DH><<<B * H * nqb, 256, 0, st>>>((const T*)qkv, (const T*)E, (const T*)ET_, key_pad, (const T*)out, lse,
                                                         (const T*)dout, (T*)dqkv, delta_ws, (T*)PT, (T*)dST, (T*)dGT, B, L, Lp,
                                                         H, M, scale);
     int rc = me_launch_status();
     if (rc) return rc;
-    rga_bwd_kv_kernel<T, DH><<<B * H * nqb, 256, 0, st>>>((const T*)PT, (const T*)dST, qT, (const T*)doutT, (T*)dqkv, B, L, Lp, H);
+    rga_bwd_kv_kernel<T, DH><<<B * H * nqb, 256, 0, st>>>((const T*)PT, (const T*)dST, (const T*)qkv, (const T*)dout, (T*)dqkv, B,
+                                                         L, Lp, H);
     rc = me_launch_status();
     if (rc) return rc;
     const int ngx = (Lp + 127) / 128;
     int eblocks = 512;                                   // ~2 per CU; every group gets at least one
     if (eblocks > ngx * B * H) eblocks = ngx * B * H;
     if (eblocks < ngx) eblocks = ngx;
-    rga_bwd_e_kernel<T, DH><<<eblocks, 256, 0, st>>>((const T*)dGT, qT, dE, B, L, Lp, H, M);
+    rga_bwd_e_kernel<T, DH><<<eblocks, 256, 0, st>>>((const T*)dGT, (const T*)qkv, dE, B, L, Lp, H, M);
     return me_launch_status();
 }
 
@@ -795,29 +792,28 @@ int dec_launch(const void* qkv_new, void* kc, void* vc, const void* E, const uin
 
 extern "C" {
 
-int me_rga_fwd(const void* qkv, const void* vT, const void* E, const uint8_t* key_pad, void* out, float* lse, int B, int L,
-               int Lp, int H, int dh, int M, int dtype, void* stream) {
+int me_rga_fwd(const void* qkv, const void* E, const uint8_t* key_pad, void* out, float* lse, int B, int L, int H, int dh,
+               int M, int dtype, void* stream) {
     me_clear_error();
-    if (!qkv || !vT || !E || !out || !lse) return ME_ERR_NULL;
-    if (B <= 0 || L <= 0 || H <= 0 || L > M || (M & 31) || (Lp & 31) || Lp < L || Lp > M) return ME_ERR_BAD_SHAPE;
-    if (!aligned16(qkv) || !aligned16(vT) || !aligned16(E) || !aligned16(out)) return ME_ERR_ALIGNMENT;
+    if (!qkv || !E || !out || !lse) return ME_ERR_NULL;
+    if (B <= 0 || L <= 0 || H <= 0 || L > M || (M & 31)) return ME_ERR_BAD_SHAPE;
+    if (!aligned16(qkv) || !aligned16(E) || !aligned16(out)) return ME_ERR_ALIGNMENT;
     hipStream_t st = (hipStream_t)stream;
-    ME_ATTN_DISPATCH((fwd_launch<T, DH>(qkv, vT, E, key_pad, out, lse, B, L, Lp, H, M, st)))
+    ME_ATTN_DISPATCH((fwd_launch<T, DH>(qkv, E, key_pad, out, lse, B, L, H, M, st)))
 }
 
-int me_rga_bwd(const void* qkv, const void* qkvT, const void* E, const void* ET_, const uint8_t* key_pad, const void* out,
-               const float* lse, const void* dout, const void* doutT, void* dqkv, float* dE, float* delta_ws, void* PT,
-               void* dST, void* dGT, int B, int L, int Lp, int H, int dh, int M, int dtype, void* stream) {
+int me_rga_bwd(const void* qkv, const void* E, const void* ET_, const uint8_t* key_pad, const void* out, const float* lse,
+               const void* dout, void* dqkv, float* dE, float* delta_ws, void* PT, void* dST, void* dGT, int B, int L,
+               int Lp, int H, int dh, int M, int dtype, void* stream) {
     me_clear_error();
-    if (!qkv || !qkvT || !E || !ET_ || !out || !lse || !dout || !doutT || !dqkv || !dE || !delta_ws || !PT || !dST || !dGT)
-        return ME_ERR_NULL;
+    if (!qkv || !E || !ET_ || !out || !lse || !dout || !dqkv || !dE || !delta_ws || !PT || !dST || !dGT) return ME_ERR_NULL;
     if (B <= 0 || L <= 0 || H <= 0 || L > M || (M & 31) || (Lp & 31) || Lp < L || Lp > M) return ME_ERR_BAD_SHAPE;
-    if (!aligned16(qkv) || !aligned16(qkvT) || !aligned16(E) || !aligned16(ET_) || !aligned16(out) || !aligned16(dout) ||
-        !aligned16(doutT) || !aligned16(dqkv) || !aligned16(PT) || !aligned16(dST) || !aligned16(dGT))
+    if (!aligned16(qkv) || !aligned16(E) || !aligned16(ET_) || !aligned16(out) || !aligned16(dout) || !aligned16(dqkv) ||
+        !aligned16(PT) || !aligned16(dST) || !aligned16(dGT))
         return ME_ERR_ALIGNMENT;
     hipStream_t st = (hipStream_t)stream;
-    ME_ATTN_DISPATCH((bwd_launch<T, DH>(qkv, qkvT, E, ET_, key_pad, out, lse, dout, doutT, dqkv, dE, delta_ws, PT, dST, dGT, B,
-                                        L, Lp, H, M, st)))
+    ME_ATTN_DISPATCH((bwd_launch<T, DH>(qkv, E, ET_, key_pad, out, lse, dout, dqkv, dE, delta_ws, PT, dST, dGT, B, L, Lp, H, M,
+                                        st)))
 }
 
 int me_rga_decode_step(const void* qkv_new, void* kcache, void* vcache, const void* E, const uint8_t* key_pad, int ld_pad,

@@ -76,6 +76,25 @@ ME_DEV void frag_load_4x2(Frag<float>& f, const float* p0, const float* p1) {
     f.lo = *reinterpret_cast<const f32x4_t*>(p0);
     f.hi = *reinterpret_cast<const f32x4_t*>(p1);
 }
+// Transposed fragment from a NATURAL LDS tile tile[row][col] (row stride ld elements): the lane's operand
+// row/column index is the tile COLUMN cbase + (lane & 31) and its 8 contraction elements are the tile rows
+// rA..rA+3 and rB..rB+3.  bf16: two ds_read_b64_tr_b16 -- inside every 16-lane group lane l supplies the
+// address of 4 contiguous elements and lane i receives element i%4 of the chunks of lanes i/4 + 4j (measured
+// on gfx950), so with lane l pointing at row r + l/4, columns 4*(l%4).., lane i gets column i for 4
+// consecutive rows.  f32: plain element gather (the exact tier is not performance critical).
+ME_DEV void frag_load_tr(Frag<bf16_t>& f, const bf16_t* tile, int ld, int rA, int rB, int cbase, int lane) {
+    typedef short v4s __attribute__((ext_vector_type(4)));
+    const int l16 = lane & 15;
+    const bf16_t* p = tile + (l16 >> 2) * ld + cbase + ((lane >> 4) & 1) * 16 + 4 * (l16 & 3);
+    v4s a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p + rA * ld));
+    v4s b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p + rB * ld));
+    f.v = __builtin_shufflevector(__builtin_bit_cast(bf16x4_t, a), __builtin_bit_cast(bf16x4_t, b), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+ME_DEV void frag_load_tr(Frag<float>& f, const float* tile, int ld, int rA, int rB, int cbase, int lane) {
+    const float* p = tile + cbase + (lane & 31);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f.lo[e] = p[(rA + e) * ld]; f.hi[e] = p[(rB + e) * ld]; }
+}
 ME_DEV void frag_zero(Frag<bf16_t>& f) { f.v = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0}; }
 ME_DEV void frag_zero(Frag<float>& f) { f.lo = (f32x4_t){0, 0, 0, 0}; f.hi = f.lo; }
 ME_DEV void frag_set(Frag<bf16_t>& f, int e, float x) { f.v[e] = (bf16_t)x; }

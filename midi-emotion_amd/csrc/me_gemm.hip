@@ -18,12 +18,6 @@ namespace {
 
 constexpr int BM = 128, BN = 128, NTHREADS = 256;
 
-// Optional second output of gemm_nt: a head-major TRANSPOSED copy of C,
-//   CT[s][b][head][dd][l]  for  column n = s*(H*dh) + head*dh + dd,  row t = b*L + l,
-// leading dimension Lp (>= L, multiple of 32; the padding is never written).  In the MFMA
-// accumulator layout a lane owns one column and 4 consecutive rows per register quad, so
-// this store is the natural one (8/16 bytes per lane).  It feeds the attention kernels
-// their contraction-contiguous K^T / V^T / Q^T / dO^T operands without any LDS transpose.
 template <typename T> ME_DEV void st4_t(T* p, float a, float b, float c, float d);
 template <> ME_DEV void st4_t<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
     bf16x4_t v; v[0] = (bf16_t)a; v[1] = (bf16_t)b; v[2] = (bf16_t)c; v[3] = (bf16_t)d;
@@ -31,10 +25,6 @@ template <> ME_DEV void st4_t<bf16_t>(bf16_t* p, float a, float b, float c, floa
 }
 template <> ME_DEV void st4_t<float>(float* p, float a, float b, float c, float d) { *reinterpret_cast<f32x4_t*>(p) = (f32x4_t){a, b, c, d}; }
 
-struct HeadT {
-    void* ptr;
-    int Bn, L, H, dh, Lp;
-};
 
 ME_DEV void acc_zero_quad(f32x16_t& a, int g) {
 #pragma unroll
@@ -116,11 +106,11 @@ ME_DEV void epi_block_swapped(const f32x16_t& acc, int row_base, int col_base, i
 // Two 64 KB slab buffers: the next slab streams in while the current one is multiplied.
 // Rows beyond M / N are clamped on the load side (their results are never stored).
 // ---------------------------------------------------------------------------------------------
-template <bool OUT_F32, bool HT>
+template <bool OUT_F32>
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(
     const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc,
     const float* __restrict__ bias, const bf16_t* __restrict__ add, int ldadd, const bf16_t* __restrict__ gate,
-    int ldgate, int M, int N, int K, int flags, HeadT ht) {
+    int ldgate, int M, int N, int K, int flags) {
     typedef bf16_t T;
     extern __shared__ __attribute__((aligned(16))) char smem[];          // [2 buffers][A 32 KB | B 32 KB]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -273,52 +263,6 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(
                         }
                     }
                 }
-                if constexpr (HT && !OUT_F32) {
-                    // ---- head-major transposed copy CT[s][b][head][dd][l]: second trip through the staging
-                    //      area, this time [column][token] (64 x 64 per pass), read back as 16-byte token runs
-#pragma unroll
-                    for (int ib = 0; ib < PASS_ROWS / 32; ++ib) {
-                        const int i = ps * (PASS_ROWS / 32) + ib;
-                        const int lr = ib * 32 + (lane & 31);
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-#pragma unroll
-                            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    const int cl = j * 32 + 8 * g + 4 * h + e;
-                                    const int col = n0 + wc * 64 + cl;
-                                    float v = acc[i][j][4 * g + e] + ((bias && col < N) ? bias[col] : 0.f);
-                                    if (relu) v = fmaxf(v, 0.f);
-                                    const int row = m0 + wr * 128 + i * 32 + (lane & 31);
-                                    if (add && row < M && col < N) v += (float)add[(size_t)row * ldadd + col];
-                                    reinterpret_cast<T*>(stg)[cl * 64 + lr] = (T)v;
-                                }
-                    }
-                    const size_t per_b = (size_t)ht.H * ht.dh * ht.Lp;
-                    const int dmh = ht.H * ht.dh;
-#pragma unroll
-                    for (int it = 0; it < 8; ++it) {
-                        const int cl = it * 8 + (lane >> 3), ch = lane & 7;
-                        const chunk16 v = ld_chunk(stg + cl * 128 + ch * 16);
-                        const int col = n0 + wc * 64 + cl;
-                        const int row0 = m0 + wr * 128 + ps * PASS_ROWS + ch * 8;        // 8 consecutive tokens
-                        if (col < N && row0 < M) {
-                            const int sec = col / dmh;
-                            T* base = reinterpret_cast<T*>(ht.ptr) + (size_t)sec * ht.Bn * per_b + (size_t)(col - sec * dmh) * ht.Lp;
-                            const int b0 = row0 / ht.L, l0 = row0 - b0 * ht.L;
-                            if (row0 + 7 < M && l0 + 7 < ht.L && (l0 & 7) == 0) {
-                                st_chunk(base + (size_t)b0 * per_b + l0, v);
-                            } else {
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) {
-                                    const int rr = row0 + e;
-                                    if (rr < M) { const int bb = rr / ht.L; base[(size_t)bb * per_b + (rr - bb * ht.L)] = reinterpret_cast<const T*>(&v)[e]; }
-                                }
-                            }
-                        }
-                    }
-                }
 #pragma unroll
                 for (int ib = 0; ib < PASS_ROWS / 32; ++ib)
 #pragma unroll
@@ -332,18 +276,17 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(
 
 // C = A.B^T.  128x128 block tile, 4 waves (2x2) x 64x64.  K-slab BKT (64 bf16 / 32 f32) is
 // double buffered in LDS: one barrier per slab, the slab after next is in flight in registers
-// while the current one is multiplied.  SWAP = true accumulates the TRANSPOSED 32x32 blocks
-// (mfma(B, A)): a lane then owns one row of C and 4 consecutive columns per register quad, so
-// the epilogue is 8/16-byte row-contiguous stores (and loads of add/gate) instead of 2-byte
-// ones.  SWAP = false (only for the head-major transposed copy) keeps lane = column.
+// while the current one is multiplied.  The 32x32 blocks are accumulated TRANSPOSED (mfma(B, A)):
+// a lane then owns one row of C and 4 consecutive columns per register quad, so the epilogue is
+// 8/16-byte row-contiguous stores (and loads of add/gate) instead of 2-byte ones.
 // Blocks are renumbered so that each XCD (private L2) works on a contiguous range of tiles.
 template <typename T> struct GemmK { static constexpr int BKT = sizeof(T) == 2 ? 64 : 32; };
 
-template <typename T, bool OUT_F32, bool SWAP>
+template <typename T, bool OUT_F32>
 __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(
     const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc,
     const float* __restrict__ bias, const T* __restrict__ add, int ldadd, const T* __restrict__ gate, int ldgate,
-    int M, int N, int K, int flags, HeadT ht) {
+    int M, int N, int K, int flags) {
     constexpr int CH = ET<T>::CH;
     constexpr int BKT = GemmK<T>::BKT;
     constexpr int CPR = BKT / CH;          // chunks per tile row
@@ -403,8 +346,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    if (SWAP) mma32(acc[i][j], fb[j], fa[i]);
-                    else mma32(acc[i][j], fa[i], fb[j]);
+                    mma32(acc[i][j], fb[j], fa[i]);          // transposed blocks: lane = row of C
                 }
         }
         if (kt + 1 < nk) {
@@ -415,62 +357,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(
     }
 
     const bool relu = flags & ME_EPI_RELU;
-    if constexpr (SWAP) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                epi_block_swapped<T, OUT_F32>(acc[i][j], m0 + wr * 64 + i * 32, n0 + wc * 64 + j * 32, lane, Cv, ldc, bias, add,
-                                              ldadd, gate, ldgate, M, N, relu);
-        return;
-    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wc * 64 + j * 32 + c_col(lane);
-            if (col >= N) continue;
-            const float bv = bias ? bias[col] : 0.f;
-            float vals[16];
-            size_t tcol = 0;                 // offset of this column inside one batch of CT (without s,b terms)
-            int sec = 0;
-            if (ht.ptr) {
-                const int dm = ht.H * ht.dh;
-                sec = col / dm;
-                tcol = (size_t)(col - sec * dm) * ht.Lp;       // (head*dh + dd) * Lp
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wr * 64 + i * 32 + c_row(r, lane);
-                if (row >= M) continue;
-                float v = acc[i][j][r] + bv;
-                if (relu) v = fmaxf(v, 0.f);
-                if (add) v += ET<T>::to_f(add[(size_t)row * ldadd + col]);
-                if (gate) v = ET<T>::to_f(gate[(size_t)row * ldgate + col]) > 0.f ? v : 0.f;
-                if (OUT_F32) reinterpret_cast<float*>(Cv)[(size_t)row * ldc + col] = v;
-                else reinterpret_cast<T*>(Cv)[(size_t)row * ldc + col] = ET<T>::from_f(v);
-                vals[r] = v;
-            }
-            if (ht.ptr) {
-                const size_t per_b = (size_t)ht.H * ht.dh * ht.Lp;
-                T* base = reinterpret_cast<T*>(ht.ptr) + (size_t)sec * ht.Bn * per_b + tcol;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int row0 = m0 + wr * 64 + i * 32 + 8 * g + 4 * (lane >> 5);   // 4 consecutive tokens
-                    if (row0 >= M) continue;
-                    const int b0 = row0 / ht.L, l0 = row0 - b0 * ht.L;
-                    if (row0 + 3 < M && l0 + 3 < ht.L && (l0 & 3) == 0) {
-                        st4_t<T>(base + (size_t)b0 * per_b + l0, vals[4 * g], vals[4 * g + 1], vals[4 * g + 2], vals[4 * g + 3]);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int rr = row0 + e;
-                            if (rr < M) { const int bb = rr / ht.L; base[(size_t)bb * per_b + (rr - bb * ht.L)] = ET<T>::from_f(vals[4 * g + e]); }
-                        }
-                    }
-                }
-            }
-        }
+        for (int j = 0; j < 2; ++j)
+            epi_block_swapped<T, OUT_F32>(acc[i][j], m0 + wr * 64 + i * 32, n0 + wc * 64 + j * 32, lane, Cv, ldc, bias, add, ldadd,
+                                          gate, ldgate, M, N, relu);
 }
 
 // dW[n][k] += sum_t A[t][n] * B[t][k].  Tiles are staged TRANSPOSED into LDS
@@ -746,40 +638,37 @@ static const bool g_disable_nt256 = getenv("MIDIEMO_NO_NT256") != nullptr;
 template <typename T>
 int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
                    const void* add, int ldadd, const void* gate, int ldgate, int M, int N, int K, int flags,
-                   hipStream_t st, HeadT ht = HeadT{nullptr, 0, 1, 1, 1, 0}) {
+                   hipStream_t st) {
     constexpr int CH = ET<T>::CH;
     if (M <= 0 || N <= 0 || K <= 0) return ME_ERR_BAD_SHAPE;
     if (K % CH || lda % CH || ldb % CH) return ME_ERR_BAD_SHAPE;
     if (!aligned16(A) || !aligned16(B)) return ME_ERR_ALIGNMENT;
     if constexpr (sizeof(T) == 2) {
-        if (K % 64 == 0 && M >= 256 && N >= 192 && !g_disable_nt256 && !(ht.ptr && (flags & ME_EPI_OUT_F32))) {
+        if (K % 64 == 0 && M >= 256 && N >= 192 && !g_disable_nt256) {
             static bool attr_set = false;
             if (!attr_set) {
-                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
                 attr_set = true;
             }
             unsigned g256 = (unsigned)(((N + 255) / 256) * ((M + 255) / 256));
             if (g256 > 256u) g256 = 256u;            // persistent: one block per CU
-#define ME_NT256(F32, HTF)                                                                                                  \
-    gemm_nt256_kernel<F32, HTF><<<g256, 512, 131072, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias,     \
-                                                           (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags, ht)
-            if (ht.ptr) ME_NT256(false, true);
-            else if (flags & ME_EPI_OUT_F32) ME_NT256(true, false);
-            else ME_NT256(false, false);
-#undef ME_NT256
+            if (flags & ME_EPI_OUT_F32)
+                gemm_nt256_kernel<true><<<g256, 512, 131072, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias,
+                                                                   (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags);
+            else
+                gemm_nt256_kernel<false><<<g256, 512, 131072, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias,
+                                                                    (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags);
             return me_launch_status();
         }
     }
     const unsigned grid = (unsigned)(((N + BN - 1) / BN) * ((M + BM - 1) / BM));
-#define ME_NT_LAUNCH(F32, SW)                                                                                              \
-    gemm_nt_kernel<T, F32, SW><<<grid, NTHREADS, 0, st>>>((const T*)A, lda, (const T*)B, ldb, C, ldc, bias, (const T*)add,     \
-                                                          ldadd, (const T*)gate, ldgate, M, N, K, flags, ht)
-    if (ht.ptr) ME_NT_LAUNCH(false, false);
-    else if (flags & ME_EPI_OUT_F32) ME_NT_LAUNCH(true, true);
-    else ME_NT_LAUNCH(false, true);
-#undef ME_NT_LAUNCH
+    if (flags & ME_EPI_OUT_F32)
+        gemm_nt_kernel<T, true><<<grid, NTHREADS, 0, st>>>((const T*)A, lda, (const T*)B, ldb, C, ldc, bias, (const T*)add, ldadd,
+                                                          (const T*)gate, ldgate, M, N, K, flags);
+    else
+        gemm_nt_kernel<T, false><<<grid, NTHREADS, 0, st>>>((const T*)A, lda, (const T*)B, ldb, C, ldc, bias, (const T*)add, ldadd,
+                                                           (const T*)gate, ldgate, M, N, K, flags);
     return me_launch_status();
 }
 
@@ -839,20 +728,6 @@ int me_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
     hipStream_t st = (hipStream_t)stream;
     if (dtype == ME_F32) return gemm_nt_launch<float>(A, lda, B, ldb, C, ldc, bias, add, ldadd, gate, ldgate, M, N, K, flags, st);
     if (dtype == ME_BF16) return gemm_nt_launch<bf16_t>(A, lda, B, ldb, C, ldc, bias, add, ldadd, gate, ldgate, M, N, K, flags, st);
-    return ME_ERR_BAD_DTYPE;
-}
-
-int me_gemm_nt_headT(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias, const void* add,
-                     int ldadd, void* CT, int Bn, int L, int H, int dh, int Lp, int M, int N, int K, int flags, int dtype,
-                     void* stream) {
-    me_clear_error();
-    if (!A || !B || !C || !CT) return ME_ERR_NULL;
-    if (Bn <= 0 || L <= 0 || H <= 0 || dh <= 0 || Lp < L || M != Bn * L || N % (H * dh) || (flags & ME_EPI_OUT_F32))
-        return ME_ERR_BAD_SHAPE;
-    hipStream_t st = (hipStream_t)stream;
-    HeadT ht{CT, Bn, L, H, dh, Lp};
-    if (dtype == ME_F32) return gemm_nt_launch<float>(A, lda, B, ldb, C, ldc, bias, add, ldadd, nullptr, 0, M, N, K, flags, st, ht);
-    if (dtype == ME_BF16) return gemm_nt_launch<bf16_t>(A, lda, B, ldb, C, ldc, bias, add, ldadd, nullptr, 0, M, N, K, flags, st, ht);
     return ME_ERR_BAD_DTYPE;
 }
 

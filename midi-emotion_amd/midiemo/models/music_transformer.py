@@ -316,8 +316,6 @@ class MusicTransformerHIP(nn.Module):
             L = _Workspace()
             L.qkv, L.att, L.o1, L.hid = e(T, 3 * d), e(T, d), e(T, d), e(T, di)
             L.lse = e(B, H, Lm, dtype=torch.float32)
-            # head-major transposed copy [3][B][H][dh][Lp] (q^T, k^T, v^T); padding columns stay zero
-            L.qkvT = torch.zeros(3, B, H, self.dh, Lp, dtype=dt, device=dev)
             if save:
                 L.s1, L.s2 = e(T, d), e(T, d)
                 L.st1, L.st2 = e(T, 2, dtype=torch.float32), e(T, 2, dtype=torch.float32)
@@ -334,7 +332,6 @@ class MusicTransformerHIP(nn.Module):
             ws.dA, ws.dB, ws.dC = e(T, d), e(T, d), e(T, d)
             ws.dhid, ws.dqkv = e(T, di), e(T, 3 * d)
             ws.delta = e(B, H, Lm, dtype=torch.float32)
-            ws.doutT = torch.zeros(B, H, self.dh, Lp, dtype=dt, device=dev)
             # materialised P^T, dS^T, dG^T of the layer being differentiated (zero-initialised once:
             # only on/below-diagonal tiles are ever written or read)
             ws.PT = torch.zeros(B * H, Lp, Lp, dtype=dt, device=dev)
@@ -393,8 +390,8 @@ class MusicTransformerHIP(nn.Module):
             x = ws.h[i % nh if not save else i]
             y = ws.h[(i + 1) % nh if not save else i + 1]
             p = f"enc_layers.{i}."
-            ops.gemm_nt_headT(x, W["Wqkv"], Lw.qkv, Lw.qkvT, B, Lm, H, dh, ws.Lp, bias=W["bqkv"], M=T, N=3 * d, K=d, dtype=dt)
-            ops.rga_fwd(Lw.qkv, Lw.qkvT[2], W["E"], ws.key_pad, Lw.att, Lw.lse, B, Lm, ws.Lp, H, dh, M)
+            ops.gemm_nt(x, W["Wqkv"], Lw.qkv, bias=W["bqkv"], M=T, N=3 * d, K=d, dtype=dt)
+            ops.rga_fwd(Lw.qkv, W["E"], ws.key_pad, Lw.att, Lw.lse, B, Lm, H, dh, M)
             ops.gemm_nt(Lw.att, W["Wo"], ws.tmp, bias=self._pview(f, p + "rga.fc.bias"), M=T, N=d, K=d, dtype=dt)
             ops.resid_ln_fwd(x, ws.tmp, self._pview(f, p + "layernorm1.weight"), self._pview(f, p + "layernorm1.bias"),
                              Lw.o1, Lw.s1, Lw.st1, T, d, self.LN_EPS, p_drop, seed, 1 + 2 * i)
@@ -442,9 +439,9 @@ class MusicTransformerHIP(nn.Module):
             ops.resid_ln_bwd(ws.dA, Lw.s1, Lw.st1, self._pview(f, p + "layernorm1.weight"), ws.dB, ws.dC,
                              gv(p + "layernorm1.weight"), gv(p + "layernorm1.bias"), T, d, p_drop, seed, 1 + 2 * i)
             ops.gemm_tn_acc(ws.dC, Lw.att, gv(p + "rga.fc.weight"), gv(p + "rga.fc.bias"), T=T, N=d, K=d, dtype=dt)
-            ops.gemm_nt_headT(ws.dC, W["WoT"], ws.dA, ws.doutT, B, Lm, H, dh, ws.Lp, M=T, N=d, K=d, dtype=dt)   # d(att)
-            ops.rga_bwd(Lw.qkv, Lw.qkvT, W["E"], W["ET"], ws.key_pad, Lw.att, Lw.lse, ws.dA, ws.doutT, ws.dqkv,
-                        gv(p + "rga.E"), ws.delta, ws.PT, ws.dST, ws.dGT, B, Lm, ws.Lp, H, dh, M)
+            ops.gemm_nt(ws.dC, W["WoT"], ws.dA, M=T, N=d, K=d, dtype=dt)                         # d(att)
+            ops.rga_bwd(Lw.qkv, W["E"], W["ET"], ws.key_pad, Lw.att, Lw.lse, ws.dA, ws.dqkv, gv(p + "rga.E"),
+                        ws.delta, ws.PT, ws.dST, ws.dGT, B, Lm, ws.Lp, H, dh, M)
             o, _, _ = self._slices[p + "rga.Wq.weight"]
             ob, _, _ = self._slices[p + "rga.Wq.bias"]
             ops.gemm_tn_acc(ws.dqkv, x, gflat[o:o + 3 * d * d].view(3 * d, d), gflat[ob:ob + 3 * d], T=T, N=3 * d, K=d,

@@ -81,26 +81,15 @@ def gemm_tn_acc(A, B, dW, dbias=None, T=None, N=None, K=None, dtype=None):
                                T, N, K, _code(dtype), _stream()), "me_gemm_tn_acc")
 
 
-def gemm_nt_headT(A, B, C, CT, Bn, L, H, dh, Lp, bias=None, add=None, M=None, N=None, K=None, flags=0, dtype=None):
-    """gemm_nt + head-major transposed copy CT[s][b][head][dd][l] (ld Lp)."""
-    dtype = dtype or A.dtype
-    M = A.shape[0] if M is None else M
-    K = A.shape[1] if K is None else K
-    N = B.shape[0] if N is None else N
-    check(lib().me_gemm_nt_headT(_ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(C), C.stride(0), _ptr(bias),
-                                 _ptr(add), add.stride(0) if add is not None else 0, _ptr(CT), Bn, L, H, dh, Lp,
-                                 M, N, K, flags, _code(dtype), _stream()), "me_gemm_nt_headT")
-
-
-def rga_fwd(qkv, vT, E, key_pad, out, lse, B, L, Lp, H, dh, M):
-    check(lib().me_rga_fwd(_ptr(qkv), _ptr(vT), _ptr(E), _ptr(key_pad), _ptr(out), _ptr(lse), B, L, Lp, H, dh, M,
+def rga_fwd(qkv, E, key_pad, out, lse, B, L, H, dh, M):
+    check(lib().me_rga_fwd(_ptr(qkv), _ptr(E), _ptr(key_pad), _ptr(out), _ptr(lse), B, L, H, dh, M,
                            _code(qkv.dtype), _stream()), "me_rga_fwd")
 
 
-def rga_bwd(qkv, qkvT, E, ET, key_pad, out, lse, dout, doutT, dqkv, dE, delta_ws, PT, dST, dGT, B, L, Lp, H, dh, M):
-    check(lib().me_rga_bwd(_ptr(qkv), _ptr(qkvT), _ptr(E), _ptr(ET), _ptr(key_pad), _ptr(out), _ptr(lse), _ptr(dout),
-                           _ptr(doutT), _ptr(dqkv), _ptr(dE), _ptr(delta_ws), _ptr(PT), _ptr(dST), _ptr(dGT),
-                           B, L, Lp, H, dh, M, _code(qkv.dtype), _stream()), "me_rga_bwd")
+def rga_bwd(qkv, E, ET, key_pad, out, lse, dout, dqkv, dE, delta_ws, PT, dST, dGT, B, L, Lp, H, dh, M):
+    check(lib().me_rga_bwd(_ptr(qkv), _ptr(E), _ptr(ET), _ptr(key_pad), _ptr(out), _ptr(lse), _ptr(dout), _ptr(dqkv),
+                           _ptr(dE), _ptr(delta_ws), _ptr(PT), _ptr(dST), _ptr(dGT), B, L, Lp, H, dh, M,
+                           _code(qkv.dtype), _stream()), "me_rga_bwd")
 
 
 def resid_ln_fwd(x, a, gamma, beta, y, s_out, stats, rows, d, eps, p, seed, site):

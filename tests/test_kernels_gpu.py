@@ -333,39 +333,26 @@ def attn_case(B, H, L, dh, M, seed, pad_rows=True):
 
 
 def run_attn(ops, dtype, q, k, v, E, dO, pad, backward=True):
-    """Drives the attention entry points the way the engine does: the fused-QKV GEMM with the
-    head-major transposed copy (identity weights), forward, d(out) GEMM with transposed copy, backward."""
     B, H, L, dh = q.shape
     M = E.shape[0]
     Lp = ((L + 31) // 32) * 32
-    d = H * dh
     to_tok = lambda t: t.permute(0, 2, 1, 3)          # [B,L,H,dh]
-    x = torch.stack([to_tok(q), to_tok(k), to_tok(v)], dim=2).contiguous().to(dtype).to(DEV).view(B * L, 3 * d)
-    eye3 = torch.eye(3 * d, dtype=dtype, device=DEV)
-    qkv = torch.empty(B * L, 3 * d, dtype=dtype, device=DEV)
-    qkvT = torch.zeros(3, B, H, dh, Lp, dtype=dtype, device=DEV)
-    ops.gemm_nt_headT(x, eye3, qkv, qkvT, B, L, H, dh, Lp)
-    assert torch.equal(qkv, x)
-    assert torch.equal(qkvT[1, :, :, :, :L], k.to(dtype).to(DEV).permute(0, 1, 3, 2))
+    qkv = torch.stack([to_tok(q), to_tok(k), to_tok(v)], dim=2).contiguous().to(dtype).to(DEV)   # [B,L,3,H,dh]
     Ed = E.to(dtype).to(DEV).contiguous()
     kp = pad.to(torch.uint8).to(DEV) if pad is not None else None
     out = torch.full((B, L, H, dh), float("nan"), dtype=dtype, device=DEV)
     lse = torch.empty(B, H, L, dtype=torch.float32, device=DEV)
-    ops.rga_fwd(qkv, qkvT[2], Ed, kp, out, lse, B, L, Lp, H, dh, M)
+    ops.rga_fwd(qkv, Ed, kp, out, lse, B, L, H, dh, M)
     res = {"O": out.permute(0, 2, 1, 3).float().cpu(), "lse": lse.cpu()}
     if backward:
-        dx = to_tok(dO).contiguous().to(dtype).to(DEV).view(B * L, d)
-        eye = torch.eye(d, dtype=dtype, device=DEV)
-        dout = torch.empty(B * L, d, dtype=dtype, device=DEV)
-        doutT = torch.zeros(B, H, dh, Lp, dtype=dtype, device=DEV)
-        ops.gemm_nt_headT(dx, eye, dout, doutT, B, L, H, dh, Lp)
+        dout = to_tok(dO).contiguous().to(dtype).to(DEV)
         dqkv = torch.full_like(qkv, float("nan"))
         dE = torch.zeros(M, dh, dtype=torch.float32, device=DEV)
         ET = Ed.t().contiguous()
         delta = torch.empty(B, H, L, dtype=torch.float32, device=DEV)
         PT, dST, dGT = (torch.zeros(B * H, Lp, Lp, dtype=dtype, device=DEV) for _ in range(3))
-        ops.rga_bwd(qkv, qkvT, Ed, ET, kp, out, lse, dout, doutT, dqkv, dE, delta, PT, dST, dGT, B, L, Lp, H, dh, M)
-        g = dqkv.view(B, L, 3, H, dh).float().cpu().permute(2, 0, 3, 1, 4)   # [3,B,H,L,dh]
+        ops.rga_bwd(qkv, Ed, ET, kp, out, lse, dout, dqkv, dE, delta, PT, dST, dGT, B, L, Lp, H, dh, M)
+        g = dqkv.float().cpu().permute(2, 0, 3, 1, 4)   # [3,B,H,L,dh]
         res.update(dq=g[0], dk=g[1], dv=g[2], dE=dE.cpu())
     return res
 

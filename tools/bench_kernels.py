@@ -36,31 +36,22 @@ def main():
     if "attn" in a.what:
         Lp = ((L + 31) // 32) * 32
         qkv = torch.randn(B, L, 3, H, dh, device=dev).to(dt)
-        qkvT = torch.zeros(3, B, H, dh, Lp, device=dev, dtype=dt)
-        qkvT[..., :L] = qkv.permute(2, 0, 3, 4, 1)
         E = torch.randn(M, dh, device=dev).to(dt)
         ET = E.t().contiguous()
         out = torch.empty(B, L, H, dh, device=dev, dtype=dt)
         lse = torch.empty(B, H, L, device=dev)
         dout = torch.randn(B, L, H, dh, device=dev).to(dt)
-        doutT = torch.zeros(B, H, dh, Lp, device=dev, dtype=dt)
-        doutT[..., :L] = dout.permute(0, 2, 3, 1)
         dqkv = torch.empty_like(qkv)
         dE = torch.zeros(M, dh, device=dev)
         delta = torch.empty(B, H, L, device=dev)
         PT, dST, dGT = (torch.zeros(B * H, Lp, Lp, device=dev, dtype=dt) for _ in range(3))
         kp = torch.zeros(B, L, dtype=torch.uint8, device=dev)
         flop = 3 * 2 * B * H * dh * L * (L + 1) / 2
-        t = timeit(lambda: ops.rga_fwd(qkv, qkvT[2], E, kp, out, lse, B, L, Lp, H, dh, M), a.iters)
+        t = timeit(lambda: ops.rga_fwd(qkv, E, kp, out, lse, B, L, H, dh, M), a.iters)
         print("rga_fwd          %9.1f us  %7.1f TF (causal-discounted 3 contractions)" % (t, flop / t / 1e6))
-        t = timeit(lambda: ops.rga_bwd(qkv, qkvT, E, ET, kp, out, lse, dout, doutT, dqkv, dE, delta, PT, dST, dGT,
-                                       B, L, Lp, H, dh, M), a.iters)
+        t = timeit(lambda: ops.rga_bwd(qkv, E, ET, kp, out, lse, dout, dqkv, dE, delta, PT, dST, dGT, B, L, Lp, H, dh, M),
+                   a.iters)
         print("rga_bwd (3 krn)  %9.1f us  %7.1f TF (2x fwd flops)" % (t, 2 * flop / t / 1e6))
-        x = torch.randn(B * L, 512, device=dev).to(dt)
-        W = torch.randn(1536, 512, device=dev).to(dt)
-        C = torch.empty(B * L, 1536, device=dev, dtype=dt)
-        t = timeit(lambda: ops.gemm_nt_headT(x, W, C, qkvT, B, L, H, dh, Lp), a.iters)
-        print("gemm_nt_headT qkv %8.1f us  %7.1f TF" % (t, 2.0 * B * L * 1536 * 512 / t / 1e6))
     if "gemm" in a.what:
         for (M_, N_, K_, tag) in [(T, 1536, 512, "qkv"), (T, 512, 512, "proj"), (T, 2048, 512, "ffn1"),
                                    (T, 512, 2048, "ffn2"), (T, 1007, 512, "head")]:
