@@ -479,7 +479,7 @@ ME_DEV bf16x4_t lds_tr4(const bf16_t* p) {
 
 __global__ __launch_bounds__(NTHREADS) void gemm_tn_bf16_kernel(
     const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, float* __restrict__ dW, int lddw,
-    float* __restrict__ dbias, int Tn, int N, int K, int t_per_block) {
+    float* __restrict__ dbias, int Tn, int N, int K, int t_per_block, int tn, int tk, int nsplit) {
     typedef bf16_t T;
     constexpr int LDN_ = 160;                      // LDS row stride (elements)
     constexpr int NCH = BT * 16 / NTHREADS;        // 16-byte chunks per thread per operand (2)
@@ -488,8 +488,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_bf16_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
-    const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
-    const int t_begin = blockIdx.z * t_per_block;
+    // 1-D grid, XCD-aware order (block b runs on XCD b % 8, each XCD has a private L2): a "pair" =
+    // (n-tile, token slab) shares one A panel; its tk k-tiles run back to back on ONE XCD so the
+    // panel is fetched from HBM once and hit in L2 by the others.
+    const int npairs = tn * nsplit;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int pair = (slot / tk) * 8 + xcd, ky = slot % tk;
+    if (pair >= npairs) return;
+    const int nx = pair % tn, z = pair / tn;
+    const int n0 = nx * 128, k0 = ky * 128;
+    const int t_begin = z * t_per_block;
     const int t_end = min(Tn, t_begin + t_per_block);
     if (t_begin >= t_end) return;
 
@@ -518,7 +526,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_bf16_kernel(
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc_zero(acc[i][j]);
     float bsum = 0.f;
-    const bool do_bias = dbias != nullptr && blockIdx.y == 0;
+    const bool do_bias = dbias != nullptr && ky == 0;
     // transpose-read lane geometry
     const int l16 = lane & 15, rbase = ((lane >> 4) & 1) * 16, h = lane >> 5;
     const int trow = l16 >> 2, tcol = rbase + 4 * (l16 & 3);
@@ -689,9 +697,11 @@ int gemm_tn_launch(const void* A, int lda, const void* B, int ldb, float* dW, in
     t_per = ((t_per + BT - 1) / BT) * BT;
     nsplit = (Tn + t_per - 1) / t_per;
     dim3 grid(tn, tk, nsplit);
-    if constexpr (sizeof(T) == 2)
-        gemm_tn_bf16_kernel<<<grid, NTHREADS, 0, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, dW, lddw, dbias, Tn, N, K, t_per);
-    else
+    if constexpr (sizeof(T) == 2) {
+        const int npairs8 = ((tn * nsplit + 7) / 8) * 8;
+        gemm_tn_bf16_kernel<<<npairs8 * tk, NTHREADS, 0, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, dW, lddw, dbias, Tn, N, K,
+                                                               t_per, tn, tk, nsplit);
+    } else
         gemm_tn_kernel<T><<<grid, NTHREADS, 0, st>>>((const T*)A, lda, (const T*)B, ldb, dW, lddw, dbias, Tn, N, K, t_per);
     return me_launch_status();
 }
