@@ -102,7 +102,7 @@ class GemmProbe:
             e0.record()
             self.orig(A, B, C, **kw)
             e1.record()
-            self.rec.append((2.0 * m * n * k, e0, e1))
+            self.rec.append((2.0 * m * n * k, e0, e1, (m * k + n * k) * A.element_size() + m * n * C.element_size()))
         self.ops.gemm_nt = nt
         return self
 
@@ -113,6 +113,7 @@ class GemmProbe:
         torch.cuda.synchronize()
         flops = sum(r[0] for r in self.rec)
         ms = sum(r[1].elapsed_time(r[2]) for r in self.rec)
+        self.alg_bytes = sum(r[3] for r in self.rec) / max(1, len(self.rec))
         return flops, ms, len(self.rec)
 
 
@@ -215,12 +216,22 @@ def main():
         }
         if probe is not None:
             flops, ms, n = probe
+            # HBM bytes/launch of the same kernel: PMC counters need their own rocprofv3 pass (guide section
+            # "HBM traffic"), so the committed summary of that pass over this exact command is quoted here --
+            # only for the workload it was collected on.
+            traffic = None
+            tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+            if args.compute_dtype == "bf16" and (B, L) == (32, 1024) and os.path.exists(tj):
+                k = json.load(open(tj)).get("gemm_nt256_kernel<false>")
+                if k:
+                    traffic = int(round((k["read_MB"] + k["write_MB"]) * 1e6))
             ach = flops / (ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": ("gemm_nt256_kernel<bf16>" if args.compute_dtype == "bf16" else "gemm_nt_kernel<float>"),
                                "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS if args.compute_dtype == "bf16" else 157.3,
                                "unit": "TFLOP/s",
                                "frac": round(ach / (PEAK_BF16_TFLOPS if args.compute_dtype == "bf16" else 157.3), 4),
-                               "traffic": None, "launches_per_step": n // 3,
+                               "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC pass, profiles/r01_hbm_traffic.txt)",
+                               "algorithmic_bytes_per_launch": int(gp.alg_bytes), "launches_per_step": n // 3,
                                "avg_launch_us": round(1000.0 * ms / n, 2),
                                "gemm_nt_ms_per_step": round(ms / 3, 3),
                                "step_frac_of_peak": round(tps * fpt / 1e12 / world / PEAK_BF16_TFLOPS, 4)}

@@ -9,10 +9,8 @@
 #include <stdlib.h>
 
 #include "me_common.h"
+#include <type_traits>
 
-#ifndef ME_GABL
-#define ME_GABL 0
-#endif
 
 namespace {
 
@@ -99,53 +97,91 @@ ME_DEV void epi_block_swapped(const f32x16_t& acc, int row_base, int col_base, i
 
 // ---------------------------------------------------------------------------------------------
 // 256x256 tile, 8 waves (2 x 4, each 128 x 64 = 4 x 2 macro-atoms), bf16, K % 64 == 0.
-// Operands go global -> LDS directly (global_load_lds, 16 B per lane, no VGPR staging, no
-// ds_write): each wave instruction fills 8 rows x 128 B of a LINEAR [256][64] slab image.  Bank
-// conflicts of the ds_read_b128 fragment reads are avoided by permuting the SOURCE chunk of
-// every lane (slot c of row r holds chunk c ^ (r & 7)) and applying the same XOR on the read.
-// Two 64 KB slab buffers: the next slab streams in while the current one is multiplied.
+// Each slab [256 rows][64 k] of A and of B lives in LDS as a LINEAR image (128 B per row); a "piece" is
+// what one wave instruction moves: 8 rows x 128 B, one 16-byte chunk per lane.  Bank conflicts of the
+// ds_read_b128 fragment reads are avoided by permuting the SOURCE chunk of every lane (slot c of row r
+// holds chunk c ^ swz(r)) and applying the same XOR on the read.
+//
+// Schedule (what the measurements on MI355X say, tools/ubench_ingest.hip + tools/ubench_mfma.hip):
+//   * with random operands the matrix pipe is power limited to ~1750 TF/s (1500 with the 6 ds_read_b128 per
+//     8 MFMAs this tile shape needs); one CU can ingest 65-70 GB/s of this operand mix; both at once in a plain
+//     8-wave loop with ONE barrier per slab reach 53 us for the K=2048 shape (vendor GEMM: 51 us);
+//   * every additional s_barrier per slab costs ~150 cycles x 8 waves (a ping-pong schedule with a barrier per
+//     k-phase lost 25 %), and direct-to-LDS pieces (global_load_lds) cost the issuing wave 60-180 cycles each
+//     and must land within one slab period;
+//   so: operands are fetched into REGISTERS a whole slab ahead (8 x global_load_dwordx4 per wave always in
+//   flight), stored into the other LDS buffer while the current slab is multiplied (ds_write_b128, waits counted:
+//   the loop body is straight-line code so the compiler's vmcnt bookkeeping stays exact), one raw s_barrier per
+//   slab (no vmcnt(0)), the two waves of a SIMD interleave MFMA bursts and LDS traffic by themselves.
+// The epilogue has its own 32 KB staging area (4 KB per wave), so the slab buffers keep streaming.
 // Rows beyond M / N are clamped on the load side (their results are never stored).
 // ---------------------------------------------------------------------------------------------
+constexpr int NT256_LDS = 2 * 65536 + 8 * 4096;
+
+ME_DEV void slot_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 template <bool OUT_F32>
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(
     const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc,
     const float* __restrict__ bias, const bf16_t* __restrict__ add, int ldadd, const bf16_t* __restrict__ gate,
     int ldgate, int M, int N, int K, int flags) {
     typedef bf16_t T;
-    extern __shared__ __attribute__((aligned(16))) char smem[];          // [2 buffers][A 32 KB | B 32 KB]
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // [2 buffers][A 32 KB | B 32 KB] | staging
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
     const int ntn = (N + 255) / 256, ntiles = ntn * ((M + 255) / 256);
     const int nk = K / 64;
-    // persistent over tiles: block b handles tiles b, b+grid, ...; the (tile, slab) sequence is
-    // one pipeline, so the first slab of the next tile streams in during this tile's epilogue
+    // persistent over tiles: block b handles tiles b, b+grid, ...
     const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int nsteps = my_tiles * nk;
-    auto tile_origin = [&](int it, int& m0, int& n0) {
+    if (nsteps <= 0) return;
+    auto tile_origin = [&](int it, int& m0, int& n0) __attribute__((always_inline)) {
         int t = it * gridDim.x + blockIdx.x;
         if ((ntiles & 7) == 0) t = (t & 7) * (ntiles >> 3) + (t >> 3);      // contiguous tile range per XCD
         m0 = (t / ntn) * 256;
         n0 = (t % ntn) * 256;
     };
 
+    // ---- operand stream.  A piece = 8 rows x 128 B (one 16-byte chunk per lane).  It is fetched into
+    // registers a whole slab ahead (R[i] always has a load in flight) and stored to the LINEAR slab image
+    // in LDS once the buffer is free: per wave and slab 8 x (global_load_dwordx4 + ds_write_b128), a few
+    // issue cycles each -- a direct-to-LDS piece (global_load_lds) costs its wave 60-180 issue cycles and
+    // must land within the same slab period (measured: 78-82 us vs 64 us without any feed on the K=2048 shape).
+    // Loads and stores are UNCONDITIONAL (past the end the stream stays on the last slab and the store goes to
+    // the free buffer): the loop body is straight-line code, so the compiler's vmcnt bookkeeping stays exact
+    // (it waits for the three oldest of eight loads in flight, not for all of them).
     const int lrow = lane >> 3;
-    auto issue = [&](int step) {
-        int m0, n0;
-        tile_origin(step / nk, m0, n0);
-        const int k0 = (step % nk) * 64;
-        char* base = smem + (step & 1) * 65536 + (wid * 4) * 1024;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = (wid * 4 + i) * 8 + lrow;
-            const int lchunk = (lane & 7) ^ ((lrow ^ (wid * 4 + i)) & 7);       // slot c of row r holds chunk c ^ swz(r)
-            const bf16_t* sa = A + (size_t)min(m0 + r, M - 1) * lda + lchunk * 8 + k0;
-            const bf16_t* sb = B + (size_t)min(n0 + r, N - 1) * ldb + lchunk * 8 + k0;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
-                                             (__attribute__((address_space(3))) void*)(base + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb,
-                                             (__attribute__((address_space(3))) void*)(base + 32768 + i * 1024), 16, 0, 0);
-        }
+    int d_step = 0, d_k = 0, d_tile = 0, d_m0, d_n0;                      // slab being fetched
+    tile_origin(0, d_m0, d_n0);
+    chunk16 R[8];
+    // piece i of the wave: rows r0 + 8 (i & 3) ..., chunk ch0 ^ (i & 3)  (blk = 4 wid + (i & 3), so
+    // swz(r) = (lrow ^ blk) & 7 = swz(r0) ^ (i & 3)); 32-bit byte offsets against the scalar bases
+    const int r0 = wid * 32 + lrow;
+    const int ch0 = (lane & 7) ^ ((lrow ^ (wid * 4)) & 7);
+    const uint32_t lda2 = (uint32_t)lda * 2u, ldb2 = (uint32_t)ldb * 2u;
+    const char* Ab = reinterpret_cast<const char*>(A);
+    const char* Bb = reinterpret_cast<const char*>(B);
+    auto ld_piece = [&](int i) __attribute__((always_inline)) {           // i = 0..3: A rows, 4..7: B rows
+        const int ii = i & 3;
+        const uint32_t col = (uint32_t)((ch0 ^ ii) * 16 + d_k * 2);
+        if (i < 4) R[i] = ld_chunk(Ab + ((uint32_t)min(d_m0 + r0 + 8 * ii, M - 1) * lda2 + col));
+        else R[i] = ld_chunk(Bb + ((uint32_t)min(d_n0 + r0 + 8 * ii, N - 1) * ldb2 + col));
+    };
+    char* const st_base = smem + wid * 4096 + lane * 16;
+    auto st_piece = [&](int i, int slab) __attribute__((always_inline)) {
+        st_chunk(st_base + (slab & 1) * 65536 + ((i >> 2) * 32768 + (i & 3) * 1024), R[i]);
+    };
+    auto ld_advance = [&]() __attribute__((always_inline)) {
+        if (d_step + 1 >= nsteps) return;                                  // stay on the last slab
+        ++d_step;
+        d_k += 64;
+        if (d_k == K) { d_k = 0; ++d_tile; tile_origin(d_tile, d_m0, d_n0); }
     };
 
     f32x16_t acc[4][2];
@@ -157,120 +193,135 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(
     const int frow = lane & 31, h = lane >> 5;
     const bool relu = flags & ME_EPI_RELU;
     const bool vec_c = (ldc % (OUT_F32 ? 4 : 8)) == 0 && (reinterpret_cast<uintptr_t>(Cv) & 15) == 0;
-    if (nsteps <= 0) return;
-    issue(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int step = 0; step < nsteps; ++step) {
-#if ME_GABL != 2
-        if (step + 1 < nsteps) issue(step + 1);
-#endif
-        const char* as = smem + (step & 1) * 65536;
-        const char* bs = as + 32768;
-        // swz(r) = (r ^ (r >> 3)) & 7 makes every 16-lane group of a ds_read_b128 hit 16 distinct
-        // 16-byte slots of the 256-byte bank row (conflict free); fragments of k-step kk+1 are
-        // fetched before the MFMAs of kk so the LDS latency hides under the matrix pipe
-        Frag<T> fa[2][4], fb[2][2];
-        auto lfrag = [&](int set, int kk) {
+
+    // swz(r) = (r ^ (r >> 3)) & 7 makes every 16-lane group of a ds_read_b128 hit 16 distinct
+    // 16-byte slots of the 256-byte bank row (conflict free).
+    // Address of k-phase kk = (row base | chunk slot) ^ (kk << 5): (2 kk + h) ^ swz = (2 kk) ^ (h ^ swz).
+    // Rows r and r + 32 differ in swz by 4 ((r >> 3) & 7 advances by 4), i.e. their slot offsets by XOR 64.
+    Frag<T> fa[4], fb[2];
+    uint32_t pa0, pb0;
+    { const int r = wr * 128 + frow; pa0 = r * 128 + ((h ^ ((r ^ (r >> 3)) & 7)) << 4); }
+    { const int r = wc * 64 + frow; pb0 = 32768 + r * 128 + ((h ^ ((r ^ (r >> 3)) & 7)) << 4); }
+    auto lfrag = [&](uint32_t bufoff, int kk) __attribute__((always_inline)) {
+        const char* ae = smem + ((pa0 + bufoff) ^ (uint32_t)(kk << 5));
+        const char* ao = smem + ((pa0 + bufoff) ^ (uint32_t)((kk << 5) ^ 64));
+        const char* be = smem + ((pb0 + bufoff) ^ (uint32_t)(kk << 5));
+        const char* bo = smem + ((pb0 + bufoff) ^ (uint32_t)((kk << 5) ^ 64));
+        frag_load(fa[0], reinterpret_cast<const T*>(ae));
+        frag_load(fa[1], reinterpret_cast<const T*>(ao + 4096));
+        frag_load(fa[2], reinterpret_cast<const T*>(ae + 8192));
+        frag_load(fa[3], reinterpret_cast<const T*>(ao + 12288));
+        frag_load(fb[0], reinterpret_cast<const T*>(be));
+        frag_load(fb[1], reinterpret_cast<const T*>(bo + 4096));
+    };
+
+    // ---- tile write-out: stage 32 rows x 128 B at a time through the wave's private 4 KB so that every
+    // store instruction writes 8 full 128-byte row segments (per-lane 8-byte pieces across 32 rows are
+    // L2-transaction bound).  bf16: a pass = 32 rows x 64 columns; f32: 32 rows x 32 columns.
+    auto epilogue = [&](int tile_it) __attribute__((always_inline)) {
+        int m0, n0;
+        tile_origin(tile_it, m0, n0);
+        char* stg = smem + 2 * 65536 + wid * 4096;
+        constexpr int NJ = OUT_F32 ? 1 : 2;                                // accumulator blocks per pass
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = wr * 128 + i * 32 + frow;
-                frag_load(fa[set][i], reinterpret_cast<const T*>(as + r * 128 + (((kk * 2 + h) ^ ((r ^ (r >> 3)) & 7)) << 4)));
-            }
+        for (int ps = 0; ps < 8 / NJ; ++ps) {
+            const int i = OUT_F32 ? ps >> 1 : ps, j0 = OUT_F32 ? ps & 1 : 0;
+            const int lr = lane & 31;
+            const int row = m0 + wr * 128 + i * 32 + lr;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int r = wc * 64 + j * 32 + frow;
-                frag_load(fb[set][j], reinterpret_cast<const T*>(bs + r * 128 + (((kk * 2 + h) ^ ((r ^ (r >> 3)) & 7)) << 4)));
-            }
-        };
-        lfrag(0, 0);
+            for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            if (kk < 3) lfrag((kk + 1) & 1, kk + 1);
+                for (int g = 0; g < 4; ++g) {
+                    const int j = j0 + jj;
+                    const int cl = j * 32 + 8 * g + 4 * h;                 // column inside the wave's 64
+                    const int col = n0 + wc * 64 + cl;
+                    float v[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[i][j][4 * g + e] + ((bias && col + e < N) ? bias[col + e] : 0.f);
+                        if (relu) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    if (add && row < M) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) { if (ME_GABL != 1) mma32(acc[i][j], fb[kk & 1][j], fa[kk & 1][i]); else acc[i][j][0] += (float)fa[kk & 1][i].v[0] * (float)fb[kk & 1][j].v[1]; }
-        }
-        if ((step + 1) % nk == 0) {
-            // ---- tile finished.  The slab buffer just consumed is free (the other one is receiving the
-            // next tile's first slab): stage the tile through it so that every store instruction writes
-            // 8 full rows of 128 B (per-lane 8-byte pieces across 32 rows are L2-transaction bound).
-            int m0, n0;
-            tile_origin(step / nk, m0, n0);
-            __syncthreads();                                   // all waves are done reading this buffer
-            char* stg = smem + (step & 1) * 65536 + wid * 8192;        // 8 KB per wave
-            constexpr int PASS_ROWS = OUT_F32 ? 32 : 64;              // rows of the wave's 128 x 64 sub-tile per pass
-            constexpr int ROWB = OUT_F32 ? 256 : 128;                  // bytes per staged row (64 columns)
+                        for (int e = 0; e < 4; ++e) if (col + e < N) v[e] += (float)add[(size_t)row * ldadd + col + e];
+                    }
+                    if (gate && row < M) {
 #pragma unroll
-            for (int ps = 0; ps < 128 / PASS_ROWS; ++ps) {
-#pragma unroll
-                for (int ib = 0; ib < PASS_ROWS / 32; ++ib) {
-                    const int i = ps * (PASS_ROWS / 32) + ib;
-                    const int lr = ib * 32 + (lane & 31);              // row inside the pass
-                    const int row = m0 + wr * 128 + i * 32 + (lane & 31);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const int cl = j * 32 + 8 * g + 4 * h;     // column inside the wave's 64
-                            const int col = n0 + wc * 64 + cl;
-                            float v[4];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                v[e] = acc[i][j][4 * g + e] + ((bias && col + e < N) ? bias[col + e] : 0.f);
-                                if (relu) v[e] = fmaxf(v[e], 0.f);
-                            }
-                            if (add && row < M) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) if (col + e < N) v[e] += (float)add[(size_t)row * ldadd + col + e];
-                            }
-                            if (gate && row < M) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) if (col + e < N) v[e] = (float)gate[(size_t)row * ldgate + col + e] > 0.f ? v[e] : 0.f;
-                            }
-                            // 16-byte slot index XOR (row & 7): spreads the 32 rows of a store over the banks
-                            if constexpr (OUT_F32) {
-                                const int slot = ((cl * 4) >> 4) ^ (lr & 7);
-                                *reinterpret_cast<f32x4_t*>(stg + lr * ROWB + (slot << 4)) = (f32x4_t){v[0], v[1], v[2], v[3]};
-                            } else {
-                                const int slot = ((cl * 2) >> 4) ^ (lr & 7);
-                                st4_t<T>(reinterpret_cast<T*>(stg + lr * ROWB + (slot << 4) + ((cl * 2) & 15)), v[0], v[1], v[2], v[3]);
-                            }
-                        }
-                }
-                // read back: lane -> (row = it*R + lane / CPRW, 16-byte chunk lane % CPRW): full-row coalesced stores
-                constexpr int CPRW = ROWB / 16;                        // chunks per row (8 / 16)
-                constexpr int RPI = 64 / CPRW;                         // rows per store instruction (8 / 4)
-#pragma unroll
-                for (int it = 0; it < PASS_ROWS / RPI; ++it) {
-                    const int lr = it * RPI + lane / CPRW, ch = lane % CPRW;
-                    const chunk16 v = ld_chunk(stg + lr * ROWB + ((ch ^ (lr & 7)) << 4));
-                    const int row = m0 + wr * 128 + ps * PASS_ROWS + lr;
-                    const int col = n0 + wc * 64 + ch * (OUT_F32 ? 4 : 8);
-                    if (row < M && col < N) {
-                        constexpr int EPC = OUT_F32 ? 4 : 8;           // elements per chunk
-                        if (col + EPC <= N && vec_c) {
-                            if constexpr (OUT_F32) st_chunk(reinterpret_cast<float*>(Cv) + (size_t)row * ldc + col, v);
-                            else st_chunk(reinterpret_cast<T*>(Cv) + (size_t)row * ldc + col, v);
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < EPC; ++e)
-                                if (col + e < N) {
-                                    if constexpr (OUT_F32) (reinterpret_cast<float*>(Cv))[(size_t)row * ldc + col + e] = reinterpret_cast<const float*>(&v)[e];
-                                    else (reinterpret_cast<T*>(Cv))[(size_t)row * ldc + col + e] = reinterpret_cast<const T*>(&v)[e];
-                                }
-                        }
+                        for (int e = 0; e < 4; ++e) if (col + e < N) v[e] = (float)gate[(size_t)row * ldgate + col + e] > 0.f ? v[e] : 0.f;
+                    }
+                    // 16-byte slot index XOR (row & 7): spreads the 32 rows of a store over the banks
+                    if constexpr (OUT_F32) {
+                        const int slot = (2 * g + h) ^ (lr & 7);
+                        *reinterpret_cast<f32x4_t*>(stg + lr * 128 + (slot << 4)) = (f32x4_t){v[0], v[1], v[2], v[3]};
+                    } else {
+                        const int slot = (jj * 4 + g) ^ (lr & 7);
+                        st4_t<T>(reinterpret_cast<T*>(stg + lr * 128 + (slot << 4) + h * 8), v[0], v[1], v[2], v[3]);
                     }
                 }
+            // read back: lane -> (row it*8 + lane/8, 16-byte chunk lane%8): full-row coalesced stores
 #pragma unroll
-                for (int ib = 0; ib < PASS_ROWS / 32; ++ib)
+            for (int it = 0; it < 4; ++it) {
+                const int rr = it * 8 + (lane >> 3), ch = lane & 7;
+                const chunk16 v = ld_chunk(stg + rr * 128 + ((ch ^ (rr & 7)) << 4));
+                const int orow = m0 + wr * 128 + i * 32 + rr;
+                constexpr int EPC = OUT_F32 ? 4 : 8;                       // elements per chunk
+                const int col = n0 + wc * 64 + j0 * 32 + ch * EPC;
+                if (orow < M && col < N) {
+                    if (col + EPC <= N && vec_c) {
+                        if constexpr (OUT_F32) st_chunk(reinterpret_cast<float*>(Cv) + (size_t)orow * ldc + col, v);
+                        else st_chunk(reinterpret_cast<T*>(Cv) + (size_t)orow * ldc + col, v);
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc_zero(acc[ps * (PASS_ROWS / 32) + ib][j]);
+                        for (int e = 0; e < EPC; ++e)
+                            if (col + e < N) {
+                                if constexpr (OUT_F32) (reinterpret_cast<float*>(Cv))[(size_t)orow * ldc + col + e] = reinterpret_cast<const float*>(&v)[e];
+                                else (reinterpret_cast<T*>(Cv))[(size_t)orow * ldc + col + e] = reinterpret_cast<const T*>(&v)[e];
+                            }
+                    }
+                }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc_zero(acc[i][j]);
+    };
+
+    // ---- prologue: slab 0 into LDS, slab 1 into the registers
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ld_piece(i);
+    ld_advance();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) st_piece(i, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ld_piece(i);
+    ld_advance();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    slot_barrier();
+
+    for (int step = 0; step < nsteps; ++step) {
+        const uint32_t buf = (uint32_t)(step & 1) * 65536u;
+        // slab step+1 (in the registers since the previous iteration) -> the other buffer; refetch slab step+2.
+        // Two pieces per k-phase, scheduled by the compiler between the MFMAs.
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            lfrag(buf, kk);
+            {
+                st_piece(2 * kk, step + 1);
+                st_piece(2 * kk + 1, step + 1);
+                ld_piece(2 * kk);
+                ld_piece(2 * kk + 1);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                mma32(acc[g][0], fb[0], fa[g]);
+                mma32(acc[g][1], fb[1], fa[g]);
+            }
+        }
+        ld_advance();
+        if ((step + 1) % nk == 0) epilogue(step / nk);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // my stores of slab step+1 are in LDS
+        slot_barrier();                                                    // everybody's; slab `step` fully consumed
     }
 }
 
@@ -652,20 +703,22 @@ int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int 
     if (K % CH || lda % CH || ldb % CH) return ME_ERR_BAD_SHAPE;
     if (!aligned16(A) || !aligned16(B)) return ME_ERR_ALIGNMENT;
     if constexpr (sizeof(T) == 2) {
-        if (K % 64 == 0 && M >= 256 && N >= 192 && !g_disable_nt256) {
+        // the 256-tile kernel addresses its operands with 32-bit byte offsets
+        const bool off32 = (unsigned long long)M * lda * 2ull < (1ull << 32) && (unsigned long long)N * ldb * 2ull < (1ull << 32);
+        if (K % 64 == 0 && M >= 256 && N >= 192 && off32 && !g_disable_nt256) {
             static bool attr_set = false;
             if (!attr_set) {
-                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
                 attr_set = true;
             }
             unsigned g256 = (unsigned)(((N + 255) / 256) * ((M + 255) / 256));
             if (g256 > 256u) g256 = 256u;            // persistent: one block per CU
             if (flags & ME_EPI_OUT_F32)
-                gemm_nt256_kernel<true><<<g256, 512, 131072, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias,
+                gemm_nt256_kernel<true><<<g256, 512, NT256_LDS, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias,
                                                                    (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags);
             else
-                gemm_nt256_kernel<false><<<g256, 512, 131072, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias,
+                gemm_nt256_kernel<false><<<g256, 512, NT256_LDS, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias,
                                                                     (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags);
             return me_launch_status();
         }

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--B", type=int, default=32)
     ap.add_argument("--L", type=int, default=1024)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--only", default="", help="comma list of GEMM shape tags to run (default all)")
     a = ap.parse_args()
     dev, dt = "cuda", torch.bfloat16
     B, L, H, dh, M, d, di = a.B, a.L, 8, 64, 2048, 512, 2048
@@ -55,19 +56,32 @@ def main():
     if "gemm" in a.what:
         for (M_, N_, K_, tag) in [(T, 1536, 512, "qkv"), (T, 512, 512, "proj"), (T, 2048, 512, "ffn1"),
                                    (T, 512, 2048, "ffn2"), (T, 1007, 512, "head")]:
+            if a.only and tag not in a.only.split(","):
+                continue
             A = torch.randn(M_, K_, device=dev).to(dt)
             Bm = torch.randn(N_, K_, device=dev).to(dt)
             C = torch.empty(M_, N_, device=dev, dtype=dt)
             bias = torch.randn(N_, device=dev)
             t = timeit(lambda: ops.gemm_nt(A, Bm, C, bias=bias), a.iters)
             print("gemm_nt %-5s M%d N%d K%d %9.1f us  %7.1f TF" % (tag, M_, N_, K_, t, 2.0 * M_ * N_ * K_ / t / 1e6))
+            if "blaslt" in a.what:      # yardstick only: the vendor library on the same shape (no bias)
+                Bt = Bm.t()
+                t = timeit(lambda: torch.matmul(A, Bt, out=C), a.iters)
+                print("   torch.matmul (hipBLASLt)      %9.1f us  %7.1f TF" % (t, 2.0 * M_ * N_ * K_ / t / 1e6))
         for (N_, K_, tag) in [(1536, 512, "dWqkv"), (512, 512, "dWo"), (2048, 512, "dW1"), (512, 2048, "dW2")]:
+            if a.only and tag not in a.only.split(","):
+                continue
             A = torch.randn(T, N_, device=dev).to(dt)
             X = torch.randn(T, K_, device=dev).to(dt)
             dW = torch.zeros(N_, K_, device=dev)
             db = torch.zeros(N_, device=dev)
             t = timeit(lambda: ops.gemm_tn_acc(A, X, dW, db), a.iters)
             print("gemm_tn %-5s T%d N%d K%d %9.1f us  %7.1f TF" % (tag, T, N_, K_, t, 2.0 * T * N_ * K_ / t / 1e6))
+            if "blaslt" in a.what:
+                At = A.t()
+                Cw = torch.empty(N_, K_, device=dev, dtype=dt)
+                t = timeit(lambda: torch.matmul(At, X, out=Cw), a.iters)
+                print("   torch.matmul (hipBLASLt)      %9.1f us  %7.1f TF" % (t, 2.0 * T * N_ * K_ / t / 1e6))
 
 
 if __name__ == "__main__":
