@@ -56,21 +56,49 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(T* __restrict__ out, con
     const float c0 = cond ? cond[b * 2] : 0.f, c1 = cond ? cond[b * 2 + 1] : 0.f;
     int64_t tok = 0;
     if (l >= shift) tok = tokens[(int64_t)b * Ltok + (l - shift)];
+    const bool vec_ok = (de % 4) == 0 && (d % 4) == 0 && (dc % 4) == 0;
     for (int col = lane * CH; col < d; col += 64 * CH) {
         float v[CH];
+        const float* pep = pe + (int64_t)l * d + col;
+        if (vec_ok && l >= shift && col + CH <= de) {
+            // chunk inside the token embedding: 16-byte loads of the table row and of the positional encoding
+            const float* ep = emb + tok * de + col;
 #pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            const int j = col + i;
-            float x;
-            if (l < shift) {
-                x = l == 0 ? cw0[j] * c0 + cb0[j] : cw1[j] * c1 + cb1[j];
-            } else if (j < de) {
-                x = emb[tok * de + j] * sq;
-            } else {
-                const int jc = j - de;
-                x = cw0[jc * 2] * c0 + cw0[jc * 2 + 1] * c1 + cb0[jc];
+            for (int q = 0; q < CH / 4; ++q) {
+                const f32x4_t e4 = *reinterpret_cast<const f32x4_t*>(ep + 4 * q);
+                const f32x4_t p4 = *reinterpret_cast<const f32x4_t*>(pep + 4 * q);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[4 * q + i] = e4[i] * sq + p4[i];
             }
-            v[i] = x + pe[(int64_t)l * d + j];
+        } else if (vec_ok && l >= shift && col >= de) {
+            // chunk inside the concatenated condition projection: cw0 is [dc][2] row-major
+            const int jc = col - de;
+#pragma unroll
+            for (int q = 0; q < CH / 4; ++q) {
+                const f32x4_t wa = *reinterpret_cast<const f32x4_t*>(cw0 + (jc + 4 * q) * 2);
+                const f32x4_t wb = *reinterpret_cast<const f32x4_t*>(cw0 + (jc + 4 * q) * 2 + 4);
+                const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(cb0 + jc + 4 * q);
+                const f32x4_t p4 = *reinterpret_cast<const f32x4_t*>(pep + 4 * q);
+                v[4 * q + 0] = wa[0] * c0 + wa[1] * c1 + b4[0] + p4[0];
+                v[4 * q + 1] = wa[2] * c0 + wa[3] * c1 + b4[1] + p4[1];
+                v[4 * q + 2] = wb[0] * c0 + wb[1] * c1 + b4[2] + p4[2];
+                v[4 * q + 3] = wb[2] * c0 + wb[3] * c1 + b4[3] + p4[3];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int j = col + i;
+                float x;
+                if (l < shift) {
+                    x = l == 0 ? cw0[j] * c0 + cb0[j] : cw1[j] * c1 + cb1[j];
+                } else if (j < de) {
+                    x = emb[tok * de + j] * sq;
+                } else {
+                    const int jc = j - de;
+                    x = cw0[jc * 2] * c0 + cw0[jc * 2 + 1] * c1 + cb0[jc];
+                }
+                v[i] = x + pe[(int64_t)l * d + j];
+            }
         }
         if (thr16) {
             float mult[CH];
@@ -115,6 +143,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const T* __restrict__ do
         for (int c = 0; c < MAXC; ++c) {
             const int col = (lane + c * 64) * CH;
             if (col >= d) break;
+            if (skip_emb && l >= shift && col + CH <= de) continue;      // embed_bwd_table_kernel owns these columns
             float g[CH];
             chunk_to_f<T>(ld_chunk(dout + row * d + col), g);
             if (thr16) {
@@ -270,36 +299,69 @@ __global__ __launch_bounds__(256) void resid_ln_fwd_kernel(const T* __restrict__
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void resid_ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ s,
+// NW waves per block: every wave keeps per-lane column partials of dgamma / dbeta over its rows, the block combines
+// them with LDS atomics and issues ONE global atomic per column -- the flush (blocks x 2 d global atomics) is a
+// visible part of the kernel, so blocks are fat (16 waves) rather than many.
+template <typename T, int NC, int NW>
+__global__ __launch_bounds__(NW * 64) void resid_ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ s,
                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
                                                            T* __restrict__ dx, T* __restrict__ da, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, int rows, int d, uint32_t thr16,
                                                            float inv_keep, uint64_t seed, uint32_t site) {
     constexpr int CH = ET<T>::CH;
-    __shared__ float red[2][4][MAXC * 64 * 8];
+    __shared__ float red[2][NC * 64 * CH];
+    for (int j = threadIdx.x; j < 2 * NC * 64 * CH; j += NW * 64) (&red[0][0])[j] = 0.f;
+    __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    float pg[MAXC][CH], pb[MAXC][CH];
+    float pg[NC][CH], pb[NC][CH];
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int i = 0; i < CH; ++i) { pg[c][i] = 0.f; pb[c][i] = 0.f; }
 
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wid; row < rows; row += (int64_t)gridDim.x * 4) {
-        const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
-        float g[MAXC][CH], xh[MAXC][CH];
+    // gamma is row independent; the next row's chunks and statistics are fetched before the current row's
+    // reductions so that every wave always has loads in flight (one row at a time ran at 2.7 TB/s)
+    float gam[NC][CH];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int col = (lane + c * 64) * CH;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) gam[c][i] = col < d ? gamma[col + i] : 0.f;
+    }
+    const int64_t stride = (int64_t)gridDim.x * NW;
+    int64_t row = (int64_t)blockIdx.x * NW + wid;
+    chunk16 ndy[NC], ns[NC];
+    float nmean = 0.f, nrstd = 0.f;
+    auto fetch = [&](int64_t r) {
+        if (r >= rows) return;
+        nmean = stats[r * 2];
+        nrstd = stats[r * 2 + 1];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = (lane + c * 64) * CH;
+            if (col < d) { ndy[c] = ld_chunk(dy + r * d + col); ns[c] = ld_chunk(s + r * d + col); }
+        }
+    };
+    fetch(row);
+    for (; row < rows; row += stride) {
+        const float mean = nmean, rstd = nrstd;
+        chunk16 cdy[NC], cs[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { cdy[c] = ndy[c]; cs[c] = ns[c]; }
+        fetch(row + stride);
+        float g[NC][CH], xh[NC][CH];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
+        for (int c = 0; c < NC; ++c) {
             const int col = (lane + c * 64) * CH;
             if (col < d) {
                 float dyv[CH], sv[CH];
-                chunk_to_f<T>(ld_chunk(dy + row * d + col), dyv);
-                chunk_to_f<T>(ld_chunk(s + row * d + col), sv);
+                chunk_to_f<T>(cdy[c], dyv);
+                chunk_to_f<T>(cs[c], sv);
 #pragma unroll
                 for (int i = 0; i < CH; ++i) {
                     xh[c][i] = (sv[i] - mean) * rstd;
-                    g[c][i] = dyv[i] * gamma[col + i];
+                    g[c][i] = dyv[i] * gam[c][i];
                     s1 += g[c][i];
                     s2 += g[c][i] * xh[c][i];
                     pg[c][i] += dyv[i] * xh[c][i];
@@ -309,7 +371,7 @@ __global__ __launch_bounds__(256) void resid_ln_bwd_kernel(const T* __restrict__
         }
         const float c1 = wave_sum(s1) / d, c2 = wave_sum(s2) / d;
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
+        for (int c = 0; c < NC; ++c) {
             const int col = (lane + c * 64) * CH;
             if (col < d) {
                 float o[CH];
@@ -327,20 +389,21 @@ __global__ __launch_bounds__(256) void resid_ln_bwd_kernel(const T* __restrict__
         }
     }
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-            red[0][wid][(c * 64 + lane) * CH + i] = pg[c][i];
-            red[1][wid][(c * 64 + lane) * CH + i] = pb[c][i];
+            atomicAdd(&red[0][(c * 64 + lane) * CH + i], pg[c][i]);
+            atomicAdd(&red[1][(c * 64 + lane) * CH + i], pb[c][i]);
         }
     __syncthreads();
-    for (int j = threadIdx.x; j < d; j += 256) {
-        atomicAdd(&dgamma[j], red[0][0][j] + red[0][1][j] + red[0][2][j] + red[0][3][j]);
-        atomicAdd(&dbeta[j], red[1][0][j] + red[1][1][j] + red[1][2][j] + red[1][3][j]);
+    for (int j = threadIdx.x; j < d; j += NW * 64) {
+        atomicAdd(&dgamma[j], red[0][j]);
+        atomicAdd(&dbeta[j], red[1][j]);
     }
 }
 
 // ------------------------------------------------------------------ cross-entropy head
+constexpr int CE_Q = 8;    // 16-byte pieces per lane of the register-resident row: V <= 2048
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, int ld,
                                                      const int64_t* __restrict__ target, float* __restrict__ row_lse,
                                                      float* __restrict__ loss_sum, float* __restrict__ n_valid, int rows,
@@ -350,11 +413,31 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
     float bl = 0.f, bn = 0.f;
     for (int64_t row = (int64_t)blockIdx.x * 4 + wid; row < rows; row += (int64_t)gridDim.x * 4) {
         const float* lg = logits + row * ld;
-        float mx = -INFINITY;
-        for (int j = lane; j < V; j += 64) mx = fmaxf(mx, lg[j]);
-        mx = wave_max(mx);
-        float se = 0.f;
-        for (int j = lane; j < V; j += 64) se += expf(lg[j] - mx);
+        float mx = -INFINITY, se = 0.f;
+        if (V <= 64 * 4 * CE_Q && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0) {
+            // one pass: the row (<= 2048 logits) sits in registers, 16-byte loads
+            f32x4_t v[CE_Q];
+#pragma unroll
+            for (int q = 0; q < CE_Q; ++q) {
+                const int j = (q * 64 + lane) * 4;
+                if (j + 3 < V) v[q] = *reinterpret_cast<const f32x4_t*>(lg + j);
+                else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[q][i] = j + i < V ? lg[j + i] : -INFINITY;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mx = fmaxf(mx, v[q][i]);
+            }
+            mx = wave_max(mx);
+#pragma unroll
+            for (int q = 0; q < CE_Q; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) se += __builtin_amdgcn_exp2f((v[q][i] - mx) * 1.4426950408889634f);   // v_exp_f32; exp2(-inf) = 0 for the padding
+        } else {
+            for (int j = lane; j < V; j += 64) mx = fmaxf(mx, lg[j]);
+            mx = wave_max(mx);
+            for (int j = lane; j < V; j += 64) se += expf(lg[j] - mx);
+        }
         se = wave_sum(se);
         const float lse = mx + logf(se);
         if (lane == 0) {
@@ -585,8 +668,19 @@ int me_resid_ln_bwd(const void* dy, const void* s, const float* stats, const flo
     const uint32_t thr = thr_of(p);
     const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
     hipStream_t st = (hipStream_t)stream;
-    ME_DISPATCH(dtype, (resid_ln_bwd_kernel<T><<<row_grid(rows, 1024), 256, 0, st>>>(
-                           (const T*)dy, (const T*)s, stats, gamma, (T*)dx, (T*)da, dgamma, dbeta, rows, d, thr, inv_keep, seed, site)));
+    // chunks per lane per row: 1 for d <= 64 CH (512 bf16), 2, or 4 -- fewer chunks = less shared memory / registers
+    ME_DISPATCH(dtype, ({
+        const int nc = (d + 64 * ET<T>::CH - 1) / (64 * ET<T>::CH);
+        constexpr int NW = 16;
+        int64_t g = (rows + NW - 1) / NW;
+        const int grid = (int)(g < 1 ? 1 : (g > 256 ? 256 : g));
+        if (nc <= 1) resid_ln_bwd_kernel<T, 1, NW><<<grid, NW * 64, 0, st>>>(
+                           (const T*)dy, (const T*)s, stats, gamma, (T*)dx, (T*)da, dgamma, dbeta, rows, d, thr, inv_keep, seed, site);
+        else if (nc == 2) resid_ln_bwd_kernel<T, 2, NW><<<grid, NW * 64, 0, st>>>(
+                           (const T*)dy, (const T*)s, stats, gamma, (T*)dx, (T*)da, dgamma, dbeta, rows, d, thr, inv_keep, seed, site);
+        else resid_ln_bwd_kernel<T, 4, NW><<<grid, NW * 64, 0, st>>>(
+                           (const T*)dy, (const T*)s, stats, gamma, (T*)dx, (T*)da, dgamma, dbeta, rows, d, thr, inv_keep, seed, site);
+    }));
     return me_launch_status();
 }
 
