@@ -612,7 +612,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_bf16_kernel(
             sstore(buf ^ 1);
             if (st + 2 < nsteps) gload(t_begin + (st + 2) * BT);
         }
-        __syncthreads();
+        // raw barrier: __syncthreads() would also wait (vmcnt(0)) for the loads of the slab after next issued just above
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        slot_barrier();
     }
     if (do_bias && tid < 128 && n0 + tid < N) atomicAdd(&dbias[n0 + tid], bsum);
 #pragma unroll
@@ -627,6 +629,181 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_bf16_kernel(
                 if (row < N) atomicAdd(&dW[(size_t)row * lddw + col], acc[i][j][r]);
             }
         }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dW[N][K] += A^T B over a token range, 256 x 256 tile, 8 waves (2 x 4, each 128 x 64), bf16.
+// Same pipeline as gemm_nt256_kernel: 64-token slabs [64 t][256 cols] of dY and of X are fetched into
+// registers a slab ahead (16-byte chunks, 512-byte row segments: two token rows per wave instruction),
+// stored to the other LDS buffer during the current slab's MFMAs, one raw s_barrier per slab.  The
+// slabs keep their natural [token][column] layout (row stride 576 B: the four token rows a
+// ds_read_b64_tr_b16 group touches fall into different bank quarters); the transposed operand
+// fragments come out of the transpose-read.  Compared with the 128 x 128 kernel the tile halves the
+// operand bytes per FLOP through L1 (813 -> 406 MB per dWqkv launch).
+// Requires N % 256 == 0 and K % 256 == 0; tokens past the range end are stored as zeros.
+// ---------------------------------------------------------------------------------------------
+constexpr int TN256_LD = 288;                                   // elements per LDS row
+constexpr int TN256_BT = 64;                                    // tokens per slab
+constexpr int TN256_OP = TN256_BT * TN256_LD * 2;               // bytes per operand slab (36864)
+constexpr int TN256_LDS = 4 * TN256_OP;                         // two buffers x two operands (147456)
+
+__global__ __launch_bounds__(512) void gemm_tn256_kernel(
+    const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, float* __restrict__ dW, int lddw,
+    float* __restrict__ dbias, int Tn, int N, int K, int t_per_block, int tn, int tk, int nsplit, float* __restrict__ ws) {
+    typedef bf16_t T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // [2 buffers][A slab | B slab]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    // XCD-aware order (block b runs on XCD b % 8): the tk k-tiles of one (n-tile, token range) pair run on ONE XCD
+    const int npairs = tn * nsplit;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int pair = (slot / tk) * 8 + xcd, ky = slot % tk;
+    if (pair >= npairs) return;
+    const int nx = pair % tn, z = pair / tn;
+    const int n0 = nx * 256, k0 = ky * 256;
+    const int t_begin = z * t_per_block;
+    const int t_end = min(Tn, t_begin + t_per_block);
+    if (t_begin >= t_end) return;
+    const int nsteps = (t_end - t_begin + TN256_BT - 1) / TN256_BT;
+
+    // ---- operand stream: piece i of the wave = token rows 2 (4 wid + (i & 3)) + {0, 1}, i < 4: dY, else X
+    const int prow = lane >> 5, pcol = (lane & 31) * 8;
+    const uint32_t lda2 = (uint32_t)lda * 2u, ldb2 = (uint32_t)ldb * 2u;
+    const char* Ab = reinterpret_cast<const char*>(A) + (size_t)(n0 + pcol) * 2;
+    const char* Bb = reinterpret_cast<const char*>(B) + (size_t)(k0 + pcol) * 2;
+    chunk16 R[8];
+    int d_slab = 0;                                                       // slab being fetched
+    auto ld_piece = [&](int i) __attribute__((always_inline)) {
+        const int row = (wid * 4 + (i & 3)) * 2 + prow;
+        const uint32_t t = (uint32_t)min(t_begin + d_slab * TN256_BT + row, Tn - 1);
+        if (i < 4) R[i] = ld_chunk(Ab + t * lda2);
+        else R[i] = ld_chunk(Bb + t * ldb2);
+    };
+    char* const st_base = smem + ((wid * 8 + prow) * TN256_LD + pcol) * 2;
+    auto st_piece = [&](int i, int slab) __attribute__((always_inline)) {
+        const int row = (wid * 4 + (i & 3)) * 2 + prow;
+        const bool valid = t_begin + slab * TN256_BT + row < t_end;       // false as well for the slab past the end
+        st_chunk(st_base + (slab & 1) * (2 * TN256_OP) + ((i >> 2) * TN256_OP + (i & 3) * 2 * TN256_LD * 2),
+                 valid ? R[i] : zero_chunk());
+    };
+    auto ld_advance = [&]() __attribute__((always_inline)) { if (d_slab + 1 < nsteps) ++d_slab; };
+
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc_zero(acc[i][j]);
+    float bsum = 0.f;
+    const bool do_bias = dbias != nullptr && ky == 0;
+
+    // transpose-read lane geometry (see frag_load_tr): lane l of a 16-lane group points at token row l / 4,
+    // columns 4 (l % 4)..; the group receives 4 consecutive token rows of 16 columns
+    const int l16 = lane & 15, h = lane >> 5;
+    const int trow = l16 >> 2, tcol = ((lane >> 4) & 1) * 16 + 4 * (l16 & 3);
+    const uint32_t fa0 = (uint32_t)(((8 * h + trow) * TN256_LD + wr * 128 + tcol) * 2);
+    const uint32_t fb0 = (uint32_t)(TN256_OP + ((8 * h + trow) * TN256_LD + wc * 64 + tcol) * 2);
+
+    // ---- prologue: slab 0 into LDS, slab 1 into the registers
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ld_piece(i);
+    ld_advance();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) st_piece(i, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ld_piece(i);
+    ld_advance();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    slot_barrier();
+
+    for (int step = 0; step < nsteps; ++step) {
+        const char* buf = smem + (step & 1) * (2 * TN256_OP);
+        if (do_bias && tid < 256) {
+            const T* col = reinterpret_cast<const T*>(buf) + tid;
+#pragma unroll 8
+            for (int t = 0; t < TN256_BT; ++t) bsum += (float)col[t * TN256_LD];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            Frag<T> fa[4], fb[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const T* pa = reinterpret_cast<const T*>(buf + fa0 + (kk * 16 * TN256_LD + i * 32) * 2);
+                fa[i].v = __builtin_shufflevector(lds_tr4(pa), lds_tr4(pa + 4 * TN256_LD), 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const T* pb = reinterpret_cast<const T*>(buf + fb0 + (kk * 16 * TN256_LD + j * 32) * 2);
+                fb[j].v = __builtin_shufflevector(lds_tr4(pb), lds_tr4(pb + 4 * TN256_LD), 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+            st_piece(2 * kk, step + 1);
+            st_piece(2 * kk + 1, step + 1);
+            ld_piece(2 * kk);
+            ld_piece(2 * kk + 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma32(acc[i][j], fa[i], fb[j]);
+        }
+        ld_advance();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // my stores of slab step+1 are in LDS
+        slot_barrier();                                                    // everybody's; slab `step` fully consumed
+    }
+    if (do_bias && tid < 256) atomicAdd(&dbias[n0 + tid], bsum);
+    if (ws) {
+        // partial tile -> workspace in register order: slot (i, j, q) of thread tid is one 16-byte store, 1 KiB
+        // contiguous per wave instruction; tn256_reduce_kernel adds the token ranges in a fixed order
+        f32x4_t* w = reinterpret_cast<f32x4_t*>(ws) + (size_t)blockIdx.x * (32 * 512) + tid;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    w[((i * 2 + j) * 4 + q) * 512] = (f32x4_t){acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = k0 + wc * 64 + j * 32 + c_col(lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = n0 + wr * 128 + i * 32 + c_row(r, lane);
+                atomicAdd(&dW[(size_t)row * lddw + col], acc[i][j][r]);
+            }
+        }
+}
+
+// dW tile (nx, ky) += sum over the token ranges z of the partial tiles gemm_tn256_kernel left in the
+// workspace (67 MB of f32 atomics cost 40-48 us per launch, the same bytes as plain stores + this pass
+// ~15 us, and the sum no longer depends on the arrival order).  grid (tn * tk, 32 slots), 512 threads.
+__global__ __launch_bounds__(512) void tn256_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, int lddw,
+                                                           int tn, int tk, int nsplit) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 2, wc = wid & 3;
+    const int nx = blockIdx.x % tn, ky = blockIdx.x / tn;
+    const int slot = blockIdx.y, q = slot & 3, j = (slot >> 2) & 1, i = slot >> 3;
+    f32x4_t sum = {0.f, 0.f, 0.f, 0.f};
+    auto part = [&](int z) -> f32x4_t {
+        const int pair = z * tn + nx;
+        const int blk = ((pair >> 3) * tk + ky) * 8 + (pair & 7);             // inverse of the kernel's block order
+        return reinterpret_cast<const f32x4_t*>(ws)[((size_t)blk * 32 + slot) * 512 + tid];
+    };
+    int z = 0;
+    for (; z + 8 <= nsplit; z += 8) {                                         // 8 loads in flight, fixed summation order
+        f32x4_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part(z + u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sum += v[u];
+    }
+    for (; z < nsplit; ++z) sum += part(z);
+    const int col = ky * 256 + wc * 64 + j * 32 + (lane & 31);
+    const int row = nx * 256 + wr * 128 + i * 32 + 8 * q + 4 * (lane >> 5);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dW[(size_t)(row + e) * lddw + col] += sum[e];
 }
 
 // f32 master -> T copy and/or T transposed copy, 32x32 tiles through LDS
@@ -751,6 +928,47 @@ int gemm_tn_launch(const void* A, int lda, const void* B, int ldb, float* dW, in
     nsplit = (Tn + t_per - 1) / t_per;
     dim3 grid(tn, tk, nsplit);
     if constexpr (sizeof(T) == 2) {
+        static const bool no256 = getenv("MIDIEMO_NO_TN256") != nullptr;
+        const bool off32 = (unsigned long long)Tn * lda * 2ull < (1ull << 32) && (unsigned long long)Tn * ldb * 2ull < (1ull << 32);
+        if (!no256 && N % 256 == 0 && K % 256 == 0 && Tn >= 2048 && off32) {
+            // one block per CU: split the tokens so that tiles x ranges just fills the chip
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN256_LDS);
+                attr_set = true;
+            }
+            const int tn2 = N / 256, tk2 = K / 256;
+            int ns = 256 / (tn2 * tk2);
+            if (ns < 1) ns = 1;
+            int tp = (Tn + ns - 1) / ns;
+            tp = ((tp + TN256_BT - 1) / TN256_BT) * TN256_BT;
+            ns = (Tn + tp - 1) / tp;
+            const int np8 = ((tn2 * ns + 7) / 8) * 8;
+            // workspace for the partial tiles (256 KB per block), cached per stream: launches on one stream are
+            // ordered, so the buffer is free again when the next weight gradient starts
+            static struct { hipStream_t st; float* p; size_t bytes; } cache[8] = {};
+            const size_t need = (size_t)np8 * tk2 * 32 * 512 * 16;
+            float* ws = nullptr;
+            static const bool tn_atomics = getenv("MIDIEMO_TN_ATOMICS") != nullptr;
+            if (!tn_atomics && ns > 1) {
+                int slot_i = -1;
+                for (int c = 0; c < 8; ++c) if (cache[c].p && cache[c].st == st) slot_i = c;
+                if (slot_i < 0) for (int c = 0; c < 8; ++c) if (!cache[c].p) { slot_i = c; break; }
+                if (slot_i >= 0) {
+                    if (cache[slot_i].bytes < need) {
+                        if (cache[slot_i].p) { (void)hipStreamSynchronize(st); (void)hipFree(cache[slot_i].p); cache[slot_i].p = nullptr; }
+                        const size_t want = need < ((size_t)80 << 20) ? ((size_t)80 << 20) : need;
+                        if (hipMalloc(&cache[slot_i].p, want) == hipSuccess) { cache[slot_i].bytes = want; cache[slot_i].st = st; }
+                        else { cache[slot_i].p = nullptr; cache[slot_i].bytes = 0; (void)hipGetLastError(); }
+                    }
+                    ws = cache[slot_i].p;
+                }
+            }
+            gemm_tn256_kernel<<<np8 * tk2, 512, TN256_LDS, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, dW, lddw, dbias, Tn, N,
+                                                             K, tp, tn2, tk2, ns, ws);
+            if (ws) tn256_reduce_kernel<<<dim3(tn2 * tk2, 32), 512, 0, st>>>(ws, dW, lddw, tn2, tk2, ns);
+            return me_launch_status();
+        }
         const int npairs8 = ((tn * nsplit + 7) / 8) * 8;
         gemm_tn_bf16_kernel<<<npairs8 * tk, NTHREADS, 0, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, dW, lddw, dbias, Tn, N, K,
                                                                t_per, tn, tk, nsplit);
