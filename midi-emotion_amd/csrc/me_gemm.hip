@@ -223,42 +223,22 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(
         tile_origin(tile_it, m0, n0);
         char* stg = smem + 2 * 65536 + wid * 4096;
         constexpr int NJ = OUT_F32 ? 1 : 2;                                // accumulator blocks per pass
-#pragma unroll
-        for (int ps = 0; ps < 8 / NJ; ++ps) {
+        constexpr int NP = 8 / NJ;                                         // passes
+        const int lr = lane & 31;
+        // one quad (4 consecutive columns of the lane's row) -> staging; 16-byte slot index XOR (row & 7) spreads
+        // the 32 rows of a store over the banks
+        auto stage = [&](int jj, int g, const float* v) __attribute__((always_inline)) {
+            if constexpr (OUT_F32) {
+                const int slot = (2 * g + h) ^ (lr & 7);
+                *reinterpret_cast<f32x4_t*>(stg + lr * 128 + (slot << 4)) = (f32x4_t){v[0], v[1], v[2], v[3]};
+            } else {
+                const int slot = (jj * 4 + g) ^ (lr & 7);
+                st4_t<T>(reinterpret_cast<T*>(stg + lr * 128 + (slot << 4) + h * 8), v[0], v[1], v[2], v[3]);
+            }
+        };
+        // read back: lane -> (row it*8 + lane/8, 16-byte chunk lane%8): full-row coalesced stores
+        auto write_out = [&](int ps) __attribute__((always_inline)) {
             const int i = OUT_F32 ? ps >> 1 : ps, j0 = OUT_F32 ? ps & 1 : 0;
-            const int lr = lane & 31;
-            const int row = m0 + wr * 128 + i * 32 + lr;
-#pragma unroll
-            for (int jj = 0; jj < NJ; ++jj)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int j = j0 + jj;
-                    const int cl = j * 32 + 8 * g + 4 * h;                 // column inside the wave's 64
-                    const int col = n0 + wc * 64 + cl;
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[i][j][4 * g + e] + ((bias && col + e < N) ? bias[col + e] : 0.f);
-                        if (relu) v[e] = fmaxf(v[e], 0.f);
-                    }
-                    if (add && row < M) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) if (col + e < N) v[e] += (float)add[(size_t)row * ldadd + col + e];
-                    }
-                    if (gate && row < M) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) if (col + e < N) v[e] = (float)gate[(size_t)row * ldgate + col + e] > 0.f ? v[e] : 0.f;
-                    }
-                    // 16-byte slot index XOR (row & 7): spreads the 32 rows of a store over the banks
-                    if constexpr (OUT_F32) {
-                        const int slot = (2 * g + h) ^ (lr & 7);
-                        *reinterpret_cast<f32x4_t*>(stg + lr * 128 + (slot << 4)) = (f32x4_t){v[0], v[1], v[2], v[3]};
-                    } else {
-                        const int slot = (jj * 4 + g) ^ (lr & 7);
-                        st4_t<T>(reinterpret_cast<T*>(stg + lr * 128 + (slot << 4) + h * 8), v[0], v[1], v[2], v[3]);
-                    }
-                }
-            // read back: lane -> (row it*8 + lane/8, 16-byte chunk lane%8): full-row coalesced stores
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int rr = it * 8 + (lane >> 3), ch = lane & 7;
@@ -279,6 +259,95 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(
                             }
                     }
                 }
+            }
+        };
+        // vmcnt is in-order: a global load issued between two passes waits for the previous pass's STORES to retire
+        // (measured: 20 us of an 80 us launch).  Hence two code paths (registers = max, not sum):
+        if (!add && !gate) {
+            // (a) bias (+ReLU): the wave's 32 bias values are fetched once, before any store
+            f32x4_t bv[2][4];
+            const bool vec_bias = (reinterpret_cast<uintptr_t>(bias) & 15) == 0;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = n0 + wc * 64 + j * 32 + 8 * g + 4 * h;
+                    bv[j][g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                    if (bias) {
+                        if (vec_bias && col + 3 < N) bv[j][g] = *reinterpret_cast<const f32x4_t*>(bias + col);
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) if (col + e < N) bv[j][g][e] = bias[col + e];
+                        }
+                    }
+                }
+#pragma unroll
+            for (int ps = 0; ps < NP; ++ps) {
+                const int i = OUT_F32 ? ps >> 1 : ps, j0 = OUT_F32 ? ps & 1 : 0;
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = acc[i][j0 + jj][4 * g + e] + bv[j0 + jj][g][e];
+                            if (relu) v[e] = fmaxf(v[e], 0.f);
+                        }
+                        stage(jj, g, v);
+                    }
+                write_out(ps);
+            }
+        } else {
+            // (b) residual add / ReLU gate (the backward GEMMs): their operands for the NEXT pass are fetched (8 bytes
+            // per quad) before this pass's stores are issued
+            const bool vec_add = add && (ldadd & 3) == 0 && (reinterpret_cast<uintptr_t>(add) & 7) == 0;
+            const bool vec_gate = gate && (ldgate & 3) == 0 && (reinterpret_cast<uintptr_t>(gate) & 7) == 0;
+            auto load4 = [&](const bf16_t* base, int ld, bool vec, int row, int col) __attribute__((always_inline)) -> bf16x4_t {
+                bf16x4_t r = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+                if (base && row < M) {
+                    if (vec && col + 3 < N) r = *reinterpret_cast<const bf16x4_t*>(base + (size_t)row * ld + col);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (col + e < N) r[e] = base[(size_t)row * ld + col + e];
+                    }
+                }
+                return r;
+            };
+            bf16x4_t av[NJ][4], gv[NJ][4];
+            auto fetch_ag = [&](int ps) __attribute__((always_inline)) {
+                const int i = OUT_F32 ? ps >> 1 : ps, j0 = OUT_F32 ? ps & 1 : 0;
+                const int row = m0 + wr * 128 + i * 32 + lr;
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int col = n0 + wc * 64 + (j0 + jj) * 32 + 8 * g + 4 * h;
+                        if (add) av[jj][g] = load4(add, ldadd, vec_add, row, col);
+                        if (gate) gv[jj][g] = load4(gate, ldgate, vec_gate, row, col);
+                    }
+            };
+            fetch_ag(0);
+#pragma unroll
+            for (int ps = 0; ps < NP; ++ps) {
+                const int i = OUT_F32 ? ps >> 1 : ps, j0 = OUT_F32 ? ps & 1 : 0;
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int col = n0 + wc * 64 + (j0 + jj) * 32 + 8 * g + 4 * h;
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = acc[i][j0 + jj][4 * g + e] + ((bias && col + e < N) ? bias[col + e] : 0.f);
+                            if (relu) v[e] = fmaxf(v[e], 0.f);
+                            if (add) v[e] += (float)av[jj][g][e];
+                            if (gate) v[e] = (float)gv[jj][g][e] > 0.f ? v[e] : 0.f;
+                        }
+                        stage(jj, g, v);
+                    }
+                if (ps + 1 < NP) fetch_ag(ps + 1);
+                write_out(ps);
             }
         }
 #pragma unroll
