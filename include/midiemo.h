@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 3
+#define ME_ABI_VERSION 4
 
 enum { ME_F32 = 0, ME_BF16 = 1 };
 
@@ -121,11 +121,12 @@ int me_rga_fwd(const void* qkv, const void* E, const uint8_t* key_pad, void* out
 
 /* Backward of me_rga_fwd.  dout: T [B,L,H,dh].  Writes dqkv (T, same layout as qkv),
  * accumulates (+=) dE f32 [M, dh].
- * Workspaces (caller-owned): delta f32 [B,H,L]; PT, dST, dGT: T [B*H][Lp][Lp] each (Lp = L rounded
- * up to 32), which must be ZERO-INITIALISED once (only on/below-diagonal tiles are written and read). */
+ * Workspaces (caller-owned): delta f32 [B,H,L]; PT, dST: T [B*H][Lp][Lp] each (Lp = L rounded
+ * up to 32) = P^T and dS^T tiles, which must be ZERO-INITIALISED once (only on/below-diagonal tiles are
+ * written and read).  The gradient of the relative table is taken from dS^T (dG is dS re-indexed). */
 int me_rga_bwd(const void* qkv, const void* E, const void* ET, const uint8_t* key_pad,
                const void* out, const float* lse, const void* dout,
-               void* dqkv, float* dE, float* delta_ws, void* PT, void* dST, void* dGT,
+               void* dqkv, float* dE, float* delta_ws, void* PT, void* dST,
                int B, int L, int Lp, int H, int dh, int M, int dtype, void* stream);
 
 /* ---- residual + dropout + LayerNorm (post-LN, eps) ---------------------------

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ q
             sstore(buf ^ 1);                      // buf^1 was last read in step kt-1 (barrier since)
             if (kt + 2 < nkt) gload(kt + 2);
         }
-        __syncthreads();
+        block_sync_lds();               // LDS hand-over only: prefetch loads / tile stores stay in flight
     }
     if (!wave_on || q >= L) return;
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
     const T* __restrict__ qkv, const T* __restrict__ E, const T* __restrict__ ET_,
     const uint8_t* __restrict__ key_pad, const T* __restrict__ out, const float* __restrict__ lse,
     const T* __restrict__ dout, T* __restrict__ dqkv, float* __restrict__ delta_ws, T* __restrict__ PT,
-    T* __restrict__ dST, T* __restrict__ dGT, int B, int L, int Lp, int H, int M, float scale) {
+    T* __restrict__ dST, int B, int L, int Lp, int H, int M, float scale) {
     using C = ACfg<T, DH>;
     constexpr int LDR = 72;                         // dG ring row (elements of T): 64-column ring + 8
     __shared__ __attribute__((aligned(16))) T Ks[2][32 * C::LDN];      // natural K tile: 16-byte fragment reads (S) and transpose reads (dQ)
@@ -362,7 +362,6 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
 
     gload(0);
     const int eb0 = (M - 32 - q0) >> 5;
-    const int cb0 = (Lp - 32 - q0) >> 5;             // column block of dG^T that E block eb0 maps to
     Frag<T> ef[C::KA];
     Frag<T> etf[C::DB][2];
     if (wave_on) {
@@ -456,17 +455,13 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
                 frag_load_4x2(dgf, dlo + 16 * t + 4 * h, dlo + 16 * t + 8 + 4 * h);
 #pragma unroll
                 for (int i = 0; i < C::DB; ++i) { if (ME_ABL != 3) mma32(dq[i], etf[i][t], dgf); }
-                const T* ge = reinterpret_cast<const T*>(&dgf);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) stg[(16 * t + 4 * h + (e & 3) + 8 * (e >> 2)) * LDX + a] = ge[e];
             }
-            if (ME_ABL != 2) flush_tile(dGT + ws_bh + (size_t)((cb0 + kt) * 32) * Lp + q0);
         }
         if (kt + 1 < nkt) {
             sstore(buf ^ 1);                      // buf^1 was last read in step kt-1 (barrier since)
             if (kt + 2 < nkt) gload(kt + 2);
         }
-        __syncthreads();
+        block_sync_lds();               // LDS hand-over only: prefetch loads / tile stores stay in flight
     }
     if (!row_on) return;
     T* dqp = dqkv + ((size_t)b * L + q) * ldq + head * DH;
@@ -553,7 +548,7 @@ __global__ __launch_bounds__(256) void rga_bwd_kv_kernel(const T* __restrict__ P
             sstore(buf ^ 1);
             if (qs + 2 < nqt) gload(qs + 2);
         }
-        __syncthreads();
+        block_sync_lds();               // LDS hand-over only: prefetch loads / tile stores stay in flight
     }
     if (!wave_on) return;
 #pragma unroll
@@ -572,11 +567,17 @@ __global__ __launch_bounds__(256) void rga_bwd_kv_kernel(const T* __restrict__ P
 // =====================================================================================
 // backward 3/3 (E-row-owned, streaming):  dE[e][d] += sum_{bh, q} dG^T[bh][c(e)][q] Q^T[bh][d][q]
 // =====================================================================================
-// Block = 128 rows of dG^T (4 waves x 32) x DH, one split of the (b, head) range; register
-// accumulation over (bh, q) and one atomic flush per block.  Column block cb only receives
-// queries q >= 32*(Lp/32 - 1 - cb); earlier slabs are skipped.
+// dG is dS re-indexed: dG^T[c][q] = dS^T[key][q] with key = c - (Lp - 1) + q (c = e - (M - Lp)).  The kernel
+// therefore reads the dS^T workspace the query kernel writes for dK anyway and applies the shear while
+// staging: a [128 c][32 q] operand tile is the band of 159 dS^T rows key = kb + kk (kb = c0 - Lp + 1 + 32 qs)
+// with element (kk, qq) landing at tile row kk - qq.  The band arrives as natural 16-byte row chunks and is
+// scattered element-wise into LDS (the kernel is HBM bound with 4 MFMAs per step, the extra LDS stores are
+// free) -- this removed the separate dG^T workspace: 268 MB written and read per layer.
+// Block = 128 rows c (4 waves x 32) x DH, one split of the (b, head) range; register accumulation over
+// (bh, q) and one atomic flush per block.  Column block cb only receives queries
+// q >= 32*(Lp/32 - 1 - cb); earlier slabs are skipped.
 template <typename T, int DH>
-__global__ __launch_bounds__(256) void rga_bwd_e_kernel(const T* __restrict__ dGT, const T* __restrict__ qkv,
+__global__ __launch_bounds__(256) void rga_bwd_e_kernel(const T* __restrict__ dST, const T* __restrict__ qkv,
                                                         float* __restrict__ dE, int B, int L, int Lp, int H, int M) {
     constexpr int CH = ET<T>::CH, LDP = 32 + CH, DB = DH / 32, LDV = ACfg<T, DH>::LDV;
     __shared__ __attribute__((aligned(16))) T Gt[2][128 * LDP];
@@ -611,23 +612,42 @@ __global__ __launch_bounds__(256) void rga_bwd_e_kernel(const T* __restrict__ dG
     const int per = (BH + nslots - 1) / nslots;
     const int bh_lo = slot * per, bh_hi = min(BH, bh_lo + per);
     const int nsteps = (bh_hi - bh_lo) * nq;
-    const int rows_valid = min(128, Lp - c0);
     if (nsteps <= 0 || nq <= 0) return;
 
     f32x16_t acc[DB];
 #pragma unroll
     for (int i = 0; i < DB; ++i) acc_zero(acc[i]);
 
-    chunk16 rg[TileT<T, 128, 32>::NPT], rq[TileT<T, 32, DH>::NPT];
+    using BandT = TileT<T, 160, 32>;                    // 159 band rows (+1 pad) x 32 queries, CPR chunks per row
+    chunk16 rg[BandT::NPT], rq[TileT<T, 32, DH>::NPT];
     const int dm = H * DH;
     const size_t ldq = (size_t)3 * dm;
     auto gload = [&](int s) {
         const int bh = bh_lo + s / nq, qs = qs0 + s % nq;
-        tile_gload<T, 128, 32>(rg, dGT + (size_t)bh * Lp * Lp + (size_t)c0 * Lp + qs * 32, (size_t)Lp, rows_valid, tid);
+        const int kb = c0 - Lp + 1 + qs * 32;            // key of tile element (row 0, column 0)
+        const T* src = dST + (size_t)bh * Lp * Lp + qs * 32;
+#pragma unroll
+        for (int i = 0; i < BandT::NPT; ++i) {
+            const int c = tid + i * 256, kk = c / BandT::CPR, cc = (c % BandT::CPR) * CH;
+            const int key = kb + kk;
+            rg[i] = (c < BandT::NCH && kk < 159 && key >= 0 && key < Lp) ? ld_chunk(src + (size_t)key * Lp + cc) : zero_chunk();
+        }
         tile_gload<T, 32, DH>(rq, qkv + ((size_t)(bh / H) * L + qs * 32) * ldq + (bh % H) * DH, ldq, L - qs * 32, tid);
     };
     auto sstore = [&](int buf) {
-        tile_sstore<T, 128, 32, LDP>(rg, Gt[buf], tid);
+        // shear: band element (kk, qq) -> tile row kk - qq; every tile element is written exactly once per step
+#pragma unroll
+        for (int i = 0; i < BandT::NPT; ++i) {
+            const int c = tid + i * 256, kk = c / BandT::CPR, cc = (c % BandT::CPR) * CH;
+            if (c < BandT::NCH) {
+                const T* v = reinterpret_cast<const T*>(&rg[i]);
+#pragma unroll
+                for (int e = 0; e < CH; ++e) {
+                    const int cl = kk - cc - e;
+                    if (cl >= 0 && cl < 128) Gt[buf][cl * LDP + cc + e] = v[e];
+                }
+            }
+        }
         tile_sstore<T, 32, DH, LDV>(rq, Qs[buf], tid);
     };
     gload(0);
@@ -654,7 +674,7 @@ __global__ __launch_bounds__(256) void rga_bwd_e_kernel(const T* __restrict__ dG
             sstore(buf ^ 1);
             if (s + 2 < nsteps) gload(s + 2);
         }
-        __syncthreads();
+        block_sync_lds();               // LDS hand-over only: prefetch loads / tile stores stay in flight
     }
     if (!wave_on) return;
 #pragma unroll
@@ -748,12 +768,12 @@ int fwd_launch(const void* qkv, const void* E, const uint8_t* key_pad, void* out
 
 template <typename T, int DH>
 int bwd_launch(const void* qkv, const void* E, const void* ET_, const uint8_t* key_pad, const void* out, const float* lse,
-               const void* dout, void* dqkv, float* dE, float* delta_ws, void* PT, void* dST, void* dGT, int B, int L,
+               const void* dout, void* dqkv, float* dE, float* delta_ws, void* PT, void* dST, int B, int L,
                int Lp, int H, int M, hipStream_t st) {
     const int nqb = (L + 127) / 128;
     const float scale = 1.f / sqrtf((float)DH);
     rga_bwd_q_kernel<T, DH><<<B * H * nqb, 256, 0, st>>>((const T*)qkv, (const T*)E, (const T*)ET_, key_pad, (const T*)out, lse,
-                                                        (const T*)dout, (T*)dqkv, delta_ws, (T*)PT, (T*)dST, (T*)dGT, B, L, Lp,
+                                                        (const T*)dout, (T*)dqkv, delta_ws, (T*)PT, (T*)dST, B, L, Lp,
                                                         H, M, scale);
     int rc = me_launch_status();
     if (rc) return rc;
@@ -765,7 +785,7 @@ int bwd_launch(const void* qkv, const void* E, const void* ET_, const uint8_t* k
     int eblocks = 512;                                   // ~2 per CU; every group gets at least one
     if (eblocks > ngx * B * H) eblocks = ngx * B * H;
     if (eblocks < ngx) eblocks = ngx;
-    rga_bwd_e_kernel<T, DH><<<eblocks, 256, 0, st>>>((const T*)dGT, (const T*)qkv, dE, B, L, Lp, H, M);
+    rga_bwd_e_kernel<T, DH><<<eblocks, 256, 0, st>>>((const T*)dST, (const T*)qkv, dE, B, L, Lp, H, M);
     return me_launch_status();
 }
 
@@ -803,16 +823,16 @@ int me_rga_fwd(const void* qkv, const void* E, const uint8_t* key_pad, void* out
 }
 
 int me_rga_bwd(const void* qkv, const void* E, const void* ET_, const uint8_t* key_pad, const void* out, const float* lse,
-               const void* dout, void* dqkv, float* dE, float* delta_ws, void* PT, void* dST, void* dGT, int B, int L,
+               const void* dout, void* dqkv, float* dE, float* delta_ws, void* PT, void* dST, int B, int L,
                int Lp, int H, int dh, int M, int dtype, void* stream) {
     me_clear_error();
-    if (!qkv || !E || !ET_ || !out || !lse || !dout || !dqkv || !dE || !delta_ws || !PT || !dST || !dGT) return ME_ERR_NULL;
+    if (!qkv || !E || !ET_ || !out || !lse || !dout || !dqkv || !dE || !delta_ws || !PT || !dST) return ME_ERR_NULL;
     if (B <= 0 || L <= 0 || H <= 0 || L > M || (M & 31) || (Lp & 31) || Lp < L || Lp > M) return ME_ERR_BAD_SHAPE;
     if (!aligned16(qkv) || !aligned16(E) || !aligned16(ET_) || !aligned16(out) || !aligned16(dout) || !aligned16(dqkv) ||
-        !aligned16(PT) || !aligned16(dST) || !aligned16(dGT))
+        !aligned16(PT) || !aligned16(dST))
         return ME_ERR_ALIGNMENT;
     hipStream_t st = (hipStream_t)stream;
-    ME_ATTN_DISPATCH((bwd_launch<T, DH>(qkv, E, ET_, key_pad, out, lse, dout, dqkv, dE, delta_ws, PT, dST, dGT, B, L, Lp, H, M,
+    ME_ATTN_DISPATCH((bwd_launch<T, DH>(qkv, E, ET_, key_pad, out, lse, dout, dqkv, dE, delta_ws, PT, dST, B, L, Lp, H, M,
                                         st)))
 }
 

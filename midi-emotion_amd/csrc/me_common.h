@@ -119,6 +119,15 @@ ME_DEV void mma32(f32x16_t& acc, const Frag<float>& a, const Frag<float>& b) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi[e], b.hi[e], acc, 0, 0, 0);
 }
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also makes the compiler wait vmcnt(0), i.e. for
+// every global load just issued as a prefetch and for every global store still draining (vmcnt is in-order on
+// gfx950); inside pipelined loops only the LDS hand-over needs the barrier.
+ME_DEV void block_sync_lds() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
 ME_DEV void acc_zero(f32x16_t& a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) a[r] = 0.f;

@@ -339,7 +339,6 @@ class MusicTransformerHIP(nn.Module):
             # only on/below-diagonal tiles are ever written or read)
             ws.PT = torch.zeros(B * H, Lp, Lp, dtype=dt, device=dev)
             ws.dST = torch.zeros(B * H, Lp, Lp, dtype=dt, device=dev)
-            ws.dGT = torch.zeros(B * H, Lp, Lp, dtype=dt, device=dev)
         self._ws[key] = ws
         return ws
 
@@ -480,7 +479,7 @@ class MusicTransformerHIP(nn.Module):
             ops.gemm_nt(ws.dC2, W["WoT"], ws.dA, M=T, N=d, K=d, dtype=dt)                        # d(att)
             reuse("dqkv")
             ops.rga_bwd(Lw.qkv, W["E"], W["ET"], ws.key_pad, Lw.att, Lw.lse, ws.dA, ws.dqkv, gv(p + "rga.E"),
-                        ws.delta, ws.PT, ws.dST, ws.dGT, B, Lm, ws.Lp, H, dh, M)
+                        ws.delta, ws.PT, ws.dST, B, Lm, ws.Lp, H, dh, M)
             o, _, _ = self._slices[p + "rga.Wq.weight"]
             ob, _, _ = self._slices[p + "rga.Wq.bias"]
             wgrad("dqkv", ws.dqkv, x, gflat[o:o + 3 * d * d].view(3 * d, d), gflat[ob:ob + 3 * d], T=T, N=3 * d, K=d,

@@ -86,9 +86,9 @@ def rga_fwd(qkv, E, key_pad, out, lse, B, L, H, dh, M):
                            _code(qkv.dtype), _stream()), "me_rga_fwd")
 
 
-def rga_bwd(qkv, E, ET, key_pad, out, lse, dout, dqkv, dE, delta_ws, PT, dST, dGT, B, L, Lp, H, dh, M):
+def rga_bwd(qkv, E, ET, key_pad, out, lse, dout, dqkv, dE, delta_ws, PT, dST, B, L, Lp, H, dh, M):
     check(lib().me_rga_bwd(_ptr(qkv), _ptr(E), _ptr(ET), _ptr(key_pad), _ptr(out), _ptr(lse), _ptr(dout), _ptr(dqkv),
-                           _ptr(dE), _ptr(delta_ws), _ptr(PT), _ptr(dST), _ptr(dGT), B, L, Lp, H, dh, M,
+                           _ptr(dE), _ptr(delta_ws), _ptr(PT), _ptr(dST), B, L, Lp, H, dh, M,
                            _code(qkv.dtype), _stream()), "me_rga_bwd")
 
 

@@ -351,8 +351,8 @@ def run_attn(ops, dtype, q, k, v, E, dO, pad, backward=True):
         dE = torch.zeros(M, dh, dtype=torch.float32, device=DEV)
         ET = Ed.t().contiguous()
         delta = torch.empty(B, H, L, dtype=torch.float32, device=DEV)
-        PT, dST, dGT = (torch.zeros(B * H, Lp, Lp, dtype=dtype, device=DEV) for _ in range(3))
-        ops.rga_bwd(qkv, Ed, ET, kp, out, lse, dout, dqkv, dE, delta, PT, dST, dGT, B, L, Lp, H, dh, M)
+        PT, dST = (torch.zeros(B * H, Lp, Lp, dtype=dtype, device=DEV) for _ in range(2))
+        ops.rga_bwd(qkv, Ed, ET, kp, out, lse, dout, dqkv, dE, delta, PT, dST, B, L, Lp, H, dh, M)
         g = dqkv.float().cpu().permute(2, 0, 3, 1, 4)   # [3,B,H,L,dh]
         res.update(dq=g[0], dk=g[1], dv=g[2], dE=dE.cpu())
     return res
