@@ -411,39 +411,72 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
     __shared__ float red[2][4];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     float bl = 0.f, bn = 0.f;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wid; row < rows; row += (int64_t)gridDim.x * 4) {
-        const float* lg = logits + row * ld;
-        float mx = -INFINITY, se = 0.f;
-        if (V <= 64 * 4 * CE_Q && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0) {
-            // one pass: the row (<= 2048 logits) sits in registers, 16-byte loads
-            f32x4_t v[CE_Q];
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t row = (int64_t)blockIdx.x * 4 + wid;
+    if (V <= 64 * 4 * CE_Q && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0) {
+        // One pass: the row (<= 2048 logits) sits in registers, 16-byte loads.  The next row (and its target) is
+        // fetched BEFORE this row's lse is stored and the target logit comes out of the registers: vmcnt is in
+        // order, so a load issued after a store cannot be consumed before that store has been acknowledged.
+        f32x4_t nv[CE_Q];
+        int64_t nt = 0;
+        auto fetch = [&](int64_t r) {
+            if (r >= rows) return;
+            const float* lg = logits + r * ld;
+            nt = target[r];
 #pragma unroll
             for (int q = 0; q < CE_Q; ++q) {
                 const int j = (q * 64 + lane) * 4;
-                if (j + 3 < V) v[q] = *reinterpret_cast<const f32x4_t*>(lg + j);
+                if (j + 3 < V) nv[q] = *reinterpret_cast<const f32x4_t*>(lg + j);
                 else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[q][i] = j + i < V ? lg[j + i] : -INFINITY;
+                    for (int i = 0; i < 4; ++i) nv[q][i] = j + i < V ? lg[j + i] : -INFINITY;
                 }
+            }
+        };
+        fetch(row);
+        for (; row < rows; row += stride) {
+            f32x4_t v[CE_Q];
+            const int64_t t = nt;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) mx = fmaxf(mx, v[q][i]);
+            for (int q = 0; q < CE_Q; ++q) v[q] = nv[q];
+            fetch(row + stride);
+            float mx = -INFINITY, se = 0.f, tv = 0.f;
+#pragma unroll
+            for (int q = 0; q < CE_Q; ++q) {
+                const int j = (q * 64 + lane) * 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    mx = fmaxf(mx, v[q][i]);
+                    tv = (t == j + i) ? v[q][i] : tv;
+                }
             }
             mx = wave_max(mx);
 #pragma unroll
             for (int q = 0; q < CE_Q; ++q)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) se += __builtin_amdgcn_exp2f((v[q][i] - mx) * 1.4426950408889634f);   // v_exp_f32; exp2(-inf) = 0 for the padding
-        } else {
+                for (int i = 0; i < 4; ++i) se += __builtin_amdgcn_exp2f((v[q][i] - mx) * 1.4426950408889634f);   // exp2(-inf) = 0 for the padding
+            se = wave_sum(se);
+            tv = wave_sum(tv);                                       // the one lane that holds logit[t]
+            const float lse = mx + logf(se);
+            if (lane == 0) {
+                if (row_lse) row_lse[row] = lse;
+                if (t != ignore_index) { bl += lse - tv; bn += 1.f; }
+            }
+        }
+    } else {
+        for (; row < rows; row += stride) {
+            const float* lg = logits + row * ld;
+            float mx = -INFINITY, se = 0.f;
             for (int j = lane; j < V; j += 64) mx = fmaxf(mx, lg[j]);
             mx = wave_max(mx);
             for (int j = lane; j < V; j += 64) se += expf(lg[j] - mx);
-        }
-        se = wave_sum(se);
-        const float lse = mx + logf(se);
-        if (lane == 0) {
-            if (row_lse) row_lse[row] = lse;
-            const int64_t t = target[row];
-            if (t != ignore_index) { bl += lse - lg[t]; bn += 1.f; }
+            se = wave_sum(se);
+            const float lse = mx + logf(se);
+            if (lane == 0) {
+                if (row_lse) row_lse[row] = lse;
+                const int64_t t = target[row];
+                if (t != ignore_index) { bl += lse - lg[t]; bn += 1.f; }
+            }
         }
     }
     if (lane == 0) { red[0][wid] = bl; red[1][wid] = bn; }
