@@ -222,7 +222,8 @@ def main():
             traffic = None
             tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")
             if args.compute_dtype == "bf16" and (B, L) == (32, 1024) and os.path.exists(tj):
-                k = json.load(open(tj)).get("gemm_nt256_kernel<false>")
+                tjd = json.load(open(tj))
+                k = tjd.get("gemm_nt256_kernel") or tjd.get("gemm_nt256_kernel<false>")
                 if k:
                     traffic = int(round((k["read_MB"] + k["write_MB"]) * 1e6))
             ach = flops / (ms * 1e-3) / 1e12
@@ -230,7 +231,7 @@ def main():
                                "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS if args.compute_dtype == "bf16" else 157.3,
                                "unit": "TFLOP/s",
                                "frac": round(ach / (PEAK_BF16_TFLOPS if args.compute_dtype == "bf16" else 157.3), 4),
-                               "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC pass, profiles/r01_hbm_traffic.txt)",
+                               "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC pass, profiles/r01_d_hbm_traffic.txt)",
                                "algorithmic_bytes_per_launch": int(gp.alg_bytes), "launches_per_step": n // 3,
                                "avg_launch_us": round(1000.0 * ms / n, 2),
                                "gemm_nt_ms_per_step": round(ms / 3, 3),

@@ -10,6 +10,8 @@
 //   col = lane & 31,  row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include "../../include/midiemo.h"
@@ -174,5 +176,6 @@ ME_DEV bool me_keep(uint64_t seed, uint32_t site, uint64_t idx, uint32_t thr16) 
 static inline void me_clear_error() { (void)hipGetLastError(); }
 static inline int me_launch_status() {
     hipError_t e = hipGetLastError();
+    if (e != hipSuccess && getenv("MIDIEMO_DEBUG")) fprintf(stderr, "midiemo: launch failed: %s\n", hipGetErrorString(e));
     return e == hipSuccess ? ME_OK : ME_ERR_LAUNCH;
 }

@@ -50,6 +50,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: it brings its own HIP runtime (libamdhip64); loading this library before it pulls a second copy
+    # from /opt/rocm into the process and whichever initialises second reports "no ROCm-capable device"
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             "libmidiemo_hip.so not built (%s). Run `python __graft_entry__.py` or "
