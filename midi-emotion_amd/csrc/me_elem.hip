@@ -332,14 +332,17 @@ __global__ __launch_bounds__(NW * 64) void resid_ln_bwd_kernel(const T* __restri
     int64_t row = (int64_t)blockIdx.x * NW + wid;
     chunk16 ndy[NC], ns[NC];
     float nmean = 0.f, nrstd = 0.f;
+    // unconditional (clamped to the last row): a load under a branch makes the compiler wait vmcnt(0) at the join,
+    // i.e. also for the stores of the row before
     auto fetch = [&](int64_t r) {
-        if (r >= rows) return;
+        r = r < rows ? r : rows - 1;
         nmean = stats[r * 2];
         nrstd = stats[r * 2 + 1];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const int col = (lane + c * 64) * CH;
-            if (col < d) { ndy[c] = ld_chunk(dy + r * d + col); ns[c] = ld_chunk(s + r * d + col); }
+            const int col = min((lane + c * 64) * CH, d - CH);
+            ndy[c] = ld_chunk(dy + r * d + col);
+            ns[c] = ld_chunk(s + r * d + col);
         }
     };
     fetch(row);
