@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 4
+#define ME_ABI_VERSION 5
 
 enum { ME_F32 = 0, ME_BF16 = 1 };
 
@@ -66,10 +66,12 @@ int me_cast_transpose(const float* src, int rows, int cols, void* dst, int ld_ds
  *   TOKEN : out = cat_seq([W0*v+b0, W1*a+b1], emb[tok]*sqrt(d)) + PE
  *                                                  (music_continuous_token.py:80-100)
  * followed by inverted dropout(p) with the counter-based mask (seed, site 0)
- * (music_multi.py:102).  emb is the f32 master table [V][d-dc]; pe is f32 [>=Lm][d]. */
+ * (music_multi.py:102).  emb is the f32 master table [V][d-dc]; pe is f32 [>=Lm][d].
+ * pos_dev (may be NULL): device int32, added to every row's position for the PE lookup -- the decode step reads
+ * its position from device memory so that the whole step is replayable as a HIP graph. */
 int me_embed_fwd(void* out, int dtype, const int64_t* tokens, const float* cond,
                  const float* emb, const float* cw0, const float* cb0,
-                 const float* cw1, const float* cb1, const float* pe,
+                 const float* cw1, const float* cb1, const float* pe, const int32_t* pos_dev,
                  int mode, int B, int Ltok, int d_model, int d_cond,
                  float p_drop, uint64_t seed, void* stream);
 
@@ -175,10 +177,10 @@ int me_adamw_step(float* p, float* g, float* m, float* v, int64_t n, const float
  * One new position `t` per sequence.  qkv_new: T [B, 3, H, dh] for the new token;
  * kcache/vcache: T [B, H, Mc, dh] (position-major); writes k,v at position t, then
  *   out[b,h,:] = softmax_j<=t( (q.k_j + q.E[M-1-(t-j)])/sqrt(dh) ) . v_j   (pad keys masked)
- * out: T [B, H, dh]. */
+ * out: T [B, H, dh].  t_dev (may be NULL): device int32 that overrides `t` (graph replay). */
 int me_rga_decode_step(const void* qkv_new, void* kcache, void* vcache, const void* E,
                        const uint8_t* key_pad, int ld_pad, void* out, int B, int H, int dh,
-                       int M, int Mc, int t, int dtype, void* stream);
+                       int M, int Mc, int t, const int32_t* t_dev, int dtype, void* stream);
 
 /* Small-M projection y[Mr,N] = x[Mr,K].W[N,K]^T + bias (Mr <= 8), optional ReLU;
  * weight-streaming kernel for the decode step (HBM-bound). */
@@ -189,6 +191,11 @@ int me_gemv_small(const void* x, int ldx, const void* W, int ldw, const float* b
  * special[0..n_special) -> -inf, argmax -> out_ids[B] (generate.py:122-136,166-183). */
 int me_greedy_pick(const float* logits, int ld, int V, const int32_t* special, int n_special,
                    int64_t* out_ids, int B, void* stream);
+
+/* Device-side decode bookkeeping: history[b][*pos] = tok[b] (int64 [B][ld_hist]); *pos += 1.
+ * With me_embed_fwd(pos_dev) and me_rga_decode_step(t_dev) a greedy decode step has no host-side state
+ * (the token loop of generate.py:99-189 for top_k = 1) and can be captured once and replayed. */
+int me_decode_commit(const int64_t* tok, int64_t* history, int ld_hist, int32_t* pos, int B, void* stream);
 
 #ifdef __cplusplus
 }

@@ -694,7 +694,9 @@ template <typename T, int DH>
 __global__ __launch_bounds__(256) void rga_decode_kernel(const T* __restrict__ qkv_new, T* __restrict__ kcache,
                                                          T* __restrict__ vcache, const T* __restrict__ E,
                                                          const uint8_t* __restrict__ key_pad, int ld_pad,
-                                                         T* __restrict__ out, int H, int M, int Mc, int t, float scale) {
+                                                         T* __restrict__ out, int H, int M, int Mc, int t_host, const int32_t* __restrict__ t_dev,
+                                                         float scale) {
+    const int t = t_dev ? min(*t_dev, min(Mc, M) - 1) : t_host;   // device-side position: the launch is replayable in a HIP graph
     __shared__ float qs[DH];
     __shared__ float ps[2048 + 8];
     __shared__ float red[256];
@@ -791,10 +793,10 @@ int bwd_launch(const void* qkv, const void* E, const void* ET_, const uint8_t* k
 
 template <typename T, int DH>
 int dec_launch(const void* qkv_new, void* kc, void* vc, const void* E, const uint8_t* key_pad, int ld_pad, void* out, int B,
-               int H, int M, int Mc, int t, hipStream_t st) {
+               int H, int M, int Mc, int t, const int32_t* t_dev, hipStream_t st) {
     const float scale = 1.f / sqrtf((float)DH);
     rga_decode_kernel<T, DH><<<B * H, 256, 0, st>>>((const T*)qkv_new, (T*)kc, (T*)vc, (const T*)E, key_pad, ld_pad, (T*)out, H, M,
-                                                   Mc, t, scale);
+                                                   Mc, t, t_dev, scale);
     return me_launch_status();
 }
 
@@ -837,12 +839,14 @@ int me_rga_bwd(const void* qkv, const void* E, const void* ET_, const uint8_t* k
 }
 
 int me_rga_decode_step(const void* qkv_new, void* kcache, void* vcache, const void* E, const uint8_t* key_pad, int ld_pad,
-                       void* out, int B, int H, int dh, int M, int Mc, int t, int dtype, void* stream) {
+                       void* out, int B, int H, int dh, int M, int Mc, int t, const int32_t* t_dev, int dtype,
+                       void* stream) {
     me_clear_error();
     if (!qkv_new || !kcache || !vcache || !E || !out) return ME_ERR_NULL;
-    if (B <= 0 || H <= 0 || t < 0 || t >= Mc || t >= M || t >= 2048) return ME_ERR_BAD_SHAPE;
+    if (B <= 0 || H <= 0 || (t_dev && Mc > 2048)) return ME_ERR_BAD_SHAPE;
+    if (!t_dev && (t < 0 || t >= Mc || t >= M || t >= 2048)) return ME_ERR_BAD_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    ME_ATTN_DISPATCH((dec_launch<T, DH>(qkv_new, kcache, vcache, E, key_pad, ld_pad, out, B, H, M, Mc, t, st)))
+    ME_ATTN_DISPATCH((dec_launch<T, DH>(qkv_new, kcache, vcache, E, key_pad, ld_pad, out, B, H, M, Mc, t, t_dev, st)))
 }
 
 }  // extern "C"

@@ -42,11 +42,13 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(T* __restrict__ out, con
                                                         const float* __restrict__ cond, const float* __restrict__ emb,
                                                         const float* __restrict__ cw0, const float* __restrict__ cb0,
                                                         const float* __restrict__ cw1, const float* __restrict__ cb1,
-                                                        const float* __restrict__ pe, int mode, int B, int Ltok, int d,
+                                                        const float* __restrict__ pe, const int32_t* __restrict__ pos_dev,
+                                                        int mode, int B, int Ltok, int d,
                                                         int dc, uint32_t thr16, float inv_keep, uint64_t seed) {
     constexpr int CH = ET<T>::CH;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int shift = mode == ME_COND_TOKEN ? 2 : 0;
+    const int pos0 = pos_dev ? *pos_dev : 0;          // decode: first position comes from device memory (graph replay)
     const int Lm = Ltok + shift;
     const int64_t row = (int64_t)blockIdx.x * 4 + wid;
     if (row >= (int64_t)B * Lm) return;
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(T* __restrict__ out, con
     const bool vec_ok = (de % 4) == 0 && (d % 4) == 0 && (dc % 4) == 0;
     for (int col = lane * CH; col < d; col += 64 * CH) {
         float v[CH];
-        const float* pep = pe + (int64_t)l * d + col;
+        const float* pep = pe + (int64_t)(l + pos0) * d + col;
         if (vec_ok && l >= shift && col + CH <= de) {
             // chunk inside the token embedding: 16-byte loads of the table row and of the positional encoding
             const float* ep = emb + tok * de + col;
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(T* __restrict__ out, con
                     const int jc = j - de;
                     x = cw0[jc * 2] * c0 + cw0[jc * 2 + 1] * c1 + cb0[jc];
                 }
-                v[i] = x + pe[(int64_t)l * d + j];
+                v[i] = x + pe[(int64_t)(l + pos0) * d + j];
             }
         }
         if (thr16) {
@@ -605,10 +607,21 @@ inline int row_grid(int64_t rows, int cap) { int64_t g = (rows + 3) / 4; return 
     else if ((dtype) == ME_BF16) { typedef bf16_t T; CALL; } \
     else return ME_ERR_BAD_DTYPE;
 
+
+// decode bookkeeping on the device (so that a whole greedy step can be replayed as one HIP graph):
+// history[b][*pos] = tok[b];  *pos += 1
+__global__ void decode_commit_kernel(const int64_t* __restrict__ tok, int64_t* __restrict__ history, int ld_hist,
+                                     int32_t* __restrict__ pos, int B) {
+    const int p = *pos;
+    if ((int)threadIdx.x < B && p < ld_hist) history[(size_t)threadIdx.x * ld_hist + p] = tok[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) *pos = p + 1;
+}
+
 extern "C" {
 
 int me_embed_fwd(void* out, int dtype, const int64_t* tokens, const float* cond, const float* emb, const float* cw0,
-                 const float* cb0, const float* cw1, const float* cb1, const float* pe, int mode, int B, int Ltok,
+                 const float* cb0, const float* cw1, const float* cb1, const float* pe, const int32_t* pos_dev, int mode, int B, int Ltok,
                  int d, int dc, float p, uint64_t seed, void* stream) {
     me_clear_error();
     if (!out || !tokens || !emb || !pe) return ME_ERR_NULL;
@@ -624,7 +637,7 @@ int me_embed_fwd(void* out, int dtype, const int64_t* tokens, const float* cond,
     const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
     hipStream_t st = (hipStream_t)stream;
     ME_DISPATCH(dtype, (embed_fwd_kernel<T><<<(unsigned)((rows + 3) / 4), 256, 0, st>>>(
-                           (T*)out, tokens, cond, emb, cw0, cb0, cw1, cb1, pe, mode, B, Ltok, d, dc, thr, inv_keep, seed)));
+                           (T*)out, tokens, cond, emb, cw0, cb0, cw1, cb1, pe, pos_dev, mode, B, Ltok, d, dc, thr, inv_keep, seed)));
     return me_launch_status();
 }
 
@@ -767,6 +780,14 @@ int me_adamw_step(float* p, float* g, float* m, float* v, int64_t n, const float
     if (blocks < 1) blocks = 1;
     adamw_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, sumsq, clip, grad_scale, lr, beta1, beta2, eps,
                                                                    weight_decay, bias_corr1, bias_corr2, zero_grad);
+    return me_launch_status();
+}
+
+int me_decode_commit(const int64_t* tok, int64_t* history, int ld_hist, int32_t* pos, int B, void* stream) {
+    me_clear_error();
+    if (!tok || !history || !pos) return ME_ERR_NULL;
+    if (B <= 0 || B > 1024 || ld_hist <= 0) return ME_ERR_BAD_SHAPE;
+    decode_commit_kernel<<<1, ((B + 63) / 64) * 64, 0, (hipStream_t)stream>>>(tok, history, ld_hist, pos, B);
     return me_launch_status();
 }
 

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("MIDIEMO_LIB") or os.path.join(HERE, "libmidiemo_hip.s
 ME_F32, ME_BF16 = 0, 1
 ME_COND_NONE, ME_COND_CONCAT, ME_COND_TOKEN = 0, 1, 2
 ME_EPI_RELU, ME_EPI_OUT_F32, ME_EPI_RELU_BWD = 1, 2, 4
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 ERRORS = {0: "ME_OK", -1: "ME_ERR_BAD_DTYPE", -2: "ME_ERR_BAD_SHAPE", -3: "ME_ERR_ALIGNMENT",
           -4: "ME_ERR_LAUNCH", -5: "ME_ERR_NULL"}
@@ -24,7 +24,7 @@ _i64, _u64, _u32 = ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint32
 SIGNATURES = {
     "me_abi_version": [],
     "me_cast_transpose": [_p, _i, _i, _p, _i, _p, _i, _i, _p],
-    "me_embed_fwd": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _u64, _p],
+    "me_embed_fwd": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _u64, _p],
     "me_embed_bwd": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _p],
     "me_key_pad_mask": [_p, _p, _i, _i, _i, _i, _p],
     "me_gemm_nt": [_p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
@@ -37,9 +37,10 @@ SIGNATURES = {
     "me_ce_bwd": [_p, _i, _p, _p, _p, _i, _p, _f, _i, _i, _i, _i, _p],
     "me_sumsq": [_p, _i64, _p, _p],
     "me_adamw_step": [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _p],
-    "me_rga_decode_step": [_p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "me_rga_decode_step": [_p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p],
     "me_gemv_small": [_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "me_greedy_pick": [_p, _i, _i, _p, _i, _p, _i, _p],
+    "me_decode_commit": [_p, _p, _i, _p, _i, _p],
 }
 
 _lib = None

@@ -42,6 +42,8 @@ class DecodeSession:
         self.qkv, self.att, self.tmp, self.o1, self.hid = e(B, 3 * d), e(B, d), e(B, d), e(B, d), e(B, di)
         self.logits = e(B, V, dtype=torch.float32)
         self.t = 0                      # next model position to be written
+        self._pos_dev = None            # device-side position: set while a step is issued for graph capture / replay
+        self._graph = None
         m._refresh_weights()
 
     def reset(self):
@@ -63,7 +65,8 @@ class DecodeSession:
             W = m._prep["layers"][i]
             p = f"enc_layers.{i}."
             self._proj(x, W["Wqkv"], W["bqkv"], self.qkv, 3 * d, d)
-            ops.rga_decode_step(self.qkv, self.kc[i], self.vc[i], W["E"], None, 0, self.att, B, H, dh, M, M, t)
+            ops.rga_decode_step(self.qkv, self.kc[i], self.vc[i], W["E"], None, 0, self.att, B, H, dh, M, M, t,
+                                t_dev=self._pos_dev)
             self._proj(self.att, W["Wo"], m._pview(f, p + "rga.fc.bias"), self.tmp, d, d)
             ops.resid_ln_fwd(x, self.tmp, m._pview(f, p + "layernorm1.weight"), m._pview(f, p + "layernorm1.bias"),
                              self.o1, None, None, B, d, m.LN_EPS, 0.0, 0, 0)
@@ -73,7 +76,8 @@ class DecodeSession:
                              y, None, None, B, d, m.LN_EPS, 0.0, 0, 0)
             x, y = y, x
         self._proj(x, m._prep["head"]["Wf"], m._pview(f, "fc.bias"), self.logits, V, d, flags=ops.ME_EPI_OUT_F32)
-        self.t += 1
+        if self._pos_dev is None:
+            self.t += 1
         return self.logits
 
     # -------------------------------------------------------------- public steps
@@ -106,13 +110,71 @@ class DecodeSession:
         f = m.flat_params
         tokens = tokens.to(device=f.device, dtype=torch.int64).reshape(self.B, 1).contiguous()
         d = m.embedding_dim
-        pe_t = m._pe[self.t:]
+        return self._embed_and_run(tokens, cond, m._pe[self.t:], None)
+
+    def _embed_and_run(self, tokens, cond, pe_t, pos_dev):
+        m = self.m
+        f = m.flat_params
+        d = m.embedding_dim
         if m.d_condition > 0:
             cond = cond.to(device=f.device, dtype=torch.float32).contiguous()
             cw0, cb0, _, _ = m._cond_params(f)
             ops.embed_fwd(self.x, tokens, cond, m._pview(f, "embedding.weight"), cw0, cb0, None, None, pe_t,
-                          ops.ME_COND_CONCAT, self.B, 1, d, m.d_condition, 0.0, 0)
+                          ops.ME_COND_CONCAT, self.B, 1, d, m.d_condition, 0.0, 0, pos_dev=pos_dev)
         else:
             ops.embed_fwd(self.x, tokens, None, m._pview(f, "embedding.weight"), None, None, None, None, pe_t,
-                          ops.ME_COND_NONE, self.B, 1, d, 0, 0.0, 0)
+                          ops.ME_COND_NONE, self.B, 1, d, 0, 0.0, 0, pos_dev=pos_dev)
         return self._layers_and_head()
+
+    # -------------------------------------------------------------- device-resident greedy loop
+    def greedy_run(self, tokens, n_steps, cond=None, special=None, use_graph=True):
+        """Feed `tokens` (int64 [B]) at the next position, then keep feeding the arg-max token back for n_steps
+        steps in total, entirely on the device (generate.py:99-189 with top_k = 1): the position lives in device
+        memory (me_embed_fwd pos_dev, me_rga_decode_step t_dev), me_greedy_pick writes the next input token and
+        me_decode_commit appends it to a history buffer and advances the position.  The step is captured once as a
+        HIP graph and replayed, so a token costs one graph launch instead of ~45 kernel launches from Python.
+        Returns the generated ids int64 [B, n_steps] (on the device)."""
+        m = self.m
+        dev = m.flat_params.device
+        n_steps = int(n_steps)
+        if self.t + n_steps > m.max_seq:
+            raise RuntimeError("decode positions %d..%d exceed max_seq %d" % (self.t, self.t + n_steps, m.max_seq))
+        if not hasattr(self, "_tok"):
+            self._tok = torch.zeros(self.B, 1, dtype=torch.int64, device=dev)
+            self._hist = torch.zeros(self.B, m.max_seq, dtype=torch.int64, device=dev)
+            self._pos = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._cond = torch.zeros(self.B, 2, dtype=torch.float32, device=dev)
+            self._special = None
+        self._tok.copy_(tokens.to(device=dev, dtype=torch.int64).reshape(self.B, 1))
+        self._pos.fill_(self.t)
+        if m.d_condition > 0:
+            self._cond.copy_(cond.to(device=dev, dtype=torch.float32))
+        sp = None if special is None else special.to(device=dev, dtype=torch.int32).contiguous()
+        if (sp is None) != (self._special is None) or (sp is not None and not torch.equal(sp, self._special)):
+            self._special, self._graph = sp, None          # the special-id list is baked into the captured step
+
+        def one_step():
+            self._pos_dev = self._pos
+            try:
+                self._embed_and_run(self._tok, self._cond if m.d_condition > 0 else None, m._pe, self._pos)
+                ops.greedy_pick(self.logits, m.vocab_size, self._special, self._tok, self.B)
+                ops.decode_commit(self._tok, self._hist, self._pos, self.B)
+            finally:
+                self._pos_dev = None
+
+        t0 = self.t
+        done = 0
+        if use_graph and self._graph is None and n_steps > 2:
+            one_step()                                      # warm-up outside the capture (lazy allocations, attributes)
+            done = 1
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                one_step()
+            self._graph = g                                 # capturing does not execute
+        for _ in range(n_steps - done):
+            if use_graph and self._graph is not None:
+                self._graph.replay()
+            else:
+                one_step()
+        self.t = t0 + n_steps
+        return self._hist[:, t0:t0 + n_steps]

@@ -42,9 +42,9 @@ def cast_transpose(src, dst, dstT, dtype):
           "me_cast_transpose")
 
 
-def embed_fwd(out, tokens, cond, emb, cw0, cb0, cw1, cb1, pe, mode, B, Ltok, d, dc, p, seed):
+def embed_fwd(out, tokens, cond, emb, cw0, cb0, cw1, cb1, pe, mode, B, Ltok, d, dc, p, seed, pos_dev=None):
     check(lib().me_embed_fwd(_ptr(out), _code(out.dtype), _ptr(tokens), _ptr(cond), _ptr(emb), _ptr(cw0), _ptr(cb0),
-                             _ptr(cw1), _ptr(cb1), _ptr(pe), mode, B, Ltok, d, dc, float(p), int(seed), _stream()),
+                             _ptr(cw1), _ptr(cb1), _ptr(pe), _ptr(pos_dev), mode, B, Ltok, d, dc, float(p), int(seed), _stream()),
           "me_embed_fwd")
 
 
@@ -127,15 +127,19 @@ def adamw_step(p, g, m, v, sumsq_t, clip, grad_scale, lr, beta1, beta2, eps, wei
           "me_adamw_step")
 
 
-def rga_decode_step(qkv_new, kcache, vcache, E, key_pad, ld_pad, out, B, H, dh, M, Mc, t):
+def rga_decode_step(qkv_new, kcache, vcache, E, key_pad, ld_pad, out, B, H, dh, M, Mc, t, t_dev=None):
     check(lib().me_rga_decode_step(_ptr(qkv_new), _ptr(kcache), _ptr(vcache), _ptr(E), _ptr(key_pad), ld_pad,
-                                   _ptr(out), B, H, dh, M, Mc, t, _code(qkv_new.dtype), _stream()), "me_rga_decode_step")
+                                   _ptr(out), B, H, dh, M, Mc, t, _ptr(t_dev), _code(qkv_new.dtype), _stream()), "me_rga_decode_step")
 
 
 def gemv_small(x, W, bias, y, Mr, N, K, flags=0, dtype=None):
     dtype = dtype or x.dtype
     check(lib().me_gemv_small(_ptr(x), x.stride(0), _ptr(W), W.stride(0), _ptr(bias), _ptr(y), y.stride(0), Mr, N, K,
                               flags, _code(dtype), _stream()), "me_gemv_small")
+
+
+def decode_commit(tok, history, pos, B):
+    check(lib().me_decode_commit(_ptr(tok), _ptr(history), history.stride(0), _ptr(pos), B, _stream()), "me_decode_commit")
 
 
 def greedy_pick(logits, V, special, out_ids, B):

@@ -77,3 +77,41 @@ def test_sampling_path_runs_and_respects_exclusions(golden_dir):
     ids = run(G, model, maps, "continuous_concat", conds, disc, 40, 24, use_cache=True, top_k=-1)
     assert ids.shape == (40, 4) and (ids[0] == 1).all()
     assert ((ids[1:] >= 2) & (ids[1:] < 1007)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("conditioning", ["none", "continuous_concat"])
+def test_device_resident_greedy_loop_matches_eager_steps(conditioning):
+    """DecodeSession.greedy_run (device-side position, HIP-graph replay) == step() + greedy_pick token by token."""
+    import torch
+    from midiemo import ops
+    from midiemo.decode import DecodeSession
+    from midiemo.models.build_model import build_model
+    torch.manual_seed(5)
+    dc = 32 if conditioning == "continuous_concat" else -1
+    model, _ = build_model(dict(vocab_size=1007, n_layer=2, n_head=2, d_model=128, d_inner=256, dropout=0.0, d_condition=dc,
+                                conditioning=conditioning, compute_dtype="fp32"))
+    model = model.cuda().eval()
+    B, n = 3, 40
+    cond = torch.rand(B, 2, device="cuda") * 2 - 1
+    special = torch.tensor([0, 1, 5], dtype=torch.int32, device="cuda")
+    tok0 = torch.tensor([1, 7, 300], device="cuda")
+    with torch.no_grad():
+        ref = DecodeSession(model, B)
+        tok, picked, want = tok0.clone(), torch.empty(B, dtype=torch.long, device="cuda"), []
+        for _ in range(n):
+            lg = ref.step(tok, cond)
+            ops.greedy_pick(lg, 1007, special, picked, B)
+            tok = picked.clone()
+            want.append(tok.clone())
+        want = torch.stack(want, 1)
+        for use_graph in (False, True):
+            sess = DecodeSession(model, B)
+            got = sess.greedy_run(tok0, n, cond, special, use_graph=use_graph)
+            assert sess.t == n
+            assert torch.equal(got, want), (use_graph, got[:, :8], want[:, :8])
+        # continue from where the graph loop stopped: positions keep counting
+        more = sess.greedy_run(got[:, -1], 5, cond, special)
+        lg = ref.step(want[:, -1], cond)
+        ops.greedy_pick(lg, 1007, special, picked, B)
+        assert torch.equal(more[:, 0], picked)

@@ -44,8 +44,25 @@ def main():
     torch.cuda.synchronize()
     total = time.perf_counter() - t_all
     lat = np.array(lat) * 1e3
-    print("decode[%s]: B=%d gen_len=%d  %.1f tok/s  total %.2f s  per-step host ms p50 %.3f p90 %.3f" %
+    print("decode[%s] eager launches : B=%d gen_len=%d  %.1f tok/s  total %.2f s  per-step host ms p50 %.3f p90 %.3f" %
           (cd, B, gen_len, B * gen_len / total, total, np.percentile(lat, 50), np.percentile(lat, 90)))
+    eager_ids = None
+    # device-resident greedy loop replayed as one HIP graph per token
+    sess2 = DecodeSession(model, B)
+    tok0 = torch.full((B,), 1, dtype=torch.long, device="cuda")
+    with torch.no_grad():
+        sess2.greedy_run(tok0, 8, cond, specials)                 # capture + warm-up
+        sess2.reset()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t_all = time.perf_counter()
+        e0.record()
+        ids = sess2.greedy_run(tok0, gen_len, cond, specials)
+        e1.record()
+        torch.cuda.synchronize()
+        total = time.perf_counter() - t_all
+    print("decode[%s] HIP-graph loop : B=%d gen_len=%d  %.1f tok/s  total %.3f s  per-step device ms %.4f  (ids checksum %d)" %
+          (cd, B, gen_len, B * gen_len / total, total, e0.elapsed_time(e1) / gen_len, int(ids.sum().item())))
 
 
 if __name__ == "__main__":
