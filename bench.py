@@ -192,11 +192,16 @@ def main():
     final_loss = float(loss.item())
 
     probe = None
-    if rank == 0 and not args.no_probe:
-        with GemmProbe(ops) as gp:
+    if not args.no_probe:
+        # every rank runs the instrumented steps (they contain the gradient all-reduce); only rank 0 times its GEMMs
+        if rank == 0:
+            with GemmProbe(ops) as gp:
+                for i in range(3):
+                    step(i)
+                probe = gp.summary()
+        else:
             for i in range(3):
                 step(i)
-            probe = gp.summary()
     fence()
 
     if rank == 0:
