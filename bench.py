@@ -139,11 +139,19 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # test hooks (single-GPU boxes): MIDIEMO_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
+    # MIDIEMO_DIST_BACKEND=gloo replaces RCCL, so the multi-rank control flow can be exercised without N GPUs
+    if os.environ.get("MIDIEMO_BENCH_ONE_DEVICE"):
+        local_rank = 0
+    backend = os.environ.get("MIDIEMO_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from midiemo import ops
     from midiemo.ddp import GradAllReducer, broadcast_params
