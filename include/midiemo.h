@@ -59,6 +59,17 @@ int me_abi_version(void);
 int me_cast_transpose(const float* src, int rows, int cols, void* dst, int ld_dst,
                       void* dstT, int ld_dstT, int dtype, void* stream);
 
+/* The same for many tensors in ONE launch.  desc_dev: device array of n_tensors descriptors, tile_begin = number
+ * of 32x32 tiles of all earlier tensors (ascending), total_tiles = sum over tensors of ceil(rows/32)*ceil(cols/32);
+ * dst / dstT as above (either may be NULL). */
+typedef struct me_ct_desc {
+    const float* src;
+    void* dst;
+    void* dstT;
+    int32_t rows, cols, ld_dst, ld_dstT, tile_begin, pad_;
+} me_ct_desc;
+int me_cast_transpose_multi(const me_ct_desc* desc_dev, int n_tensors, int total_tiles, int dtype, void* stream);
+
 /* ---- embedding prologue ---------------------------------------------------
  * out[B, Lm, d] (T).  Lm = Ltok (+2 for ME_COND_TOKEN).
  *   NONE  : out = emb[tok]*sqrt(d) + PE                       (music_multi.py:91-92,101)

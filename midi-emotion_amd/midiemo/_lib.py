@@ -24,6 +24,7 @@ _i64, _u64, _u32 = ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint32
 SIGNATURES = {
     "me_abi_version": [],
     "me_cast_transpose": [_p, _i, _i, _p, _i, _p, _i, _i, _p],
+    "me_cast_transpose_multi": [_p, _i, _i, _i, _p],
     "me_embed_fwd": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _u64, _p],
     "me_embed_bwd": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _p],
     "me_key_pad_mask": [_p, _p, _i, _i, _i, _i, _p],

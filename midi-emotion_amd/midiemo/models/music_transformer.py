@@ -133,6 +133,7 @@ class MusicTransformerHIP(nn.Module):
         self._fwd_count = 0
         self._ws = {}
         self._prep = None
+        self._ct_desc = None
         self._prep_version = None
         self._dirty = True
         self._pe = None
@@ -208,6 +209,7 @@ class MusicTransformerHIP(nn.Module):
         self._flat, self._gflat, self._slices, self._buckets = flat, gflat, slices, buckets
         self._ws = {}
         self._prep = None
+        self._ct_desc = None
         self._dirty = True
         self._pe = sinusoid_table(self.max_seq, self.embedding_dim).to(dev)
 
@@ -275,24 +277,29 @@ class MusicTransformerHIP(nn.Module):
                 head["Wf"] = buf(V, d)
             self._prep = {"layers": layers, "head": head}
         f = self._flat
-        for i, L in enumerate(self._prep["layers"]):
-            p = f"enc_layers.{i}."
-            o, _, _ = self._slices[p + "rga.Wq.weight"]
-            wqkv = f[o:o + 3 * d * d].view(3 * d, d)
-            srcs = {"Wqkv": wqkv, "Wo": self._pview(f, p + "rga.fc.weight"), "W1": self._pview(f, p + "FFN_pre.weight"),
-                    "W2": self._pview(f, p + "FFN_suf.weight"), "E": self._pview(f, p + "rga.E")}
-            for k, src in srcs.items():
-                nat = L.get(k) if dt != torch.float32 else None
-                ops.cast_transpose(src, nat, L[k + "T"], dt)
-                if dt == torch.float32:
-                    L[k] = src
-            ob, _, _ = self._slices[p + "rga.Wq.bias"]
-            L["bqkv"] = f[ob:ob + 3 * d]
-        H = self._prep["head"]
-        src = self._pview(f, "fc.weight")
-        ops.cast_transpose(src, H.get("Wf") if dt != torch.float32 else None, H["WfT"], dt)
-        if dt == torch.float32:
-            H["Wf"] = src
+        if getattr(self, "_ct_desc", None) is None or self._ct_desc_ptr != f.data_ptr():
+            # one descriptor table for all prepared weights: the refresh is a single multi-tensor launch
+            items = []
+            for i, L in enumerate(self._prep["layers"]):
+                p = f"enc_layers.{i}."
+                o, _, _ = self._slices[p + "rga.Wq.weight"]
+                wqkv = f[o:o + 3 * d * d].view(3 * d, d)
+                srcs = {"Wqkv": wqkv, "Wo": self._pview(f, p + "rga.fc.weight"), "W1": self._pview(f, p + "FFN_pre.weight"),
+                        "W2": self._pview(f, p + "FFN_suf.weight"), "E": self._pview(f, p + "rga.E")}
+                for k, src in srcs.items():
+                    items.append((src, L.get(k) if dt != torch.float32 else None, L[k + "T"]))
+                    if dt == torch.float32:
+                        L[k] = src
+                ob, _, _ = self._slices[p + "rga.Wq.bias"]
+                L["bqkv"] = f[ob:ob + 3 * d]
+            H = self._prep["head"]
+            src = self._pview(f, "fc.weight")
+            items.append((src, H.get("Wf") if dt != torch.float32 else None, H["WfT"]))
+            if dt == torch.float32:
+                H["Wf"] = src
+            self._ct_desc = ops.make_ct_desc(items, dev)
+            self._ct_desc_ptr = f.data_ptr()
+        ops.cast_transpose_multi(self._ct_desc[0], self._ct_desc[1], self._ct_desc[2], dt)
         self._prep_version = ver
         self._dirty = False
 

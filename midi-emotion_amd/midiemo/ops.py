@@ -42,6 +42,28 @@ def cast_transpose(src, dst, dstT, dtype):
           "me_cast_transpose")
 
 
+def cast_transpose_multi(desc_dev, n_tensors, total_tiles, dtype):
+    """desc_dev: uint8 device tensor holding n_tensors packed me_ct_desc structs (see make_ct_desc)."""
+    check(lib().me_cast_transpose_multi(_ptr(desc_dev), n_tensors, total_tiles, _code(dtype), _stream()),
+          "me_cast_transpose_multi")
+
+
+def make_ct_desc(items, device):
+    """items: list of (src f32 [rows, cols], dst or None, dstT or None) -> (desc uint8 device tensor, n, total_tiles).
+    Layout = struct me_ct_desc {const float* src; void* dst; void* dstT; int32 rows, cols, ld_dst, ld_dstT,
+    tile_begin, pad;} (48 bytes)."""
+    import struct
+    blob, tiles = b"", 0
+    for src, dst, dstT in items:
+        rows, cols = src.shape
+        blob += struct.pack("<QQQiiiiii", src.data_ptr(), dst.data_ptr() if dst is not None else 0,
+                            dstT.data_ptr() if dstT is not None else 0, rows, cols,
+                            dst.stride(0) if dst is not None else 0, dstT.stride(0) if dstT is not None else 0, tiles, 0)
+        tiles += ((rows + 31) // 32) * ((cols + 31) // 32)
+    t = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
+    return t, len(items), tiles
+
+
 def embed_fwd(out, tokens, cond, emb, cw0, cb0, cw1, cb1, pe, mode, B, Ltok, d, dc, p, seed, pos_dev=None):
     check(lib().me_embed_fwd(_ptr(out), _code(out.dtype), _ptr(tokens), _ptr(cond), _ptr(emb), _ptr(cw0), _ptr(cb0),
                              _ptr(cw1), _ptr(cb1), _ptr(pe), _ptr(pos_dev), mode, B, Ltok, d, dc, float(p), int(seed), _stream()),
