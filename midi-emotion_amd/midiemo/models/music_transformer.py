@@ -272,7 +272,7 @@ class MusicTransformerHIP(nn.Module):
                     L.update(Wqkv=buf(3 * d, d), Wo=buf(d, d), W1=buf(di, d), W2=buf(d, di), E=buf(M, dh))
                 L.update(WqkvT=buf(d, 3 * d), WoT=buf(d, d), W1T=buf(d, di), W2T=buf(di, d), ET=buf(dh, M))
                 layers.append(L)
-            head = {"WfT": buf(d, V, _round_up(V, 16))}
+            head = {"WfT": buf(d, V, _round_up(V, 64))}
             if dt != torch.float32:
                 head["Wf"] = buf(V, d)
             self._prep = {"layers": layers, "head": head}
@@ -334,7 +334,7 @@ class MusicTransformerHIP(nn.Module):
             ws.layers.append(L)
         ws.tmp = e(T, d)
         if save:
-            ldv = _round_up(V, 16)
+            ldv = _round_up(V, 64)
             ws.logits = e(T, ldv, dtype=torch.float32)
             ws.row_lse = e(T, dtype=torch.float32)
             ws.dlogits = torch.zeros(T, ldv, dtype=dt, device=dev)
