@@ -709,7 +709,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_bf16_kernel(
 // ds_read_b64_tr_b16 group touches fall into different bank quarters); the transposed operand
 // fragments come out of the transpose-read.  Compared with the 128 x 128 kernel the tile halves the
 // operand bytes per FLOP through L1 (813 -> 406 MB per dWqkv launch).
-// Requires N % 256 == 0 and K % 256 == 0; tokens past the range end are stored as zeros.
+// Requires K % 256 == 0 and dY rows readable up to the next multiple of 256 columns (lda >= that; columns >= N
+// only produce rows >= N of the tile, which are dropped); tokens past the range end are stored as zeros.
 // ---------------------------------------------------------------------------------------------
 constexpr int TN256_LD = 288;                                   // elements per LDS row
 constexpr int TN256_BT = 64;                                    // tokens per slab
@@ -823,7 +824,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // my stores of slab step+1 are in LDS
         slot_barrier();                                                    // everybody's; slab `step` fully consumed
     }
-    if (do_bias && tid < 256) atomicAdd(&dbias[n0 + tid], bsum);
+    if (do_bias && tid < 256 && n0 + tid < N) atomicAdd(&dbias[n0 + tid], bsum);
     if (ws) {
         // partial tile -> workspace in register order: slot (i, j, q) of thread tid is one 16-byte store, 1 KiB
         // contiguous per wave instruction; tn256_reduce_kernel adds the token ranges in a fixed order
@@ -845,7 +846,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = n0 + wr * 128 + i * 32 + c_row(r, lane);
-                atomicAdd(&dW[(size_t)row * lddw + col], acc[i][j][r]);
+                if (row < N) atomicAdd(&dW[(size_t)row * lddw + col], acc[i][j][r]);
             }
         }
 }
@@ -854,7 +855,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(
 // workspace (67 MB of f32 atomics cost 40-48 us per launch, the same bytes as plain stores + this pass
 // ~15 us, and the sum no longer depends on the arrival order).  grid (tn * tk, 32 slots), 512 threads.
 __global__ __launch_bounds__(512) void tn256_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, int lddw,
-                                                           int tn, int tk, int nsplit) {
+                                                           int tn, int tk, int nsplit, int N) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 2, wc = wid & 3;
     const int nx = blockIdx.x % tn, ky = blockIdx.x / tn;
@@ -878,7 +879,7 @@ __global__ __launch_bounds__(512) void tn256_reduce_kernel(const float* __restri
     const int col = ky * 256 + wc * 64 + j * 32 + (lane & 31);
     const int row = nx * 256 + wr * 128 + i * 32 + 8 * q + 4 * (lane >> 5);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) dW[(size_t)(row + e) * lddw + col] += sum[e];
+    for (int e = 0; e < 4; ++e) if (row + e < N) dW[(size_t)(row + e) * lddw + col] += sum[e];
 }
 
 // f32 master -> T copy and/or T transposed copy, 32x32 tiles through LDS
@@ -1037,14 +1038,15 @@ int gemm_tn_launch(const void* A, int lda, const void* B, int ldb, float* dW, in
     if constexpr (sizeof(T) == 2) {
         static const bool no256 = getenv("MIDIEMO_NO_TN256") != nullptr;
         const bool off32 = (unsigned long long)Tn * lda * 2ull < (1ull << 32) && (unsigned long long)Tn * ldb * 2ull < (1ull << 32);
-        if (!no256 && N % 256 == 0 && K % 256 == 0 && Tn >= 2048 && off32) {
+        const int n256 = ((N + 255) / 256) * 256;
+        if (!no256 && (N % 256 == 0 || lda >= n256) && K % 256 == 0 && Tn >= 2048 && off32) {
             // one block per CU: split the tokens so that tiles x ranges just fills the chip
             static bool attr_set = false;
             if (!attr_set) {
                 (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN256_LDS);
                 attr_set = true;
             }
-            const int tn2 = N / 256, tk2 = K / 256;
+            const int tn2 = n256 / 256, tk2 = K / 256;
             int ns = 256 / (tn2 * tk2);
             if (ns < 1) ns = 1;
             int tp = (Tn + ns - 1) / ns;
@@ -1073,7 +1075,7 @@ int gemm_tn_launch(const void* A, int lda, const void* B, int ldb, float* dW, in
             }
             gemm_tn256_kernel<<<grid256, 512, TN256_LDS, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, dW, lddw, dbias, Tn, N,
                                                              K, tp, tn2, tk2, ns, ws);
-            if (ws) tn256_reduce_kernel<<<dim3(tn2 * tk2, 32), 512, 0, st>>>(ws, dW, lddw, tn2, tk2, ns);
+            if (ws) tn256_reduce_kernel<<<dim3(tn2 * tk2, 32), 512, 0, st>>>(ws, dW, lddw, tn2, tk2, ns, N);
             return me_launch_status();
         }
         const int npairs8 = ((tn * nsplit + 7) / 8) * 8;

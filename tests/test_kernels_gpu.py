@@ -114,10 +114,12 @@ def test_gemm_nt_epilogues(ops, dtype):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("T,N,K", [(256, 128, 128), (1000, 136, 72), (21, 1007, 64), (4096, 96, 256), (4096, 512, 512),
                                    (2048, 1007, 256), (8192, 200, 1536),
-                                   (5000, 256, 512), (2101, 512, 256), (32768, 1536, 512)])   # 256-tile kernel, ragged ranges
+                                   (5000, 256, 512), (2101, 512, 256), (32768, 1536, 512), (4100, 1007, 512)])   # 256-tile kernel, ragged ranges
 def test_gemm_tn_acc(ops, dtype, T, N, K):
     ch = 4 if dtype == torch.float32 else 8
     ldA = ((N + ch - 1) // ch) * ch + ch
+    if (T, N, K) == (4100, 1007, 512):
+        ldA = 1024                      # rows readable up to the next multiple of 256: 256-tile kernel with N % 256 != 0
     A = torch.zeros(T, ldA, dtype=dtype)
     A[:, :N] = rnd(T, N, seed=9).to(dtype)
     B = rnd(T, K, seed=10).to(dtype)
