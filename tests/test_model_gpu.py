@@ -177,6 +177,29 @@ def test_grads_vs_oracle_random_batch(mode, cd):
     assert not bad, bad
 
 
+def test_max_seq_discrete_token_config4_shape():
+    """BASELINE config 4's shape: discrete_token (V = 1017, two bin tokens in front), L = max_seq = 2048 -- the largest
+    sequence the model accepts.  Logits, loss and every gradient against the oracle (f32 tier), PAD tail included."""
+    cfg = O.Cfg(1017, 2, 2, 128, 256, conditioning="discrete_token")
+    P = O.seeded_params(cfg, 2)
+    model = make_model(cfg, P, "fp32").train()
+    tok, cond, tgt = O.synthetic_batch(cfg, 1, 2048, seed=3)
+    tok[0, -37:] = 0
+    tgt[0, -38:] = 0
+    loss_ref, lg_ref, G = O.loss_and_grads(cfg, P, tok, cond, tgt)
+    loss = model.loss_and_backward(tok.to(DEV), cond.to(DEV), tgt.to(DEV))
+    model.link_grads()
+    assert abs(loss.item() - loss_ref.item()) < 1e-4, (loss.item(), loss_ref.item())
+    worst = max(relerr(p.grad, G[k]) for k, p in model.named_parameters() if not k.endswith("Wk.bias"))
+    assert worst < 2e-4, worst
+    with torch.no_grad():
+        lg = model.eval()(tok.to(DEV), cond.to(DEV))
+    assert relerr(lg, lg_ref) < 1e-4
+    report("config-4 shape (discrete_token, L=2048, f32): logits rel %.2e, worst grad rel %.2e" % (relerr(lg, lg_ref), worst))
+    with pytest.raises((RuntimeError, ValueError)):
+        model(torch.zeros(1, 2049, dtype=torch.long, device=DEV), cond.to(DEV))          # L > max_seq is rejected
+
+
 def test_f2_cfg1_logits_and_trajectory(golden_dir):
     """BASELINE config 1 (none, 2L d256 h4 di1024 L256 B2) through the HIP engine, f32 tier."""
     z = np.load(os.path.join(golden_dir, "f2_cfg1.npz"))
