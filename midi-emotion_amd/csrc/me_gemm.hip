@@ -125,16 +125,24 @@ ME_DEV void slot_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <bool OUT_F32>
-__global__ __launch_bounds__(512) void gemm_nt256_kernel(
+// WR x WC = wave grid over the 256 x 256 tile: 2 x 4 (8 waves, 128 x 64 per wave, two waves per SIMD) or
+// 2 x 2 (4 waves, 128 x 128 per wave, one wave per SIMD with the whole 512-entry register file: 8 instead of
+// 12 fragment reads per 16 MFMAs).
+template <bool OUT_F32, int WR, int WC>
+__global__ __launch_bounds__(WR * WC * 64) void gemm_nt256_kernel(
     const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc,
     const float* __restrict__ bias, const bf16_t* __restrict__ add, int ldadd, const bf16_t* __restrict__ gate,
     int ldgate, int M, int N, int K, int flags) {
     typedef bf16_t T;
+    constexpr int NW = WR * WC;
+    constexpr int TM = 256 / WR, TN = 256 / WC;                           // wave tile
+    constexpr int AI = TM / 32, BJ = TN / 32;                             // macro-atoms per wave tile
+    constexpr int PPH = 32 / NW;                                          // pieces per operand, wave and slab
+    constexpr int PP = 2 * PPH;
     extern __shared__ __attribute__((aligned(16))) char smem[];          // [2 buffers][A 32 KB | B 32 KB] | staging
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wid >> 2, wc = wid & 3;
+    const int wr = wid / WC, wc = wid % WC;
     const int ntn = (N + 255) / 256, ntiles = ntn * ((M + 255) / 256);
     const int nk = K / 64;
     // persistent over tiles: block b handles tiles b, b+grid, ...
@@ -150,32 +158,32 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(
 
     // ---- operand stream.  A piece = 8 rows x 128 B (one 16-byte chunk per lane).  It is fetched into
     // registers a whole slab ahead (R[i] always has a load in flight) and stored to the LINEAR slab image
-    // in LDS once the buffer is free: per wave and slab 8 x (global_load_dwordx4 + ds_write_b128), a few
+    // in LDS once the buffer is free: per wave and slab PP x (global_load_dwordx4 + ds_write_b128), a few
     // issue cycles each -- a direct-to-LDS piece (global_load_lds) costs its wave 60-180 issue cycles and
     // must land within the same slab period (measured: 78-82 us vs 64 us without any feed on the K=2048 shape).
     // Loads and stores are UNCONDITIONAL (past the end the stream stays on the last slab and the store goes to
     // the free buffer): the loop body is straight-line code, so the compiler's vmcnt bookkeeping stays exact
-    // (it waits for the three oldest of eight loads in flight, not for all of them).
+    // (it waits for the oldest of the loads in flight, not for all of them).
     const int lrow = lane >> 3;
     int d_step = 0, d_k = 0, d_tile = 0, d_m0, d_n0;                      // slab being fetched
     tile_origin(0, d_m0, d_n0);
-    chunk16 R[8];
-    // piece i of the wave: rows r0 + 8 (i & 3) ..., chunk ch0 ^ (i & 3)  (blk = 4 wid + (i & 3), so
-    // swz(r) = (lrow ^ blk) & 7 = swz(r0) ^ (i & 3)); 32-bit byte offsets against the scalar bases
-    const int r0 = wid * 32 + lrow;
-    const int ch0 = (lane & 7) ^ ((lrow ^ (wid * 4)) & 7);
+    chunk16 R[PP];
+    // piece i of the wave (i < PPH: A rows, else B rows): 8-row block blk = PPH wid + ii, rows r0 + 8 ii,
+    // chunk ch0 ^ ii (swz(r) = (lrow ^ blk) & 7 = swz(r0) ^ ii); 32-bit byte offsets against the scalar bases
+    const int r0 = wid * PPH * 8 + lrow;
+    const int ch0 = (lane & 7) ^ ((lrow ^ (wid * PPH)) & 7);
     const uint32_t lda2 = (uint32_t)lda * 2u, ldb2 = (uint32_t)ldb * 2u;
     const char* Ab = reinterpret_cast<const char*>(A);
     const char* Bb = reinterpret_cast<const char*>(B);
-    auto ld_piece = [&](int i) __attribute__((always_inline)) {           // i = 0..3: A rows, 4..7: B rows
-        const int ii = i & 3;
+    auto ld_piece = [&](int i) __attribute__((always_inline)) {
+        const int ii = i % PPH;
         const uint32_t col = (uint32_t)((ch0 ^ ii) * 16 + d_k * 2);
-        if (i < 4) R[i] = ld_chunk(Ab + ((uint32_t)min(d_m0 + r0 + 8 * ii, M - 1) * lda2 + col));
+        if (i < PPH) R[i] = ld_chunk(Ab + ((uint32_t)min(d_m0 + r0 + 8 * ii, M - 1) * lda2 + col));
         else R[i] = ld_chunk(Bb + ((uint32_t)min(d_n0 + r0 + 8 * ii, N - 1) * ldb2 + col));
     };
-    char* const st_base = smem + wid * 4096 + lane * 16;
+    char* const st_base = smem + wid * PPH * 1024 + lane * 16;
     auto st_piece = [&](int i, int slab) __attribute__((always_inline)) {
-        st_chunk(st_base + (slab & 1) * 65536 + ((i >> 2) * 32768 + (i & 3) * 1024), R[i]);
+        st_chunk(st_base + (slab & 1) * 65536 + ((i / PPH) * 32768 + (i % PPH) * 1024), R[i]);
     };
     auto ld_advance = [&]() __attribute__((always_inline)) {
         if (d_step + 1 >= nsteps) return;                                  // stay on the last slab
@@ -184,11 +192,11 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(
         if (d_k == K) { d_k = 0; ++d_tile; tile_origin(d_tile, d_m0, d_n0); }
     };
 
-    f32x16_t acc[4][2];
+    f32x16_t acc[AI][BJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < AI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc_zero(acc[i][j]);
+        for (int j = 0; j < BJ; ++j) acc_zero(acc[i][j]);
 
     const int frow = lane & 31, h = lane >> 5;
     const bool relu = flags & ME_EPI_RELU;
@@ -198,21 +206,19 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(
     // 16-byte slots of the 256-byte bank row (conflict free).
     // Address of k-phase kk = (row base | chunk slot) ^ (kk << 5): (2 kk + h) ^ swz = (2 kk) ^ (h ^ swz).
     // Rows r and r + 32 differ in swz by 4 ((r >> 3) & 7 advances by 4), i.e. their slot offsets by XOR 64.
-    Frag<T> fa[4], fb[2];
+    Frag<T> fa[AI], fb[BJ];
     uint32_t pa0, pb0;
-    { const int r = wr * 128 + frow; pa0 = r * 128 + ((h ^ ((r ^ (r >> 3)) & 7)) << 4); }
-    { const int r = wc * 64 + frow; pb0 = 32768 + r * 128 + ((h ^ ((r ^ (r >> 3)) & 7)) << 4); }
+    { const int r = wr * TM + frow; pa0 = r * 128 + ((h ^ ((r ^ (r >> 3)) & 7)) << 4); }
+    { const int r = wc * TN + frow; pb0 = 32768 + r * 128 + ((h ^ ((r ^ (r >> 3)) & 7)) << 4); }
     auto lfrag = [&](uint32_t bufoff, int kk) __attribute__((always_inline)) {
         const char* ae = smem + ((pa0 + bufoff) ^ (uint32_t)(kk << 5));
         const char* ao = smem + ((pa0 + bufoff) ^ (uint32_t)((kk << 5) ^ 64));
         const char* be = smem + ((pb0 + bufoff) ^ (uint32_t)(kk << 5));
         const char* bo = smem + ((pb0 + bufoff) ^ (uint32_t)((kk << 5) ^ 64));
-        frag_load(fa[0], reinterpret_cast<const T*>(ae));
-        frag_load(fa[1], reinterpret_cast<const T*>(ao + 4096));
-        frag_load(fa[2], reinterpret_cast<const T*>(ae + 8192));
-        frag_load(fa[3], reinterpret_cast<const T*>(ao + 12288));
-        frag_load(fb[0], reinterpret_cast<const T*>(be));
-        frag_load(fb[1], reinterpret_cast<const T*>(bo + 4096));
+#pragma unroll
+        for (int i = 0; i < AI; ++i) frag_load(fa[i], reinterpret_cast<const T*>(((i & 1) ? ao : ae) + i * 4096));
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) frag_load(fb[j], reinterpret_cast<const T*>(((j & 1) ? bo : be) + j * 4096));
     };
 
     // ---- tile write-out: stage 32 rows x 128 B at a time through the wave's private 4 KB so that every
@@ -221,9 +227,10 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(
     auto epilogue = [&](int tile_it) __attribute__((always_inline)) {
         int m0, n0;
         tile_origin(tile_it, m0, n0);
-        char* stg = smem + 2 * 65536 + wid * 4096;
+        char* stg = smem + 2 * 65536 + wid * (32768 / NW);
         constexpr int NJ = OUT_F32 ? 1 : 2;                                // accumulator blocks per pass
-        constexpr int NP = 8 / NJ;                                         // passes
+        constexpr int JP = BJ / NJ;                                        // passes per 32-row group
+        constexpr int NP = AI * JP;                                        // passes
         const int lr = lane & 31;
         // one quad (4 consecutive columns of the lane's row) -> staging; 16-byte slot index XOR (row & 7) spreads
         // the 32 rows of a store over the banks
@@ -238,14 +245,14 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(
         };
         // read back: lane -> (row it*8 + lane/8, 16-byte chunk lane%8): full-row coalesced stores
         auto write_out = [&](int ps) __attribute__((always_inline)) {
-            const int i = OUT_F32 ? ps >> 1 : ps, j0 = OUT_F32 ? ps & 1 : 0;
+            const int i = ps / JP, j0 = (ps % JP) * NJ;
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int rr = it * 8 + (lane >> 3), ch = lane & 7;
                 const chunk16 v = ld_chunk(stg + rr * 128 + ((ch ^ (rr & 7)) << 4));
-                const int orow = m0 + wr * 128 + i * 32 + rr;
+                const int orow = m0 + wr * TM + i * 32 + rr;
                 constexpr int EPC = OUT_F32 ? 4 : 8;                       // elements per chunk
-                const int col = n0 + wc * 64 + j0 * 32 + ch * EPC;
+                const int col = n0 + wc * TN + j0 * 32 + ch * EPC;
                 if (orow < M && col < N) {
                     if (col + EPC <= N && vec_c) {
                         if constexpr (OUT_F32) st_chunk(reinterpret_cast<float*>(Cv) + (size_t)orow * ldc + col, v);
@@ -264,14 +271,14 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(
         // vmcnt is in-order: a global load issued between two passes waits for the previous pass's STORES to retire
         // (measured: 20 us of an 80 us launch).  Hence two code paths (registers = max, not sum):
         if (!add && !gate) {
-            // (a) bias (+ReLU): the wave's 32 bias values are fetched once, before any store
-            f32x4_t bv[2][4];
+            // (a) bias (+ReLU): the wave's bias values are fetched once, before any store
+            f32x4_t bv[BJ][4];
             const bool vec_bias = (reinterpret_cast<uintptr_t>(bias) & 15) == 0;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < BJ; ++j)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int col = n0 + wc * 64 + j * 32 + 8 * g + 4 * h;
+                    const int col = n0 + wc * TN + j * 32 + 8 * g + 4 * h;
                     bv[j][g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
                     if (bias) {
                         if (vec_bias && col + 3 < N) bv[j][g] = *reinterpret_cast<const f32x4_t*>(bias + col);
@@ -283,7 +290,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(
                 }
 #pragma unroll
             for (int ps = 0; ps < NP; ++ps) {
-                const int i = OUT_F32 ? ps >> 1 : ps, j0 = OUT_F32 ? ps & 1 : 0;
+                const int i = ps / JP, j0 = (ps % JP) * NJ;
 #pragma unroll
                 for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
@@ -316,13 +323,13 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(
             };
             bf16x4_t av[NJ][4], gv[NJ][4];
             auto fetch_ag = [&](int ps) __attribute__((always_inline)) {
-                const int i = OUT_F32 ? ps >> 1 : ps, j0 = OUT_F32 ? ps & 1 : 0;
-                const int row = m0 + wr * 128 + i * 32 + lr;
+                const int i = ps / JP, j0 = (ps % JP) * NJ;
+                const int row = m0 + wr * TM + i * 32 + lr;
 #pragma unroll
                 for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const int col = n0 + wc * 64 + (j0 + jj) * 32 + 8 * g + 4 * h;
+                        const int col = n0 + wc * TN + (j0 + jj) * 32 + 8 * g + 4 * h;
                         if (add) av[jj][g] = load4(add, ldadd, vec_add, row, col);
                         if (gate) gv[jj][g] = load4(gate, ldgate, vec_gate, row, col);
                     }
@@ -330,12 +337,12 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(
             fetch_ag(0);
 #pragma unroll
             for (int ps = 0; ps < NP; ++ps) {
-                const int i = OUT_F32 ? ps >> 1 : ps, j0 = OUT_F32 ? ps & 1 : 0;
+                const int i = ps / JP, j0 = (ps % JP) * NJ;
 #pragma unroll
                 for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const int col = n0 + wc * 64 + (j0 + jj) * 32 + 8 * g + 4 * h;
+                        const int col = n0 + wc * TN + (j0 + jj) * 32 + 8 * g + 4 * h;
                         float v[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -351,19 +358,19 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < AI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc_zero(acc[i][j]);
+            for (int j = 0; j < BJ; ++j) acc_zero(acc[i][j]);
     };
 
     // ---- prologue: slab 0 into LDS, slab 1 into the registers
 #pragma unroll
-    for (int i = 0; i < 8; ++i) ld_piece(i);
+    for (int i = 0; i < PP; ++i) ld_piece(i);
     ld_advance();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) st_piece(i, 0);
+    for (int i = 0; i < PP; ++i) st_piece(i, 0);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) ld_piece(i);
+    for (int i = 0; i < PP; ++i) ld_piece(i);
     ld_advance();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     slot_barrier();
@@ -371,21 +378,18 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(
     for (int step = 0; step < nsteps; ++step) {
         const uint32_t buf = (uint32_t)(step & 1) * 65536u;
         // slab step+1 (in the registers since the previous iteration) -> the other buffer; refetch slab step+2.
-        // Two pieces per k-phase, scheduled by the compiler between the MFMAs.
+        // PP / 4 pieces per k-phase, scheduled by the compiler between the MFMAs.
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             lfrag(buf, kk);
-            {
-                st_piece(2 * kk, step + 1);
-                st_piece(2 * kk + 1, step + 1);
-                ld_piece(2 * kk);
-                ld_piece(2 * kk + 1);
-            }
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                mma32(acc[g][0], fb[0], fa[g]);
-                mma32(acc[g][1], fb[1], fa[g]);
-            }
+            for (int q = 0; q < PP / 4; ++q) st_piece((PP / 4) * kk + q, step + 1);
+#pragma unroll
+            for (int q = 0; q < PP / 4; ++q) ld_piece((PP / 4) * kk + q);
+#pragma unroll
+            for (int g = 0; g < AI; ++g)
+#pragma unroll
+                for (int j = 0; j < BJ; ++j) mma32(acc[g][j], fb[j], fa[g]);
         }
         ld_advance();
         if ((step + 1) % nk == 0) epilogue(step / nk);
@@ -993,18 +997,20 @@ int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int 
         if (K % 64 == 0 && M >= 256 && N >= 192 && off32 && !g_disable_nt256) {
             static bool attr_set = false;
             if (!attr_set) {
-                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
-                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<true, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
                 attr_set = true;
             }
             unsigned g256 = (unsigned)(((N + 255) / 256) * ((M + 255) / 256));
             if (g256 > 256u) g256 = 256u;            // persistent: one block per CU
+            // 2 x 4 waves.  The 2 x 2 instantiation (128 x 128 per wave, one wave per SIMD, accumulators in the 256
+            // AGPRs) is correct but hipcc spills the 16 prefetch pieces to scratch inside the main loop: 45 TF/s.
             if (flags & ME_EPI_OUT_F32)
-                gemm_nt256_kernel<true><<<g256, 512, NT256_LDS, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias,
-                                                                   (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags);
+                gemm_nt256_kernel<true, 2, 4><<<g256, 512, NT256_LDS, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias,
+                                                                         (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags);
             else
-                gemm_nt256_kernel<false><<<g256, 512, NT256_LDS, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias,
-                                                                    (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags);
+                gemm_nt256_kernel<false, 2, 4><<<g256, 512, NT256_LDS, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias,
+                                                                          (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags);
             return me_launch_status();
         }
     }
