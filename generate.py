@@ -108,6 +108,7 @@ def generate(model, maps, device, out_dir, conditioning, short_filename=False,
     sess = None
     fed = 0                                                      # tokens of gen_song already in the cache
     picked = torch.empty(batch_size, dtype=torch.long, device=device)
+    n_choices_buf = torch.empty(batch_size, dtype=torch.int32, device=device)
 
     with torch.no_grad():
         i = 0
@@ -145,29 +146,39 @@ def generate(model, maps, device, out_dir, conditioning, short_filename=False,
                 repeat_counts += 1                                # one choice (<= 2) every step
                 continue
 
-            output = output.float().clone()
-            output[output != output] = 0                          # generate.py:123
-            output[:, specials.long()] = -float("inf")            # generate.py:131-136
+            # ---- sampling tail (generate.py:122-189) in one launch: NaN->0, specials->-inf, log_softmax, per-row
+            # temperature, top-k, nucleus cut, renormalise, draw, n_choices.  The draw is the inverse CDF at a uniform
+            # from torch's generator (the reference's torch.multinomial stream itself is not reproducible).
             prev = gen_inds[0]
             temp = torch.where(is_timeshift[prev], torch.tensor(temp_note, device=device),
                                torch.tensor(temp_rest, device=device))           # generate.py:138-150
-            output = F.log_softmax(output, dim=-1)
             if penalty_coeff > 0:                                 # generate.py:155-160
                 mult = torch.clamp(torch.log((repeat_counts + 1) / 4) * penalty_coeff, min=0)
                 temp = temp + mult * temp
-            output = output / temp[:, None]
-            k_eff = V if (top_k <= 0 or top_k > V) else top_k
-            output, top_inds = torch.topk(output, k_eff)
-            if 0 < top_p < 1:                                     # generate.py:173-177
-                cum = torch.cumsum(F.softmax(output, dim=-1), dim=-1)
-                remove = cum > top_p
-                remove[:, 0] = False
-                output[remove] = -float("inf")
-            probs = F.softmax(output, dim=-1)
-            sampled = torch.multinomial(probs, 1, replacement=True)
-            gen_inds = top_inds.gather(1, sampled).t()
-            n_choices = (probs > 0).sum(-1)                       # generate.py:186-189
-            repeat_counts = torch.where(n_choices <= 2, repeat_counts + 1, torch.floor(repeat_counts / 2))
+            lg = output.float()
+            lg = lg if lg.is_contiguous() else lg.contiguous()
+            if V <= 1024:
+                uni = torch.rand(batch_size, device=device)
+                ops.sample_topk_topp(lg, V, specials, temp.float().contiguous(), top_k, top_p, uni, picked, n_choices_buf)
+                gen_inds = picked.clone()[None, :]
+                n_choices = n_choices_buf
+            else:                                                 # vocabulary larger than the kernel's sort: torch path
+                out2 = lg.clone()
+                out2[out2 != out2] = 0
+                out2[:, specials.long()] = -float("inf")
+                out2 = F.log_softmax(out2, dim=-1) / temp[:, None]
+                k_eff = V if (top_k <= 0 or top_k > V) else top_k
+                out2, top_inds = torch.topk(out2, k_eff)
+                if 0 < top_p < 1:                                 # generate.py:173-177
+                    cum = torch.cumsum(F.softmax(out2, dim=-1), dim=-1)
+                    remove = cum > top_p
+                    remove[:, 0] = False
+                    out2[remove] = -float("inf")
+                probs = F.softmax(out2, dim=-1)
+                sampled = torch.multinomial(probs, 1, replacement=True)
+                gen_inds = top_inds.gather(1, sampled).t()
+                n_choices = (probs > 0).sum(-1)
+            repeat_counts = torch.where(n_choices <= 2, repeat_counts + 1, torch.floor(repeat_counts / 2))   # :186-189
 
     ids = gen_song.cpu()
     redo_primers, redo_discrete, redo_continuous = [], [], []

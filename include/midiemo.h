@@ -203,6 +203,17 @@ int me_gemv_small(const void* x, int ldx, const void* W, int ldw, const float* b
 int me_greedy_pick(const float* logits, int ld, int V, const int32_t* special, int n_special,
                    int64_t* out_ids, int B, void* stream);
 
+/* Sampling tail of generate() for one step (generate.py:122-189), one launch for the whole batch, V <= 1024:
+ * NaN -> 0, ids in special[] -> -inf, log_softmax, / temp[b], keep the top_k largest (all if top_k <= 0), nucleus
+ * cut at top_p (0 < top_p < 1; the first entry always stays), renormalise, draw by inverse CDF from the caller's
+ * uniform u[b] in [0,1) -> out_ids[b]; n_choices[b] (may be NULL) = number of entries with probability > 0
+ * (drives the repeat-penalty counter, generate.py:186-189).  dbg_p / dbg_i (may be NULL, f32 / int32 [B][1024]):
+ * the final sorted probabilities and their vocabulary ids.  The reference draws with torch.multinomial, whose
+ * random stream cannot be reproduced; the distribution is identical (tested), the draw is inverse-CDF. */
+int me_sample_topk_topp(const float* logits, int ld, int V, const int32_t* special, int n_special,
+                        const float* temp, int top_k, float top_p, const float* u, int64_t* out_ids,
+                        int32_t* n_choices, float* dbg_p, int32_t* dbg_i, int B, void* stream);
+
 /* Device-side decode bookkeeping: history[b][*pos] = tok[b] (int64 [B][ld_hist]); *pos += 1.
  * With me_embed_fwd(pos_dev) and me_rga_decode_step(t_dev) a greedy decode step has no host-side state
  * (the token loop of generate.py:99-189 for top_k = 1) and can be captured once and replayed. */

@@ -618,6 +618,144 @@ __global__ void decode_commit_kernel(const int64_t* __restrict__ tok, int64_t* _
     if (threadIdx.x == 0) *pos = p + 1;
 }
 
+
+// ------------------------------------------------------------------ sampling tail of generate()
+// One block per sequence, V <= 1024.  Mirrors generate.py:122-189 for one step: NaN -> 0, special ids -> -inf,
+// log_softmax, divide by the row's temperature, keep the top_k largest (all if top_k <= 0), nucleus cut (drop
+// sorted entries whose cumulative probability exceeds top_p, never the first), renormalise, draw by inverse CDF
+// from the caller's uniform u[b] in [0,1), report n_choices = #(probability > 0).  Descending order comes from
+// a bitonic sort of (value, index) pairs in LDS (ties: lower index first).  dbg_p / dbg_i (optional, [B][1024])
+// receive the final sorted probabilities and their vocabulary ids so tests can compare with the torch path.
+__global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ logits, int ld, int V,
+                                                     const int32_t* __restrict__ special, int n_special,
+                                                     const float* __restrict__ temp, int top_k, float top_p,
+                                                     const float* __restrict__ u, int64_t* __restrict__ out_ids,
+                                                     int32_t* __restrict__ n_choices, float* __restrict__ dbg_p,
+                                                     int32_t* __restrict__ dbg_i) {
+    __shared__ float key[1024];
+    __shared__ int idx[1024];
+    __shared__ float part[256];
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, b = blockIdx.x;
+    const float* lg = logits + (size_t)b * ld;
+    auto block_sum = [&](float v) -> float {
+        v = wave_sum(v);
+        __syncthreads();
+        if (lane == 0) red[wid] = v;
+        __syncthreads();
+        return red[0] + red[1] + red[2] + red[3];
+    };
+    auto block_max = [&](float v) -> float {
+        v = wave_max(v);
+        __syncthreads();
+        if (lane == 0) red[wid] = v;
+        __syncthreads();
+        return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    };
+    // ---- load, NaN -> 0, specials -> -inf
+    for (int j = tid; j < 1024; j += 256) {
+        float x = -INFINITY;
+        if (j < V) { x = lg[j]; if (x != x) x = 0.f; }
+        key[j] = x;
+        idx[j] = j;
+    }
+    __syncthreads();
+    for (int j = tid; j < n_special; j += 256) { const int sidx = special[j]; if (sidx >= 0 && sidx < V) key[sidx] = -INFINITY; }
+    __syncthreads();
+    // ---- log_softmax, / temperature
+    float mx = -INFINITY;
+    for (int j = tid; j < 1024; j += 256) mx = fmaxf(mx, key[j]);
+    mx = block_max(mx);
+    float se = 0.f;
+    for (int j = tid; j < 1024; j += 256) se += expf(key[j] - mx);
+    se = block_sum(se);
+    const float lse = mx + logf(se), inv_t = 1.f / temp[b];
+    for (int j = tid; j < 1024; j += 256) key[j] = (key[j] - lse) * inv_t;
+    __syncthreads();
+    // ---- bitonic sort, descending by value, ascending index among equals
+    for (int k = 2; k <= 1024; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < 512; t += 256) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p2 = i | j;
+                const bool desc = (i & k) == 0;
+                const float a = key[i], c = key[p2];
+                const int ia = idx[i], ic = idx[p2];
+                const bool a_first = a > c || (a == c && ia < ic);          // a belongs before c in descending order
+                if (a_first != desc) { key[i] = c; key[p2] = a; idx[i] = ic; idx[p2] = ia; }
+            }
+            __syncthreads();
+        }
+    // ---- top-k, softmax over the kept head, nucleus cut
+    const int k_eff = (top_k <= 0 || top_k > V) ? V : top_k;
+    const float y0 = key[0];
+    float e[4];
+    float loc = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = tid * 4 + q;
+        e[q] = i < k_eff ? expf(key[i] - y0) : 0.f;
+        loc += e[q];
+    }
+    const float tot = block_sum(loc);
+    // inclusive prefix of the chunk sums (each thread owns 4 consecutive sorted entries)
+    part[tid] = loc;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const float v = tid >= off ? part[tid - off] : 0.f;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    float run = (part[tid] - loc) / tot;
+    float loc2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = tid * 4 + q;
+        run += e[q] / tot;                                                   // cumulative probability incl. entry i
+        const bool cut = top_p > 0.f && top_p < 1.f && i > 0 && run > top_p;
+        if (cut || i >= k_eff) e[q] = 0.f;
+        loc2 += e[q];
+    }
+    const float tot2 = block_sum(loc2);
+    // ---- renormalised CDF and inverse-CDF draw
+    __syncthreads();
+    part[tid] = loc2;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const float v = tid >= off ? part[tid - off] : 0.f;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    const float target = u[b] * tot2;
+    float c0 = part[tid] - loc2;
+    int cnt = 0, pick = -1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = tid * 4 + q;
+        const float pq = e[q] / tot2;
+        if (pq > 0.f) ++cnt;
+        const float c1 = c0 + e[q];
+        if (pick < 0 && e[q] > 0.f && target < c1 && target >= c0) pick = i;
+        c0 = c1;
+        if (dbg_p) { dbg_p[(size_t)b * 1024 + i] = pq; dbg_i[(size_t)b * 1024 + i] = idx[i]; }
+    }
+    // number of choices and the (unique) picked position; fall back to the last positive entry for u ~ 1
+    __shared__ int s_pick, s_cnt, s_last;
+    if (tid == 0) { s_pick = 1 << 30; s_cnt = 0; s_last = 0; }
+    __syncthreads();
+    if (pick >= 0) atomicMin(&s_pick, pick);
+    atomicAdd(&s_cnt, cnt);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) if (e[q] > 0.f) atomicMax(&s_last, tid * 4 + q);
+    __syncthreads();
+    if (tid == 0) {
+        const int pos = s_pick < (1 << 30) ? s_pick : s_last;
+        out_ids[b] = idx[pos];
+        if (n_choices) n_choices[b] = s_cnt;
+    }
+}
+
 extern "C" {
 
 int me_embed_fwd(void* out, int dtype, const int64_t* tokens, const float* cond, const float* emb, const float* cw0,
@@ -780,6 +918,17 @@ int me_adamw_step(float* p, float* g, float* m, float* v, int64_t n, const float
     if (blocks < 1) blocks = 1;
     adamw_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, sumsq, clip, grad_scale, lr, beta1, beta2, eps,
                                                                    weight_decay, bias_corr1, bias_corr2, zero_grad);
+    return me_launch_status();
+}
+
+int me_sample_topk_topp(const float* logits, int ld, int V, const int32_t* special, int n_special, const float* temp,
+                        int top_k, float top_p, const float* u, int64_t* out_ids, int32_t* n_choices, float* dbg_p,
+                        int32_t* dbg_i, int B, void* stream) {
+    me_clear_error();
+    if (!logits || !temp || !u || !out_ids) return ME_ERR_NULL;
+    if (B <= 0 || V <= 0 || V > 1024 || ld < V || (dbg_p && !dbg_i)) return ME_ERR_BAD_SHAPE;
+    sample_kernel<<<B, 256, 0, (hipStream_t)stream>>>(logits, ld, V, special, special ? n_special : 0, temp, top_k, top_p, u,
+                                                      out_ids, n_choices, dbg_p, dbg_i);
     return me_launch_status();
 }
 

@@ -41,6 +41,7 @@ SIGNATURES = {
     "me_rga_decode_step": [_p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p],
     "me_gemv_small": [_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "me_greedy_pick": [_p, _i, _i, _p, _i, _p, _i, _p],
+    "me_sample_topk_topp": [_p, _i, _i, _p, _i, _p, _i, _f, _p, _p, _p, _p, _p, _i, _p],
     "me_decode_commit": [_p, _p, _i, _p, _i, _p],
 }
 

@@ -160,6 +160,14 @@ def gemv_small(x, W, bias, y, Mr, N, K, flags=0, dtype=None):
                               flags, _code(dtype), _stream()), "me_gemv_small")
 
 
+def sample_topk_topp(logits, V, special, temp, top_k, top_p, u, out_ids, n_choices=None, dbg_p=None, dbg_i=None):
+    B = out_ids.numel()
+    check(lib().me_sample_topk_topp(_ptr(logits), logits.stride(0), V, _ptr(special),
+                                    special.numel() if special is not None else 0, _ptr(temp), int(top_k), float(top_p),
+                                    _ptr(u), _ptr(out_ids), _ptr(n_choices), _ptr(dbg_p), _ptr(dbg_i), B, _stream()),
+          "me_sample_topk_topp")
+
+
 def decode_commit(tok, history, pos, B):
     check(lib().me_decode_commit(_ptr(tok), _ptr(history), history.stride(0), _ptr(pos), B, _stream()), "me_decode_commit")
 
