@@ -408,7 +408,8 @@ __global__ __launch_bounds__(NW * 64) void resid_ln_bwd_kernel(const T* __restri
 }
 
 // ------------------------------------------------------------------ cross-entropy head
-constexpr int CE_Q = 8;    // 16-byte pieces per lane of the register-resident row: V <= 2048
+// CE_Q = 16-byte pieces per lane of the register-resident row (V <= 256 CE_Q): 4 for the 1007 / 1017 vocabularies
+template <int CE_Q>
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, int ld,
                                                      const int64_t* __restrict__ target, float* __restrict__ row_lse,
                                                      float* __restrict__ loss_sum, float* __restrict__ n_valid, int rows,
@@ -425,17 +426,17 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
         f32x4_t nv[CE_Q];
         int64_t nt = 0;
         auto fetch = [&](int64_t r) {
-            if (r >= rows) return;
+            r = r < rows ? r : rows - 1;                  // clamped, not skipped: loads under a branch serialise the loop
             const float* lg = logits + r * ld;
             nt = target[r];
 #pragma unroll
             for (int q = 0; q < CE_Q; ++q) {
                 const int j = (q * 64 + lane) * 4;
-                if (j + 3 < V) nv[q] = *reinterpret_cast<const f32x4_t*>(lg + j);
-                else {
+                // rows are padded to a multiple of 4 floats (ld % 4 == 0), so the 16-byte load is always in bounds for
+                // j < ld; entries at or beyond V are masked after the load
+                nv[q] = j < ld ? *reinterpret_cast<const f32x4_t*>(lg + j) : (f32x4_t){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) nv[q][i] = j + i < V ? lg[j + i] : -INFINITY;
-                }
+                for (int i = 0; i < 4; ++i) nv[q][i] = j + i < V ? nv[q][i] : -INFINITY;
             }
         };
         fetch(row);
@@ -877,7 +878,10 @@ int me_ce_fwd(const float* logits, int ld, const int64_t* target, float* row_lse
     if (!logits || !target || !loss_sum || !n_valid) return ME_ERR_NULL;
     if (rows <= 0) return ME_OK;
     if (V <= 0 || ld < V) return ME_ERR_BAD_SHAPE;
-    ce_fwd_kernel<<<row_grid(rows, 2048), 256, 0, (hipStream_t)stream>>>(logits, ld, target, row_lse, loss_sum, n_valid, rows, V, ignore_index);
+    if (V <= 1024)
+        ce_fwd_kernel<4><<<row_grid(rows, 2048), 256, 0, (hipStream_t)stream>>>(logits, ld, target, row_lse, loss_sum, n_valid, rows, V, ignore_index);
+    else
+        ce_fwd_kernel<8><<<row_grid(rows, 2048), 256, 0, (hipStream_t)stream>>>(logits, ld, target, row_lse, loss_sum, n_valid, rows, V, ignore_index);
     return me_launch_status();
 }
 
