@@ -114,11 +114,16 @@ int me_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                const float* bias, const void* add, int ldadd, const void* gate, int ldgate,
                int M, int N, int K, int flags, int dtype, void* stream);
 
-/* ---- GEMM  dW[N,K] += A[T,N]^T . B[T,K]   (f32 atomic accumulation) ----------
+/* ---- GEMM  dW[N,K] += A[T,N]^T . B[T,K] ---------------------------------------
  * A = dY (T, lda), B = X (T, ldb), dW f32 (lddw).  If dbias != NULL also
- * dbias[N] += column sums of A.  Replaces the weight/bias gradients of nn.Linear. */
+ * dbias[N] += column sums of A.  Replaces the weight/bias gradients of nn.Linear.
+ * The token dimension is split over the CUs; partial tiles are summed in a fixed order (bf16, N/K multiples of
+ * 256) or by f32 atomics (other shapes).  flags: ME_TN_ASYNC_REDUCE lets that final summation run on a private
+ * side stream; dW is then only valid on `stream` after me_gemm_tn_join(stream). */
+#define ME_TN_ASYNC_REDUCE 1
 int me_gemm_tn_acc(const void* A, int lda, const void* B, int ldb, float* dW, int lddw,
-                   float* dbias, int T, int N, int K, int dtype, void* stream);
+                   float* dbias, int T, int N, int K, int flags, int dtype, void* stream);
+int me_gemm_tn_join(void* stream);
 
 /* ---- relative global attention ---------------------------------------------
  * qkv  : T [B, L, 3, H, dh]  (token-major output of the fused QKV projection; the kernels read

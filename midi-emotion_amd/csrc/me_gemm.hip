@@ -1024,9 +1024,28 @@ int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int 
     return me_launch_status();
 }
 
+// Partial-tile workspaces of gemm_tn256_kernel, cached per caller stream (launches on one stream are ordered).
+// With ME_TN_ASYNC_REDUCE two buffers alternate and the reduce runs on a private side stream.
+struct TnCache {
+    hipStream_t st;
+    bool used;
+    float* p[2];
+    size_t bytes[2];
+    int flip;
+    hipStream_t side;
+    hipEvent_t ev_main, ev_red[2];
+    bool pending;
+};
+static TnCache g_tn_cache[8] = {};
+static TnCache* tn_cache_slot(hipStream_t st) {
+    for (int c = 0; c < 8; ++c) if (g_tn_cache[c].used && g_tn_cache[c].st == st) return &g_tn_cache[c];
+    for (int c = 0; c < 8; ++c) if (!g_tn_cache[c].used) { g_tn_cache[c].used = true; g_tn_cache[c].st = st; return &g_tn_cache[c]; }
+    return nullptr;
+}
+
 template <typename T>
 int gemm_tn_launch(const void* A, int lda, const void* B, int ldb, float* dW, int lddw, float* dbias, int Tn, int N,
-                   int K, hipStream_t st) {
+                   int K, int flags, hipStream_t st) {
     constexpr int CH = ET<T>::CH;
     if (Tn <= 0 || N <= 0 || K <= 0) return ME_ERR_BAD_SHAPE;
     if (lda % CH || ldb % CH || K % CH) return ME_ERR_BAD_SHAPE;
@@ -1061,27 +1080,49 @@ int gemm_tn_launch(const void* A, int lda, const void* B, int ldb, float* dW, in
             const int grid256 = ((tn2 * tk2 * ns + 7) / 8) * 8;
             // workspace for the partial tiles (256 KB per block), cached per stream: launches on one stream are
             // ordered, so the buffer is free again when the next weight gradient starts
-            static struct { hipStream_t st; float* p; size_t bytes; } cache[8] = {};
             const size_t need = (size_t)grid256 * 32 * 512 * 16;
             float* ws = nullptr;
             static const bool tn_atomics = getenv("MIDIEMO_TN_ATOMICS") != nullptr;
+            TnCache* c = nullptr;
+            const bool async = (flags & ME_TN_ASYNC_REDUCE) != 0;
+            int buf = 0;
             if (!tn_atomics && ns > 1) {
-                int slot_i = -1;
-                for (int c = 0; c < 8; ++c) if (cache[c].p && cache[c].st == st) slot_i = c;
-                if (slot_i < 0) for (int c = 0; c < 8; ++c) if (!cache[c].p) { slot_i = c; break; }
-                if (slot_i >= 0) {
-                    if (cache[slot_i].bytes < need) {
-                        if (cache[slot_i].p) { (void)hipStreamSynchronize(st); (void)hipFree(cache[slot_i].p); cache[slot_i].p = nullptr; }
-                        const size_t want = need < ((size_t)80 << 20) ? ((size_t)80 << 20) : need;
-                        if (hipMalloc(&cache[slot_i].p, want) == hipSuccess) { cache[slot_i].bytes = want; cache[slot_i].st = st; }
-                        else { cache[slot_i].p = nullptr; cache[slot_i].bytes = 0; (void)hipGetLastError(); }
+                c = tn_cache_slot(st);
+                if (c) {
+                    buf = async ? (c->flip ^= 1) : 0;
+                    if (async && !c->side) {
+                        if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+                            hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming) != hipSuccess ||
+                            hipEventCreateWithFlags(&c->ev_red[0], hipEventDisableTiming) != hipSuccess ||
+                            hipEventCreateWithFlags(&c->ev_red[1], hipEventDisableTiming) != hipSuccess) {
+                            (void)hipGetLastError();
+                            return ME_ERR_LAUNCH;
+                        }
                     }
-                    ws = cache[slot_i].p;
+                    if (c->bytes[buf] < need) {
+                        if (c->p[buf]) { (void)hipDeviceSynchronize(); (void)hipFree(c->p[buf]); c->p[buf] = nullptr; }
+                        const size_t want = need < ((size_t)80 << 20) ? ((size_t)80 << 20) : need;
+                        if (hipMalloc(&c->p[buf], want) == hipSuccess) c->bytes[buf] = want;
+                        else { c->p[buf] = nullptr; c->bytes[buf] = 0; (void)hipGetLastError(); }
+                    }
+                    ws = c->p[buf];
                 }
             }
+            // the reduce that last read this workspace buffer must be done before the partial tiles are overwritten
+            if (ws && async) (void)hipStreamWaitEvent(st, c->ev_red[buf], 0);
             gemm_tn256_kernel<<<grid256, 512, TN256_LDS, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, dW, lddw, dbias, Tn, N,
                                                              K, tp, tn2, tk2, ns, ws);
-            if (ws) tn256_reduce_kernel<<<dim3(tn2 * tk2, 32), 512, 0, st>>>(ws, dW, lddw, tn2, tk2, ns, N);
+            if (ws && async) {
+                // the reduce has no consumer until the caller joins (me_gemm_tn_join): it runs on a side stream under
+                // whatever the caller enqueues next
+                (void)hipEventRecord(c->ev_main, st);
+                (void)hipStreamWaitEvent(c->side, c->ev_main, 0);
+                tn256_reduce_kernel<<<dim3(tn2 * tk2, 32), 512, 0, c->side>>>(ws, dW, lddw, tn2, tk2, ns, N);
+                (void)hipEventRecord(c->ev_red[buf], c->side);
+                c->pending = true;
+            } else if (ws) {
+                tn256_reduce_kernel<<<dim3(tn2 * tk2, 32), 512, 0, st>>>(ws, dW, lddw, tn2, tk2, ns, N);
+            }
             return me_launch_status();
         }
         const int npairs8 = ((tn * nsplit + 7) / 8) * 8;
@@ -1128,13 +1169,27 @@ int me_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
 }
 
 int me_gemm_tn_acc(const void* A, int lda, const void* B, int ldb, float* dW, int lddw, float* dbias, int T, int N,
-                   int K, int dtype, void* stream) {
+                   int K, int flags, int dtype, void* stream) {
     me_clear_error();
     if (!A || !B || !dW) return ME_ERR_NULL;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == ME_F32) return gemm_tn_launch<float>(A, lda, B, ldb, dW, lddw, dbias, T, N, K, st);
-    if (dtype == ME_BF16) return gemm_tn_launch<bf16_t>(A, lda, B, ldb, dW, lddw, dbias, T, N, K, st);
+    if (dtype == ME_F32) return gemm_tn_launch<float>(A, lda, B, ldb, dW, lddw, dbias, T, N, K, flags, st);
+    if (dtype == ME_BF16) return gemm_tn_launch<bf16_t>(A, lda, B, ldb, dW, lddw, dbias, T, N, K, flags, st);
     return ME_ERR_BAD_DTYPE;
+}
+
+int me_gemm_tn_join(void* stream) {
+    me_clear_error();
+    hipStream_t st = (hipStream_t)stream;
+    for (int c = 0; c < 8; ++c) {
+        TnCache& t = g_tn_cache[c];
+        if (t.used && t.st == st && t.pending) {
+            (void)hipStreamWaitEvent(st, t.ev_red[0], 0);
+            (void)hipStreamWaitEvent(st, t.ev_red[1], 0);
+            t.pending = false;
+        }
+    }
+    return me_launch_status();
 }
 
 int me_cast_transpose(const float* src, int rows, int cols, void* dst, int ld_dst, void* dstT, int ld_dstT,

@@ -29,7 +29,8 @@ SIGNATURES = {
     "me_embed_bwd": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _p],
     "me_key_pad_mask": [_p, _p, _i, _i, _i, _i, _p],
     "me_gemm_nt": [_p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
-    "me_gemm_tn_acc": [_p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p],
+    "me_gemm_tn_acc": [_p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p],
+    "me_gemm_tn_join": [_p],
     "me_rga_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "me_rga_bwd": [_p] * 12 + [_i, _i, _i, _i, _i, _i, _i, _p],
     "me_resid_ln_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _f, _u64, _u32, _i, _p],

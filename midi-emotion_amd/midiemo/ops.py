@@ -93,14 +93,23 @@ def gemm_nt(A, B, C, bias=None, add=None, gate=None, M=None, N=None, K=None, fla
                            M, N, K, flags, _code(dtype), _stream()), "me_gemm_nt")
 
 
-def gemm_tn_acc(A, B, dW, dbias=None, T=None, N=None, K=None, dtype=None):
-    """dW[N,K] += A[T,N]^T . B[T,K] ; dbias[N] += colsum(A)."""
+ME_TN_ASYNC_REDUCE = 1
+
+
+def gemm_tn_join():
+    """Make the current stream wait for every asynchronous weight-gradient summation issued on its behalf."""
+    check(lib().me_gemm_tn_join(_stream()), "me_gemm_tn_join")
+
+
+def gemm_tn_acc(A, B, dW, dbias=None, T=None, N=None, K=None, dtype=None, flags=0):
+    """dW[N,K] += A[T,N]^T . B[T,K] ; dbias[N] += colsum(A).  flags=ME_TN_ASYNC_REDUCE: dW is only valid after
+    gemm_tn_join() on the same stream."""
     dtype = dtype or A.dtype
     T = A.shape[0] if T is None else T
     N = A.shape[1] if N is None else N
     K = B.shape[1] if K is None else K
     check(lib().me_gemm_tn_acc(_ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(dW), dW.stride(0), _ptr(dbias),
-                               T, N, K, _code(dtype), _stream()), "me_gemm_tn_acc")
+                               T, N, K, int(flags), _code(dtype), _stream()), "me_gemm_tn_acc")
 
 
 def rga_fwd(qkv, E, key_pad, out, lse, B, L, H, dh, M):
