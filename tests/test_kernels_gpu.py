@@ -134,6 +134,22 @@ def test_gemm_tn_acc(ops, dtype, T, N, K):
     assert relerr(db, refb) < 2e-5, relerr(db, refb)
 
 
+def test_gemm_tn_acc_async_reduce_then_join(ops):
+    """ME_TN_ASYNC_REDUCE: the partial-tile summation runs on the library's side stream; after me_gemm_tn_join the
+    result on the caller's stream equals the synchronous one (two back-to-back launches alternate workspaces)."""
+    T, N, K = 8192, 512, 256
+    A = rnd(T, N, seed=21).to(torch.bfloat16).to(DEV)
+    B = rnd(T, K, seed=22).to(torch.bfloat16).to(DEV)
+    want = torch.zeros(N, K, device=DEV)
+    ops.gemm_tn_acc(A, B, want, None, T=T, N=N, K=K)
+    got = [torch.zeros(N, K, device=DEV) for _ in range(3)]
+    for g in got:
+        ops.gemm_tn_acc(A, B, g, None, T=T, N=N, K=K, flags=ops.ME_TN_ASYNC_REDUCE)
+    ops.gemm_tn_join()
+    for g in got:
+        assert torch.equal(g, want)                      # fixed summation order: bit-identical
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_cast_transpose(ops, dtype):
     src = rnd(70, 1007, seed=13).float().to(DEV)
