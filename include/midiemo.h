@@ -133,7 +133,7 @@ int me_gemm_tn_join(void* stream);
  * out  : T [B, L, H, dh]   lse : f32 [B, H, L]
  *   logits[l,j] = (q_l.k_j + q_l.E[M-1-(l-j)]) / sqrt(dh),  j<=l and key j not pad
  * Replaces music_multi.py:196-235 (head split/permute, einsum QE, _qe_masking, _skewing, QK^T,
- * mask, softmax, PV, head merge).  dh in {32, 64}; M % 32 == 0; L <= M. */
+ * mask, softmax, PV, head merge).  dh in {32, 48, 64}; M % 32 == 0; L <= M. */
 int me_rga_fwd(const void* qkv, const void* E, const uint8_t* key_pad, void* out, float* lse,
                int B, int L, int H, int dh, int M, int dtype, void* stream);
 

@@ -45,11 +45,12 @@ constexpr int LDG2 = 68;  // forward G ring row: 64-column ring + 4
 template <typename T, int DH> struct ACfg {
     static constexpr int CH = ET<T>::CH;
     static constexpr int KA = DH / 16;       // contraction atoms over the head dim
-    static constexpr int DB = DH / 32;       // 32-wide blocks of the head dim
+    static constexpr int DB = (DH + 31) / 32;   // 32-wide blocks of the head dim; DH = 48: the upper half of block 1 is padding
+                                                // (guarded global loads / stores; MFMA garbage there only reaches discarded outputs)
     static constexpr int LDN = DH + CH;      // natural [row][DH] tile row (elements), read with 16-byte fragment loads
     // tile only read through transpose reads: a row stride of 192 B (mod 256) puts the 4 x 2 row segments of a
     // 32-lane half on disjoint banks
-    static constexpr int LDV = sizeof(T) == 2 ? (DH == 64 ? 96 : 32) : DH + 4;
+    static constexpr int LDV = sizeof(T) == 2 ? (DH > 32 ? 96 : 32) : DH + 4;
 };
 
 // ---- generic ROWS x COLS chunk tiles (16-byte chunks, lanes walk a row) ----------------
@@ -268,8 +269,9 @@ __global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ q
     for (int i = 0; i < C::DB; ++i)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq)
-            st4<T>(op + i * 32 + 8 * gq + 4 * h, o[i][4 * gq] * inv, o[i][4 * gq + 1] * inv, o[i][4 * gq + 2] * inv,
-                   o[i][4 * gq + 3] * inv);
+            if (i * 32 + 8 * gq + 4 * h < DH)
+                st4<T>(op + i * 32 + 8 * gq + 4 * h, o[i][4 * gq] * inv, o[i][4 * gq + 1] * inv, o[i][4 * gq + 2] * inv,
+                       o[i][4 * gq + 3] * inv);
 }
 
 // =====================================================================================
@@ -356,7 +358,8 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const T* ep = ET_ + (size_t)(i * 32 + a) * M + eb * 32 + 16 * t + 4 * h;
-                frag_load_4x2(f[i][t], ep, ep + 8);
+                if (i * 32 + a < DH) frag_load_4x2(f[i][t], ep, ep + 8);
+                else frag_zero(f[i][t]);
             }
     };
 
@@ -469,7 +472,8 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
     for (int i = 0; i < C::DB; ++i)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq)
-            st4<T>(dqp + i * 32 + 8 * gq + 4 * h, dq[i][4 * gq], dq[i][4 * gq + 1], dq[i][4 * gq + 2], dq[i][4 * gq + 3]);
+            if (i * 32 + 8 * gq + 4 * h < DH)
+                st4<T>(dqp + i * 32 + 8 * gq + 4 * h, dq[i][4 * gq], dq[i][4 * gq + 1], dq[i][4 * gq + 2], dq[i][4 * gq + 3]);
 }
 
 // =====================================================================================
@@ -483,7 +487,7 @@ template <typename T, int DH>
 __global__ __launch_bounds__(256) void rga_bwd_kv_kernel(const T* __restrict__ PT, const T* __restrict__ dST,
                                                          const T* __restrict__ qkv, const T* __restrict__ dout,
                                                          T* __restrict__ dqkv, int B, int L, int Lp, int H) {
-    constexpr int CH = ET<T>::CH, LDP = 32 + CH, DB = DH / 32, LDV = ACfg<T, DH>::LDV;
+    constexpr int CH = ET<T>::CH, LDP = 32 + CH, DB = ACfg<T, DH>::DB, LDV = ACfg<T, DH>::LDV;
     __shared__ __attribute__((aligned(16))) T Pt[2][128 * LDP];
     __shared__ __attribute__((aligned(16))) T St[2][128 * LDP];
     __shared__ __attribute__((aligned(16))) T Os[2][32 * LDV];         // natural dO / Q slabs [32 q][DH], transpose-read
@@ -556,7 +560,7 @@ __global__ __launch_bounds__(256) void rga_bwd_kv_kernel(const T* __restrict__ P
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = k0 + c_row(r, lane);
-            if (key < L) {
+            if (key < L && i * 32 + a < DH) {
                 T* base = dqkv + ((size_t)b * L + key) * ldq + head * DH + i * 32 + a;
                 base[dm] = ET<T>::from_f(dk[i][r]);
                 base[2 * dm] = ET<T>::from_f(dv[i][r]);
@@ -579,7 +583,7 @@ __global__ __launch_bounds__(256) void rga_bwd_kv_kernel(const T* __restrict__ P
 template <typename T, int DH>
 __global__ __launch_bounds__(256) void rga_bwd_e_kernel(const T* __restrict__ dST, const T* __restrict__ qkv,
                                                         float* __restrict__ dE, int B, int L, int Lp, int H, int M) {
-    constexpr int CH = ET<T>::CH, LDP = 32 + CH, DB = DH / 32, LDV = ACfg<T, DH>::LDV;
+    constexpr int CH = ET<T>::CH, LDP = 32 + CH, DB = ACfg<T, DH>::DB, LDV = ACfg<T, DH>::LDV;
     __shared__ __attribute__((aligned(16))) T Gt[2][128 * LDP];
     __shared__ __attribute__((aligned(16))) T Qs[2][32 * LDV];         // natural Q slab [32 q][DH], transpose-read
 
@@ -683,7 +687,7 @@ __global__ __launch_bounds__(256) void rga_bwd_e_kernel(const T* __restrict__ dS
         for (int r = 0; r < 16; ++r) {
             const int e = cbw * 32 + c_row(r, lane) + (M - Lp);
             const float v = acc[i][r];
-            if (e >= 0 && e < M && v != 0.f) atomicAdd(&dE[(size_t)e * DH + i * 32 + a], v);
+            if (e >= 0 && e < M && v != 0.f && i * 32 + a < DH) atomicAdd(&dE[(size_t)e * DH + i * 32 + a], v);
         }
 }
 
@@ -742,7 +746,7 @@ __global__ __launch_bounds__(256) void rga_decode_kernel(const T* __restrict__ q
     constexpr int NG = 256 / DH;
     const int d = tid % DH, grp = tid / DH;
     float acc = 0.f;
-    for (int j = grp; j <= t; j += NG) {
+    for (int j = grp; grp < NG && j <= t; j += NG) {          // 256 % DH threads (DH = 48: 16) sit this part out
         const T* vr = (j == t) ? (qn + 2 * dm) : (vc + (size_t)j * DH);
         acc += ps[j] * ET<T>::to_f(vr[d]);
     }
@@ -805,9 +809,11 @@ int dec_launch(const void* qkv_new, void* kc, void* vc, const void* E, const uin
 #define ME_ATTN_DISPATCH(CALL)                                                   \
     if (dtype == ME_F32) {                                                       \
         if (dh == 64) { typedef float T; constexpr int DH = 64; return CALL; }   \
+        if (dh == 48) { typedef float T; constexpr int DH = 48; return CALL; }   \
         if (dh == 32) { typedef float T; constexpr int DH = 32; return CALL; }   \
     } else if (dtype == ME_BF16) {                                               \
         if (dh == 64) { typedef bf16_t T; constexpr int DH = 64; return CALL; }  \
+        if (dh == 48) { typedef bf16_t T; constexpr int DH = 48; return CALL; }  \
         if (dh == 32) { typedef bf16_t T; constexpr int DH = 32; return CALL; }  \
     } else return ME_ERR_BAD_DTYPE;                                              \
     return ME_ERR_BAD_SHAPE;

@@ -112,8 +112,8 @@ class MusicTransformerHIP(nn.Module):
         self.d_condition = d_condition
         self.dropout_p = float(dropout)
         self.dh = embedding_dim // num_head
-        if embedding_dim % num_head or self.dh not in (32, 64):
-            raise ValueError("head dim %d unsupported by the HIP attention kernels (32 or 64)" % self.dh)
+        if embedding_dim % num_head or self.dh not in (32, 48, 64):
+            raise ValueError("head dim %d unsupported by the HIP attention kernels (32, 48 or 64)" % self.dh)
         if max_seq % 32:
             raise ValueError("max_seq must be a multiple of 32")
         self.compute_dtype = _DTYPES[compute_dtype] if isinstance(compute_dtype, str) else compute_dtype

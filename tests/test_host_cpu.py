@@ -84,9 +84,12 @@ def test_reference_init_distributions():
 
 def test_unsupported_configs_raise():
     from midiemo.models.build_model import build_model
+    m, _ = build_model(dict(vocab_size=1007, n_layer=1, n_head=16, d_model=768, d_inner=3072, dropout=0.1,
+                            d_condition=-1, conditioning="none"))       # dh = 48 (published checkpoints): supported
+    assert m.dh == 48
     with pytest.raises(ValueError, match="head dim"):
-        build_model(dict(vocab_size=1007, n_layer=1, n_head=16, d_model=768, d_inner=3072, dropout=0.1,
-                         d_condition=-1, conditioning="none"))          # dh = 48: documented gap
+        build_model(dict(vocab_size=1007, n_layer=1, n_head=16, d_model=640, d_inner=1024, dropout=0.1,
+                         d_condition=-1, conditioning="none"))          # dh = 40: no kernel instantiation
     with pytest.raises(NotImplementedError):
         build_model(dict(vocab_size=1007, n_layer=1, n_head=8, d_model=512, d_inner=2048, dropout=0.1,
                          d_condition=-1, conditioning="none", regression=True))

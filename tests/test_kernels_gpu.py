@@ -402,7 +402,8 @@ def test_rga_golden_f5(ops, dtype, golden_dir):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,H,L,dh,M", [(2, 2, 1, 32, 64), (1, 3, 7, 64, 64), (2, 2, 33, 32, 64), (2, 4, 64, 64, 64),
-                                         (1, 2, 130, 64, 256), (2, 2, 256, 64, 2048), (1, 1, 300, 32, 512)])
+                                         (1, 2, 130, 64, 256), (2, 2, 256, 64, 2048), (1, 1, 300, 32, 512),
+                                         (2, 3, 70, 48, 128), (1, 2, 260, 48, 2048), (2, 2, 1, 48, 64)])   # dh 48: published checkpoints
 def test_rga_fwd_bwd_shapes(ops, dtype, B, H, L, dh, M):
     q, k, v, E, dO, pad = attn_case(B, H, L, dh, M, seed=100 + L)
     got = run_attn(ops, dtype, q, k, v, E, dO, pad)
@@ -442,8 +443,9 @@ def test_rga_prefix_invariance(ops):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_rga_decode_step_matches_full(ops, dtype):
-    B, H, L, dh, M = 3, 2, 45, 64, 2048
+@pytest.mark.parametrize("dh", [64, 48])
+def test_rga_decode_step_matches_full(ops, dtype, dh):
+    B, H, L, M = 3, 2, 45, 2048
     q, k, v, E, dO, pad = attn_case(B, H, L, dh, M, seed=77, pad_rows=False)
     ref = ref_attn(q, k, v, E, dO, None, dtype)["O"]            # [B,H,L,dh]
     Ed = E.to(dtype).to(DEV).contiguous()

@@ -200,6 +200,34 @@ def test_max_seq_discrete_token_config4_shape():
         model(torch.zeros(1, 2049, dtype=torch.long, device=DEV), cond.to(DEV))          # L > max_seq is rejected
 
 
+@pytest.mark.parametrize("cd", ["fp32", "bf16"])
+def test_head_dim_48_like_published_checkpoints(cd):
+    """The reference's published models are d768 / 16 heads (head dim 48).  Same geometry, small: d = 96, 2 heads;
+    logits, loss, every gradient and a KV-cached decode step against the oracle."""
+    cfg = O.Cfg(1007, 2, 2, 96, 192, d_condition=32, conditioning="continuous_concat")
+    P = O.seeded_params(cfg, 8)
+    model = make_model(cfg, P, cd).train()
+    tok, cond, tgt = O.synthetic_batch(cfg, 2, 75, seed=4)
+    tok[1, -6:] = 0
+    tgt[1, -7:] = 0
+    loss_ref, lg_ref, G = O.loss_and_grads(cfg, {k: v.double() for k, v in P.items()}, tok, cond.double(), tgt)
+    loss = model.loss_and_backward(tok.to(DEV), cond.to(DEV), tgt.to(DEV))
+    model.link_grads()
+    assert abs(loss.item() - loss_ref.item()) < (1e-4 if cd == "fp32" else 5e-2)
+    worst = max(relerr(p.grad, G[k]) for k, p in model.named_parameters() if not k.endswith("Wk.bias"))
+    assert worst < (2e-4 if cd == "fp32" else 8e-2), worst
+    model.eval()
+    with torch.no_grad():
+        lg = model(tok.to(DEV), cond.to(DEV))
+        assert relerr(lg, lg_ref) < (1e-4 if cd == "fp32" else 1e-2)
+        from midiemo.decode import DecodeSession
+        sess = DecodeSession(model, 2)
+        for t in range(12):
+            step_lg = sess.step(tok[:, t].to(DEV), cond.to(DEV))
+        assert relerr(step_lg, lg_ref[:, 11]) < (1e-4 if cd == "fp32" else 1e-2)
+    report("head dim 48 (%s): logits rel %.2e, worst grad rel %.2e" % (cd, relerr(lg, lg_ref), worst))
+
+
 def test_f2_cfg1_logits_and_trajectory(golden_dir):
     """BASELINE config 1 (none, 2L d256 h4 di1024 L256 B2) through the HIP engine, f32 tier."""
     z = np.load(os.path.join(golden_dir, "f2_cfg1.npz"))
