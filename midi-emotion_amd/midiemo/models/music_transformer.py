@@ -539,7 +539,8 @@ class MusicTransformerHIP(nn.Module):
         params = [p for g in self._param_order() for _, p in g]
         return _EngineFn.apply(self, tokens, cond, (B, Ltok, Lm), p_drop, self._next_seed(), *params)
 
-    def loss_and_backward(self, x, condition, target, grad_scale=1.0, bucket_hook=None, backward=True):
+    def loss_and_backward(self, x, condition, target, grad_scale=1.0, bucket_hook=None, backward=True,
+                          return_logits=False):
         """Fused train-step front half: forward, CrossEntropyLoss(ignore_index=pad) (mean over
         non-pad targets), backward into `flat_grads` (+=).  Returns the loss as a device scalar
         (no host sync).  Replaces Runner.forward_pass + loss.backward() (train.py:276-292,317)."""
@@ -557,6 +558,8 @@ class MusicTransformerHIP(nn.Module):
         if backward:
             ops.ce_bwd(ws.logits, target, ws.row_lse, ws.dlogits, ws.acc[1:2], grad_scale, T, V, self.pad_token)
             self._backward_impl(ws, tokens, cond, B, Ltok, Lm, p_drop, seed, self._gflat, bucket_hook)
+        if return_logits:                                   # f32 [B, Lm, V] view of the workspace (valid until the next call)
+            return loss, ws.logits[:, :V].view(B, Lm, V)
         return loss
 
 

@@ -20,10 +20,18 @@ def test_train_cli_config1_and_checkpoints(tmp_path, capsys):
     out = capsys.readouterr().out
     losses = [float(l.split("| loss")[1].split("|")[0]) for l in out.splitlines() if "| loss" in l]
     assert len(losses) == 3 and losses[-1] < losses[0] - 0.05, losses
-    assert "valid loss" in out
+    assert "valid loss" in out and "top-1" in out and "top-5" in out
+    ev = [l for l in out.splitlines() if "top-1" in l][0]
+    top1, top5 = float(ev.split("top-1")[1].split("|")[0]), float(ev.split("top-5")[1])
+    assert 0.0 <= top1 <= top5 <= 1.0
     run = [d for d in os.listdir(tmp_path)][0]
     files = set(os.listdir(tmp_path / run))
-    assert {"model.pt", "optimizer.pt", "stats.pt", "model_config.pt", "mappings.pt"} <= files
+    assert {"model.pt", "optimizer.pt", "stats.pt", "model_config.pt", "mappings.pt", "performance.csv"} <= files
+    import csv
+    rows = list(csv.DictReader(open(tmp_path / run / "performance.csv")))
+    assert list(rows[0].keys()) == ["epoch", "step", "hour", "lr", "trn_loss", "val_loss", "val_l1_v", "val_l1_a"]
+    assert [int(r["step"]) for r in rows] == [10, 20, 30, 30]           # three log rows + one eval row (train.py:389,426)
+    assert rows[-1]["trn_loss"] == "nan" and float(rows[-1]["val_loss"]) > 0
     sd = torch.load(tmp_path / run / "model.pt")
     assert "enc_layers.1.rga.E" in sd and sd["fc.weight"].shape == (1007, 256)
     assert torch.load(tmp_path / run / "stats.pt")["step"] == 30

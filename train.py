@@ -169,18 +169,43 @@ def main(argv=None):
     tok_per_micro = world * B * L
 
     def evaluate():
+        """Mean loss and top-1 / top-5 token accuracy over non-PAD targets (train.py:222-275, utils.accuracy)."""
         model.eval()
-        tot = torch.zeros((), device=device)
+        acc = torch.zeros(4, device=device, dtype=torch.float64)          # loss-sum, top1, top5, #targets
         n = min(args.max_eval_step, 8)
         with torch.no_grad():
             for i in range(n):
                 x, c, y = synthetic_batch(args, V, B, L, 10_000_019 + i * 31 + rank, device)
-                tot += model.loss_and_backward(x, c, y, backward=False)
+                loss, logits = model.loss_and_backward(x, c, y, backward=False, return_logits=True)
+                valid = y.reshape(-1) != pad_idx
+                top5 = logits.reshape(-1, logits.size(-1)).topk(5, dim=-1).indices
+                hit = top5 == y.reshape(-1, 1)
+                nv = valid.sum()
+                acc[0] += loss.double() * nv
+                acc[1] += (hit[:, 0] & valid).sum()
+                acc[2] += (hit.any(-1) & valid).sum()
+                acc[3] += nv
         model.train()
         if world > 1:
-            dist.all_reduce(tot)
-            tot /= world
-        return float(tot.item()) / n
+            dist.all_reduce(acc)
+        a = acc.tolist()
+        den = max(a[3], 1.0)
+        return a[0] / den, {1: a[1] / den, 5: a[2] / den}
+
+    # performance.csv: same columns as the reference (train.py:116-118), one row per log / eval event
+    import csv
+    perf_cols = ["epoch", "step", "hour", "lr", "trn_loss", "val_loss", "val_l1_v", "val_l1_a"]
+    perf_path = os.path.join(work_dir, "performance.csv")
+
+    def perf_row(**kw):
+        if rank != 0 or args.debug:
+            return
+        new_file = not os.path.exists(perf_path)
+        with open(perf_path, "a", newline="") as fh:
+            w = csv.DictWriter(fh, fieldnames=perf_cols)
+            if new_file:
+                w.writeheader()
+            w.writerow({k: kw.get(k, float("nan")) for k in perf_cols})
 
     try:
         while step < args.max_step:
@@ -206,6 +231,8 @@ def main(argv=None):
                     print("| step {:>8d} | lr {:.3e} | ms/batch {:7.2f} | tok/s {:10.0f} | loss {:7.4f} | ppl {:9.3f}".format(
                         step, opt.param_groups[0]["lr"], 1000 * el / max(n_acc, 1), n_acc * tok_per_micro / el, cur,
                         math.exp(min(cur, 20))))
+                    perf_row(epoch=stats["epoch"], step=step, hour=stats["hour"] + el / 3600, lr=opt.param_groups[0]["lr"],
+                             trn_loss=cur)
                     if not args.debug:
                         stats.update(step=step, hour=stats["hour"] + el / 3600)
                         torch.save(model.state_dict(), os.path.join(work_dir, "model.pt"))
@@ -215,9 +242,11 @@ def main(argv=None):
                 n_acc = 0
                 t0 = time.time()
             if step % args.eval_step == 0:
-                v = evaluate()
+                v, accs = evaluate()
                 if rank == 0:
-                    print("| eval at step {:>8d} | valid loss {:7.4f} | ppl {:9.3f}".format(step, v, math.exp(min(v, 20))))
+                    print("| eval at step {:>8d} | valid loss {:7.4f} | ppl {:9.3f} | top-1 {:.4f} | top-5 {:.4f}".format(
+                        step, v, math.exp(min(v, 20)), accs[1], accs[5]))
+                perf_row(epoch=stats["epoch"], step=step, hour=stats["hour"], lr=opt.param_groups[0]["lr"], val_loss=v)
     except KeyboardInterrupt:
         print("Exiting from training early")
     if world > 1:
