@@ -12,9 +12,9 @@ or a per-step varying condition is given, the loop falls back to the reference's
 full recompute, so token streams are identical to the reference in every case.
 `--topk 1` is the greedy mode used for bit-exact parity.
 
-Outputs: inds_*.pt (token ids) and txt_*.txt (symbols) per sample.  MIDI files
-need the optional `pretty_midi` writer of the reference's data package, which is
-outside the accelerated path.
+Outputs per sample: inds_*.pt (token ids), txt_*.txt (symbols) and *.mid (Standard MIDI
+File written by midiemo/midi_writer.py: the reference's tuples_to_mid semantics without the
+pretty_midi dependency).
 """
 import datetime
 import os
@@ -34,6 +34,7 @@ import torch.nn.functional as F  # noqa: E402
 from midiemo import ops  # noqa: E402
 from midiemo.decode import DecodeSession  # noqa: E402
 from midiemo.models.build_model import build_model  # noqa: E402
+from midiemo.midi_writer import write_midi  # noqa: E402
 from midiemo.vocab import (emotion_symbols, get_maps, get_n_instruments, ind_list_to_str,  # noqa: E402
                            special_token_ids, timeshift_token_mask)
 
@@ -197,6 +198,7 @@ def generate(model, maps, device, out_dir, conditioning, short_filename=False,
                 torch.save(ids[:, s].clone(), os.path.join(out_dir, "inds_" + name + ".pt"))
                 with open(os.path.join(out_dir, "txt_" + name + ".txt"), "w") as fh:
                     fh.write("\n".join(symbols))
+                write_midi(os.path.join(out_dir, name + ".mid"), symbols)      # generate.py:216-232, no pretty_midi needed
                 if verbose:
                     print(f"Saved to {os.path.join(out_dir, 'inds_' + name + '.pt')}")
         else:

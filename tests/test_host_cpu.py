@@ -136,3 +136,33 @@ def test_gradient_allreduce_two_gloo_processes(tmp_path):
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+def test_midi_writer_round_trip_and_reference_semantics():
+    """midiemo.midi_writer == data/data_processing_reverse.py:12-53 (tuples_to_mid) written out as a Standard MIDI
+    File with pretty_midi's default timing (120 bpm, 220 ticks per quarter: 1 s = 440 ticks); read back and compared."""
+    from midiemo.midi_writer import PROGRAMS, VELOCITIES, read_midi, symbols_to_midi_bytes, symbols_to_notes
+    from midiemo.vocab import get_maps, ind_list_to_str
+    maps = get_maps()
+    t2i = maps["tuple2idx"]
+    ev = maps["event2idx"]
+    ids = [t2i["<START>"], t2i[(ev["ON_PIANO"], 60)], t2i[(ev["TIMESHIFT"], 400)], t2i[(ev["ON_DRUMS"], 36)],
+           t2i[(ev["TIMESHIFT"], 104)], t2i[(ev["OFF_PIANO"], 60)], t2i[(ev["OFF_GUITAR"], 50)],      # OFF without ON: ignored
+           t2i[(ev["ON_STRINGS"], 72)], t2i[(ev["TIMESHIFT"], 1000)], t2i[(ev["OFF_DRUMS"], 36)],
+           t2i[(ev["OFF_STRINGS"], 72)], t2i[(ev["ON_BASS"], 40)], t2i["<PAD>"]]                       # dangling ON: no note
+    symbols = ind_list_to_str(ids, maps)
+    notes = symbols_to_notes(symbols)
+    assert notes["PIANO"] == [(0.0, 0.504, 60)] and notes["GUITAR"] == [] and notes["BASS"] == []
+    assert notes["DRUMS"] == [(0.4, 1.504, 36)] and notes["STRINGS"] == [(0.504, 1.504, 72)]
+    data = symbols_to_midi_bytes(symbols)
+    res, tempo, tracks = read_midi(data)
+    assert (res, tempo) == (220, 500000) and set(tracks) == {k.lower() for k in PROGRAMS}
+    assert tracks["drums"]["channel"] == 9 and tracks["piano"]["channel"] == 0
+    assert len({t["channel"] for t in tracks.values()}) == 5
+    for name, (program, _) in PROGRAMS.items():
+        assert tracks[name.lower()]["program"] == program
+    tk = lambda s: int(round(s * 440))
+    assert tracks["piano"]["notes"] == [(0, tk(0.504), 60, VELOCITIES["PIANO"])]
+    assert tracks["drums"]["notes"] == [(tk(0.4), tk(1.504), 36, VELOCITIES["DRUMS"])]
+    assert tracks["strings"]["notes"] == [(tk(0.504), tk(1.504), 72, VELOCITIES["STRINGS"])]
+    assert tracks["guitar"]["notes"] == [] and tracks["bass"]["notes"] == []
