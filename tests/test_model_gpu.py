@@ -228,6 +228,25 @@ def test_head_dim_48_like_published_checkpoints(cd):
     report("head dim 48 (%s): logits rel %.2e, worst grad rel %.2e" % (cd, relerr(lg, lg_ref), worst))
 
 
+def test_published_geometry_one_layer_f32():
+    """One layer of the reference's default / published geometry (d768, 16 heads of 48, d_inner 3072, d_condition
+    192, tgt_len-like ragged L): logits, loss and every gradient against the oracle in the exact-f32 tier."""
+    cfg = O.Cfg(1007, 1, 16, 768, 3072, d_condition=192, conditioning="continuous_concat")
+    P = O.seeded_params(cfg, 13)
+    model = make_model(cfg, P, "fp32").train()
+    tok, cond, tgt = O.synthetic_batch(cfg, 2, 76, seed=6)
+    loss_ref, lg_ref, G = O.loss_and_grads(cfg, P, tok, cond, tgt)
+    loss = model.loss_and_backward(tok.to(DEV), cond.to(DEV), tgt.to(DEV))
+    model.link_grads()
+    assert abs(loss.item() - loss_ref.item()) < 1e-4, (loss.item(), loss_ref.item())
+    worst = max(relerr(p.grad, G[k]) for k, p in model.named_parameters() if not k.endswith("Wk.bias"))
+    assert worst < 2e-4, worst
+    with torch.no_grad():
+        lg = model.eval()(tok.to(DEV), cond.to(DEV))
+    assert relerr(lg, lg_ref) < 1e-4
+    report("published geometry, 1 layer (f32): logits rel %.2e, worst grad rel %.2e" % (relerr(lg, lg_ref), worst))
+
+
 def test_f2_cfg1_logits_and_trajectory(golden_dir):
     """BASELINE config 1 (none, 2L d256 h4 di1024 L256 B2) through the HIP engine, f32 tier."""
     z = np.load(os.path.join(golden_dir, "f2_cfg1.npz"))
