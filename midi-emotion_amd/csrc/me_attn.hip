@@ -32,6 +32,7 @@
 // Only tiles on/below the diagonal are ever written or read; the workspaces must be
 // zero-initialised once (rows q >= L and the unreachable corner stay zero).
 #include "me_common.h"
+#include <type_traits>
 
 #ifndef ME_ABL
 #define ME_ABL 0
@@ -70,6 +71,16 @@ ME_DEV void tile_gload(chunk16* r, const T* origin, size_t ld, int rows_valid, i
             const int row = c / TT::CPR, cc = (c % TT::CPR) * TT::CH;
             r[i] = row < rows_valid ? ld_chunk(origin + (size_t)row * ld + cc) : zero_chunk();
         }
+    }
+}
+// all ROWS rows in bounds: no predicate, so the loads stay in the caller's basic block (exact vmcnt bookkeeping)
+template <typename T, int ROWS, int COLS>
+ME_DEV void tile_gload_full(chunk16* r, const T* origin, size_t ld, int tid) {
+    using TT = TileT<T, ROWS, COLS>;
+#pragma unroll
+    for (int i = 0; i < TT::NPT; ++i) {
+        const int c = (TT::NCH % 256 == 0) ? tid + i * 256 : min(tid + i * 256, TT::NCH - 1);   // spare threads re-load the last chunk
+        r[i] = ld_chunk(origin + (size_t)(c / TT::CPR) * ld + (c % TT::CPR) * TT::CH);
     }
 }
 template <typename T, int ROWS, int COLS, int LDS_LD>
@@ -331,16 +342,27 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
     for (int i = lane; i < 32 * LDR; i += 64) Ds[wid][i] = ET<T>::from_f(0.f);
 
     chunk16 rk[TileT<T, 32, DH>::NPT], rv[TileT<T, 32, DH>::NPT];
-    uint32_t rp = 0;
-    auto gload = [&](int kt) {
+    uint32_t rp = 0, rpm = 0;
+    // pad flags: always one byte load per thread (a valid dummy row when there is no mask) -- a load under a
+    // branch would make every later vmcnt wait conservative
+    const uint8_t* kp_ = key_pad ? key_pad + (size_t)b * L : reinterpret_cast<const uint8_t*>(lse);
+    const uint32_t kp_on = key_pad ? 0xffu : 0u;
+    auto gload = [&](int kt) __attribute__((always_inline)) {
         tile_gload<T, 32, DH>(rk, kb_ + (size_t)kt * 32 * ldq, ldq, L - kt * 32, tid);
         tile_gload<T, 32, DH>(rv, vb_ + (size_t)kt * 32 * ldq, ldq, L - kt * 32, tid);
-        if (key_pad && tid < 32) { const int key = kt * 32 + tid; rp = key < L ? key_pad[(size_t)b * L + key] : 0; }
+        rp = kp_[min(kt * 32 + (tid & 31), L - 1)];
+        rpm = kt * 32 + (tid & 31) < L ? kp_on : 0u;
     };
-    auto sstore = [&](int buf) {
+    auto gload_full = [&](int kt) __attribute__((always_inline)) {       // tile kt entirely below L
+        tile_gload_full<T, 32, DH>(rk, kb_ + (size_t)kt * 32 * ldq, ldq, tid);
+        tile_gload_full<T, 32, DH>(rv, vb_ + (size_t)kt * 32 * ldq, ldq, tid);
+        rp = kp_[kt * 32 + (tid & 31)];            // masked when it is stored: no early use, no early wait
+        rpm = kp_on;
+    };
+    auto sstore = [&](int buf) __attribute__((always_inline)) {
         tile_sstore<T, 32, DH, C::LDN>(rk, Ks[buf], tid);
         tile_sstore<T, 32, DH, C::LDN>(rv, Vs[buf], tid);
-        if (key_pad && tid < 32) Ps[buf][tid] = rp;
+        if (tid < 32) Ps[buf][tid] = rp & rpm;
     };
     auto g_block = [&](const Frag<T>* ef, int eb) {
         f32x16_t g; acc_zero(g);
@@ -357,8 +379,10 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
         for (int i = 0; i < C::DB; ++i)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const T* ep = ET_ + (size_t)(i * 32 + a) * M + eb * 32 + 16 * t + 4 * h;
-                if (i * 32 + a < DH) frag_load_4x2(f[i][t], ep, ep + 8);
+                // contraction map e = 16 t + 8 h + j on both operands (E^T here, dG^T from the ring): one 16-byte load
+                const T* ep = (ME_ABL == 9) ? ET_ + (size_t)eb * 32 * DH + ((i * 2 + t) * 64 + lane) * 8
+                                            : ET_ + (size_t)(i * 32 + a) * M + eb * 32 + 16 * t + 8 * h;
+                if (i * 32 + a < DH) frag_load(f[i][t], ep);
                 else frag_zero(f[i][t]);
             }
     };
@@ -376,17 +400,24 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
     sstore(0);
     if (nkt > 1) gload(1);
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
+    // One key tile.  MAIN = every wave of the block is strictly above its diagonal tile and tiles kt + 1,
+    // kt + 2 lie entirely below L: no wave-, tile- or bounds-dependent branch encloses a global load or
+    // store, so the compiler's s_waitcnt bookkeeping stays exact (vmcnt is in order: one conservative
+    // vmcnt(0) exposes the K / V prefetch latency and the tile-store acknowledgements in every step).
+    auto step = [&](int kt, auto main_tag) __attribute__((always_inline)) {
+        constexpr bool MAIN = decltype(main_tag)::value;
         const int buf = kt & 1;
-        if (wave_on && kt <= my_last_kt) {
+        if (MAIN || (wave_on && kt <= my_last_kt)) {
             const int k0 = kt * 32;
-            const bool diag = kt == my_last_kt;
+            const bool diag = !MAIN && kt == my_last_kt;
             const int eb_lo = eb0 + kt;
-            if (!diag) {
+            if constexpr (MAIN) {
+                g_block(ef, eb_lo + 1);               // the next block's E rows are fetched after the softmax (register budget)
+            } else if (!diag) {
                 g_block(ef, eb_lo + 1);
                 if (kt + 1 < my_last_kt) row_frags<T, DH>(ef, E + (size_t)((eb_lo + 2) * 32 + a) * DH, true, h);
             }
-            if (ME_ABL != 3) et_frags(etf, eb_lo);      // E^T block of this step's lo block: in flight during S / dP / softmax
+            if (ME_ABL != 3 && !(MAIN && ME_ABL == 8)) et_frags(etf, eb_lo);      // E^T block of this step's lo block: in flight during S / dP / softmax
             f32x16_t s, dp; acc_zero(s); acc_zero(dp);
 #pragma unroll
             for (int kk = 0; kk < C::KA; ++kk) {
@@ -402,20 +433,38 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
             const float* grow = &Gs[wid][a * LDG2];
             T* drow = &Ds[wid][a * LDR];
             const int t0 = (eb_lo & 1) * 32 + 31 - a + 4 * h;
-            const bool plain = !diag && pbits == 0u && k0 + 32 <= L;
+            const bool plain = !diag && pbits == 0u && k0 + 32 <= L && q0 + 32 <= L;
+            // the 16 ring reads are issued as one batch and every element is computed branch-free: per-element
+            // exec-mask branches serialise the LDS latency (one read -> wait -> exp per basic block)
+            const float nds = -delta * scale;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int bk = (r & 3) + 8 * (r >> 2) + 4 * h, key = k0 + bk;
-                const int col = (t0 + (r & 3) + 8 * (r >> 2)) & 63;
-                const bool masked = !row_on || (!plain && (key > q || key >= L || ((pbits >> bk) & 1u)));
-                float p = 0.f, ds = 0.f;
-                if (!masked) {
-                    p = fast_exp2((s[r] + grow[col]) * c2 - lse2);
-                    ds = p * (dp[r] - delta) * scale;
+            for (int r0 = 0; r0 < 16; r0 += 8) {                 // two batches of 8 ring reads (register budget)
+                float gv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) gv[j] = grow[(t0 + ((r0 + j) & 3) + 8 * ((r0 + j) >> 2)) & 63];
+                if (plain) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int r = r0 + j;
+                        const float p = fast_exp2(fmaf(s[r] + gv[j], c2, -lse2));
+                        s[r] = p * fmaf(dp[r], scale, nds);
+                        dp[r] = p;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int r = r0 + j;
+                        const int bk = (r & 3) + 8 * (r >> 2) + 4 * h, key = k0 + bk;
+                        const bool masked = !row_on || key > q || key >= L || ((pbits >> bk) & 1u);
+                        const float p = fast_exp2(masked ? -INFINITY : fmaf(s[r] + gv[j], c2, -lse2));     // exp2(-inf) = 0
+                        s[r] = masked ? 0.f : p * fmaf(dp[r], scale, nds);
+                        dp[r] = p;
+                    }
                 }
-                s[r] = ds;
-                dp[r] = p;
-                if (ME_ABL != 4) drow[col] = ET<T>::from_f(ds);
+            }
+            if (ME_ABL != 4) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) drow[(t0 + (r & 3) + 8 * (r >> 2)) & 63] = ET<T>::from_f(s[r]);
             }
             // ---- materialise P^T, dS^T tiles [key][q]: transpose through the (now dead) lo slot of the G
             //      ring so that the tiles leave as 16-byte row-contiguous stores.  Rows key >= L and
@@ -424,20 +473,24 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
             T* stg = reinterpret_cast<T*>(&Gs[wid][(eb_lo & 1) * 32]);
             constexpr int LDX = LDG2 * (int)(sizeof(float) / sizeof(T));   // staging row stride in elements of T
             constexpr int CPRX = 32 / C::CH;                        // chunks per 32-wide row
-            auto flush_tile = [&](T* gdst) {                        // stg[32][LDX] -> gdst[32 rows][ld Lp]
+            auto flush_tile = [&](T* gdst) {                        // stg[32][LDX] -> one contiguous [32 key][32 q] tile
 #pragma unroll
                 for (int it = 0; it < 32 * CPRX / 64; ++it) {
                     const int c = it * 64 + lane, row = c / CPRX, cc = (c % CPRX) * C::CH;
-                    st_chunk(gdst + (size_t)row * Lp + cc, ld_chunk(&stg[row * LDX + cc]));
+                    st_chunk(gdst + row * 32 + cc, ld_chunk(&stg[row * LDX + cc]));
                 }
             };
+            const size_t tile_off = ws_bh + ((size_t)(q0 >> 5) * (Lp >> 5) + kt) * 1024;
+            if constexpr (MAIN && ME_ABL != 8)      // issued BEFORE the tile stores: in-order vmcnt then never makes the next step wait for them
+                row_frags<T, DH>(ef, (ME_ABL == 9) ? E + (size_t)min(eb_lo + 2, (M >> 5) - 1) * 32 * DH + lane * 8 - h * 8
+                                                   : E + (size_t)(min(eb_lo + 2, (M >> 5) - 1) * 32 + a) * DH, true, h);   // clamped: unused past the diagonal
             if (ME_ABL != 1) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * h) * LDX + a] = ET<T>::from_f(dp[r]);
-                flush_tile(PT + ws_bh + (size_t)k0 * Lp + q0);
+                flush_tile(PT + tile_off);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * h) * LDX + a] = ET<T>::from_f(s[r]);
-                flush_tile(dST + ws_bh + (size_t)k0 * Lp + q0);
+                flush_tile(dST + tile_off);
             }
             // ---- dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
 #pragma unroll
@@ -455,17 +508,25 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
             for (int t = 0; t < 2; ++t) {
                 Frag<T> dgf;
                 const T* dlo = drow + (eb_lo & 1) * 32;
-                frag_load_4x2(dgf, dlo + 16 * t + 4 * h, dlo + 16 * t + 8 + 4 * h);
+                frag_load(dgf, dlo + 16 * t + 8 * h);
 #pragma unroll
                 for (int i = 0; i < C::DB; ++i) { if (ME_ABL != 3) mma32(dq[i], etf[i][t], dgf); }
             }
         }
-        if (kt + 1 < nkt) {
+        if constexpr (MAIN) {
             sstore(buf ^ 1);                      // buf^1 was last read in step kt-1 (barrier since)
+            gload_full(kt + 2);
+        } else if (kt + 1 < nkt) {
+            sstore(buf ^ 1);
             if (kt + 2 < nkt) gload(kt + 2);
         }
-        block_sync_lds();               // LDS hand-over only: prefetch loads / tile stores stay in flight
-    }
+        if (!(MAIN && ME_ABL == 7)) block_sync_lds();               // LDS hand-over only: prefetch loads / tile stores stay in flight
+    };
+    // MAIN steps: all four waves on and off-diagonal (kt < 4 qb), tiles kt + 1, kt + 2 whole (kt + 3 <= L / 32)
+    const int nmain = (qb * 128 + 96 < L) ? max(0, min(qb * 4, (L >> 5) - 2)) : 0;
+    int kt = 0;
+    for (; kt < nmain; ++kt) step(kt, std::true_type{});
+    for (; kt < nkt; ++kt) step(kt, std::false_type{});
     if (!row_on) return;
     T* dqp = dqkv + ((size_t)b * L + q) * ldq + head * DH;
 #pragma unroll
@@ -504,8 +565,9 @@ __global__ __launch_bounds__(256) void rga_bwd_kv_kernel(const T* __restrict__ P
     const int nqt = (L + 31) / 32;
     const int qs0 = kb * 4;
     const int rows_valid = min(128, Lp - kb * 128);
-    const T* pt_ = PT + (size_t)bh * Lp * Lp + (size_t)kb * 128 * Lp;
-    const T* st_ = dST + (size_t)bh * Lp * Lp + (size_t)kb * 128 * Lp;
+    const size_t slab = (size_t)Lp * 32;                            // one query tile: [Lp key][32 q], contiguous
+    const T* pt_ = PT + (size_t)bh * Lp * Lp + (size_t)kb * 128 * 32;
+    const T* st_ = dST + (size_t)bh * Lp * Lp + (size_t)kb * 128 * 32;
     const T* q_ = qkv + (size_t)b * L * ldq + head * DH;
     const T* o_ = dout + (size_t)b * L * dm + head * DH;
 
@@ -515,8 +577,8 @@ __global__ __launch_bounds__(256) void rga_bwd_kv_kernel(const T* __restrict__ P
 
     chunk16 rp[TileT<T, 128, 32>::NPT], rs[TileT<T, 128, 32>::NPT], ro[TileT<T, 32, DH>::NPT], rq[TileT<T, 32, DH>::NPT];
     auto gload = [&](int qs) {
-        tile_gload<T, 128, 32>(rp, pt_ + qs * 32, (size_t)Lp, rows_valid, tid);
-        tile_gload<T, 128, 32>(rs, st_ + qs * 32, (size_t)Lp, rows_valid, tid);
+        tile_gload<T, 128, 32>(rp, pt_ + qs * slab, (size_t)32, rows_valid, tid);
+        tile_gload<T, 128, 32>(rs, st_ + qs * slab, (size_t)32, rows_valid, tid);
         tile_gload<T, 32, DH>(ro, o_ + (size_t)qs * 32 * dm, (size_t)dm, L - qs * 32, tid);
         tile_gload<T, 32, DH>(rq, q_ + (size_t)qs * 32 * ldq, ldq, L - qs * 32, tid);
     };
@@ -629,12 +691,12 @@ __global__ __launch_bounds__(256) void rga_bwd_e_kernel(const T* __restrict__ dS
     auto gload = [&](int s) {
         const int bh = bh_lo + s / nq, qs = qs0 + s % nq;
         const int kb = c0 - Lp + 1 + qs * 32;            // key of tile element (row 0, column 0)
-        const T* src = dST + (size_t)bh * Lp * Lp + qs * 32;
+        const T* src = dST + (size_t)bh * Lp * Lp + (size_t)qs * Lp * 32;     // query tile qs: [Lp key][32 q]
 #pragma unroll
         for (int i = 0; i < BandT::NPT; ++i) {
             const int c = tid + i * 256, kk = c / BandT::CPR, cc = (c % BandT::CPR) * CH;
             const int key = kb + kk;
-            rg[i] = (c < BandT::NCH && kk < 159 && key >= 0 && key < Lp) ? ld_chunk(src + (size_t)key * Lp + cc) : zero_chunk();
+            rg[i] = (c < BandT::NCH && kk < 159 && key >= 0 && key < Lp) ? ld_chunk(src + key * 32 + cc) : zero_chunk();
         }
         tile_gload<T, 32, DH>(rq, qkv + ((size_t)(bh / H) * L + qs * 32) * ldq + (bh % H) * DH, ldq, L - qs * 32, tid);
     };

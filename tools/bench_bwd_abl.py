@@ -1,8 +1,8 @@
 import os, sys
-sys.path.insert(0, "midi-emotion_amd")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "midi-emotion_amd"))
 import torch
 from midiemo import ops
-def timeit(fn, iters=10, warm=3):
+def timeit(fn, iters=int(os.environ.get("ITERS", 10)), warm=int(os.environ.get("WARM", 3))):
     for _ in range(warm): fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
