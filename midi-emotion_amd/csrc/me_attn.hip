@@ -112,6 +112,18 @@ ME_DEV void row_frags(Frag<T>* f, const T* rowptr, bool valid, int h) {
     }
 }
 
+// P^T / dS^T workspace of one (b, head): element offset of the 32-query row segment (key, query tile qt).
+// Layout 2 (default): [key tile][query tile][32 key][32 q], every tile 32 x 32 contiguous; 0: plain [key][q] rows;
+// 1: query-tile-major [Lp/32 qt][Lp key][32 q].  Measured in the train step (q / kv kernels, us): 0: 319 / 188, 1: 303 / 178, 2: 298 / 173.
+#ifndef ME_WS_LAYOUT
+#define ME_WS_LAYOUT 2
+#endif
+ME_DEV size_t ws_row(int key, int qt, int Lp) {
+    if (ME_WS_LAYOUT == 0) return (size_t)key * Lp + qt * 32;
+    if (ME_WS_LAYOUT == 1) return ((size_t)qt * Lp + key) * 32;
+    return (((size_t)(key >> 5) * (Lp >> 5) + qt) * 32 + (key & 31)) * 32;
+}
+
 // v_exp_f32 without the denormal-range fix-up of exp2f (arguments here are <= 0: tiny results may flush to 0)
 ME_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
@@ -167,16 +179,27 @@ __global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ q
     float m_run = -INFINITY, l_run = 0.f;
 
     chunk16 rk[TileT<T, 32, DH>::NPT], rv[TileT<T, 32, DH>::NPT];
-    uint32_t rp = 0;
-    auto gload = [&](int kt) {
+    uint32_t rp = 0, rpm = 0;
+    // pad flags: always one byte load per thread (a valid dummy row when there is no mask), masked when stored:
+    // a load under a branch, or an early use, would make the later vmcnt waits conservative
+    const uint8_t* kp_ = key_pad ? key_pad + (size_t)b * L : reinterpret_cast<const uint8_t*>(qkv);
+    const uint32_t kp_on = key_pad ? 0xffu : 0u;
+    auto gload = [&](int kt) __attribute__((always_inline)) {
         tile_gload<T, 32, DH>(rk, kb_ + (size_t)kt * 32 * ldq, ldq, L - kt * 32, tid);
         tile_gload<T, 32, DH>(rv, vb_ + (size_t)kt * 32 * ldq, ldq, L - kt * 32, tid);
-        if (key_pad && tid < 32) { const int key = kt * 32 + tid; rp = key < L ? key_pad[(size_t)b * L + key] : 0; }
+        rp = kp_[min(kt * 32 + (tid & 31), L - 1)];
+        rpm = kt * 32 + (tid & 31) < L ? kp_on : 0u;
     };
-    auto sstore = [&](int buf) {
+    auto gload_full = [&](int kt) __attribute__((always_inline)) {       // tile kt entirely below L
+        tile_gload_full<T, 32, DH>(rk, kb_ + (size_t)kt * 32 * ldq, ldq, tid);
+        tile_gload_full<T, 32, DH>(rv, vb_ + (size_t)kt * 32 * ldq, ldq, tid);
+        rp = kp_[kt * 32 + (tid & 31)];
+        rpm = kp_on;
+    };
+    auto sstore = [&](int buf) __attribute__((always_inline)) {
         tile_sstore<T, 32, DH, C::LDN>(rk, Ks[buf], tid);
         tile_sstore<T, 32, DH, C::LDN>(rv, Vs[buf], tid);
-        if (key_pad && tid < 32) Ps[buf][tid] = rp;
+        if (tid < 32) Ps[buf][tid] = rp & rpm;
     };
     auto g_block = [&](const Frag<T>* ef, int eb) {     // G^T[m][q] = E[eb*32+m] . Q[q] -> ring slot eb&1
         f32x16_t g; acc_zero(g);
@@ -200,13 +223,20 @@ __global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ q
     if (nkt > 1) gload(1);
     __syncthreads();
 
-    for (int kt = 0; kt < nkt; ++kt) {
+    // One key tile.  MAIN = every wave of the block is strictly above its diagonal tile and tiles kt + 1, kt + 2
+    // lie entirely below L: no branch encloses a global load, so the s_waitcnt bookkeeping stays exact (a
+    // conservative vmcnt(0) at the top of the step exposes the K / V prefetch issued just before the barrier).
+    auto step = [&](int kt, auto main_tag) __attribute__((always_inline)) {
+        constexpr bool MAIN = decltype(main_tag)::value;
         const int buf = kt & 1;
-        if (wave_on && kt <= my_last_kt) {
+        if (MAIN || (wave_on && kt <= my_last_kt)) {
             const int k0 = kt * 32;
-            const bool diag = kt == my_last_kt;
+            const bool diag = !MAIN && kt == my_last_kt;
             const int eb_lo = eb0 + kt;
-            if (!diag) {
+            if constexpr (MAIN) {
+                g_block(ef, eb_lo + 1);
+                row_frags<T, DH>(ef, E + (size_t)(min(eb_lo + 2, (M >> 5) - 1) * 32 + a) * DH, true, h);   // clamped: unused past the diagonal
+            } else if (!diag) {
                 g_block(ef, eb_lo + 1);
                 if (kt + 1 < my_last_kt) row_frags<T, DH>(ef, E + (size_t)((eb_lo + 2) * 32 + a) * DH, true, h);
             }
@@ -265,12 +295,19 @@ __global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ q
                 }
             }
         }
-        if (kt + 1 < nkt) {
+        if constexpr (MAIN) {
             sstore(buf ^ 1);                      // buf^1 was last read in step kt-1 (barrier since)
+            gload_full(kt + 2);
+        } else if (kt + 1 < nkt) {
+            sstore(buf ^ 1);
             if (kt + 2 < nkt) gload(kt + 2);
         }
-        block_sync_lds();               // LDS hand-over only: prefetch loads / tile stores stay in flight
-    }
+        block_sync_lds();               // LDS hand-over only: prefetch loads stay in flight
+    };
+    const int nmain = (qb * 128 + 96 < L) ? max(0, min(qb * 4, (L >> 5) - 2)) : 0;
+    int kt = 0;
+    for (; kt < nmain; ++kt) step(kt, std::true_type{});
+    for (; kt < nkt; ++kt) step(kt, std::false_type{});
     if (!wave_on || q >= L) return;
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.f / l_tot;
@@ -477,10 +514,10 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
 #pragma unroll
                 for (int it = 0; it < 32 * CPRX / 64; ++it) {
                     const int c = it * 64 + lane, row = c / CPRX, cc = (c % CPRX) * C::CH;
-                    st_chunk(gdst + row * 32 + cc, ld_chunk(&stg[row * LDX + cc]));
+                    st_chunk(gdst + (size_t)row * (ME_WS_LAYOUT == 0 ? Lp : 32) + cc, ld_chunk(&stg[row * LDX + cc]));
                 }
             };
-            const size_t tile_off = ws_bh + ((size_t)(q0 >> 5) * (Lp >> 5) + kt) * 1024;
+            const size_t tile_off = ws_bh + ws_row(k0, q0 >> 5, Lp);
             if constexpr (MAIN && ME_ABL != 8)      // issued BEFORE the tile stores: in-order vmcnt then never makes the next step wait for them
                 row_frags<T, DH>(ef, (ME_ABL == 9) ? E + (size_t)min(eb_lo + 2, (M >> 5) - 1) * 32 * DH + lane * 8 - h * 8
                                                    : E + (size_t)(min(eb_lo + 2, (M >> 5) - 1) * 32 + a) * DH, true, h);   // clamped: unused past the diagonal
@@ -565,9 +602,8 @@ __global__ __launch_bounds__(256) void rga_bwd_kv_kernel(const T* __restrict__ P
     const int nqt = (L + 31) / 32;
     const int qs0 = kb * 4;
     const int rows_valid = min(128, Lp - kb * 128);
-    const size_t slab = (size_t)Lp * 32;                            // one query tile: [Lp key][32 q], contiguous
-    const T* pt_ = PT + (size_t)bh * Lp * Lp + (size_t)kb * 128 * 32;
-    const T* st_ = dST + (size_t)bh * Lp * Lp + (size_t)kb * 128 * 32;
+    const T* pt_ = PT + (size_t)bh * Lp * Lp;
+    const T* st_ = dST + (size_t)bh * Lp * Lp;
     const T* q_ = qkv + (size_t)b * L * ldq + head * DH;
     const T* o_ = dout + (size_t)b * L * dm + head * DH;
 
@@ -577,8 +613,13 @@ __global__ __launch_bounds__(256) void rga_bwd_kv_kernel(const T* __restrict__ P
 
     chunk16 rp[TileT<T, 128, 32>::NPT], rs[TileT<T, 128, 32>::NPT], ro[TileT<T, 32, DH>::NPT], rq[TileT<T, 32, DH>::NPT];
     auto gload = [&](int qs) {
-        tile_gload<T, 128, 32>(rp, pt_ + qs * slab, (size_t)32, rows_valid, tid);
-        tile_gload<T, 128, 32>(rs, st_ + qs * slab, (size_t)32, rows_valid, tid);
+#pragma unroll
+        for (int i = 0; i < TileT<T, 128, 32>::NPT; ++i) {
+            const int c = tid + i * 256, row = c / TileT<T, 128, 32>::CPR, cc = (c % TileT<T, 128, 32>::CPR) * CH;
+            const size_t o = ws_row(kb * 128 + min(row, rows_valid - 1), qs, Lp) + cc;
+            rp[i] = row < rows_valid ? ld_chunk(pt_ + o) : zero_chunk();
+            rs[i] = row < rows_valid ? ld_chunk(st_ + o) : zero_chunk();
+        }
         tile_gload<T, 32, DH>(ro, o_ + (size_t)qs * 32 * dm, (size_t)dm, L - qs * 32, tid);
         tile_gload<T, 32, DH>(rq, q_ + (size_t)qs * 32 * ldq, ldq, L - qs * 32, tid);
     };
@@ -691,12 +732,12 @@ __global__ __launch_bounds__(256) void rga_bwd_e_kernel(const T* __restrict__ dS
     auto gload = [&](int s) {
         const int bh = bh_lo + s / nq, qs = qs0 + s % nq;
         const int kb = c0 - Lp + 1 + qs * 32;            // key of tile element (row 0, column 0)
-        const T* src = dST + (size_t)bh * Lp * Lp + (size_t)qs * Lp * 32;     // query tile qs: [Lp key][32 q]
+        const T* src = dST + (size_t)bh * Lp * Lp;
 #pragma unroll
         for (int i = 0; i < BandT::NPT; ++i) {
             const int c = tid + i * 256, kk = c / BandT::CPR, cc = (c % BandT::CPR) * CH;
             const int key = kb + kk;
-            rg[i] = (c < BandT::NCH && kk < 159 && key >= 0 && key < Lp) ? ld_chunk(src + key * 32 + cc) : zero_chunk();
+            rg[i] = (c < BandT::NCH && kk < 159 && key >= 0 && key < Lp) ? ld_chunk(src + ws_row(min(max(key, 0), Lp - 1), qs, Lp) + cc) : zero_chunk();
         }
         tile_gload<T, 32, DH>(rq, qkv + ((size_t)(bh / H) * L + qs * 32) * ldq + (bh % H) * DH, ldq, L - qs * 32, tid);
     };
