@@ -687,7 +687,7 @@ template <typename T, int DH>
 __global__ __launch_bounds__(256) void rga_bwd_e_kernel(const T* __restrict__ dST, const T* __restrict__ qkv,
                                                         float* __restrict__ dE, int B, int L, int Lp, int H, int M) {
     constexpr int CH = ET<T>::CH, LDP = 32 + CH, DB = ACfg<T, DH>::DB, LDV = ACfg<T, DH>::LDV;
-    __shared__ __attribute__((aligned(16))) T Gt[2][128 * LDP];
+    __shared__ __attribute__((aligned(16))) T Gt[2][(128 + 16) * LDP];  // + 16 dump rows: out-of-tile band elements are stored there, not branched around
     __shared__ __attribute__((aligned(16))) T Qs[2][32 * LDV];         // natural Q slab [32 q][DH], transpose-read
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, a = lane & 31, h = lane >> 5;
@@ -727,39 +727,49 @@ __global__ __launch_bounds__(256) void rga_bwd_e_kernel(const T* __restrict__ dS
 
     using BandT = TileT<T, 160, 32>;                    // 159 band rows (+1 pad) x 32 queries, CPR chunks per row
     chunk16 rg[BandT::NPT], rq[TileT<T, 32, DH>::NPT];
+    bool rgv[BandT::NPT];                               // band row inside the workspace?  applied when the chunk is sheared into LDS
     const int dm = H * DH;
     const size_t ldq = (size_t)3 * dm;
-    auto gload = [&](int s) {
+    // No branch encloses a global load or an LDS store in the steady state: rows are clamped, invalid band rows
+    // are zeroed by a select at shear time and out-of-tile elements go to dump rows (exact s_waitcnt bookkeeping,
+    // no exec-mask branch per element).
+    auto gload = [&](int s) __attribute__((always_inline)) {
         const int bh = bh_lo + s / nq, qs = qs0 + s % nq;
         const int kb = c0 - Lp + 1 + qs * 32;            // key of tile element (row 0, column 0)
         const T* src = dST + (size_t)bh * Lp * Lp;
 #pragma unroll
         for (int i = 0; i < BandT::NPT; ++i) {
-            const int c = tid + i * 256, kk = c / BandT::CPR, cc = (c % BandT::CPR) * CH;
+            const int c = min(tid + i * 256, BandT::NCH - 1), kk = c / BandT::CPR, cc = (c % BandT::CPR) * CH;
             const int key = kb + kk;
-            rg[i] = (c < BandT::NCH && kk < 159 && key >= 0 && key < Lp) ? ld_chunk(src + ws_row(min(max(key, 0), Lp - 1), qs, Lp) + cc) : zero_chunk();
+            rgv[i] = kk < 159 && key >= 0 && key < Lp;
+            rg[i] = ld_chunk(src + ws_row(min(max(key, 0), Lp - 1), qs, Lp) + cc);
         }
-        tile_gload<T, 32, DH>(rq, qkv + ((size_t)(bh / H) * L + qs * 32) * ldq + (bh % H) * DH, ldq, L - qs * 32, tid);
+        const T* qsrc = qkv + ((size_t)(bh / H) * L + qs * 32) * ldq + (bh % H) * DH;
+        using QT = TileT<T, 32, DH>;
+#pragma unroll
+        for (int i = 0; i < QT::NPT; ++i) {              // rows past L repeat the last row: their dS^T columns are exact zeros
+            const int c = min(tid + i * 256, QT::NCH - 1);
+            rq[i] = ld_chunk(qsrc + (size_t)min(c / QT::CPR, L - 1 - qs * 32) * ldq + (c % QT::CPR) * CH);
+        }
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](int buf) __attribute__((always_inline)) {
         // shear: band element (kk, qq) -> tile row kk - qq; every tile element is written exactly once per step
 #pragma unroll
         for (int i = 0; i < BandT::NPT; ++i) {
             const int c = tid + i * 256, kk = c / BandT::CPR, cc = (c % BandT::CPR) * CH;
-            if (c < BandT::NCH) {
-                const T* v = reinterpret_cast<const T*>(&rg[i]);
+            const T* v = reinterpret_cast<const T*>(&rg[i]);
 #pragma unroll
-                for (int e = 0; e < CH; ++e) {
-                    const int cl = kk - cc - e;
-                    if (cl >= 0 && cl < 128) Gt[buf][cl * LDP + cc + e] = v[e];
-                }
+            for (int e = 0; e < CH; ++e) {
+                const int cl = kk - cc - e;
+                const int row = (cl >= 0 && cl < 128) ? cl : 128 + (kk & 15);     // threads past the band (kk >= 160) land in the dump rows too
+                Gt[buf][row * LDP + cc + e] = rgv[i] ? v[e] : ET<T>::from_f(0.f);
             }
         }
         tile_sstore<T, 32, DH, LDV>(rq, Qs[buf], tid);
     };
     gload(0);
     sstore(0);
-    if (nsteps > 1) gload(1);
+    gload(min(1, nsteps - 1));
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
@@ -777,10 +787,8 @@ __global__ __launch_bounds__(256) void rga_bwd_e_kernel(const T* __restrict__ dS
                 }
             }
         }
-        if (s + 1 < nsteps) {
-            sstore(buf ^ 1);
-            if (s + 2 < nsteps) gload(s + 2);
-        }
+        sstore(buf ^ 1);                            // past the last step: a harmless re-store of the last slab
+        gload(min(s + 2, nsteps - 1));
         block_sync_lds();               // LDS hand-over only: prefetch loads / tile stores stay in flight
     }
     if (!wave_on) return;

@@ -10,7 +10,11 @@ CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 INCLUDE = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include")
 LIB = os.path.join(HERE, "libmidiemo_hip.so")
 SOURCES = ["me_gemm.hip", "me_elem.hip", "me_attn.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-value"]
+# -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs.  Without it hipcc parks the accumulators of loops whose
+# MFMAs sit under a wave-uniform branch in AGPRs and copies all of them (v_accvgpr_read/write) around every
+# iteration: 128 of ~250 VALU instructions per step in rga_bwd_kv, 96 of ~230 in rga_bwd_e.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-value",
+         "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 
 
 def _hipcc():
