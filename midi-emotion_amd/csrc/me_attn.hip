@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ q
                     mt = fmaxf(mt, v);
                 }
             }
-            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+            mt = half_max(mt);
             const float m_new = fmaxf(m_run, mt);
             const float m_safe = m_new == -INFINITY ? 0.f : m_new;
             const float alpha = fast_exp2(m_run - m_safe);
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ q
     for (; kt < nmain; ++kt) step(kt, std::true_type{});
     for (; kt < nkt; ++kt) step(kt, std::false_type{});
     if (!wave_on || q >= L) return;
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = half_sum(l_run);
     const float inv = 1.f / l_tot;
     if (h == 0) lse[((size_t)b * H + head) * L + q] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
     T* op = out + ((size_t)b * L + q) * dm + head * DH;
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
                 delta += ET<T>::to_f(dout[orow + kk * 16 + h * 8 + e]) * ET<T>::to_f(out[orow + kk * 16 + h * 8 + e]);
         lse2 = lse[((size_t)b * H + head) * L + q] * 1.4426950408889634f;
     }
-    delta += __shfl_xor(delta, 32, 64);
+    delta = half_sum(delta);
     if (row_on && h == 0) delta_ws[((size_t)b * H + head) * L + q] = delta;
 
     f32x16_t dq[C::DB];

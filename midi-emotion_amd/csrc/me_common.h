@@ -138,16 +138,37 @@ ME_DEV void acc_zero(f32x16_t& a) {
 // ---------------------------------------------------------------------------
 // wave reductions (64 lanes)
 // ---------------------------------------------------------------------------
-ME_DEV float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// Wave-wide reductions without the LDS crossbar.  __shfl_xor compiles to ds_bpermute_b32 + s_waitcnt lgkmcnt(0) per
+// level: six serialised LDS round trips per reduction (measured: the LDS unit was busy half of resid_ln_bwd's
+// run time).  Here: four DPP levels inside a 16-lane row (quad butterflies, half-row mirror, row mirror: every
+// lane then holds its row's total), then the four row totals are combined through v_readlane.
+template <int CTRL> ME_DEV float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
-ME_DEV float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+template <typename OP> ME_DEV float wave_reduce(float v, OP op) {
+    v = op(v, dpp_move<0xB1>(v));       // quad_perm [1,0,3,2]
+    v = op(v, dpp_move<0x4E>(v));       // quad_perm [2,3,0,1]
+    v = op(v, dpp_move<0x141>(v));      // row_half_mirror
+    v = op(v, dpp_move<0x140>(v));      // row_mirror
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return op(op(r0, r1), op(r2, r3));
 }
+// op(v[lane], v[lane ^ 32]) in every lane: v_permlane32_swap exchanges the upper half of one register with the lower
+// half of another (gfx950), so two copies of v become {lo, lo} and {hi, hi}
+template <typename OP> ME_DEV float half_reduce(float v, OP op) {
+    // inline asm: through __builtin_amdgcn_permlane32_swap hipcc (ROCm 7.2) folds the two results into one when both
+    // inputs carry the same value (max(r0, r1) -> r0).  s_nop: VALU write -> permlane read / permlane write -> VALU read.
+    unsigned lo = __builtin_bit_cast(unsigned, v), hi = lo;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
+    return op(__builtin_bit_cast(float, lo), __builtin_bit_cast(float, hi));       // lo = {v.lo, v.lo}, hi = {v.hi, v.hi}
+}
+ME_DEV float half_sum(float v) { return half_reduce(v, [](float a, float b) { return a + b; }); }
+ME_DEV float half_max(float v) { return half_reduce(v, [](float a, float b) { return fmaxf(a, b); }); }
+ME_DEV float wave_sum(float v) { return wave_reduce(v, [](float a, float b) { return a + b; }); }
+ME_DEV float wave_max(float v) { return wave_reduce(v, [](float a, float b) { return fmaxf(a, b); }); }
 
 // ---------------------------------------------------------------------------
 // counter-based dropout RNG: 32-bit avalanche hash of (seed, site, element).
