@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 5
+#define ME_ABI_VERSION 6
 
 enum { ME_F32 = 0, ME_BF16 = 1 };
 
@@ -66,8 +66,11 @@ typedef struct me_ct_desc {
     const float* src;
     void* dst;
     void* dstT;
-    int32_t rows, cols, ld_dst, ld_dstT, tile_begin, pad_;
+    int32_t rows, cols, ld_dst, ld_dstT, tile_begin;
+    int32_t mode;   /* 0: dstT = transposed copy; 1 (ME_CT_PACK_REL): src is a relative table E [M][dh] and dstT receives
+                     * its packed fragment images (the layout of me_rga_pack_rel; ld_dstT unused) */
 } me_ct_desc;
+#define ME_CT_PACK_REL 1
 int me_cast_transpose_multi(const me_ct_desc* desc_dev, int n_tensors, int total_tiles, int dtype, void* stream);
 
 /* ---- embedding prologue ---------------------------------------------------
@@ -133,16 +136,24 @@ int me_gemm_tn_join(void* stream);
  * out  : T [B, L, H, dh]   lse : f32 [B, H, L]
  *   logits[l,j] = (q_l.k_j + q_l.E[M-1-(l-j)]) / sqrt(dh),  j<=l and key j not pad
  * Replaces music_multi.py:196-235 (head split/permute, einsum QE, _qe_masking, _skewing, QK^T,
- * mask, softmax, PV, head merge).  dh in {32, 48, 64}; M % 32 == 0; L <= M. */
-int me_rga_fwd(const void* qkv, const void* E, const uint8_t* key_pad, void* out, float* lse,
+ * mask, softmax, PV, head merge).  dh in {32, 48, 64}; M % 32 == 0; L <= M.  Epk = me_rga_pack_rel(E). */
+int me_rga_fwd(const void* qkv, const void* Epk, const uint8_t* key_pad, void* out, float* lse,
                int B, int L, int H, int dh, int M, int dtype, void* stream);
 
+/* Packs the relative table E (T [M][dh], music_multi.py:191 self.E) into the fragment images me_rga_fwd / me_rga_bwd
+ * read: per block of 32 rows, dh/16 images of the rows themselves (operand of Q.E^T) followed by 2*ceil(dh/32) images
+ * of the transposed block (operand of dQ += dG.E); every image is 64 lanes x 8 elements, i.e. one coalesced 1 KB load
+ * per wave instruction instead of 32 cache lines.  Epk: T [(M/32) * (dh/16 + 2*ceil(dh/32)) * 512], 16-byte aligned.
+ * Call it whenever E changes (the model does it inside its multi-tensor weight refresh, me_ct_desc.mode = 1). */
+int me_rga_pack_rel(const void* E, void* Epk, int M, int dh, int dtype, void* stream);
+
 /* Backward of me_rga_fwd.  dout: T [B,L,H,dh].  Writes dqkv (T, same layout as qkv),
- * accumulates (+=) dE f32 [M, dh].
- * Workspaces (caller-owned): delta f32 [B,H,L]; PT, dST: T [B*H][Lp][Lp] each (Lp = L rounded
- * up to 32) = P^T and dS^T tiles, which must be ZERO-INITIALISED once (only on/below-diagonal tiles are
- * written and read).  The gradient of the relative table is taken from dS^T (dG is dS re-indexed). */
-int me_rga_bwd(const void* qkv, const void* E, const void* ET, const uint8_t* key_pad,
+ * accumulates (+=) dE f32 [M, dh] (natural layout).
+ * Workspaces (caller-owned): delta f32 [B,H,L]; PT, dST: T [B*H][Lp*Lp] each (Lp = L rounded
+ * up to 32) = P^T and dS^T as contiguous 32x32 tiles [key tile][query tile][32 key][32 q], which must be
+ * ZERO-INITIALISED once (only on/below-diagonal tiles are written and read).  The gradient of the relative
+ * table is taken from dS^T (dG is dS re-indexed). */
+int me_rga_bwd(const void* qkv, const void* Epk, const uint8_t* key_pad,
                const void* out, const float* lse, const void* dout,
                void* dqkv, float* dE, float* delta_ws, void* PT, void* dST,
                int B, int L, int Lp, int H, int dh, int M, int dtype, void* stream);

@@ -52,6 +52,9 @@ template <typename T, int DH> struct ACfg {
     // tile only read through transpose reads: a row stride of 192 B (mod 256) puts the 4 x 2 row segments of a
     // 32-lane half on disjoint banks
     static constexpr int LDV = sizeof(T) == 2 ? (DH > 32 ? 96 : 32) : DH + 4;
+    // packed relative table (me_rga_pack_rel): per 32-row block KA fragment images of E rows, then 2 DB images of E^T
+    static constexpr int PK_B = KA * 512;                 // element offset of the E^T images inside a block
+    static constexpr int PK = (KA + 2 * DB) * 512;        // elements per packed block
 };
 
 // ---- generic ROWS x COLS chunk tiles (16-byte chunks, lanes walk a row) ----------------
@@ -145,7 +148,7 @@ template <> ME_DEV void st4<float>(float* p, float a, float b, float c, float d)
 // registers right after the current block's MFMAs were issued, the pad flags travel with the
 // tile, and tiles that need no masking skip all per-element predicates.  exp2-domain softmax.
 template <typename T, int DH>
-__global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ qkv, const T* __restrict__ E, const uint8_t* __restrict__ key_pad,
+__global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ qkv, const T* __restrict__ Epk, const uint8_t* __restrict__ key_pad,
                                                       T* __restrict__ out, float* __restrict__ lse, int B, int L, int H, int M,
                                                       float scale) {
     using C = ACfg<T, DH>;
@@ -211,13 +214,19 @@ __global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ q
             *reinterpret_cast<f32x4_t*>(gs + 8 * gq + 4 * h) = (f32x4_t){g[4 * gq], g[4 * gq + 1], g[4 * gq + 2], g[4 * gq + 3]};
     };
 
+    // E rows of block eb as A-operand fragments: one contiguous 1 KB image per contraction atom (me_rga_pack_rel);
+    // fragment-shaped loads from the natural [M][dh] table touch 32 cache lines per instruction
+    auto e_frags = [&](Frag<T>* f, int eb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kk = 0; kk < C::KA; ++kk) frag_load(f[kk], Epk + (size_t)eb * C::PK + (kk * 64 + lane) * 8);
+    };
     gload(0);
     const int eb0 = (M - 32 - q0) >> 5;
     Frag<T> ef[C::KA];
     if (wave_on) {
-        row_frags<T, DH>(ef, E + (size_t)(eb0 * 32 + a) * DH, true, h);
+        e_frags(ef, eb0);
         g_block(ef, eb0);
-        if (my_last_kt > 0) row_frags<T, DH>(ef, E + (size_t)((eb0 + 1) * 32 + a) * DH, true, h);
+        if (my_last_kt > 0) e_frags(ef, eb0 + 1);
     }
     sstore(0);
     if (nkt > 1) gload(1);
@@ -235,10 +244,10 @@ __global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ q
             const int eb_lo = eb0 + kt;
             if constexpr (MAIN) {
                 g_block(ef, eb_lo + 1);
-                row_frags<T, DH>(ef, E + (size_t)(min(eb_lo + 2, (M >> 5) - 1) * 32 + a) * DH, true, h);   // clamped: unused past the diagonal
+                e_frags(ef, min(eb_lo + 2, (M >> 5) - 1));          // clamped: unused past the diagonal
             } else if (!diag) {
                 g_block(ef, eb_lo + 1);
-                if (kt + 1 < my_last_kt) row_frags<T, DH>(ef, E + (size_t)((eb_lo + 2) * 32 + a) * DH, true, h);
+                if (kt + 1 < my_last_kt) e_frags(ef, eb_lo + 2);
             }
             f32x16_t s; acc_zero(s);
 #pragma unroll
@@ -327,7 +336,7 @@ __global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ q
 // =====================================================================================
 template <typename T, int DH>
 __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
-    const T* __restrict__ qkv, const T* __restrict__ E, const T* __restrict__ ET_,
+    const T* __restrict__ qkv, const T* __restrict__ Epk,
     const uint8_t* __restrict__ key_pad, const T* __restrict__ out, const float* __restrict__ lse,
     const T* __restrict__ dout, T* __restrict__ dqkv, float* __restrict__ delta_ws, T* __restrict__ PT,
     T* __restrict__ dST, int B, int L, int Lp, int H, int M, float scale) {
@@ -410,28 +419,26 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
         for (int gq = 0; gq < 4; ++gq)
             *reinterpret_cast<f32x4_t*>(gs + 8 * gq + 4 * h) = (f32x4_t){g[4 * gq], g[4 * gq + 1], g[4 * gq + 2], g[4 * gq + 3]};
     };
-    // E^T fragments of one 32-column block: A operand of dQ^T[d][q] += E^T[d][e] dG^T[e][q]
-    auto et_frags = [&](Frag<T> (*f)[2], int eb) {
+    // packed relative table (me_rga_pack_rel): every fragment is one contiguous 1 KB image
+    auto e_frags = [&](Frag<T>* f, int eb) __attribute__((always_inline)) {      // E rows of block eb: A operand of G^T = E . Q^T
+#pragma unroll
+        for (int kk = 0; kk < C::KA; ++kk) frag_load(f[kk], Epk + (size_t)eb * C::PK + (kk * 64 + lane) * 8);
+    };
+    // E^T of block eb: A operand of dQ^T[d][q] += E^T[d][e] dG^T[e][q], contraction map e = 16 t + 8 h + j on both operands
+    auto et_frags = [&](Frag<T> (*f)[2], int eb) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < C::DB; ++i)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                // contraction map e = 16 t + 8 h + j on both operands (E^T here, dG^T from the ring): one 16-byte load
-                const T* ep = (ME_ABL == 9) ? ET_ + (size_t)eb * 32 * DH + ((i * 2 + t) * 64 + lane) * 8
-                                            : ET_ + (size_t)(i * 32 + a) * M + eb * 32 + 16 * t + 8 * h;
-                if (i * 32 + a < DH) frag_load(f[i][t], ep);
-                else frag_zero(f[i][t]);
-            }
+            for (int t = 0; t < 2; ++t) frag_load(f[i][t], Epk + (size_t)eb * C::PK + C::PK_B + ((i * 2 + t) * 64 + lane) * 8);
     };
-
     gload(0);
     const int eb0 = (M - 32 - q0) >> 5;
     Frag<T> ef[C::KA];
     Frag<T> etf[C::DB][2];
     if (wave_on) {
-        row_frags<T, DH>(ef, E + (size_t)(eb0 * 32 + a) * DH, true, h);
+        e_frags(ef, eb0);
         g_block(ef, eb0);
-        if (my_last_kt > 0) row_frags<T, DH>(ef, E + (size_t)((eb0 + 1) * 32 + a) * DH, true, h);
+        if (my_last_kt > 0) e_frags(ef, eb0 + 1);
     }
     const size_t ws_bh = (size_t)bh * Lp * Lp;
     sstore(0);
@@ -452,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
                 g_block(ef, eb_lo + 1);               // the next block's E rows are fetched after the softmax (register budget)
             } else if (!diag) {
                 g_block(ef, eb_lo + 1);
-                if (kt + 1 < my_last_kt) row_frags<T, DH>(ef, E + (size_t)((eb_lo + 2) * 32 + a) * DH, true, h);
+                if (kt + 1 < my_last_kt) e_frags(ef, eb_lo + 2);
             }
             if (ME_ABL != 3 && !(MAIN && ME_ABL == 8)) et_frags(etf, eb_lo);      // E^T block of this step's lo block: in flight during S / dP / softmax
             f32x16_t s, dp; acc_zero(s); acc_zero(dp);
@@ -519,8 +526,7 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
             };
             const size_t tile_off = ws_bh + ws_row(k0, q0 >> 5, Lp);
             if constexpr (MAIN && ME_ABL != 8)      // issued BEFORE the tile stores: in-order vmcnt then never makes the next step wait for them
-                row_frags<T, DH>(ef, (ME_ABL == 9) ? E + (size_t)min(eb_lo + 2, (M >> 5) - 1) * 32 * DH + lane * 8 - h * 8
-                                                   : E + (size_t)(min(eb_lo + 2, (M >> 5) - 1) * 32 + a) * DH, true, h);   // clamped: unused past the diagonal
+                e_frags(ef, min(eb_lo + 2, (M >> 5) - 1));          // clamped: unused past the diagonal
             if (ME_ABL != 1) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * h) * LDX + a] = ET<T>::from_f(dp[r]);
@@ -872,24 +878,51 @@ __global__ __launch_bounds__(256) void rga_decode_kernel(const T* __restrict__ q
 }
 
 
+// =====================================================================================
+// relative table E [M][DH] -> packed fragment images (what rga_fwd / rga_bwd_q load with one 16-byte chunk per lane)
+// =====================================================================================
+// block eb (32 rows of E), PK elements:   image kk < KA      : lane (a, h) holds E[32 eb + a][16 kk + 8 h + 0..7]
+//                                         image KA + 2 i + t : lane (a, h) holds E[32 eb + 16 t + 8 h + 0..7][32 i + a]
+// (zero where 32 i + a >= DH).  The multi-tensor weight refresh (me_cast_transpose_multi, mode 1) writes the same layout.
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void rel_pack_kernel(const T* __restrict__ E, T* __restrict__ Epk) {
+    using C = ACfg<T, DH>;
+    const int eb = blockIdx.x;
+    for (int idx = threadIdx.x; idx < C::PK; idx += 256) {
+        const int img = idx >> 9, lane = (idx >> 3) & 63, j = idx & 7, a = lane & 31, h = lane >> 5;
+        T v = ET<T>::from_f(0.f);
+        if (img < C::KA) v = E[(size_t)(eb * 32 + a) * DH + img * 16 + h * 8 + j];
+        else {
+            const int i = (img - C::KA) >> 1, t = (img - C::KA) & 1;
+            if (i * 32 + a < DH) v = E[(size_t)(eb * 32 + 16 * t + 8 * h + j) * DH + i * 32 + a];
+        }
+        Epk[(size_t)eb * C::PK + idx] = v;
+    }
+}
+template <typename T, int DH>
+int pack_launch(const void* E, void* Epk, int M, hipStream_t st) {
+    rel_pack_kernel<T, DH><<<M / 32, 256, 0, st>>>((const T*)E, (T*)Epk);
+    return me_launch_status();
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <typename T, int DH>
-int fwd_launch(const void* qkv, const void* E, const uint8_t* key_pad, void* out, float* lse, int B, int L, int H, int M,
+int fwd_launch(const void* qkv, const void* Epk, const uint8_t* key_pad, void* out, float* lse, int B, int L, int H, int M,
                hipStream_t st) {
     const int nqb = (L + 127) / 128;
     const float scale = 1.f / sqrtf((float)DH);
-    rga_fwd_kernel<T, DH><<<B * H * nqb, 256, 0, st>>>((const T*)qkv, (const T*)E, key_pad, (T*)out, lse, B, L, H, M, scale);
+    rga_fwd_kernel<T, DH><<<B * H * nqb, 256, 0, st>>>((const T*)qkv, (const T*)Epk, key_pad, (T*)out, lse, B, L, H, M, scale);
     return me_launch_status();
 }
 
 template <typename T, int DH>
-int bwd_launch(const void* qkv, const void* E, const void* ET_, const uint8_t* key_pad, const void* out, const float* lse,
+int bwd_launch(const void* qkv, const void* Epk, const uint8_t* key_pad, const void* out, const float* lse,
                const void* dout, void* dqkv, float* dE, float* delta_ws, void* PT, void* dST, int B, int L,
                int Lp, int H, int M, hipStream_t st) {
     const int nqb = (L + 127) / 128;
     const float scale = 1.f / sqrtf((float)DH);
-    rga_bwd_q_kernel<T, DH><<<B * H * nqb, 256, 0, st>>>((const T*)qkv, (const T*)E, (const T*)ET_, key_pad, (const T*)out, lse,
+    rga_bwd_q_kernel<T, DH><<<B * H * nqb, 256, 0, st>>>((const T*)qkv, (const T*)Epk, key_pad, (const T*)out, lse,
                                                         (const T*)dout, (T*)dqkv, delta_ws, (T*)PT, (T*)dST, B, L, Lp,
                                                         H, M, scale);
     int rc = me_launch_status();
@@ -931,27 +964,36 @@ int dec_launch(const void* qkv_new, void* kc, void* vc, const void* E, const uin
 
 extern "C" {
 
-int me_rga_fwd(const void* qkv, const void* E, const uint8_t* key_pad, void* out, float* lse, int B, int L, int H, int dh,
-               int M, int dtype, void* stream) {
+int me_rga_pack_rel(const void* E, void* Epk, int M, int dh, int dtype, void* stream) {
     me_clear_error();
-    if (!qkv || !E || !out || !lse) return ME_ERR_NULL;
-    if (B <= 0 || L <= 0 || H <= 0 || L > M || (M & 31)) return ME_ERR_BAD_SHAPE;
-    if (!aligned16(qkv) || !aligned16(E) || !aligned16(out)) return ME_ERR_ALIGNMENT;
+    if (!E || !Epk) return ME_ERR_NULL;
+    if (M <= 0 || (M & 31)) return ME_ERR_BAD_SHAPE;
+    if (!aligned16(Epk)) return ME_ERR_ALIGNMENT;
     hipStream_t st = (hipStream_t)stream;
-    ME_ATTN_DISPATCH((fwd_launch<T, DH>(qkv, E, key_pad, out, lse, B, L, H, M, st)))
+    ME_ATTN_DISPATCH((pack_launch<T, DH>(E, Epk, M, st)))
 }
 
-int me_rga_bwd(const void* qkv, const void* E, const void* ET_, const uint8_t* key_pad, const void* out, const float* lse,
+int me_rga_fwd(const void* qkv, const void* Epk, const uint8_t* key_pad, void* out, float* lse, int B, int L, int H, int dh,
+               int M, int dtype, void* stream) {
+    me_clear_error();
+    if (!qkv || !Epk || !out || !lse) return ME_ERR_NULL;
+    if (B <= 0 || L <= 0 || H <= 0 || L > M || (M & 31)) return ME_ERR_BAD_SHAPE;
+    if (!aligned16(qkv) || !aligned16(Epk) || !aligned16(out)) return ME_ERR_ALIGNMENT;
+    hipStream_t st = (hipStream_t)stream;
+    ME_ATTN_DISPATCH((fwd_launch<T, DH>(qkv, Epk, key_pad, out, lse, B, L, H, M, st)))
+}
+
+int me_rga_bwd(const void* qkv, const void* Epk, const uint8_t* key_pad, const void* out, const float* lse,
                const void* dout, void* dqkv, float* dE, float* delta_ws, void* PT, void* dST, int B, int L,
                int Lp, int H, int dh, int M, int dtype, void* stream) {
     me_clear_error();
-    if (!qkv || !E || !ET_ || !out || !lse || !dout || !dqkv || !dE || !delta_ws || !PT || !dST) return ME_ERR_NULL;
+    if (!qkv || !Epk || !out || !lse || !dout || !dqkv || !dE || !delta_ws || !PT || !dST) return ME_ERR_NULL;
     if (B <= 0 || L <= 0 || H <= 0 || L > M || (M & 31) || (Lp & 31) || Lp < L || Lp > M) return ME_ERR_BAD_SHAPE;
-    if (!aligned16(qkv) || !aligned16(E) || !aligned16(ET_) || !aligned16(out) || !aligned16(dout) || !aligned16(dqkv) ||
+    if (!aligned16(qkv) || !aligned16(Epk) || !aligned16(out) || !aligned16(dout) || !aligned16(dqkv) ||
         !aligned16(PT) || !aligned16(dST))
         return ME_ERR_ALIGNMENT;
     hipStream_t st = (hipStream_t)stream;
-    ME_ATTN_DISPATCH((bwd_launch<T, DH>(qkv, E, ET_, key_pad, out, lse, dout, dqkv, dE, delta_ws, PT, dST, B, L, Lp, H, M,
+    ME_ATTN_DISPATCH((bwd_launch<T, DH>(qkv, Epk, key_pad, out, lse, dout, dqkv, dE, delta_ws, PT, dST, B, L, Lp, H, M,
                                         st)))
 }
 

@@ -935,6 +935,22 @@ __global__ __launch_bounds__(256) void cast_transpose_multi_kernel(const me_ct_d
     }
     if (!dstT) return;
     __syncthreads();
+    if (dsc.mode == ME_CT_PACK_REL) {
+        // relative table: this 32 x 32 tile (row block eb, column block ib) holds two row images (kk = 2 ib, 2 ib + 1)
+        // and the two transposed images (ib, t = 0 / 1) of the packed block -- layout of rel_pack_kernel (me_attn.hip)
+        const int KA = cols / 16, DB = (cols + 31) / 32, eb = r0 >> 5, ib = c0 >> 5;
+        T* blk = dstT + (size_t)eb * (KA + 2 * DB) * 512;
+        const int img = (threadIdx.x >> 6) & 1, lane = threadIdx.x & 63, a = lane & 31, h = lane >> 5, j0 = (threadIdx.x >> 7) * 4;
+        if (2 * ib + img < KA) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                blk[((2 * ib + img) * 64 + lane) * 8 + j0 + j] = ET<T>::from_f(tile[a][img * 16 + h * 8 + j0 + j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            blk[(KA + 2 * ib + img) * 512 + lane * 8 + j0 + j] = ET<T>::from_f(tile[16 * img + 8 * h + j0 + j][a]);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = c0 + ty + i * 8, r = r0 + tx;    // dstT[c][r]

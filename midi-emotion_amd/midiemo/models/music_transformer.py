@@ -271,7 +271,8 @@ class MusicTransformerHIP(nn.Module):
                 L = {}
                 if dt != torch.float32:
                     L.update(Wqkv=buf(3 * d, d), Wo=buf(d, d), W1=buf(di, d), W2=buf(d, di), E=buf(M, dh))
-                L.update(WqkvT=buf(d, 3 * d), WoT=buf(d, d), W1T=buf(d, di), W2T=buf(di, d), ET=buf(dh, M))
+                L.update(WqkvT=buf(d, 3 * d), WoT=buf(d, d), W1T=buf(d, di), W2T=buf(di, d),
+                         Epk=torch.zeros(ops.rel_pack_numel(M, dh), dtype=dt, device=dev))
                 layers.append(L)
             head = {"WfT": buf(d, V, _round_up(V, 64))}
             if dt != torch.float32:
@@ -288,7 +289,10 @@ class MusicTransformerHIP(nn.Module):
                 srcs = {"Wqkv": wqkv, "Wo": self._pview(f, p + "rga.fc.weight"), "W1": self._pview(f, p + "FFN_pre.weight"),
                         "W2": self._pview(f, p + "FFN_suf.weight"), "E": self._pview(f, p + "rga.E")}
                 for k, src in srcs.items():
-                    items.append((src, L.get(k) if dt != torch.float32 else None, L[k + "T"]))
+                    if k == "E":      # relative table: natural cast copy (decode) + packed fragment images (fwd / bwd)
+                        items.append((src, L.get(k) if dt != torch.float32 else None, L["Epk"], 1))
+                    else:
+                        items.append((src, L.get(k) if dt != torch.float32 else None, L[k + "T"]))
                     if dt == torch.float32:
                         L[k] = src
                 ob, _, _ = self._slices[p + "rga.Wq.bias"]
@@ -401,7 +405,7 @@ class MusicTransformerHIP(nn.Module):
             y = ws.h[(i + 1) % nh if not save else i + 1]
             p = f"enc_layers.{i}."
             ops.gemm_nt(x, W["Wqkv"], Lw.qkv, bias=W["bqkv"], M=T, N=3 * d, K=d, dtype=dt)
-            ops.rga_fwd(Lw.qkv, W["E"], ws.key_pad, Lw.att, Lw.lse, B, Lm, H, dh, M)
+            ops.rga_fwd(Lw.qkv, W["Epk"], ws.key_pad, Lw.att, Lw.lse, B, Lm, H, dh, M)
             ops.gemm_nt(Lw.att, W["Wo"], ws.tmp, bias=self._pview(f, p + "rga.fc.bias"), M=T, N=d, K=d, dtype=dt)
             ops.resid_ln_fwd(x, ws.tmp, self._pview(f, p + "layernorm1.weight"), self._pview(f, p + "layernorm1.bias"),
                              Lw.o1, Lw.s1, Lw.st1, T, d, self.LN_EPS, p_drop, seed, 1 + 2 * i)
@@ -494,7 +498,7 @@ class MusicTransformerHIP(nn.Module):
             wgrad("dC2", ws.dC2, Lw.att, gv(p + "rga.fc.weight"), gv(p + "rga.fc.bias"), T=T, N=d, K=d, dtype=dt)
             ops.gemm_nt(ws.dC2, W["WoT"], ws.dA, M=T, N=d, K=d, dtype=dt)                        # d(att)
             reuse("dqkv")
-            ops.rga_bwd(Lw.qkv, W["E"], W["ET"], ws.key_pad, Lw.att, Lw.lse, ws.dA, ws.dqkv, gv(p + "rga.E"),
+            ops.rga_bwd(Lw.qkv, W["Epk"], ws.key_pad, Lw.att, Lw.lse, ws.dA, ws.dqkv, gv(p + "rga.E"),
                         ws.delta, ws.PT, ws.dST, B, Lm, ws.Lp, H, dh, M)
             o, _, _ = self._slices[p + "rga.Wq.weight"]
             ob, _, _ = self._slices[p + "rga.Wq.bias"]

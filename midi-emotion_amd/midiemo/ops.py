@@ -49,16 +49,19 @@ def cast_transpose_multi(desc_dev, n_tensors, total_tiles, dtype):
 
 
 def make_ct_desc(items, device):
-    """items: list of (src f32 [rows, cols], dst or None, dstT or None) -> (desc uint8 device tensor, n, total_tiles).
-    Layout = struct me_ct_desc {const float* src; void* dst; void* dstT; int32 rows, cols, ld_dst, ld_dstT,
-    tile_begin, pad;} (48 bytes)."""
+    """items: list of (src f32 [rows, cols], dst or None, dstT or None[, mode]) -> (desc uint8 device tensor, n,
+    total_tiles).  Layout = struct me_ct_desc {const float* src; void* dst; void* dstT; int32 rows, cols, ld_dst,
+    ld_dstT, tile_begin, mode;} (48 bytes)."""
     import struct
     blob, tiles = b"", 0
-    for src, dst, dstT in items:
+    for it in items:
+        src, dst, dstT = it[:3]
+        mode = it[3] if len(it) > 3 else 0           # 1 (ME_CT_PACK_REL): dstT = packed relative table (1-D)
         rows, cols = src.shape
         blob += struct.pack("<QQQiiiiii", src.data_ptr(), dst.data_ptr() if dst is not None else 0,
                             dstT.data_ptr() if dstT is not None else 0, rows, cols,
-                            dst.stride(0) if dst is not None else 0, dstT.stride(0) if dstT is not None else 0, tiles, 0)
+                            dst.stride(0) if dst is not None else 0,
+                            dstT.stride(0) if (dstT is not None and mode == 0) else 0, tiles, mode)
         tiles += ((rows + 31) // 32) * ((cols + 31) // 32)
     t = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
     return t, len(items), tiles
@@ -112,13 +115,29 @@ def gemm_tn_acc(A, B, dW, dbias=None, T=None, N=None, K=None, dtype=None, flags=
                                T, N, K, int(flags), _code(dtype), _stream()), "me_gemm_tn_acc")
 
 
-def rga_fwd(qkv, E, key_pad, out, lse, B, L, H, dh, M):
-    check(lib().me_rga_fwd(_ptr(qkv), _ptr(E), _ptr(key_pad), _ptr(out), _ptr(lse), B, L, H, dh, M,
+def rel_pack_numel(M, dh):
+    """Elements of the packed relative table (me_rga_pack_rel): per 32-row block dh/16 row images + 2*ceil(dh/32)
+    transposed images of 512 elements."""
+    return (M // 32) * (dh // 16 + 2 * ((dh + 31) // 32)) * 512
+
+
+def rga_pack_rel(E, out=None):
+    """E [M, dh] (compute dtype) -> packed fragment images read by rga_fwd / rga_bwd."""
+    M, dh = E.shape
+    if out is None:
+        out = torch.empty(rel_pack_numel(M, dh), dtype=E.dtype, device=E.device)
+    check(lib().me_rga_pack_rel(_ptr(E), _ptr(out), M, dh, _code(E.dtype), _stream()), "me_rga_pack_rel")
+    return out
+
+
+def rga_fwd(qkv, Epk, key_pad, out, lse, B, L, H, dh, M):
+    """Epk = rga_pack_rel(E)."""
+    check(lib().me_rga_fwd(_ptr(qkv), _ptr(Epk), _ptr(key_pad), _ptr(out), _ptr(lse), B, L, H, dh, M,
                            _code(qkv.dtype), _stream()), "me_rga_fwd")
 
 
-def rga_bwd(qkv, E, ET, key_pad, out, lse, dout, dqkv, dE, delta_ws, PT, dST, B, L, Lp, H, dh, M):
-    check(lib().me_rga_bwd(_ptr(qkv), _ptr(E), _ptr(ET), _ptr(key_pad), _ptr(out), _ptr(lse), _ptr(dout), _ptr(dqkv),
+def rga_bwd(qkv, Epk, key_pad, out, lse, dout, dqkv, dE, delta_ws, PT, dST, B, L, Lp, H, dh, M):
+    check(lib().me_rga_bwd(_ptr(qkv), _ptr(Epk), _ptr(key_pad), _ptr(out), _ptr(lse), _ptr(dout), _ptr(dqkv),
                            _ptr(dE), _ptr(delta_ws), _ptr(PT), _ptr(dST), B, L, Lp, H, dh, M,
                            _code(qkv.dtype), _stream()), "me_rga_bwd")
 

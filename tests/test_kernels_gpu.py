@@ -361,16 +361,16 @@ def run_attn(ops, dtype, q, k, v, E, dO, pad, backward=True):
     kp = pad.to(torch.uint8).to(DEV) if pad is not None else None
     out = torch.full((B, L, H, dh), float("nan"), dtype=dtype, device=DEV)
     lse = torch.empty(B, H, L, dtype=torch.float32, device=DEV)
-    ops.rga_fwd(qkv, Ed, kp, out, lse, B, L, H, dh, M)
+    Epk = ops.rga_pack_rel(Ed)
+    ops.rga_fwd(qkv, Epk, kp, out, lse, B, L, H, dh, M)
     res = {"O": out.permute(0, 2, 1, 3).float().cpu(), "lse": lse.cpu()}
     if backward:
         dout = to_tok(dO).contiguous().to(dtype).to(DEV)
         dqkv = torch.full_like(qkv, float("nan"))
         dE = torch.zeros(M, dh, dtype=torch.float32, device=DEV)
-        ET = Ed.t().contiguous()
         delta = torch.empty(B, H, L, dtype=torch.float32, device=DEV)
         PT, dST = (torch.zeros(B * H, Lp, Lp, dtype=dtype, device=DEV) for _ in range(2))
-        ops.rga_bwd(qkv, Ed, ET, kp, out, lse, dout, dqkv, dE, delta, PT, dST, B, L, Lp, H, dh, M)
+        ops.rga_bwd(qkv, Epk, kp, out, lse, dout, dqkv, dE, delta, PT, dST, B, L, Lp, H, dh, M)
         g = dqkv.float().cpu().permute(2, 0, 3, 1, 4)   # [3,B,H,L,dh]
         res.update(dq=g[0], dk=g[1], dv=g[2], dE=dE.cpu())
     return res
@@ -458,3 +458,37 @@ def test_rga_decode_step_matches_full(ops, dtype, dh):
         ops.rga_decode_step(qkv_new, kc, vc, Ed, None, 0, out, B, H, dh, M, Mc, t)
         e = relerr(out, ref[:, :, t])
         assert e < tol(dtype, 2e-5, 1.5e-2), (t, e)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dh", [32, 48, 64])
+def test_rel_pack_layout_and_refresh_path(ops, dtype, dh):
+    """me_rga_pack_rel against its definition (include/midiemo.h) and against the multi-tensor refresh (mode 1), bit-exact."""
+    M = 96
+    g = torch.Generator().manual_seed(5)
+    E32 = torch.randn(M, dh, generator=g)
+    Ed = E32.to(dtype).to(DEV)
+    pk = ops.rga_pack_rel(Ed).cpu()
+    KA, DB = dh // 16, (dh + 31) // 32
+    ref = torch.zeros(M // 32, KA + 2 * DB, 64, 8, dtype=dtype)
+    Eh = Ed.cpu()
+    for eb in range(M // 32):
+        for lane in range(64):
+            a, h = lane & 31, lane >> 5
+            for kk in range(KA):
+                ref[eb, kk, lane] = Eh[eb * 32 + a, kk * 16 + h * 8: kk * 16 + h * 8 + 8]
+            for i in range(DB):
+                for t in range(2):
+                    if i * 32 + a < dh:
+                        ref[eb, KA + 2 * i + t, lane] = Eh[eb * 32 + 16 * t + 8 * h: eb * 32 + 16 * t + 8 * h + 8, i * 32 + a]
+    assert torch.equal(pk.view_as(ref), ref)
+    # refresh path: f32 master -> (cast copy, packed images) in one multi-tensor launch
+    src = E32.to(DEV).contiguous()
+    dst = torch.zeros(M, dh, dtype=dtype, device=DEV) if dtype != torch.float32 else None
+    pk2 = torch.zeros(ops.rel_pack_numel(M, dh), dtype=dtype, device=DEV)
+    desc, n, tiles = ops.make_ct_desc([(src, dst, pk2, 1)], DEV)
+    ops.cast_transpose_multi(desc, n, tiles, dtype)
+    assert torch.equal(pk2.cpu(), pk)
+    if dst is not None:
+        assert torch.equal(dst.cpu(), Eh)

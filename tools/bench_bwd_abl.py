@@ -12,10 +12,10 @@ def timeit(fn, iters=int(os.environ.get("ITERS", 10)), warm=int(os.environ.get("
 dev, dt = "cuda", torch.bfloat16
 B, L, H, dh, M = 32, 1024, 8, 64, 2048
 Lp = L
-qkv = torch.randn(B, L, 3, H, dh, device=dev).to(dt); E = torch.randn(M, dh, device=dev).to(dt); ET = E.t().contiguous()
+qkv = torch.randn(B, L, 3, H, dh, device=dev).to(dt); E = torch.randn(M, dh, device=dev).to(dt); Epk = ops.rga_pack_rel(E)
 out = torch.randn(B, L, H, dh, device=dev).to(dt); lse = torch.randn(B, H, L, device=dev).abs() + 5
 dout = torch.randn(B, L, H, dh, device=dev).to(dt); dqkv = torch.empty_like(qkv); dE = torch.zeros(M, dh, device=dev)
 delta = torch.empty(B, H, L, device=dev); kp = torch.zeros(B, L, dtype=torch.uint8, device=dev)
 PT, dST = (torch.zeros(B * H, Lp, Lp, device=dev, dtype=dt) for _ in range(2))
-t = timeit(lambda: ops.rga_bwd(qkv, E, ET, kp, out, lse, dout, dqkv, dE, delta, PT, dST, B, L, Lp, H, dh, M))
+t = timeit(lambda: ops.rga_bwd(qkv, Epk, kp, out, lse, dout, dqkv, dE, delta, PT, dST, B, L, Lp, H, dh, M))
 print("%s rga_bwd total %.1f us" % (os.environ.get("TAG", ""), t))

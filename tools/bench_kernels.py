@@ -38,7 +38,7 @@ def main():
         Lp = ((L + 31) // 32) * 32
         qkv = torch.randn(B, L, 3, H, dh, device=dev).to(dt)
         E = torch.randn(M, dh, device=dev).to(dt)
-        ET = E.t().contiguous()
+        Epk = ops.rga_pack_rel(E)
         out = torch.empty(B, L, H, dh, device=dev, dtype=dt)
         lse = torch.empty(B, H, L, device=dev)
         dout = torch.randn(B, L, H, dh, device=dev).to(dt)
@@ -48,9 +48,9 @@ def main():
         PT, dST = (torch.zeros(B * H, Lp, Lp, device=dev, dtype=dt) for _ in range(2))
         kp = torch.zeros(B, L, dtype=torch.uint8, device=dev)
         flop = 3 * 2 * B * H * dh * L * (L + 1) / 2
-        t = timeit(lambda: ops.rga_fwd(qkv, E, kp, out, lse, B, L, H, dh, M), a.iters)
+        t = timeit(lambda: ops.rga_fwd(qkv, Epk, kp, out, lse, B, L, H, dh, M), a.iters)
         print("rga_fwd          %9.1f us  %7.1f TF (causal-discounted 3 contractions)" % (t, flop / t / 1e6))
-        t = timeit(lambda: ops.rga_bwd(qkv, E, ET, kp, out, lse, dout, dqkv, dE, delta, PT, dST, B, L, Lp, H, dh, M),
+        t = timeit(lambda: ops.rga_bwd(qkv, Epk, kp, out, lse, dout, dqkv, dE, delta, PT, dST, B, L, Lp, H, dh, M),
                    a.iters)
         print("rga_bwd (3 krn)  %9.1f us  %7.1f TF (2x fwd flops)" % (t, 2 * flop / t / 1e6))
     if "chunk" in a.what:
@@ -58,7 +58,7 @@ def main():
         Lp = ((L + 31) // 32) * 32
         qkv = torch.randn(B, L, 3, H, dh, device=dev).to(dt)
         E = torch.randn(M, dh, device=dev).to(dt)
-        ET = E.t().contiguous()
+        Epk = ops.rga_pack_rel(E)
         out = torch.randn(B, L, H, dh, device=dev).to(dt)
         lse = torch.randn(B, H, L, device=dev).abs() + 5
         dout = torch.randn(B, L, H, dh, device=dev).to(dt)
@@ -68,14 +68,14 @@ def main():
         kp = torch.zeros(B, L, dtype=torch.uint8, device=dev)
         PT, dST = (torch.zeros(B * H, Lp, Lp, device=dev, dtype=dt) for _ in range(2))
         dE = torch.zeros(M, dh, device=dev)
-        t = timeit(lambda: ops.rga_bwd(qkv, E, ET, kp, out, lse, dout, dqkv, dE, delta, PT, dST, B, L, Lp, H, dh, M), a.iters)
+        t = timeit(lambda: ops.rga_bwd(qkv, Epk, kp, out, lse, dout, dqkv, dE, delta, PT, dST, B, L, Lp, H, dh, M), a.iters)
         print("rga_bwd one call, workspace %4d MB x3      %9.1f us" % (PT.numel() * 2 // 2**20, t))
         dE1 = torch.zeros(M, dh, device=dev)
-        ops.rga_bwd(qkv, E, ET, kp, out, lse, dout, dqkv, dE1, delta, PT, dST, B, L, Lp, H, dh, M)
+        ops.rga_bwd(qkv, Epk, kp, out, lse, dout, dqkv, dE1, delta, PT, dST, B, L, Lp, H, dh, M)
         for Bc in (16, 8, 4, 2, 1):
             def run(dq, dEx):
                 for b0 in range(0, B, Bc):
-                    ops.rga_bwd(qkv[b0:b0 + Bc], E, ET, kp[b0:b0 + Bc], out[b0:b0 + Bc], lse[b0:b0 + Bc], dout[b0:b0 + Bc],
+                    ops.rga_bwd(qkv[b0:b0 + Bc], Epk, kp[b0:b0 + Bc], out[b0:b0 + Bc], lse[b0:b0 + Bc], dout[b0:b0 + Bc],
                                 dq[b0:b0 + Bc], dEx, delta[b0:b0 + Bc], PT, dST, Bc, L, Lp, H, dh, M)
             t = timeit(lambda: run(dqkv2, dE), a.iters)
             dE2 = torch.zeros(M, dh, device=dev)
