@@ -527,7 +527,45 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
             const size_t tile_off = ws_bh + ws_row(k0, q0 >> 5, Lp);
             if constexpr (MAIN && ME_ABL != 8)      // issued BEFORE the tile stores: in-order vmcnt then never makes the next step wait for them
                 e_frags(ef, min(eb_lo + 2, (M >> 5) - 1));          // clamped: unused past the diagonal
-            if (ME_ABL != 1) {
+            if constexpr (sizeof(T) == 2) {
+                // 16-bit tier: the accumulator rows go to LDS in their NATURAL [q][key] order (4 x ds_write_b64: the lane's
+                // 4 consecutive keys of each register quad) and come back transposed through ds_read_b64_tr_b16 -- 8 LDS
+                // instructions per tile instead of 16 two-byte scatters + 2 reads, and two 16-byte stores that each write 16
+                // complete 64-byte tile rows.  Chunk slot XOR (row >> 3) & 1: the 16-lane write groups hit 16 distinct bank pairs.
+                char* stgb = reinterpret_cast<char*>(stg);
+                constexpr int LDB = LDG2 * 4;                                         // staging row stride (bytes)
+                const int gidx = lane >> 4, l16 = lane & 15;
+                auto put_tile = [&](const f32x16_t& v) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        st4<T>(reinterpret_cast<T*>(stgb + a * LDB + (((2 * g + h) ^ ((a >> 3) & 1)) << 3)), v[4 * g], v[4 * g + 1], v[4 * g + 2],
+                               v[4 * g + 3]);
+                };
+                // lane (group gidx, l16) supplies the chunk (row 8 gidx + 4 s + l16 / 4, keys 16 kh + 4 (l16 % 4) ..) and receives
+                // key 16 kh + l16, queries 8 gidx + 4 s .. + 3: with s = 0, 1 that is 16 contiguous bytes of tile row `key`
+                auto flush_tr = [&](T* gdst) __attribute__((always_inline)) {
+                    typedef short v4s __attribute__((ext_vector_type(4)));
+#pragma unroll
+                    for (int kh = 0; kh < 2; ++kh) {
+                        v4s x[2];
+#pragma unroll
+                        for (int s_ = 0; s_ < 2; ++s_) {
+                            const char* src = stgb + (8 * gidx + 4 * s_ + (l16 >> 2)) * LDB + (((kh * 4 + (l16 & 3)) ^ (gidx & 1)) << 3);
+                            x[s_] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)src);
+                        }
+                        chunk16 c;
+                        reinterpret_cast<v4s*>(&c)[0] = x[0];
+                        reinterpret_cast<v4s*>(&c)[1] = x[1];
+                        st_chunk(gdst + (size_t)(kh * 16 + l16) * (ME_WS_LAYOUT == 0 ? Lp : 32) + 8 * gidx, c);
+                    }
+                };
+                if (ME_ABL != 1) {
+                    put_tile(dp);
+                    flush_tr(PT + tile_off);
+                    put_tile(s);
+                    flush_tr(dST + tile_off);
+                }
+            } else if (ME_ABL != 1) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * h) * LDX + a] = ET<T>::from_f(dp[r]);
                 flush_tile(PT + tile_off);
