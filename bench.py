@@ -244,7 +244,7 @@ def main():
                                "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS if args.compute_dtype == "bf16" else 157.3,
                                "unit": "TFLOP/s",
                                "frac": round(ach / (PEAK_BF16_TFLOPS if args.compute_dtype == "bf16" else 157.3), 4),
-                               "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC pass, profiles/r01_e_hbm_traffic.txt)",
+                               "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC pass, profiles/r01_f_hbm_traffic.txt)",
                                "algorithmic_bytes_per_launch": int(gp.alg_bytes), "launches_per_step": n // 3,
                                "avg_launch_us": round(1000.0 * ms / n, 2),
                                "gemm_nt_ms_per_step": round(ms / 3, 3),
