@@ -68,3 +68,54 @@ def test_train_cli_grad_accumulation_matches_big_batch():
     FusedAdamW(m1, lr=1e-3).step()
     FusedAdamW(m2, lr=1e-3).step()
     assert float((m1.flat_params - m2.flat_params).abs().max()) < 1e-5
+
+
+def _make_song_collection(root, n_songs=12, seed=0):
+    """A tiny collection in the reference's on-disk format: <root>/songs/*.pt ({"bars": [int16 [n, 2]]}), <root>/maps.pt
+    and a feature table with the columns data/preprocess_features.py reads."""
+    import numpy as np
+    from midiemo import data as D, vocab
+    rng = np.random.default_rng(seed)
+    maps = vocab.get_maps()
+    maps["transposable_event_inds"] = D.transposable_event_inds(maps)
+    os.makedirs(os.path.join(root, "songs"))
+    torch.save(maps, os.path.join(root, "maps.pt"))
+    ev = maps["event2idx"]
+    ins = ["DRUMS", "GUITAR", "BASS", "PIANO", "STRINGS"]
+    rows = []
+    for s in range(n_songs):
+        bars = []
+        for _ in range(24):
+            r = []
+            for _ in range(40):
+                if rng.random() < 0.3:
+                    r.append((ev["TIMESHIFT"], int(rng.integers(1, 126)) * 8))
+                else:
+                    r.append((ev["%s_%s" % ("ON" if rng.random() < 0.5 else "OFF", ins[int(rng.integers(0, 5))])],
+                              int(rng.integers(30, 100))))
+            bars.append(torch.tensor(r, dtype=torch.int16))
+        torch.save({"bars": bars}, os.path.join(root, "songs", "s%02d.pt" % s))
+        rows.append("s%02d,%.4f,%.4f,5,True" % (s, 0.1 + 0.8 * rng.random(), 1.0 + rng.random()))
+    with open(os.path.join(root, "features.csv"), "w") as fh:
+        fh.write("file,valence,note_density_per_instrument,n_instruments,is_matched\n" + "\n".join(rows) + "\n")
+    return os.path.join(root, "songs"), os.path.join(root, "features.csv")
+
+
+@pytest.mark.parametrize("mode", ["continuous_concat", "discrete_token", "continuous_token"])
+def test_train_cli_real_data_path(tmp_path, capsys, mode):
+    """--feature_file switches train.py to the reference's data path (feature table -> Loader -> filter_collate)."""
+    import train
+    folder, csv_file = _make_song_collection(str(tmp_path / "lpd"))
+    argv = ["--conditioning", mode, "--n_layer", "1", "--d_model", "128", "--n_head", "2", "--d_inner", "256",
+            "--d_condition", "32", "--tgt_len", "128", "--batch_size", "4", "--lr", "1e-3", "--max_step", "12", "--log_step", "6",
+            "--eval_step", "12", "--max_eval_step", "2", "--work_dir", str(tmp_path / "out"), "--seed", "3", "--num_workers", "0",
+            "--data_folder", folder, "--feature_file", csv_file]
+    train.main(argv)
+    out = capsys.readouterr().out
+    assert "Data loader lengths" in out
+    losses = [float(l.split("| loss")[1].split("|")[0]) for l in out.splitlines() if "| loss" in l]
+    assert len(losses) == 2 and all(0 < v < 8 for v in losses) and losses[1] < losses[0], losses
+    assert "valid loss" in out
+    run = os.listdir(tmp_path / "out")[0]
+    maps = torch.load(tmp_path / "out" / run / "mappings.pt", weights_only=False)
+    assert len(maps["tuple2idx"]) == (1017 if mode == "discrete_token" else 1007)      # 12 songs cover all 2 x 5 bins

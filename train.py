@@ -65,7 +65,15 @@ def parse_args(argv=None):
     p.add_argument("--overwrite_lr", action="store_true")
     p.add_argument("--regression", action="store_true")
     # ---- additions
-    p.add_argument("--synthetic", action="store_true", default=True, help="synthetic token batches (SURVEY 8d)")
+    p.add_argument("--synthetic", action="store_true", default=True, help="synthetic token batches (SURVEY 8d); the default")
+    # real data (config.py:10-12, train.py:45-93): used when --feature_file is given
+    p.add_argument("--data_folder", type=str, default="../data_files/lpd_5/lpd_5_full_transposable")
+    p.add_argument("--feature_file", type=str, default=None,
+                   help="CSV of per-song features (the reference hard-codes ../data_files/features/pianoroll/"
+                        "full_dataset_features_summarized.csv); giving it switches from synthetic to real batches")
+    p.add_argument("--full_dataset", action="store_true", help="also train on songs without emotion labels")
+    p.add_argument("--always_use_discrete_condition", action="store_true")
+    p.add_argument("--num_workers", type=int, default=4)
     p.add_argument("--weight_decay", type=float, default=0.0, help="decoupled decay; 0 == reference Adam")
     args = p.parse_args(argv)
     if args.conditioning != "continuous_concat":
@@ -124,7 +132,40 @@ def main(argv=None):
     from midiemo.vocab import get_maps
 
     torch.manual_seed(args.seed if args.seed > 0 else 0)
-    maps = get_maps(n_emotion_bins=args.n_emotion_bins if args.conditioning == "discrete_token" else 0)
+    train_loader = test_loader = None
+    if args.feature_file:
+        # real data: feature table -> splits -> per-song bar files (train.py:45-93); one shard of the songs per rank
+        import random as _random
+        import numpy as _np
+        from midiemo.data import Loader, filter_collate, preprocess_features
+        if args.seed > 0:
+            _random.seed(args.seed + rank)
+            _np.random.seed(args.seed + rank)
+        n_bins = args.n_emotion_bins if args.conditioning == "discrete_token" else None
+        train_feats, test_feats = preprocess_features(args.feature_file, n_bins=n_bins,
+                                                      conditional=args.conditioning != "none",
+                                                      use_labeled_only=not args.full_dataset)
+        kw = dict(always_use_discrete_condition=args.always_use_discrete_condition)
+        train_ds = Loader(args.data_folder, train_feats, args.tgt_len, args.conditioning, **kw)
+        test_ds = Loader(args.data_folder, test_feats, args.tgt_len, args.conditioning, **kw)
+        if args.conditioning == "discrete_token":
+            # the reference takes the vocabulary from the test split alone (train.py:76-80), which silently assumes that
+            # every emotion bin occurs there; use the union of both splits so that small collections train too
+            syms = sorted({s[k] for ds in (train_ds, test_ds) for s in ds.data for k in ("valence", "arousal")})
+            train_ds.set_extra_tokens(syms)
+            test_ds.set_extra_tokens(syms)
+        maps = test_ds.get_maps()
+
+        def make_loader(ds, shuffle):
+            sampler = torch.utils.data.distributed.DistributedSampler(ds, world, rank, shuffle=shuffle) if world > 1 else None
+            return torch.utils.data.DataLoader(ds, args.batch_size, shuffle=shuffle and sampler is None, sampler=sampler,
+                                               num_workers=args.num_workers, collate_fn=filter_collate, pin_memory=True,
+                                               drop_last=True)
+        train_loader, test_loader = make_loader(train_ds, not args.debug), make_loader(test_ds, False)
+        if rank == 0:
+            print(f"Data loader lengths\nTrain: {len(train_ds)}\nTest: {len(test_ds)}")
+    else:
+        maps = get_maps(n_emotion_bins=args.n_emotion_bins if args.conditioning == "discrete_token" else 0)
     V = len(maps["tuple2idx"])
     pad_idx = maps["tuple2idx"]["<PAD>"]
     config = dict(vars(args), vocab_size=V, compute_dtype="fp32" if args.no_amp else "bf16")
@@ -168,14 +209,45 @@ def main(argv=None):
     t0 = time.time()
     tok_per_micro = world * B * L
 
+    def to_device(batch):
+        """collated (input, condition, target) -> device tensors; None when every sample of the batch was rejected."""
+        if not batch or not isinstance(batch[0], torch.Tensor) or batch[0].numel() == 0:
+            return None
+        x, c, y = batch
+        return x.to(device, non_blocking=True), c.to(device, non_blocking=True), y.to(device, non_blocking=True)
+
+    def real_batches(loader, epochs_counter=None):
+        while True:
+            if hasattr(loader.sampler, "set_epoch"):
+                loader.sampler.set_epoch(stats["epoch"])
+            n = 0
+            for batch in loader:
+                b = to_device(batch)
+                if b is not None:
+                    n += 1
+                    yield b
+            if epochs_counter is not None:
+                stats["epoch"] += 1
+            if n == 0:
+                raise SystemExit("the data loader produced no usable sample (check --data_folder / min_n_instruments)")
+
+    train_iter = real_batches(train_loader, True) if train_loader is not None else None
+
     def evaluate():
         """Mean loss and top-1 / top-5 token accuracy over non-PAD targets (train.py:222-275, utils.accuracy)."""
         model.eval()
         acc = torch.zeros(4, device=device, dtype=torch.float64)          # loss-sum, top1, top5, #targets
-        n = min(args.max_eval_step, 8)
+        n = min(args.max_eval_step, 8) if test_loader is None else args.max_eval_step
+        test_iter = iter(test_loader) if test_loader is not None else None
         with torch.no_grad():
             for i in range(n):
-                x, c, y = synthetic_batch(args, V, B, L, 10_000_019 + i * 31 + rank, device)
+                if test_iter is None:
+                    x, c, y = synthetic_batch(args, V, B, L, 10_000_019 + i * 31 + rank, device)
+                else:
+                    b = to_device(next(test_iter, None))
+                    if b is None:
+                        break
+                    x, c, y = b
                 loss, logits = model.loss_and_backward(x, c, y, backward=False, return_logits=True)
                 valid = y.reshape(-1) != pad_idx
                 top5 = logits.reshape(-1, logits.size(-1)).topk(5, dim=-1).indices
@@ -209,7 +281,10 @@ def main(argv=None):
 
     try:
         while step < args.max_step:
-            x, c, y = synthetic_batch(args, V, B, L, 1234 + rank + 7919 * (step * args.accumulate_step + micro), device)
+            if train_iter is None:
+                x, c, y = synthetic_batch(args, V, B, L, 1234 + rank + 7919 * (step * args.accumulate_step + micro), device)
+            else:
+                x, c, y = next(train_iter)
             last = (micro + 1) % args.accumulate_step == 0
             # every micro-batch contributes grad/accumulate_step (train.py:309); buckets are exchanged on the last one
             loss = model.loss_and_backward(x, c, y, grad_scale=1.0 / args.accumulate_step,
