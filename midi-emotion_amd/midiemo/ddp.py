@@ -1,7 +1,7 @@
 """Data-parallel gradient exchange: one process per GPU, RCCL (torch.distributed
 backend "nccl" on ROCm) all-reduce of contiguous buckets of the flat gradient
-buffer, issued as soon as the backward pass has finished a bucket so the
-transfer over xGMI overlaps the remaining backward kernels.
+buffer, issued while the backward pass is still running so that the transfer over
+xGMI overlaps it (by default inside the attention-backward windows, see GradAllReducer).
 
 The reference has no distributed code at all; this is the one
 exchange step data-parallel training needs.  Buckets = model.bucket_ranges():
@@ -15,37 +15,76 @@ import torch.distributed as dist
 
 
 class GradAllReducer:
-    def __init__(self, flat_grads_fn, bucket_ranges, group=None):
+    """policy (env MIDIEMO_DDP_POLICY):
+      "window" (default) -- a finished bucket is parked and launched when the engine announces a comm window
+                 (hook(-1): the attention backward of the next layer, ~0.5 ms of kernels with thousands of small blocks,
+                 is about to be enqueued).  Why: an RCCL channel is a 256-VGPR, 37 KB-LDS workgroup that owns its CU for
+                 the whole collective, and the GEMMs are persistent kernels of exactly one block per CU -- every CU taken
+                 away makes one of their blocks wait for a whole tile round (up to 2x for that launch), whereas the
+                 attention kernels just lose k/256 of their throughput.
+      "eager"  -- launch in hook(i) as soon as the bucket is final (maximal overlap, GEMMs included).
+      "end"    -- one all-reduce over the whole flat buffer in finish() (no overlap, no contention)."""
+
+    def __init__(self, flat_grads_fn, bucket_ranges, group=None, policy=None):
+        import os
         self._flat = flat_grads_fn
         self.ranges = list(bucket_ranges)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.policy = policy or os.environ.get("MIDIEMO_DDP_POLICY", "window")
+        if self.policy not in ("window", "eager", "end"):
+            raise ValueError("MIDIEMO_DDP_POLICY must be window, eager or end")
         self._works = []
+        self._pending = []
         self._done = set()
 
     @property
     def grad_scale(self):
         return 1.0 / self.world
 
-    def hook(self, bucket_index):
-        """Called by the engine's backward when bucket `bucket_index` is final on the compute stream."""
-        if self.world == 1:
-            return
-        if bucket_index in self._done:
-            raise RuntimeError("bucket %d reduced twice in one step" % bucket_index)
-        self._done.add(bucket_index)
-        lo, hi = self.ranges[bucket_index]
+    def _launch(self, lo, hi):
         if hi > lo:
             self._works.append(dist.all_reduce(self._flat()[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
                                                async_op=True))
 
+    def _flush(self):
+        # adjacent parked buckets travel as one collective
+        runs = []
+        for lo, hi in sorted(self._pending):
+            if runs and runs[-1][1] == lo:
+                runs[-1][1] = hi
+            else:
+                runs.append([lo, hi])
+        self._pending.clear()
+        for lo, hi in runs:
+            self._launch(lo, hi)
+
+    def hook(self, bucket_index):
+        """Called by the engine's backward: bucket_index >= 0 -- that bucket is final on the compute stream;
+        -1 -- a comm window opens (see the class docstring)."""
+        if self.world == 1:
+            return
+        if bucket_index < 0:
+            if self.policy == "window":
+                self._flush()
+            return
+        if bucket_index in self._done:
+            raise RuntimeError("bucket %d reduced twice in one step" % bucket_index)
+        self._done.add(bucket_index)
+        if self.policy == "eager":
+            self._launch(*self.ranges[bucket_index])
+        else:
+            self._pending.append(tuple(self.ranges[bucket_index]))
+
     def finish(self):
-        """Make the compute stream wait for every outstanding bucket (no host block on GPU backends)."""
+        """Launch what is still parked, then make the compute stream wait for every outstanding bucket (no host
+        block on GPU backends)."""
         if self.world == 1:
             return
         if len(self._done) != len(self.ranges):
             missing = sorted(set(range(len(self.ranges))) - self._done)
             raise RuntimeError("backward did not report buckets %s" % missing)
+        self._flush()
         for w in self._works:
             w.wait()
         self._works.clear()

@@ -498,6 +498,8 @@ class MusicTransformerHIP(nn.Module):
             wgrad("dC2", ws.dC2, Lw.att, gv(p + "rga.fc.weight"), gv(p + "rga.fc.bias"), T=T, N=d, K=d, dtype=dt)
             ops.gemm_nt(ws.dC2, W["WoT"], ws.dA, M=T, N=d, K=d, dtype=dt)                        # d(att)
             reuse("dqkv")
+            if bucket_hook:
+                bucket_hook(-1)            # comm window: ~0.5 ms of attention-backward kernels follow (ddp.GradAllReducer)
             ops.rga_bwd(Lw.qkv, W["Epk"], ws.key_pad, Lw.att, Lw.lse, ws.dA, ws.dqkv, gv(p + "rga.E"),
                         ws.delta, ws.PT, ws.dST, B, Lm, ws.Lp, H, dh, M)
             o, _, _ = self._slices[p + "rga.Wq.weight"]

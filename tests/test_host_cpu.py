@@ -108,12 +108,23 @@ params = torch.randn(2000)
 broadcast_params(params)
 ref = [torch.empty(2000) for _ in range(world)]
 dist.all_gather(ref, flat.clone())
-red = GradAllReducer(lambda: flat, ranges)
-for b in (3, 2, 1, 0):            # backward order: head, layers reversed, embedding
-    red.hook(b)
-red.finish()
-assert torch.allclose(flat, sum(ref), atol=1e-6)
-assert abs(red.grad_scale - 1.0 / world) < 1e-12
+base = flat.clone()
+for policy in ("window", "eager", "end"):
+    flat.copy_(base)
+    red = GradAllReducer(lambda: flat, ranges, policy=policy)
+    assert red.policy == policy
+    red.hook(3)                   # backward order: head, [window, layer] x 2, embedding
+    for b in (2, 1):
+        red.hook(-1)              # comm window: parked buckets are launched here under "window"
+        if policy == "window":
+            assert not red._pending
+        red.hook(b)
+    red.hook(0)
+    n_before = len(red._works)
+    assert n_before == {"window": 2, "eager": 4, "end": 0}[policy], (policy, n_before)
+    red.finish()
+    assert torch.allclose(flat, sum(ref), atol=1e-6), policy
+    assert abs(red.grad_scale - 1.0 / world) < 1e-12
 p0 = [torch.empty(2000) for _ in range(world)]
 dist.all_gather(p0, params)
 assert all(torch.equal(p0[0], q) for q in p0)
