@@ -970,7 +970,9 @@ int bwd_launch(const void* qkv, const void* Epk, const uint8_t* key_pad, const v
     rc = me_launch_status();
     if (rc) return rc;
     const int ngx = (Lp + 127) / 128;
-    int eblocks = 512;                                   // ~2 per CU; every group gets at least one
+    // grid sweep at C2 (us per launch): 512: 131, 768: 118, 1024: 127, 1160: 108, 1536: 106, 2048: 113, 4096: 111 --
+    // ~6 blocks per CU (4 resident): short blocks fill the tail left by the proportional group split
+    int eblocks = 1536;
     if (eblocks > ngx * B * H) eblocks = ngx * B * H;
     if (eblocks < ngx) eblocks = ngx;
     rga_bwd_e_kernel<T, DH><<<eblocks, 256, 0, st>>>((const T*)dST, (const T*)qkv, dE, B, L, Lp, H, M);
