@@ -3,6 +3,7 @@
 // key-pad mask, greedy pick.  One wavefront (64 lanes) owns one row; every lane
 // moves 16-byte chunks; row statistics are wave shuffles, no LDS.
 #include "me_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -859,15 +860,19 @@ int me_resid_ln_bwd(const void* dy, const void* s, const float* stats, const flo
     // chunks per lane per row: 1 for d <= 64 CH (512 bf16), 2, or 4 -- fewer chunks = less shared memory / registers
     ME_DISPATCH(dtype, ({
         const int nc = (d + 64 * ET<T>::CH - 1) / (64 * ET<T>::CH);
-        constexpr int NW = 16;
-        int64_t g = (rows + NW - 1) / NW;
-        const int grid = (int)(g < 1 ? 1 : (g > 256 ? 256 : g));
-        if (nc <= 1) resid_ln_bwd_kernel<T, 1, NW><<<grid, NW * 64, 0, st>>>(
-                           (const T*)dy, (const T*)s, stats, gamma, (T*)dx, (T*)da, dgamma, dbeta, rows, d, thr, inv_keep, seed, site);
-        else if (nc == 2) resid_ln_bwd_kernel<T, 2, NW><<<grid, NW * 64, 0, st>>>(
-                           (const T*)dy, (const T*)s, stats, gamma, (T*)dx, (T*)da, dgamma, dbeta, rows, d, thr, inv_keep, seed, site);
-        else resid_ln_bwd_kernel<T, 4, NW><<<grid, NW * 64, 0, st>>>(
-                           (const T*)dy, (const T*)s, stats, gamma, (T*)dx, (T*)da, dgamma, dbeta, rows, d, thr, inv_keep, seed, site);
+        // 16 waves per block for one chunk per lane; wider rows get 8-wave blocks (twice the blocks): a 1024-thread block
+        // caps the kernel at 128 VGPRs and the 2- and 4-chunk variants spilled to scratch under it
+        auto launch = [&](auto nc_tag, auto nw_tag) {
+            constexpr int NC = decltype(nc_tag)::value, NW = decltype(nw_tag)::value;
+            int64_t g = (rows + NW - 1) / NW;
+            const int cap = 256 * 16 / NW;
+            const int grid = (int)(g < 1 ? 1 : (g > cap ? cap : g));
+            resid_ln_bwd_kernel<T, NC, NW><<<grid, NW * 64, 0, st>>>(
+                (const T*)dy, (const T*)s, stats, gamma, (T*)dx, (T*)da, dgamma, dbeta, rows, d, thr, inv_keep, seed, site);
+        };
+        if (nc <= 1) launch(std::integral_constant<int, 1>{}, std::integral_constant<int, 16>{});
+        else if (nc == 2) launch(std::integral_constant<int, 2>{}, std::integral_constant<int, 8>{});
+        else launch(std::integral_constant<int, 4>{}, std::integral_constant<int, 8>{});
     }));
     return me_launch_status();
 }
