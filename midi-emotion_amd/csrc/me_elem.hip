@@ -189,6 +189,64 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const T* __restrict__ do
     }
 }
 
+// Condition-projection gradient of the concat mode when the table kernel owns the embedding columns:
+//   d Wc[j][0..1] += sum_rows g[row][de + j] * cond[b][0..1],   d bc[j] += sum_rows g[row][de + j].
+// Only the dc trailing columns are read: a wave covers 64 * CH / dc rows at once (lane = row-in-group x chunk), the
+// three partial sums stay in registers over the block's rows, waves are combined through LDS slices (plain stores) and
+// a block issues one atomic per output.  <= 128 blocks of 8 waves: with 512 four-wave blocks the same-address atomics
+// were 40 of the old kernel's 44 us.
+template <typename T>
+__global__ __launch_bounds__(512) void embed_bwd_cond_kernel(const T* __restrict__ dout, const float* __restrict__ cond,
+                                                               float* __restrict__ g_cw0, float* __restrict__ g_cb0, int B,
+                                                               int Lm, int d, int dc, uint32_t thr16, float inv_keep,
+                                                               uint64_t seed) {
+    constexpr int CH = ET<T>::CH;
+    __shared__ float red[8][3][64 * CH];                 // 48 KB (16-bit tier)
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int cpr = dc / CH;                        // chunks per row of the condition part (<= 64)
+    const int rpw = 64 / cpr;                       // rows per wave pass
+    const int rl = lane / cpr, ch = lane % cpr;
+    const int de = d - dc;
+    const int64_t rows = (int64_t)B * Lm;
+    float pw0[CH], pw1[CH], pb[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) { pw0[i] = 0.f; pw1[i] = 0.f; pb[i] = 0.f; }
+    const bool lane_on = rl < rpw;
+    for (int64_t r0 = ((int64_t)blockIdx.x * 8 + wid) * rpw; r0 < rows; r0 += (int64_t)gridDim.x * 8 * rpw) {
+        const int64_t row = r0 + rl;
+        if (!lane_on || row >= rows) continue;
+        const int col = de + ch * CH;
+        float g[CH];
+        chunk_to_f<T>(ld_chunk(dout + row * d + col), g);
+        if (thr16) {
+            float mult[CH];
+            drop_mult<CH>(mult, seed, 0u, (uint64_t)row * d + col, thr16, inv_keep);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) g[i] *= mult[i];
+        }
+        const int b = (int)(row / Lm);
+        const float c0 = cond[b * 2], c1 = cond[b * 2 + 1];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) { pw0[i] += g[i] * c0; pw1[i] += g[i] * c1; pb[i] += g[i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        red[wid][0][i * 64 + lane] = pw0[i];
+        red[wid][1][i * 64 + lane] = pw1[i];
+        red[wid][2][i * 64 + lane] = pb[i];
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 3 * dc; j += 512) {
+        const int which = j / dc, jc = j % dc, c = jc / CH, i = jc % CH;
+        float acc = 0.f;
+        for (int w = 0; w < 8; ++w)
+            for (int r = 0; r < rpw; ++r) acc += red[w][which][i * 64 + r * cpr + c];
+        if (which == 0) atomicAdd(&g_cw0[jc * 2], acc);
+        else if (which == 1) atomicAdd(&g_cw0[jc * 2 + 1], acc);
+        else atomicAdd(&g_cb0[jc], acc);
+    }
+}
+
 // Embedding-table gradient with LDS-privatised accumulation: a block owns an 8-column slice of the
 // table (V x 8 floats in LDS) and a slice of the tokens; gradients are scattered with LDS atomics
 // and flushed once, coalesced, with one global atomic per table element.  Replaces T x (d - dc)
@@ -312,9 +370,10 @@ __global__ __launch_bounds__(NW * 64) void resid_ln_bwd_kernel(const T* __restri
                                                            float* __restrict__ dbeta, int rows, int d, uint32_t thr16,
                                                            float inv_keep, uint64_t seed, uint32_t site) {
     constexpr int CH = ET<T>::CH;
-    __shared__ float red[2][NC * 64 * CH];
-    for (int j = threadIdx.x; j < 2 * NC * 64 * CH; j += NW * 64) (&red[0][0])[j] = 0.f;
-    __syncthreads();
+    // per-wave partial sums of d(gamma) / d(beta): one slice per wave, plain stores, summed after a barrier.
+    // (ds_add_f32 costs ~85 cycles per wave instruction: combining through LDS atomics held every block for
+    // 1.3 us x waves -- 21 of the kernel's 41 us at 16 waves.)
+    __shared__ float red[NW][2][NC * 64 * CH];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     float pg[NC][CH], pb[NC][CH];
 #pragma unroll
@@ -398,28 +457,37 @@ __global__ __launch_bounds__(NW * 64) void resid_ln_bwd_kernel(const T* __restri
     for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-            atomicAdd(&red[0][(c * 64 + lane) * CH + i], pg[c][i]);
-            atomicAdd(&red[1][(c * 64 + lane) * CH + i], pb[c][i]);
+            // element-major layout [i][c][lane]: the 64 lanes of one store hit 64 consecutive words
+            red[wid][0][(i * NC + c) * 64 + lane] = pg[c][i];
+            red[wid][1][(i * NC + c) * 64 + lane] = pb[c][i];
         }
     __syncthreads();
-    for (int j = threadIdx.x; j < d; j += NW * 64) {
-        atomicAdd(&dgamma[j], red[0][j]);
-        atomicAdd(&dbeta[j], red[1][j]);
+    for (int j = threadIdx.x; j < 2 * d; j += NW * 64) {
+        const int which = j >= d, col = which ? j - d : j;
+        const int q = col / CH, idx = ((col % CH) * NC + q / 64) * 64 + (q & 63);      // column = ((c * 64 + lane) * CH + i)
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) acc += red[w][which][idx];
+        atomicAdd(which ? &dbeta[col] : &dgamma[col], acc);
     }
 }
 
 // ------------------------------------------------------------------ cross-entropy head
 // CE_Q = 16-byte pieces per lane of the register-resident row (V <= 256 CE_Q): 4 for the 1007 / 1017 vocabularies
+// CE_NW waves per block, at most one block per CU: the loss / count partials end in ONE pair of same-address global
+// atomics per block, and same-address atomics serialise at ~15 ns each -- with 2048 four-wave blocks they were 55 of the
+// kernel's 64 us.
+constexpr int CE_NW = 16;
 template <int CE_Q>
-__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, int ld,
+__global__ __launch_bounds__(CE_NW * 64) void ce_fwd_kernel(const float* __restrict__ logits, int ld,
                                                      const int64_t* __restrict__ target, float* __restrict__ row_lse,
                                                      float* __restrict__ loss_sum, float* __restrict__ n_valid, int rows,
                                                      int V, int ignore_index) {
-    __shared__ float red[2][4];
+    __shared__ float red[2][CE_NW];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     float bl = 0.f, bn = 0.f;
-    const int64_t stride = (int64_t)gridDim.x * 4;
-    int64_t row = (int64_t)blockIdx.x * 4 + wid;
+    const int64_t stride = (int64_t)gridDim.x * CE_NW;
+    int64_t row = (int64_t)blockIdx.x * CE_NW + wid;
     if (V <= 64 * 4 * CE_Q && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0) {
         // One pass: the row (<= 2048 logits) sits in registers, 16-byte loads.  The next row (and its target) is
         // fetched BEFORE this row's lse is stored and the target logit comes out of the registers: vmcnt is in
@@ -489,8 +557,11 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
     if (lane == 0) { red[0][wid] = bl; red[1][wid] = bn; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(loss_sum, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-        atomicAdd(n_valid, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        float sl = 0.f, sn = 0.f;
+#pragma unroll
+        for (int w = 0; w < CE_NW; ++w) { sl += red[0][w]; sn += red[1][w]; }
+        atomicAdd(loss_sum, sl);
+        atomicAdd(n_valid, sn);
     }
 }
 
@@ -515,13 +586,14 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
 }
 
 // ------------------------------------------------------------------ clip + AdamW
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
-    __shared__ float red[4];
+// <= 256 blocks of 16 waves: one same-address atomic per block (at ~15 ns each, 1024 blocks cost 12 us of a 24 us kernel)
+__global__ __launch_bounds__(1024) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+    __shared__ float red[16];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     float s = 0.f;
     const int64_t n4 = n >> 2;
     const f32x4_t* g4 = reinterpret_cast<const f32x4_t*>(g);
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 1024) {
         const f32x4_t v = g4[i];
         s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
     }
@@ -529,7 +601,12 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     s = wave_sum(s);
     if (lane == 0) red[wid] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[w];
+        atomicAdd(out, t);
+    }
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
@@ -812,6 +889,16 @@ int me_embed_bwd(const void* dout, int dtype, const int64_t* tokens, const float
         int rc = me_launch_status();
         if (rc) return rc;
         if (mode == ME_COND_NONE) return ME_OK;        // nothing but the table to differentiate
+        const int chx = dtype == ME_F32 ? 4 : 8;
+        if (mode == ME_COND_CONCAT && dc > 0 && dc % chx == 0 && dc / chx <= 64 && 64 % (dc / chx) == 0) {
+            const int rpw = 64 / (dc / chx);
+            int64_t nb = ((int64_t)B * Lm + 8 * rpw * 8 - 1) / (8 * rpw * 8);         // >= 8 passes per wave
+            if (nb > 128) nb = 128;
+            if (nb < 1) nb = 1;
+            ME_DISPATCH(dtype, (embed_bwd_cond_kernel<T><<<(unsigned)nb, 512, 0, st>>>((const T*)dout, cond, g_cw0, g_cb0, B, Lm, d,
+                                                                                       dc, thr, inv_keep, seed)));
+            return me_launch_status();
+        }
     }
     ME_DISPATCH(dtype, (embed_bwd_kernel<T><<<grid, 256, 0, st>>>((const T*)dout, tokens, cond, g_emb, g_cw0, g_cb0, g_cw1,
                                                                   g_cb1, mode, B, Ltok, d, dc, pad_token, thr, inv_keep, seed,
@@ -865,7 +952,7 @@ int me_resid_ln_bwd(const void* dy, const void* s, const float* stats, const flo
         auto launch = [&](auto nc_tag, auto nw_tag) {
             constexpr int NC = decltype(nc_tag)::value, NW = decltype(nw_tag)::value;
             int64_t g = (rows + NW - 1) / NW;
-            const int cap = 256 * 16 / NW;
+            const int cap = 256 * 16 / NW;            // 256 x 16 waves: 30.5 us at C2 (512 blocks: 38.5; 8-wave blocks: 32.0)
             const int grid = (int)(g < 1 ? 1 : (g > cap ? cap : g));
             resid_ln_bwd_kernel<T, NC, NW><<<grid, NW * 64, 0, st>>>(
                 (const T*)dy, (const T*)s, stats, gamma, (T*)dx, (T*)da, dgamma, dbeta, rows, d, thr, inv_keep, seed, site);
@@ -883,10 +970,12 @@ int me_ce_fwd(const float* logits, int ld, const int64_t* target, float* row_lse
     if (!logits || !target || !loss_sum || !n_valid) return ME_ERR_NULL;
     if (rows <= 0) return ME_OK;
     if (V <= 0 || ld < V) return ME_ERR_BAD_SHAPE;
+    const int64_t gb = ((int64_t)rows + CE_NW - 1) / CE_NW;
+    const int grid = (int)(gb > 256 ? 256 : gb);
     if (V <= 1024)
-        ce_fwd_kernel<4><<<row_grid(rows, 2048), 256, 0, (hipStream_t)stream>>>(logits, ld, target, row_lse, loss_sum, n_valid, rows, V, ignore_index);
+        ce_fwd_kernel<4><<<grid, CE_NW * 64, 0, (hipStream_t)stream>>>(logits, ld, target, row_lse, loss_sum, n_valid, rows, V, ignore_index);
     else
-        ce_fwd_kernel<8><<<row_grid(rows, 2048), 256, 0, (hipStream_t)stream>>>(logits, ld, target, row_lse, loss_sum, n_valid, rows, V, ignore_index);
+        ce_fwd_kernel<8><<<grid, CE_NW * 64, 0, (hipStream_t)stream>>>(logits, ld, target, row_lse, loss_sum, n_valid, rows, V, ignore_index);
     return me_launch_status();
 }
 
@@ -908,9 +997,9 @@ int me_sumsq(const float* g, int64_t n, float* out, void* stream) {
     if (n <= 0) return ME_OK;
     if (!aligned16(g)) return ME_ERR_ALIGNMENT;
     int64_t blocks = (n / 4 + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 256) blocks = 256;
     if (blocks < 1) blocks = 1;
-    sumsq_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(g, n, out);
+    sumsq_kernel<<<(unsigned)blocks, 1024, 0, (hipStream_t)stream>>>(g, n, out);
     return me_launch_status();
 }
 

@@ -20,3 +20,13 @@ t = timeit(lambda: ops.resid_ln_bwd(dy, s, stats, gamma, dx, da, dg, db, T, d, 0
 print("%s resid_ln_bwd %.1f us  (%.2f TB/s)" % (os.environ.get("TAG", ""), t, 4 * T * d * 2 / t / 1e6))
 t = timeit(lambda: ops.resid_ln_fwd(x, a, gamma, beta, y, so, stats, T, d, 1e-5, 0.1, 123, 3))
 print("%s resid_ln_fwd %.1f us  (%.2f TB/s)" % (os.environ.get("TAG", ""), t, 4 * T * d * 2 / t / 1e6))
+t = timeit(lambda: ops.resid_ln_bwd(dy, s, stats, gamma, dx, da, dg, db, T, d, 0.0, 123, 3))
+print("%s resid_ln_bwd p=0 %.1f us  (%.2f TB/s)" % (os.environ.get("TAG", ""), t, 4 * T * d * 2 / t / 1e6))
+t = timeit(lambda: ops.resid_ln_fwd(x, a, gamma, beta, y, so, stats, T, d, 1e-5, 0.0, 123, 3))
+print("%s resid_ln_fwd p=0 %.1f us  (%.2f TB/s)" % (os.environ.get("TAG", ""), t, 4 * T * d * 2 / t / 1e6))
+c = torch.empty_like(dy)
+t = timeit(lambda: c.copy_(dy))
+print("torch copy 33.5 MB -> 33.5 MB %.1f us (%.2f TB/s r+w)" % (t, 2 * T * d * 2 / t / 1e6))
+big = torch.randn(4 * T, d, device="cuda").to(dt); big2 = torch.empty_like(big)
+t = timeit(lambda: big2.copy_(big))
+print("torch copy 134 MB -> 134 MB %.1f us (%.2f TB/s r+w)" % (t, 2 * 4 * T * d * 2 / t / 1e6))
