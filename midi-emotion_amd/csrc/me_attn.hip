@@ -625,13 +625,15 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
 // [128 key][32 q] and dO^T, Q^T tiles [DH][32 q]; all four are contraction-contiguous, so the
 // fragments are plain 16-byte LDS reads.  The materialised tensors are read exactly once:
 // the kernel is HBM-bound (2 x Lp^2/2 elements per (b, head)).
-template <typename T, int DH>
-__global__ __launch_bounds__(256) void rga_bwd_kv_kernel(const T* __restrict__ PT, const T* __restrict__ dST,
-                                                         const T* __restrict__ qkv, const T* __restrict__ dout,
-                                                         T* __restrict__ dqkv, int B, int L, int Lp, int H) {
+template <typename T, int DH, int NWK>
+__global__ __launch_bounds__(NWK * 64) void rga_bwd_kv_kernel(const T* __restrict__ PT, const T* __restrict__ dST,
+                                                              const T* __restrict__ qkv, const T* __restrict__ dout,
+                                                              T* __restrict__ dqkv, int B, int L, int Lp, int H) {
+    // NWK waves x 32 keys per block.  8 waves (256 keys): the Q / dO slabs every block streams are fetched half as often
     constexpr int CH = ET<T>::CH, LDP = 32 + CH, DB = ACfg<T, DH>::DB, LDV = ACfg<T, DH>::LDV;
-    __shared__ __attribute__((aligned(16))) T Pt[2][128 * LDP];
-    __shared__ __attribute__((aligned(16))) T St[2][128 * LDP];
+    constexpr int KB = NWK * 32, NTHR = NWK * 64;
+    __shared__ __attribute__((aligned(16))) T Pt[2][KB * LDP];
+    __shared__ __attribute__((aligned(16))) T St[2][KB * LDP];
     __shared__ __attribute__((aligned(16))) T Os[2][32 * LDV];         // natural dO / Q slabs [32 q][DH], transpose-read
     __shared__ __attribute__((aligned(16))) T Qs[2][32 * LDV];
 
@@ -641,11 +643,11 @@ __global__ __launch_bounds__(256) void rga_bwd_kv_kernel(const T* __restrict__ P
     const int b = bh / H, head = bh % H;
     const int dm = H * DH;
     const size_t ldq = (size_t)3 * dm;
-    const int k0 = kb * 128 + wid * 32;
+    const int k0 = kb * KB + wid * 32;
     const bool wave_on = k0 < L;
     const int nqt = (L + 31) / 32;
-    const int qs0 = kb * 4;
-    const int rows_valid = min(128, Lp - kb * 128);
+    const int qs0 = kb * NWK;
+    const int rows_valid = min(KB, Lp - kb * KB);
     const T* pt_ = PT + (size_t)bh * Lp * Lp;
     const T* st_ = dST + (size_t)bh * Lp * Lp;
     const T* q_ = qkv + (size_t)b * L * ldq + head * DH;
@@ -655,23 +657,38 @@ __global__ __launch_bounds__(256) void rga_bwd_kv_kernel(const T* __restrict__ P
 #pragma unroll
     for (int i = 0; i < DB; ++i) { acc_zero(dk[i]); acc_zero(dv[i]); }
 
-    chunk16 rp[TileT<T, 128, 32>::NPT], rs[TileT<T, 128, 32>::NPT], ro[TileT<T, 32, DH>::NPT], rq[TileT<T, 32, DH>::NPT];
-    auto gload = [&](int qs) {
+    constexpr int CPRP = 32 / CH, NPTP = KB * CPRP / NTHR;              // P^T / dS^T tile [KB][32]: chunks per thread
+    constexpr int CPRQ = DH / CH, NCHQ = 32 * CPRQ, NPTQ = (NCHQ + NTHR - 1) / NTHR;   // Q / dO slab [32][DH]
+    chunk16 rp[NPTP], rs[NPTP], ro[NPTQ], rq[NPTQ];
+    auto gload = [&](int qs) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < TileT<T, 128, 32>::NPT; ++i) {
-            const int c = tid + i * 256, row = c / TileT<T, 128, 32>::CPR, cc = (c % TileT<T, 128, 32>::CPR) * CH;
-            const size_t o = ws_row(kb * 128 + min(row, rows_valid - 1), qs, Lp) + cc;
+        for (int i = 0; i < NPTP; ++i) {
+            const int c = tid + i * NTHR, row = c / CPRP, cc = (c % CPRP) * CH;
+            const size_t o = ws_row(kb * KB + min(row, rows_valid - 1), qs, Lp) + cc;
             rp[i] = row < rows_valid ? ld_chunk(pt_ + o) : zero_chunk();
             rs[i] = row < rows_valid ? ld_chunk(st_ + o) : zero_chunk();
         }
-        tile_gload<T, 32, DH>(ro, o_ + (size_t)qs * 32 * dm, (size_t)dm, L - qs * 32, tid);
-        tile_gload<T, 32, DH>(rq, q_ + (size_t)qs * 32 * ldq, ldq, L - qs * 32, tid);
+        const int qv = L - qs * 32;
+#pragma unroll
+        for (int i = 0; i < NPTQ; ++i) {
+            const int c = tid + i * NTHR, row = c / CPRQ, cc = (c % CPRQ) * CH;
+            const bool ok = c < NCHQ && row < qv;
+            ro[i] = ok ? ld_chunk(o_ + ((size_t)qs * 32 + row) * dm + cc) : zero_chunk();
+            rq[i] = ok ? ld_chunk(q_ + ((size_t)qs * 32 + row) * ldq + cc) : zero_chunk();
+        }
     };
-    auto sstore = [&](int buf) {
-        tile_sstore<T, 128, 32, LDP>(rp, Pt[buf], tid);
-        tile_sstore<T, 128, 32, LDP>(rs, St[buf], tid);
-        tile_sstore<T, 32, DH, LDV>(ro, Os[buf], tid);
-        tile_sstore<T, 32, DH, LDV>(rq, Qs[buf], tid);
+    auto sstore = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NPTP; ++i) {
+            const int c = tid + i * NTHR, row = c / CPRP, cc = (c % CPRP) * CH;
+            st_chunk(&Pt[buf][row * LDP + cc], rp[i]);
+            st_chunk(&St[buf][row * LDP + cc], rs[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NPTQ; ++i) {
+            const int c = tid + i * NTHR, row = c / CPRQ, cc = (c % CPRQ) * CH;
+            if (c < NCHQ) { st_chunk(&Os[buf][row * LDV + cc], ro[i]); st_chunk(&Qs[buf][row * LDV + cc], rq[i]); }
+        }
     };
     gload(qs0);
     sstore(0);
@@ -965,8 +982,18 @@ int bwd_launch(const void* qkv, const void* Epk, const uint8_t* key_pad, const v
                                                         H, M, scale);
     int rc = me_launch_status();
     if (rc) return rc;
-    rga_bwd_kv_kernel<T, DH><<<B * H * nqb, 256, 0, st>>>((const T*)PT, (const T*)dST, (const T*)qkv, (const T*)dout, (T*)dqkv, B,
-                                                         L, Lp, H);
+    static const int kv8 = getenv("MIDIEMO_KV8") ? atoi(getenv("MIDIEMO_KV8")) : 1;   // 256-key blocks (16-bit tier): 181 -> 175 us at C2
+    bool big = false;
+    if constexpr (sizeof(T) == 2) {
+        if (kv8) {
+            big = true;
+            rga_bwd_kv_kernel<T, DH, 8><<<B * H * ((L + 255) / 256), 512, 0, st>>>((const T*)PT, (const T*)dST, (const T*)qkv,
+                                                                                  (const T*)dout, (T*)dqkv, B, L, Lp, H);
+        }
+    }
+    if (!big)
+        rga_bwd_kv_kernel<T, DH, 4><<<B * H * nqb, 256, 0, st>>>((const T*)PT, (const T*)dST, (const T*)qkv, (const T*)dout,
+                                                                (T*)dqkv, B, L, Lp, H);
     rc = me_launch_status();
     if (rc) return rc;
     const int ngx = (Lp + 127) / 128;
