@@ -323,3 +323,48 @@ def test_cpu_model_fails_loudly():
                               max_seq=64, dropout=0.0, pad_token=0)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.randint(2, 97, (1, 8)), None)
+
+
+def test_full_size_c2_properties_bf16():
+    """BASELINE config 2 at its full size (B = 32 x L = 1024, bf16), through properties that need no oracle run:
+    batch independence (bit-exact), causality (bit-exact), gradient additivity over a batch split, and the
+    engine's loss against a float64 cross-entropy of its own logits."""
+    from midiemo.models.build_model import build_model
+    torch.manual_seed(0)
+    args = dict(vocab_size=1007, n_layer=6, n_head=8, d_model=512, d_inner=2048, dropout=0.0, d_condition=128,
+                conditioning="continuous_concat", compute_dtype="bf16")
+    model, _ = build_model(args)
+    model = model.to(DEV).train()
+    g = torch.Generator().manual_seed(11)
+    B, L = 32, 1024
+    tok = torch.randint(2, 1007, (B, L + 1), generator=g)
+    tok[5, 900:] = 0                                            # one padded tail
+    x, y = tok[:, :-1].contiguous().to(DEV), tok[:, 1:].contiguous().to(DEV)
+    cond = (torch.rand(B, 2, generator=g) * 2 - 1).to(DEV)
+    with torch.no_grad():
+        full = model(x, cond).float()
+        assert full.shape == (B, L, 1007) and bool(torch.isfinite(full).all())
+        # batch independence: rows 4..7 alone give bit-identical logits
+        part = model(x[4:8], cond[4:8]).float()
+        assert torch.equal(part, full[4:8])
+        # causality: changing the tokens from position 700 on leaves every earlier logit bit-identical
+        x2 = x.clone()
+        x2[:, 700:] = torch.randint(2, 1007, (B, L - 700), generator=g).to(DEV)
+        alt = model(x2, cond).float()
+        assert torch.equal(alt[:, :700], full[:, :700])
+        assert not torch.equal(alt[:, 700:], full[:, 700:])
+    # loss of the fused path == float64 CE of the engine's own logits (ignore_index = 0)
+    model.zero_grad_flat() if hasattr(model, "zero_grad_flat") else model.flat_grads.zero_()
+    loss = model.loss_and_backward(x, cond, y)
+    ref = torch.nn.functional.cross_entropy(full.double().reshape(-1, 1007), y.reshape(-1), ignore_index=0)
+    assert abs(float(loss) - float(ref)) < 2e-4 * abs(float(ref)), (float(loss), float(ref))
+    g_full = model.flat_grads.clone()
+    assert bool(torch.isfinite(g_full).all()) and float(g_full.norm()) > 0
+    # additivity: mean-over-valid-targets gradients of the two half batches, recombined with their target counts
+    n = [int((y[:16] != 0).sum()), int((y[16:] != 0).sum())]
+    model.flat_grads.zero_()
+    model.loss_and_backward(x[:16], cond[:16], y[:16], grad_scale=n[0] / (n[0] + n[1]))
+    model.loss_and_backward(x[16:], cond[16:], y[16:], grad_scale=n[1] / (n[0] + n[1]))
+    e = relerr(model.flat_grads, g_full)
+    report("full-size C2 bf16: grad additivity rel %.2e, loss %.5f vs f64 CE of own logits %.5f" % (e, float(loss), float(ref)))
+    assert e < 2e-3, e
