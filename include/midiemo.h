@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 6
+#define ME_ABI_VERSION 7
 
 enum { ME_F32 = 0, ME_BF16 = 1 };
 
@@ -136,9 +136,12 @@ int me_gemm_tn_join(void* stream);
  * out  : T [B, L, H, dh]   lse : f32 [B, H, L]
  *   logits[l,j] = (q_l.k_j + q_l.E[M-1-(l-j)]) / sqrt(dh),  j<=l and key j not pad
  * Replaces music_multi.py:196-235 (head split/permute, einsum QE, _qe_masking, _skewing, QK^T,
- * mask, softmax, PV, head merge).  dh in {32, 48, 64}; M % 32 == 0; L <= M.  Epk = me_rga_pack_rel(E). */
+ * mask, softmax, PV, head merge).  dh in {32, 48, 64}; M % 32 == 0; L <= M.  Epk = me_rga_pack_rel(E).
+ * causal = 1: the language model (generate_mask: key <= q and not padded).  causal = 0: the bidirectional attention of
+ * MusicRegression (models/music_regression.py:79, mask = None): all keys, relative term only for key <= q (the
+ * reference's skewing leaves zeros above the diagonal); forward only -- me_rga_bwd differentiates causal = 1. */
 int me_rga_fwd(const void* qkv, const void* Epk, const uint8_t* key_pad, void* out, float* lse,
-               int B, int L, int H, int dh, int M, int dtype, void* stream);
+               int B, int L, int H, int dh, int M, int causal, int dtype, void* stream);
 
 /* Packs the relative table E (T [M][dh], music_multi.py:191 self.E) into the fragment images me_rga_fwd / me_rga_bwd
  * read: per block of 32 rows, dh/16 images of the rows themselves (operand of Q.E^T) followed by 2*ceil(dh/32) images

@@ -147,7 +147,10 @@ template <> ME_DEV void st4<float>(float* p, float a, float b, float c, float d)
 // during the whole step), the E fragments of the NEXT step's new block are fetched into
 // registers right after the current block's MFMAs were issued, the pad flags travel with the
 // tile, and tiles that need no masking skip all per-element predicates.  exp2-domain softmax.
-template <typename T, int DH>
+// CAUSAL = false: the bidirectional variant of MusicRegression (models/music_regression.py:79, mask = None): every key
+// is attended; the relative term exists only for key <= q (the reference's _qe_masking + _skewing leave exact zeros
+// above the diagonal), nothing is masked but keys >= L and padded keys.
+template <typename T, int DH, bool CAUSAL = true>
 __global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ qkv, const T* __restrict__ Epk, const uint8_t* __restrict__ key_pad,
                                                       T* __restrict__ out, float* __restrict__ lse, int B, int L, int H, int M,
                                                       float scale) {
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ q
     const int q0 = qb * 128 + wid * 32;
     const int q = q0 + a;
     const bool wave_on = q0 < L;
-    const int nkt = min((L + 31) / 32, qb * 4 + 4);
+    const int nkt = CAUSAL ? min((L + 31) / 32, qb * 4 + 4) : (L + 31) / 32;
     const int my_last_kt = qb * 4 + wid;            // diagonal tile of this wave
     const float c2 = scale * 1.4426950408889634f;   // logits are kept in log2 units
 
@@ -238,14 +241,15 @@ __global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ q
     auto step = [&](int kt, auto main_tag) __attribute__((always_inline)) {
         constexpr bool MAIN = decltype(main_tag)::value;
         const int buf = kt & 1;
-        if (MAIN || (wave_on && kt <= my_last_kt)) {
+        if (MAIN || (wave_on && (!CAUSAL || kt <= my_last_kt))) {
             const int k0 = kt * 32;
             const bool diag = !MAIN && kt == my_last_kt;
+            const bool upper = !CAUSAL && !MAIN && kt > my_last_kt;      // bidirectional only: tile above the diagonal, no relative term
             const int eb_lo = eb0 + kt;
             if constexpr (MAIN) {
                 g_block(ef, eb_lo + 1);
                 e_frags(ef, min(eb_lo + 2, (M >> 5) - 1));          // clamped: unused past the diagonal
-            } else if (!diag) {
+            } else if (!diag && !upper) {
                 g_block(ef, eb_lo + 1);
                 if (kt + 1 < my_last_kt) e_frags(ef, eb_lo + 2);
             }
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ q
             const float* grow = &Gs[wid][a * LDG2];
             const int t0 = (eb_lo & 1) * 32 + 31 - a + 4 * h;
             float mt = -INFINITY;
-            if (!diag && pbits == 0u && k0 + 32 <= L) {
+            if (!diag && !upper && pbits == 0u && k0 + 32 <= L) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     s[r] = (s[r] + grow[(t0 + (r & 3) + 8 * (r >> 2)) & 63]) * c2;
@@ -271,9 +275,13 @@ __global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ q
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int bk = (r & 3) + 8 * (r >> 2) + 4 * h, key = k0 + bk;
-                    const bool masked = key > q || key >= L || ((pbits >> bk) & 1u);
+                    const bool masked = (CAUSAL && key > q) || key >= L || ((pbits >> bk) & 1u);
                     float v = -INFINITY;
-                    if (!masked) v = (s[r] + grow[(t0 + (r & 3) + 8 * (r >> 2)) & 63]) * c2;
+                    if (!masked) {
+                        float g = 0.f;
+                        if (CAUSAL || (!upper && key <= q)) g = grow[(t0 + (r & 3) + 8 * (r >> 2)) & 63];
+                        v = (s[r] + g) * c2;
+                    }
                     s[r] = v;
                     mt = fmaxf(mt, v);
                 }
@@ -964,10 +972,13 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 template <typename T, int DH>
 int fwd_launch(const void* qkv, const void* Epk, const uint8_t* key_pad, void* out, float* lse, int B, int L, int H, int M,
-               hipStream_t st) {
+               int causal, hipStream_t st) {
     const int nqb = (L + 127) / 128;
     const float scale = 1.f / sqrtf((float)DH);
-    rga_fwd_kernel<T, DH><<<B * H * nqb, 256, 0, st>>>((const T*)qkv, (const T*)Epk, key_pad, (T*)out, lse, B, L, H, M, scale);
+    if (causal)
+        rga_fwd_kernel<T, DH, true><<<B * H * nqb, 256, 0, st>>>((const T*)qkv, (const T*)Epk, key_pad, (T*)out, lse, B, L, H, M, scale);
+    else
+        rga_fwd_kernel<T, DH, false><<<B * H * nqb, 256, 0, st>>>((const T*)qkv, (const T*)Epk, key_pad, (T*)out, lse, B, L, H, M, scale);
     return me_launch_status();
 }
 
@@ -1041,13 +1052,13 @@ int me_rga_pack_rel(const void* E, void* Epk, int M, int dh, int dtype, void* st
 }
 
 int me_rga_fwd(const void* qkv, const void* Epk, const uint8_t* key_pad, void* out, float* lse, int B, int L, int H, int dh,
-               int M, int dtype, void* stream) {
+               int M, int causal, int dtype, void* stream) {
     me_clear_error();
     if (!qkv || !Epk || !out || !lse) return ME_ERR_NULL;
     if (B <= 0 || L <= 0 || H <= 0 || L > M || (M & 31)) return ME_ERR_BAD_SHAPE;
     if (!aligned16(qkv) || !aligned16(Epk) || !aligned16(out)) return ME_ERR_ALIGNMENT;
     hipStream_t st = (hipStream_t)stream;
-    ME_ATTN_DISPATCH((fwd_launch<T, DH>(qkv, Epk, key_pad, out, lse, B, L, H, M, st)))
+    ME_ATTN_DISPATCH((fwd_launch<T, DH>(qkv, Epk, key_pad, out, lse, B, L, H, M, causal, st)))
 }
 
 int me_rga_bwd(const void* qkv, const void* Epk, const uint8_t* key_pad, const void* out, const float* lse,

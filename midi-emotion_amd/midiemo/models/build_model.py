@@ -3,11 +3,12 @@
 Same signature, dict keys, defaults and return value as the reference
 (models/build_model.py:9-48): reads vocab_size, n_layer, n_head, d_model,
 d_inner, dropout, d_condition, conditioning (+regression, overwrite_dropout),
-forces max_seq=2048 and pad_token=0, drops d_condition for continuous_token.
+forces max_seq=2048 and pad_token=0, drops d_condition for continuous_token; regression=True builds the
+evaluation model MusicRegression (output_size 2; forward only here).
 One extra optional key, `compute_dtype` ("bf16" default, "fp32" = exact-f32
 parity tier), selects the storage type of the HIP engine.
 """
-from .music_transformer import MusicTransformerContinuousToken, MusicTransformerMulti
+from .music_transformer import MusicRegression, MusicTransformerContinuousToken, MusicTransformerMulti
 
 
 def set_dropout(model, rate):
@@ -38,10 +39,9 @@ def build_model(args, load_config_dict=None):
         args["regression"] = False
 
     if args["regression"]:
-        raise NotImplementedError(
-            "MusicRegression (evaluation-only model, models/music_regression.py) is outside the "
-            "accelerated hot path of this build")
-    if args["conditioning"] == "continuous_token":
+        config["output_size"] = 2                       # build_model.py:29-32; inference only in this build
+        model = MusicRegression(**config)
+    elif args["conditioning"] == "continuous_token":
         del config["d_condition"]
         model = MusicTransformerContinuousToken(**config)
     else:

@@ -98,8 +98,10 @@ class MusicTransformerHIP(nn.Module):
 
     def __init__(self, embedding_dim=None, d_inner=None, d_condition=-1, vocab_size=None, num_layer=None,
                  num_head=None, max_seq=2048, dropout=0.1, pad_token=0, token_conditioning=False,
-                 compute_dtype="bf16"):
+                 compute_dtype="bf16", head_size=None, causal=True):
         super().__init__()
+        self.head_size = vocab_size if head_size is None else head_size     # output features of the head (vocab; 2 for regression)
+        self.causal = bool(causal)                                           # False: MusicRegression's bidirectional attention
         self.max_seq = max_seq
         self.num_layer = num_layer
         self.num_head = num_head
@@ -127,7 +129,7 @@ class MusicTransformerHIP(nn.Module):
             self.fc_condition = _Lin(2, d_condition)
         self.enc_layers = nn.ModuleList([_EncoderLayer(embedding_dim, d_inner, num_head, max_seq)
                                          for _ in range(num_layer)])
-        self.fc = _Lin(embedding_dim, vocab_size)
+        self.fc = self._make_head(embedding_dim, self.head_size)
         self.init_weights()
 
         self._step_seed = 0x5EED
@@ -141,14 +143,23 @@ class MusicTransformerHIP(nn.Module):
         self._packing = False
         self._pack()
 
+    # ------------------------------------------------------------------ head (overridden by MusicRegression: Sequential(Linear, Tanh))
+    _HEAD_W, _HEAD_B = "fc.weight", "fc.bias"
+
+    def _make_head(self, d, n_out):
+        return _Lin(d, n_out)
+
+    def _head_linear(self):
+        return self.fc
+
     # ------------------------------------------------------------------ init / packing
     def init_weights(self):
         """music_multi.py:75-82 / music_continuous_token.py:68-75."""
         r = 0.1
         with torch.no_grad():
             self.embedding.weight.uniform_(-r, r)
-            self.fc.bias.zero_()
-            self.fc.weight.uniform_(-r, r)
+            self._head_linear().bias.zero_()
+            self._head_linear().weight.uniform_(-r, r)
             if self.token_conditioning:
                 for m in self.fc_condition:
                     m.weight.uniform_(-r, r)
@@ -181,7 +192,7 @@ class MusicTransformerHIP(nn.Module):
                 (p + "layernorm1.weight", l.layernorm1.weight), (p + "layernorm1.bias", l.layernorm1.bias),
                 (p + "layernorm2.weight", l.layernorm2.weight), (p + "layernorm2.bias", l.layernorm2.bias),
             ])
-        groups.append([("fc.weight", self.fc.weight), ("fc.bias", self.fc.bias)])
+        groups.append([(self._HEAD_W, self._head_linear().weight), (self._HEAD_B, self._head_linear().bias)])
         return groups
 
     def _pack(self):
@@ -262,7 +273,7 @@ class MusicTransformerHIP(nn.Module):
             return
         dt = self.compute_dtype
         dev = self._flat.device
-        d, di, V, dh, M = self.embedding_dim, self.d_inner, self.vocab_size, self.dh, self.max_seq
+        d, di, V, dh, M = self.embedding_dim, self.d_inner, self.head_size, self.dh, self.max_seq
         if self._prep is None:
             def buf(r, c, ld=None):
                 return torch.zeros(r, ld or c, dtype=dt, device=dev)
@@ -298,7 +309,7 @@ class MusicTransformerHIP(nn.Module):
                 ob, _, _ = self._slices[p + "rga.Wq.bias"]
                 L["bqkv"] = f[ob:ob + 3 * d]
             H = self._prep["head"]
-            src = self._pview(f, "fc.weight")
+            src = self._pview(f, self._HEAD_W)
             items.append((src, H.get("Wf") if dt != torch.float32 else None, H["WfT"]))
             if dt == torch.float32:
                 H["Wf"] = src
@@ -317,7 +328,7 @@ class MusicTransformerHIP(nn.Module):
         if len(self._ws) > 6:
             self._ws.clear()
         dt, dev = self.compute_dtype, self._flat.device
-        d, di, H, V, N = self.embedding_dim, self.d_inner, self.num_head, self.vocab_size, self.num_layer
+        d, di, H, V, N = self.embedding_dim, self.d_inner, self.num_head, self.head_size, self.num_layer
         T = B * Lm
         Lp = _round_up(Lm, 32)
         e = lambda *s, dtype=dt: torch.empty(*s, dtype=dtype, device=dev)
@@ -386,7 +397,7 @@ class MusicTransformerHIP(nn.Module):
 
     def _forward_impl(self, tokens, cond, B, Ltok, Lm, save, p_drop, seed, logits_out):
         dt = self.compute_dtype
-        d, di, H, dh, V, N, M = (self.embedding_dim, self.d_inner, self.num_head, self.dh, self.vocab_size,
+        d, di, H, dh, V, N, M = (self.embedding_dim, self.d_inner, self.num_head, self.dh, self.head_size,
                                  self.num_layer, self.max_seq)
         T = B * Lm
         ws = self._workspace(B, Lm, save)
@@ -405,7 +416,8 @@ class MusicTransformerHIP(nn.Module):
             y = ws.h[(i + 1) % nh if not save else i + 1]
             p = f"enc_layers.{i}."
             ops.gemm_nt(x, W["Wqkv"], Lw.qkv, bias=W["bqkv"], M=T, N=3 * d, K=d, dtype=dt)
-            ops.rga_fwd(Lw.qkv, W["Epk"], ws.key_pad, Lw.att, Lw.lse, B, Lm, H, dh, M)
+            ops.rga_fwd(Lw.qkv, W["Epk"], ws.key_pad if self.causal else None, Lw.att, Lw.lse, B, Lm, H, dh, M,
+                        causal=self.causal)             # bidirectional (mask=None in the reference): no pad mask either
             ops.gemm_nt(Lw.att, W["Wo"], ws.tmp, bias=self._pview(f, p + "rga.fc.bias"), M=T, N=d, K=d, dtype=dt)
             ops.resid_ln_fwd(x, ws.tmp, self._pview(f, p + "layernorm1.weight"), self._pview(f, p + "layernorm1.bias"),
                              Lw.o1, Lw.s1, Lw.st1, T, d, self.LN_EPS, p_drop, seed, 1 + 2 * i)
@@ -416,7 +428,7 @@ class MusicTransformerHIP(nn.Module):
                              y, Lw.s2, Lw.st2, T, d, self.LN_EPS, p_drop, seed, 2 + 2 * i)
         hN = ws.h[N % nh if not save else N]
         out = logits_out if logits_out is not None else ws.logits
-        ops.gemm_nt(hN, self._prep["head"]["Wf"], out, bias=self._pview(f, "fc.bias"), M=T, N=V, K=d,
+        ops.gemm_nt(hN, self._prep["head"]["Wf"], out, bias=self._pview(f, self._HEAD_B), M=T, N=V, K=d,
                     flags=ops.ME_EPI_OUT_F32, dtype=dt)
         return ws
 
@@ -424,7 +436,7 @@ class MusicTransformerHIP(nn.Module):
     def _backward_impl(self, ws, tokens, cond, B, Ltok, Lm, p_drop, seed, gflat, bucket_hook=None):
         """dlogits in ws.dlogits (T, padded ld) -> accumulates every parameter gradient into gflat."""
         dt = self.compute_dtype
-        d, di, H, dh, V, N, M = (self.embedding_dim, self.d_inner, self.num_head, self.dh, self.vocab_size,
+        d, di, H, dh, V, N, M = (self.embedding_dim, self.d_inner, self.num_head, self.dh, self.head_size,
                                  self.num_layer, self.max_seq)
         T = B * Lm
         f = self._flat
@@ -471,7 +483,7 @@ class MusicTransformerHIP(nn.Module):
             if tn_flags:
                 ops.gemm_tn_join()
 
-        wgrad("dlogits", ws.dlogits, hN, gv("fc.weight"), gv("fc.bias"), T=T, N=V, K=d, dtype=dt)
+        wgrad("dlogits", ws.dlogits, hN, gv(self._HEAD_W), gv(self._HEAD_B), T=T, N=V, K=d, dtype=dt)
         ops.gemm_nt(ws.dlogits, head["WfT"], ws.dA, M=T, N=d, K=ldv, dtype=dt)
         if bucket_hook:
             join()
@@ -535,7 +547,7 @@ class MusicTransformerHIP(nn.Module):
     def forward(self, x, condition=None):
         """model(x, condition) -> logits f32 [B, L(+2), V]   (music_multi.py:84-108)."""
         tokens, cond, B, Ltok, Lm = self._check_inputs(x, condition)
-        V = self.vocab_size
+        V = self.head_size
         p_drop = self.dropout_p if self.training else 0.0
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if not need_grad:
@@ -552,7 +564,7 @@ class MusicTransformerHIP(nn.Module):
         (no host sync).  Replaces Runner.forward_pass + loss.backward() (train.py:276-292,317)."""
         tokens, cond, B, Ltok, Lm = self._check_inputs(x, condition)
         target = target.to(device=self._flat.device, dtype=torch.int64).contiguous().view(-1)
-        T, V = B * Lm, self.vocab_size
+        T, V = B * Lm, self.head_size
         if target.numel() != T:
             raise ValueError("target has %d elements, model output has %d positions" % (target.numel(), T))
         p_drop = self.dropout_p if self.training else 0.0
@@ -576,7 +588,7 @@ class _EngineFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, tokens, cond, dims, p_drop, seed, *params):
         B, Ltok, Lm = dims
-        V = model.vocab_size
+        V = model.head_size
         out = torch.empty(B * Lm, V, dtype=torch.float32, device=model._flat.device)
         ws = model._forward_impl(tokens, cond, B, Ltok, Lm, True, p_drop, seed, out)
         ctx.model, ctx.ws, ctx.args = model, ws, (tokens, cond, B, Ltok, Lm, p_drop, seed)
@@ -590,7 +602,7 @@ class _EngineFn(torch.autograd.Function):
         if ctx.stamp != model._fwd_count:
             raise RuntimeError("backward() after another forward() of the same shape: activations of the "
                                "HIP engine live in a shared workspace (one forward in flight per shape)")
-        V = model.vocab_size
+        V = model.head_size
         ws.dlogits[:, :V].copy_(dlogits.reshape(B * Lm, V))
         gbuf = torch.zeros_like(model._gflat)
         model._backward_impl(ws, tokens, cond, B, Ltok, Lm, p_drop, seed, gbuf)
@@ -622,3 +634,47 @@ class MusicTransformerContinuousToken(MusicTransformerHIP):
                          pad_token=pad_token, token_conditioning=True, compute_dtype=compute_dtype)
         self.has_start_token = has_start_token
         self.n_conditions = n_conditions
+
+
+class MusicRegression(MusicTransformerHIP):
+    """Evaluation model of the reference (models/music_regression.py:34-92): token embedding * sqrt(d) + PE, the same
+    post-LN encoder layers with BIDIRECTIONAL relative attention (`no_mask=True`: mask=None, nothing masked, relative
+    term only for key <= q), and tanh(Linear(d, output_size)) of position 0 (the <CLS> token the loader prepends).
+    Same constructor kwargs and `state_dict` keys (`fc.0.weight` / `fc.0.bias`).  Inference only: the attention
+    backward kernels differentiate the causal variant, so loss_and_backward() / autograd raise.  With
+    `no_mask=False` the reference applies the causal + pad mask of the language model, which is the base class."""
+    _HEAD_W, _HEAD_B = "fc.0.weight", "fc.0.bias"
+
+    def __init__(self, embedding_dim=None, d_inner=None, vocab_size=None, num_layer=None, num_head=None,
+                 max_seq=None, dropout=None, pad_token=None, output_size=None, d_condition=-1, no_mask=True,
+                 compute_dtype="bf16"):
+        assert d_condition is None or d_condition <= 0                       # music_regression.py:41
+        self.output_size = output_size
+        self.no_mask = no_mask
+        super().__init__(embedding_dim=embedding_dim, d_inner=d_inner, d_condition=-1, vocab_size=vocab_size,
+                         num_layer=num_layer, num_head=num_head, max_seq=max_seq, dropout=dropout, pad_token=pad_token,
+                         token_conditioning=False, compute_dtype=compute_dtype, head_size=output_size,
+                         causal=not no_mask)
+
+    def _make_head(self, d, n_out):
+        return nn.Sequential(_Lin(d, n_out), nn.Tanh())
+
+    def _head_linear(self):
+        return self.fc[0]
+
+    def init_weights(self):
+        """music_regression.py:72-74: only the embedding is re-initialised."""
+        with torch.no_grad():
+            self.embedding.weight.uniform_(-0.1, 0.1)
+
+    def forward(self, x):
+        """tokens [B, L] -> tanh(head(x[:, 0])) f32 [B, output_size]."""
+        tokens, cond, B, Ltok, Lm = self._check_inputs(x, None)
+        p_drop = self.dropout_p if self.training else 0.0
+        out = torch.empty(B * Lm, self.head_size, dtype=torch.float32, device=self._flat.device)
+        with torch.no_grad():
+            self._forward_impl(tokens, cond, B, Ltok, Lm, False, p_drop, self._next_seed(), out)
+            return torch.tanh(out.view(B, Lm, self.head_size)[:, 0, :]).clone()
+
+    def loss_and_backward(self, *a, **k):
+        raise NotImplementedError("MusicRegression is inference-only in this build (no bidirectional attention backward)")

@@ -130,9 +130,9 @@ def rga_pack_rel(E, out=None):
     return out
 
 
-def rga_fwd(qkv, Epk, key_pad, out, lse, B, L, H, dh, M):
-    """Epk = rga_pack_rel(E)."""
-    check(lib().me_rga_fwd(_ptr(qkv), _ptr(Epk), _ptr(key_pad), _ptr(out), _ptr(lse), B, L, H, dh, M,
+def rga_fwd(qkv, Epk, key_pad, out, lse, B, L, H, dh, M, causal=True):
+    """Epk = rga_pack_rel(E).  causal=False: bidirectional attention of the regression model (forward only)."""
+    check(lib().me_rga_fwd(_ptr(qkv), _ptr(Epk), _ptr(key_pad), _ptr(out), _ptr(lse), B, L, H, dh, M, 1 if causal else 0,
                            _code(qkv.dtype), _stream()), "me_rga_fwd")
 
 

@@ -174,15 +174,17 @@ def rga_scores_rel(q: Tensor, E: Tensor) -> Tensor:
 
 
 def rga_attention_core(q: Tensor, k: Tensor, v: Tensor, E: Tensor,
-                       pad: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
+                       pad: Optional[Tensor], causal: bool = True) -> Tuple[Tensor, Tensor]:
     """Relative global attention on head-major q,k,v [B,H,L,dh].
-    music_multi.py:213-232.  Returns (O [B,H,L,dh], LSE [B,H,L])."""
+    music_multi.py:213-232.  Returns (O [B,H,L,dh], LSE [B,H,L]).
+    causal=False: MusicRegression's call with mask=None (music_regression.py:79,107): nothing is masked (except the
+    optional pad keys of this restatement) and the relative term keeps its zeros above the diagonal."""
     L = q.shape[2]
     dh = q.shape[3]
     s = (q @ k.transpose(2, 3) + rga_scores_rel(q, E)) / math.sqrt(dh)     # :219-222
     l = torch.arange(L)[:, None]
     j = torch.arange(L)[None, :]
-    masked = (j > l)[None, None]                                           # causal
+    masked = (j > l)[None, None] if causal else torch.zeros(1, 1, L, L, dtype=torch.bool)
     if pad is not None:
         masked = masked | pad[:, None, None, :]                            # key padding
     s = s.masked_fill(masked, float("-inf"))                               # :224-229
@@ -198,7 +200,7 @@ def layer_norm(x: Tensor, w: Tensor, b: Tensor, eps: float = 1e-6) -> Tensor:
     return (x - mu) / torch.sqrt(var + eps) * w + b
 
 
-def encoder_layer(cfg: Cfg, P: Dict[str, Tensor], i: int, x: Tensor, pad: Optional[Tensor]) -> Tensor:
+def encoder_layer(cfg: Cfg, P: Dict[str, Tensor], i: int, x: Tensor, pad: Optional[Tensor], causal: bool = True) -> Tensor:
     """music_multi.py:126-135 (post-LN, ReLU FFN, dropout off)."""
     p = f"enc_layers.{i}."
     B, L, d = x.shape
@@ -207,7 +209,7 @@ def encoder_layer(cfg: Cfg, P: Dict[str, Tensor], i: int, x: Tensor, pad: Option
     def proj(name):
         y = x @ P[p + f"rga.{name}.weight"].t() + P[p + f"rga.{name}.bias"]
         return y.view(B, L, H, dh).permute(0, 2, 1, 3)                     # :196-209
-    o, _ = rga_attention_core(proj("Wq"), proj("Wk"), proj("Wv"), P[p + "rga.E"], pad)
+    o, _ = rga_attention_core(proj("Wq"), proj("Wk"), proj("Wv"), P[p + "rga.E"], pad, causal)
     o = o.permute(0, 2, 1, 3).reshape(B, L, d)                             # :234-235
     a = o @ P[p + "rga.fc.weight"].t() + P[p + "rga.fc.bias"]              # :237
     o1 = layer_norm(a + x, P[p + "layernorm1.weight"], P[p + "layernorm1.bias"])   # :129
@@ -336,3 +338,45 @@ def greedy_decode(cfg: Cfg, P, conds: Tensor, gen_len: int, max_input_len: int,
         out[:, specials] = float("-inf")
         cur = out.argmax(-1)[None, :]
     return song
+
+
+# ----------------------------------------------------------------------------- MusicRegression (evaluation model)
+def regression_param_shapes(vocab_size: int, n_layer: int, d: int, d_inner: int, dh: int, max_seq: int, output_size: int = 2):
+    """state_dict of models/music_regression.py:34-70 (no condition projection; head = Sequential(Linear, Tanh))."""
+    shp = {"embedding.weight": (vocab_size, d)}
+    for i in range(n_layer):
+        p = f"enc_layers.{i}."
+        for nm in ("Wq", "Wk", "Wv", "fc"):
+            shp[p + f"rga.{nm}.weight"] = (d, d)
+            shp[p + f"rga.{nm}.bias"] = (d,)
+        shp[p + "rga.E"] = (max_seq, dh)
+        shp[p + "FFN_pre.weight"], shp[p + "FFN_pre.bias"] = (d_inner, d), (d_inner,)
+        shp[p + "FFN_suf.weight"], shp[p + "FFN_suf.bias"] = (d, d_inner), (d,)
+        for ln in ("layernorm1", "layernorm2"):
+            shp[p + ln + ".weight"], shp[p + ln + ".bias"] = (d,), (d,)
+    shp["fc.0.weight"], shp["fc.0.bias"] = (output_size, d), (output_size,)
+    return shp
+
+
+def regression_forward(cfg: Cfg, P: Dict[str, Tensor], tokens: Tensor) -> Tensor:
+    """MusicRegression.forward with no_mask=True (music_regression.py:76-92): embedding * sqrt(d) + PE, bidirectional
+    encoder layers, tanh(Linear(x[:, 0]))."""
+    d = cfg.d_model
+    x = P["embedding.weight"][tokens] * math.sqrt(d)
+    x = x + sinusoid_pe(cfg.max_seq, d)[: tokens.shape[1]].to(x.dtype)
+    for i in range(cfg.n_layer):
+        x = encoder_layer(cfg, P, i, x, None, causal=False)
+    return torch.tanh(x[:, 0, :] @ P["fc.0.weight"].t() + P["fc.0.bias"])
+
+
+def regression_seeded_params(shapes, seed: int) -> Dict[str, Tensor]:
+    """Deterministic weights for the regression fixtures: keys in sorted order, N(0, 0.1) entries (a well-conditioned net: the bf16 tier is compared too),
+    LayerNorm gains around 1 (regenerated from the seed by the generator script and by the tests)."""
+    g = torch.Generator().manual_seed(seed)
+    P = {}
+    for k in sorted(shapes):
+        shp = shapes[k]
+        P[k] = (torch.randn(shp, generator=g) * (0.1 if len(shp) > 1 else 0.1)).float()
+        if "layernorm" in k and k.endswith("weight"):
+            P[k] = P[k] + 1.0
+    return P

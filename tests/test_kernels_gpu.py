@@ -351,7 +351,7 @@ def attn_case(B, H, L, dh, M, seed, pad_rows=True):
     return q, k, v, E, dO, pad
 
 
-def run_attn(ops, dtype, q, k, v, E, dO, pad, backward=True):
+def run_attn(ops, dtype, q, k, v, E, dO, pad, backward=True, causal=True):
     B, H, L, dh = q.shape
     M = E.shape[0]
     Lp = ((L + 31) // 32) * 32
@@ -362,7 +362,7 @@ def run_attn(ops, dtype, q, k, v, E, dO, pad, backward=True):
     out = torch.full((B, L, H, dh), float("nan"), dtype=dtype, device=DEV)
     lse = torch.empty(B, H, L, dtype=torch.float32, device=DEV)
     Epk = ops.rga_pack_rel(Ed)
-    ops.rga_fwd(qkv, Epk, kp, out, lse, B, L, H, dh, M)
+    ops.rga_fwd(qkv, Epk, kp, out, lse, B, L, H, dh, M, causal=causal)
     res = {"O": out.permute(0, 2, 1, 3).float().cpu(), "lse": lse.cpu()}
     if backward:
         dout = to_tok(dO).contiguous().to(dtype).to(DEV)
@@ -492,3 +492,23 @@ def test_rel_pack_layout_and_refresh_path(ops, dtype, dh):
     assert torch.equal(pk2.cpu(), pk)
     if dst is not None:
         assert torch.equal(dst.cpu(), Eh)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,L,dh,M", [(2, 2, 1, 32, 64), (1, 3, 7, 64, 64), (2, 2, 33, 32, 64), (1, 2, 130, 64, 256),
+                                         (2, 2, 256, 64, 2048), (1, 1, 300, 48, 512), (2, 4, 520, 64, 2048)])
+def test_rga_fwd_bidirectional(ops, dtype, B, H, L, dh, M):
+    """causal = 0 (MusicRegression, mask = None): every key attended, relative term only on / below the diagonal;
+    with and without padded keys; against the fp64 oracle."""
+    q, k, v, E, dO, pad = attn_case(B, H, L, dh, M, seed=300 + L)
+    for use_pad in (None, pad):
+        got = run_attn(ops, dtype, q, k, v, E, dO, use_pad, backward=False, causal=False)
+        r = lambda t: t.to(dtype).double()
+        o, lse = O.rga_attention_core(r(q), r(k), r(v), r(E), use_pad, causal=False)
+        errs = {"O": relerr(got["O"], o), "lse": relerr(got["lse"], lse)}
+        assert all(e < tol(dtype, 3e-5, 1.5e-2) for e in errs.values()), (errs, use_pad is not None)
+    # and it really differs from the causal result once there is more than one key
+    if L > 1:
+        c = run_attn(ops, dtype, q, k, v, E, dO, None, backward=False, causal=True)
+        assert relerr(c["O"], o) > 1e-2

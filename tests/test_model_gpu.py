@@ -368,3 +368,28 @@ def test_full_size_c2_properties_bf16():
     e = relerr(model.flat_grads, g_full)
     report("full-size C2 bf16: grad additivity rel %.2e, loss %.5f vs f64 CE of own logits %.5f" % (e, float(loss), float(ref)))
     assert e < 2e-3, e
+
+
+@pytest.mark.parametrize("cd", ["fp32", "bf16"])
+def test_f6_regression_model_vs_reference_golden(golden_dir, cd):
+    """MusicRegression (evaluation model, forward only) against outputs of the imported reference."""
+    from midiemo.models.music_transformer import MusicRegression
+    z = np.load(os.path.join(golden_dir, "f6_regression.npz"))
+    V, N, H, d, di, M = [int(x) for x in z["cfg"]]
+    if d // H not in (32, 48, 64):
+        pytest.skip("fixture head dim")
+    P = O.regression_seeded_params(O.regression_param_shapes(V, N, d, di, d // H, M), int(z["seed"][0]))
+    model = MusicRegression(embedding_dim=d, d_inner=di, vocab_size=V, num_layer=N, num_head=H, max_seq=M, dropout=0.0,
+                            pad_token=0, output_size=2, compute_dtype=cd)
+    res = model.load_state_dict(P, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    model = model.to(DEV).eval()
+    worst = 0.0
+    for L in (1, 7, 33, 64):
+        y = model(torch.from_numpy(z["tok_%d" % L]).to(DEV)).cpu()
+        assert y.shape == (3, 2)
+        worst = max(worst, float((y.double() - torch.from_numpy(z["y_%d" % L]).double()).abs().max()))
+    report("F6 regression[%s]: max abs err of tanh outputs %.2e" % (cd, worst))
+    assert worst < (2e-5 if cd == "fp32" else 3e-2), worst
+    with pytest.raises(NotImplementedError):
+        model.loss_and_backward(None, None, None)

@@ -152,3 +152,20 @@ def test_f5_attention_core_fp64(golden_dir):
     (o * torch.from_numpy(z["dO"])).sum().backward()
     for t, n in ((q, "dq"), (k, "dk"), (v, "dv"), (E, "dE")):
         np.testing.assert_allclose(t.grad.numpy(), z[n], rtol=1e-9, atol=1e-11, err_msg=n)
+
+
+def test_regression_forward_vs_reference_golden(golden_dir):
+    """F6: the oracle's MusicRegression restatement (bidirectional relative attention, tanh head of position 0) against
+    outputs of the imported reference (oracle/make_regression_fixtures.py)."""
+    z = np.load(os.path.join(golden_dir, "f6_regression.npz"))
+    V, N, H, d, di, M = [int(x) for x in z["cfg"]]
+    assert str(z["build_class"][0]) == "MusicRegression"
+    shapes = O.regression_param_shapes(V, N, d, di, d // H, M)
+    # the reference's build_model(regression=True) yields the same key set (its max_seq is 2048, only E's shape differs)
+    assert sorted(shapes) == sorted(str(k) for k in z["build_keys"])
+    P = O.regression_seeded_params(shapes, int(z["seed"][0]))
+    cfg = O.Cfg(V, N, H, d, di, max_seq=M)
+    for L in (1, 7, 33, 64):
+        tok = torch.from_numpy(z["tok_%d" % L])
+        y = O.regression_forward(cfg, {k: v.double() for k, v in P.items()}, tok)
+        assert float((y - torch.from_numpy(z["y_%d" % L]).double()).abs().max()) < 2e-5, L

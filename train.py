@@ -79,7 +79,8 @@ def parse_args(argv=None):
     if args.conditioning != "continuous_concat":
         args.d_condition = -1                                  # config.py:120-121
     if args.regression:
-        raise SystemExit("--regression (evaluation-only model) is outside this build's hot path")
+        raise SystemExit("--regression: the evaluation model MusicRegression is available for inference "
+                         "(build_model(regression=True)), but this build has no bidirectional attention backward to train it")
     return args
 
 
