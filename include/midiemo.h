@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 7
+#define ME_ABI_VERSION 8
 
 enum { ME_F32 = 0, ME_BF16 = 1 };
 
@@ -139,7 +139,8 @@ int me_gemm_tn_join(void* stream);
  * mask, softmax, PV, head merge).  dh in {32, 48, 64}; M % 32 == 0; L <= M.  Epk = me_rga_pack_rel(E).
  * causal = 1: the language model (generate_mask: key <= q and not padded).  causal = 0: the bidirectional attention of
  * MusicRegression (models/music_regression.py:79, mask = None): all keys, relative term only for key <= q (the
- * reference's skewing leaves zeros above the diagonal); forward only -- me_rga_bwd differentiates causal = 1. */
+ * reference's skewing leaves zeros above the diagonal); me_rga_bwd takes the same flag (causal = 0 writes and reads
+ * every tile of the P^T / dS^T workspaces, so they need not be zero-initialised for it). */
 int me_rga_fwd(const void* qkv, const void* Epk, const uint8_t* key_pad, void* out, float* lse,
                int B, int L, int H, int dh, int M, int causal, int dtype, void* stream);
 
@@ -159,7 +160,7 @@ int me_rga_pack_rel(const void* E, void* Epk, int M, int dh, int dtype, void* st
 int me_rga_bwd(const void* qkv, const void* Epk, const uint8_t* key_pad,
                const void* out, const float* lse, const void* dout,
                void* dqkv, float* dE, float* delta_ws, void* PT, void* dST,
-               int B, int L, int Lp, int H, int dh, int M, int dtype, void* stream);
+               int B, int L, int Lp, int H, int dh, int M, int causal, int dtype, void* stream);
 
 /* ---- residual + dropout + LayerNorm (post-LN, eps) ---------------------------
  *   s = x + dropout(a) ;  y = LN(s) * gamma + beta          (music_multi.py:128-129,133-134)

@@ -342,7 +342,9 @@ __global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ q
 // =====================================================================================
 // backward 1/3 (query-owned): delta, dQ, and the materialised P^T, dS^T, dG^T
 // =====================================================================================
-template <typename T, int DH>
+// CAUSAL = false: backward of the bidirectional forward (MusicRegression): every key tile is visited and written; tiles
+// above the diagonal have no relative term (no G, no dG, no E^T product).
+template <typename T, int DH, bool CAUSAL = true>
 __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
     const T* __restrict__ qkv, const T* __restrict__ Epk,
     const uint8_t* __restrict__ key_pad, const T* __restrict__ out, const float* __restrict__ lse,
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
     const int q = q0 + a;
     const bool wave_on = q0 < L;
     const bool row_on = wave_on && q < L;
-    const int nkt = min((L + 31) / 32, qb * 4 + 4);
+    const int nkt = CAUSAL ? min((L + 31) / 32, qb * 4 + 4) : (L + 31) / 32;
     const int my_last_kt = qb * 4 + wid;
     const float c2 = scale * 1.4426950408889634f;
 
@@ -459,17 +461,18 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
     auto step = [&](int kt, auto main_tag) __attribute__((always_inline)) {
         constexpr bool MAIN = decltype(main_tag)::value;
         const int buf = kt & 1;
-        if (MAIN || (wave_on && kt <= my_last_kt)) {
+        if (MAIN || (wave_on && (!CAUSAL || kt <= my_last_kt))) {
             const int k0 = kt * 32;
             const bool diag = !MAIN && kt == my_last_kt;
+            const bool upper = !CAUSAL && !MAIN && kt > my_last_kt;      // bidirectional only: above the diagonal, no relative term
             const int eb_lo = eb0 + kt;
             if constexpr (MAIN) {
                 g_block(ef, eb_lo + 1);               // the next block's E rows are fetched after the softmax (register budget)
-            } else if (!diag) {
+            } else if (!diag && !upper) {
                 g_block(ef, eb_lo + 1);
                 if (kt + 1 < my_last_kt) e_frags(ef, eb_lo + 2);
             }
-            if (ME_ABL != 3 && !(MAIN && ME_ABL == 8)) et_frags(etf, eb_lo);      // E^T block of this step's lo block: in flight during S / dP / softmax
+            if (ME_ABL != 3 && !(MAIN && ME_ABL == 8) && !upper) et_frags(etf, eb_lo);      // E^T block of this step's lo block: in flight during S / dP / softmax
             f32x16_t s, dp; acc_zero(s); acc_zero(dp);
 #pragma unroll
             for (int kk = 0; kk < C::KA; ++kk) {
@@ -485,7 +488,7 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
             const float* grow = &Gs[wid][a * LDG2];
             T* drow = &Ds[wid][a * LDR];
             const int t0 = (eb_lo & 1) * 32 + 31 - a + 4 * h;
-            const bool plain = !diag && pbits == 0u && k0 + 32 <= L && q0 + 32 <= L;
+            const bool plain = !diag && !upper && pbits == 0u && k0 + 32 <= L && q0 + 32 <= L;
             // the 16 ring reads are issued as one batch and every element is computed branch-free: per-element
             // exec-mask branches serialise the LDS latency (one read -> wait -> exp per basic block)
             const float nds = -delta * scale;
@@ -507,16 +510,21 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
                     for (int j = 0; j < 8; ++j) {
                         const int r = r0 + j;
                         const int bk = (r & 3) + 8 * (r >> 2) + 4 * h, key = k0 + bk;
-                        const bool masked = !row_on || key > q || key >= L || ((pbits >> bk) & 1u);
-                        const float p = fast_exp2(masked ? -INFINITY : fmaf(s[r] + gv[j], c2, -lse2));     // exp2(-inf) = 0
+                        const bool masked = !row_on || (CAUSAL && key > q) || key >= L || ((pbits >> bk) & 1u);
+                        const float gq = (CAUSAL || (!upper && key <= q)) ? gv[j] : 0.f;                   // no relative term above the diagonal
+                        const float p = fast_exp2(masked ? -INFINITY : fmaf(s[r] + gq, c2, -lse2));       // exp2(-inf) = 0
                         s[r] = masked ? 0.f : p * fmaf(dp[r], scale, nds);
                         dp[r] = p;
                     }
                 }
             }
-            if (ME_ABL != 4) {
+            if (ME_ABL != 4 && !upper) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) drow[(t0 + (r & 3) + 8 * (r >> 2)) & 63] = ET<T>::from_f(s[r]);
+                for (int r = 0; r < 16; ++r) {
+                    // dG collects dS only where the relative term exists (bidirectional diagonal tile: key <= q)
+                    const bool rel = CAUSAL || k0 + (r & 3) + 8 * (r >> 2) + 4 * h <= q;
+                    drow[(t0 + (r & 3) + 8 * (r >> 2)) & 63] = ET<T>::from_f(rel ? s[r] : 0.f);
+                }
             }
             // ---- materialise P^T, dS^T tiles [key][q]: transpose through the (now dead) lo slot of the G
             //      ring so that the tiles leave as 16-byte row-contiguous stores.  Rows key >= L and
@@ -593,6 +601,7 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
                 }
             }
             // ---- the lo block of dG is complete now: relative part of dQ and flush of dG^T
+            if (!upper)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 Frag<T> dgf;
@@ -633,7 +642,7 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
 // [128 key][32 q] and dO^T, Q^T tiles [DH][32 q]; all four are contraction-contiguous, so the
 // fragments are plain 16-byte LDS reads.  The materialised tensors are read exactly once:
 // the kernel is HBM-bound (2 x Lp^2/2 elements per (b, head)).
-template <typename T, int DH, int NWK>
+template <typename T, int DH, int NWK, bool CAUSAL = true>
 __global__ __launch_bounds__(NWK * 64) void rga_bwd_kv_kernel(const T* __restrict__ PT, const T* __restrict__ dST,
                                                               const T* __restrict__ qkv, const T* __restrict__ dout,
                                                               T* __restrict__ dqkv, int B, int L, int Lp, int H) {
@@ -654,7 +663,7 @@ __global__ __launch_bounds__(NWK * 64) void rga_bwd_kv_kernel(const T* __restric
     const int k0 = kb * KB + wid * 32;
     const bool wave_on = k0 < L;
     const int nqt = (L + 31) / 32;
-    const int qs0 = kb * NWK;
+    const int qs0 = CAUSAL ? kb * NWK : 0;                          // bidirectional: every query tile contributes
     const int rows_valid = min(KB, Lp - kb * KB);
     const T* pt_ = PT + (size_t)bh * Lp * Lp;
     const T* st_ = dST + (size_t)bh * Lp * Lp;
@@ -704,7 +713,7 @@ __global__ __launch_bounds__(NWK * 64) void rga_bwd_kv_kernel(const T* __restric
     __syncthreads();
     for (int qs = qs0; qs < nqt; ++qs) {
         const int buf = (qs - qs0) & 1;
-        if (wave_on && qs * 32 + 31 >= k0) {
+        if (wave_on && (!CAUSAL || qs * 32 + 31 >= k0)) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 Frag<T> pf, sf;
@@ -985,26 +994,36 @@ int fwd_launch(const void* qkv, const void* Epk, const uint8_t* key_pad, void* o
 template <typename T, int DH>
 int bwd_launch(const void* qkv, const void* Epk, const uint8_t* key_pad, const void* out, const float* lse,
                const void* dout, void* dqkv, float* dE, float* delta_ws, void* PT, void* dST, int B, int L,
-               int Lp, int H, int M, hipStream_t st) {
+               int Lp, int H, int M, int causal, hipStream_t st) {
     const int nqb = (L + 127) / 128;
     const float scale = 1.f / sqrtf((float)DH);
-    rga_bwd_q_kernel<T, DH><<<B * H * nqb, 256, 0, st>>>((const T*)qkv, (const T*)Epk, key_pad, (const T*)out, lse,
-                                                        (const T*)dout, (T*)dqkv, delta_ws, (T*)PT, (T*)dST, B, L, Lp,
-                                                        H, M, scale);
+    if (causal)
+        rga_bwd_q_kernel<T, DH, true><<<B * H * nqb, 256, 0, st>>>((const T*)qkv, (const T*)Epk, key_pad, (const T*)out, lse,
+                                                                  (const T*)dout, (T*)dqkv, delta_ws, (T*)PT, (T*)dST, B, L, Lp,
+                                                                  H, M, scale);
+    else
+        rga_bwd_q_kernel<T, DH, false><<<B * H * nqb, 256, 0, st>>>((const T*)qkv, (const T*)Epk, key_pad, (const T*)out, lse,
+                                                                   (const T*)dout, (T*)dqkv, delta_ws, (T*)PT, (T*)dST, B, L, Lp,
+                                                                   H, M, scale);
     int rc = me_launch_status();
     if (rc) return rc;
     static const int kv8 = getenv("MIDIEMO_KV8") ? atoi(getenv("MIDIEMO_KV8")) : 1;   // 256-key blocks (16-bit tier): 181 -> 175 us at C2
     bool big = false;
     if constexpr (sizeof(T) == 2) {
-        if (kv8) {
+        if (kv8 && causal) {
             big = true;
-            rga_bwd_kv_kernel<T, DH, 8><<<B * H * ((L + 255) / 256), 512, 0, st>>>((const T*)PT, (const T*)dST, (const T*)qkv,
-                                                                                  (const T*)dout, (T*)dqkv, B, L, Lp, H);
+            rga_bwd_kv_kernel<T, DH, 8, true><<<B * H * ((L + 255) / 256), 512, 0, st>>>((const T*)PT, (const T*)dST, (const T*)qkv,
+                                                                                        (const T*)dout, (T*)dqkv, B, L, Lp, H);
         }
     }
-    if (!big)
-        rga_bwd_kv_kernel<T, DH, 4><<<B * H * nqb, 256, 0, st>>>((const T*)PT, (const T*)dST, (const T*)qkv, (const T*)dout,
-                                                                (T*)dqkv, B, L, Lp, H);
+    if (!big) {
+        if (causal)
+            rga_bwd_kv_kernel<T, DH, 4, true><<<B * H * nqb, 256, 0, st>>>((const T*)PT, (const T*)dST, (const T*)qkv, (const T*)dout,
+                                                                          (T*)dqkv, B, L, Lp, H);
+        else
+            rga_bwd_kv_kernel<T, DH, 4, false><<<B * H * nqb, 256, 0, st>>>((const T*)PT, (const T*)dST, (const T*)qkv, (const T*)dout,
+                                                                           (T*)dqkv, B, L, Lp, H);
+    }
     rc = me_launch_status();
     if (rc) return rc;
     const int ngx = (Lp + 127) / 128;
@@ -1063,7 +1082,7 @@ int me_rga_fwd(const void* qkv, const void* Epk, const uint8_t* key_pad, void* o
 
 int me_rga_bwd(const void* qkv, const void* Epk, const uint8_t* key_pad, const void* out, const float* lse,
                const void* dout, void* dqkv, float* dE, float* delta_ws, void* PT, void* dST, int B, int L,
-               int Lp, int H, int dh, int M, int dtype, void* stream) {
+               int Lp, int H, int dh, int M, int causal, int dtype, void* stream) {
     me_clear_error();
     if (!qkv || !Epk || !out || !lse || !dout || !dqkv || !dE || !delta_ws || !PT || !dST) return ME_ERR_NULL;
     if (B <= 0 || L <= 0 || H <= 0 || L > M || (M & 31) || (Lp & 31) || Lp < L || Lp > M) return ME_ERR_BAD_SHAPE;
@@ -1072,7 +1091,7 @@ int me_rga_bwd(const void* qkv, const void* Epk, const uint8_t* key_pad, const v
         return ME_ERR_ALIGNMENT;
     hipStream_t st = (hipStream_t)stream;
     ME_ATTN_DISPATCH((bwd_launch<T, DH>(qkv, Epk, key_pad, out, lse, dout, dqkv, dE, delta_ws, PT, dST, B, L, Lp, H, M,
-                                        st)))
+                                        causal, st)))
 }
 
 int me_rga_decode_step(const void* qkv_new, void* kcache, void* vcache, const void* E, const uint8_t* key_pad, int ld_pad,

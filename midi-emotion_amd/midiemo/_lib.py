@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("MIDIEMO_LIB") or os.path.join(HERE, "libmidiemo_hip.s
 ME_F32, ME_BF16 = 0, 1
 ME_COND_NONE, ME_COND_CONCAT, ME_COND_TOKEN = 0, 1, 2
 ME_EPI_RELU, ME_EPI_OUT_F32, ME_EPI_RELU_BWD = 1, 2, 4
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 ERRORS = {0: "ME_OK", -1: "ME_ERR_BAD_DTYPE", -2: "ME_ERR_BAD_SHAPE", -3: "ME_ERR_ALIGNMENT",
           -4: "ME_ERR_LAUNCH", -5: "ME_ERR_NULL"}
@@ -33,7 +33,7 @@ SIGNATURES = {
     "me_gemm_tn_join": [_p],
     "me_rga_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "me_rga_pack_rel": [_p, _p, _i, _i, _i, _p],
-    "me_rga_bwd": [_p] * 11 + [_i, _i, _i, _i, _i, _i, _i, _p],
+    "me_rga_bwd": [_p] * 11 + [_i, _i, _i, _i, _i, _i, _i, _i, _p],
     "me_resid_ln_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _f, _u64, _u32, _i, _p],
     "me_resid_ln_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _u64, _u32, _i, _p],
     "me_ce_fwd": [_p, _i, _p, _p, _p, _p, _i, _i, _i, _p],

@@ -512,8 +512,8 @@ class MusicTransformerHIP(nn.Module):
             reuse("dqkv")
             if bucket_hook:
                 bucket_hook(-1)            # comm window: ~0.5 ms of attention-backward kernels follow (ddp.GradAllReducer)
-            ops.rga_bwd(Lw.qkv, W["Epk"], ws.key_pad, Lw.att, Lw.lse, ws.dA, ws.dqkv, gv(p + "rga.E"),
-                        ws.delta, ws.PT, ws.dST, B, Lm, ws.Lp, H, dh, M)
+            ops.rga_bwd(Lw.qkv, W["Epk"], ws.key_pad if self.causal else None, Lw.att, Lw.lse, ws.dA, ws.dqkv,
+                        gv(p + "rga.E"), ws.delta, ws.PT, ws.dST, B, Lm, ws.Lp, H, dh, M, causal=self.causal)
             o, _, _ = self._slices[p + "rga.Wq.weight"]
             ob, _, _ = self._slices[p + "rga.Wq.bias"]
             wgrad("dqkv", ws.dqkv, x, gflat[o:o + 3 * d * d].view(3 * d, d), gflat[ob:ob + 3 * d], T=T, N=3 * d, K=d,
@@ -640,8 +640,8 @@ class MusicRegression(MusicTransformerHIP):
     """Evaluation model of the reference (models/music_regression.py:34-92): token embedding * sqrt(d) + PE, the same
     post-LN encoder layers with BIDIRECTIONAL relative attention (`no_mask=True`: mask=None, nothing masked, relative
     term only for key <= q), and tanh(Linear(d, output_size)) of position 0 (the <CLS> token the loader prepends).
-    Same constructor kwargs and `state_dict` keys (`fc.0.weight` / `fc.0.bias`).  Inference only: the attention
-    backward kernels differentiate the causal variant, so loss_and_backward() / autograd raise.  With
+    Same constructor kwargs and `state_dict` keys (`fc.0.weight` / `fc.0.bias`).  forward() is inference (no autograd
+    graph); training goes through loss_and_backward() (L1 loss, bidirectional attention backward).  With
     `no_mask=False` the reference applies the causal + pad mask of the language model, which is the base class."""
     _HEAD_W, _HEAD_B = "fc.0.weight", "fc.0.bias"
 
@@ -676,5 +676,22 @@ class MusicRegression(MusicTransformerHIP):
             self._forward_impl(tokens, cond, B, Ltok, Lm, False, p_drop, self._next_seed(), out)
             return torch.tanh(out.view(B, Lm, self.head_size)[:, 0, :]).clone()
 
-    def loss_and_backward(self, *a, **k):
-        raise NotImplementedError("MusicRegression is inference-only in this build (no bidirectional attention backward)")
+    def loss_and_backward(self, x, target, grad_scale=1.0, bucket_hook=None, backward=True):
+        """L1Loss(tanh(head(x[:, 0])), target) (train.py:282-284: `self.l1_loss(output, condition)`, mean over B x
+        output_size) and its backward into `flat_grads` (+=).  target: [B, output_size] (valence, arousal)."""
+        tokens, cond, B, Ltok, Lm = self._check_inputs(x, None)
+        n_out = self.head_size
+        target = torch.as_tensor(target).to(device=self._flat.device, dtype=torch.float32).reshape(B, n_out)
+        p_drop = self.dropout_p if self.training else 0.0
+        seed = self._next_seed()
+        ws = self._forward_impl(tokens, cond, B, Ltok, Lm, True, p_drop, seed, None)
+        ldv = ws.logits.shape[1]
+        y = torch.tanh(ws.logits.view(B, Lm, ldv)[:, 0, :n_out])
+        diff = y - target
+        loss = diff.abs().mean()
+        if backward:
+            dz = torch.sign(diff) * (1.0 - y * y) * (float(grad_scale) / diff.numel())
+            ws.dlogits.zero_()                                   # only position 0 of every sequence feeds the head
+            ws.dlogits.view(B, Lm, ldv)[:, 0, :n_out] = dz.to(ws.dlogits.dtype)
+            self._backward_impl(ws, tokens, cond, B, Ltok, Lm, p_drop, seed, self._gflat, bucket_hook)
+        return loss

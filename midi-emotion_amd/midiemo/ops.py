@@ -136,9 +136,9 @@ def rga_fwd(qkv, Epk, key_pad, out, lse, B, L, H, dh, M, causal=True):
                            _code(qkv.dtype), _stream()), "me_rga_fwd")
 
 
-def rga_bwd(qkv, Epk, key_pad, out, lse, dout, dqkv, dE, delta_ws, PT, dST, B, L, Lp, H, dh, M):
+def rga_bwd(qkv, Epk, key_pad, out, lse, dout, dqkv, dE, delta_ws, PT, dST, B, L, Lp, H, dh, M, causal=True):
     check(lib().me_rga_bwd(_ptr(qkv), _ptr(Epk), _ptr(key_pad), _ptr(out), _ptr(lse), _ptr(dout), _ptr(dqkv),
-                           _ptr(dE), _ptr(delta_ws), _ptr(PT), _ptr(dST), B, L, Lp, H, dh, M,
+                           _ptr(dE), _ptr(delta_ws), _ptr(PT), _ptr(dST), B, L, Lp, H, dh, M, 1 if causal else 0,
                            _code(qkv.dtype), _stream()), "me_rga_bwd")
 
 

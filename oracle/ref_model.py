@@ -380,3 +380,12 @@ def regression_seeded_params(shapes, seed: int) -> Dict[str, Tensor]:
         if "layernorm" in k and k.endswith("weight"):
             P[k] = P[k] + 1.0
     return P
+
+
+def regression_loss_and_grads(cfg: Cfg, P: Dict[str, Tensor], tokens: Tensor, target: Tensor):
+    """torch.nn.L1Loss()(model(tokens), target) and its gradients (train.py:282-284, 317), dropout off."""
+    Q = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+    y = regression_forward(cfg, Q, tokens)
+    loss = (y - target.to(y.dtype)).abs().mean()
+    loss.backward()
+    return loss.detach(), y.detach(), {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in Q.items()}

@@ -90,14 +90,14 @@ def test_unsupported_configs_raise():
     with pytest.raises(ValueError, match="head dim"):
         build_model(dict(vocab_size=1007, n_layer=1, n_head=16, d_model=640, d_inner=1024, dropout=0.1,
                          d_condition=-1, conditioning="none"))          # dh = 40: no kernel instantiation
-    # regression=True builds the evaluation model (forward only): reference state_dict keys, training entry points raise
+    # regression=True builds the evaluation model: reference state_dict keys; like every model here it needs a HIP device
     r, _ = build_model(dict(vocab_size=1008, n_layer=1, n_head=8, d_model=512, d_inner=2048, dropout=0.1,
                             d_condition=-1, conditioning="none", regression=True))
     assert type(r).__name__ == "MusicRegression" and r.head_size == 2 and not r.causal
     keys = set(r.state_dict().keys())
     assert {"fc.0.weight", "fc.0.bias", "embedding.weight", "enc_layers.0.rga.E"} <= keys and "fc.weight" not in keys
-    with pytest.raises(NotImplementedError):
-        r.loss_and_backward(None, None, None)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        r.loss_and_backward(torch.ones(1, 8, dtype=torch.long), torch.zeros(1, 2))
 
 
 WORKER = r'''

@@ -370,17 +370,17 @@ def run_attn(ops, dtype, q, k, v, E, dO, pad, backward=True, causal=True):
         dE = torch.zeros(M, dh, dtype=torch.float32, device=DEV)
         delta = torch.empty(B, H, L, dtype=torch.float32, device=DEV)
         PT, dST = (torch.zeros(B * H, Lp, Lp, dtype=dtype, device=DEV) for _ in range(2))
-        ops.rga_bwd(qkv, Epk, kp, out, lse, dout, dqkv, dE, delta, PT, dST, B, L, Lp, H, dh, M)
+        ops.rga_bwd(qkv, Epk, kp, out, lse, dout, dqkv, dE, delta, PT, dST, B, L, Lp, H, dh, M, causal=causal)
         g = dqkv.float().cpu().permute(2, 0, 3, 1, 4)   # [3,B,H,L,dh]
         res.update(dq=g[0], dk=g[1], dv=g[2], dE=dE.cpu())
     return res
 
 
-def ref_attn(q, k, v, E, dO, pad, dtype):
+def ref_attn(q, k, v, E, dO, pad, dtype, causal=True):
     """fp64 oracle on inputs rounded to the storage dtype."""
     r = lambda t: t.to(dtype).double().requires_grad_(True)
     q, k, v, E = r(q), r(k), r(v), r(E)
-    o, lse = O.rga_attention_core(q, k, v, E, pad)
+    o, lse = O.rga_attention_core(q, k, v, E, pad, causal)
     (o * dO.to(dtype).double()).sum().backward()
     return {"O": o.detach(), "lse": lse.detach(), "dq": q.grad, "dk": k.grad, "dv": v.grad, "dE": E.grad}
 
@@ -512,3 +512,18 @@ def test_rga_fwd_bidirectional(ops, dtype, B, H, L, dh, M):
     if L > 1:
         c = run_attn(ops, dtype, q, k, v, E, dO, None, backward=False, causal=True)
         assert relerr(c["O"], o) > 1e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,L,dh,M", [(2, 2, 1, 32, 64), (1, 3, 7, 64, 64), (2, 2, 33, 32, 64), (1, 2, 130, 64, 256),
+                                         (2, 2, 256, 64, 2048), (1, 1, 300, 48, 512), (1, 2, 520, 64, 2048)])
+def test_rga_bwd_bidirectional(ops, dtype, B, H, L, dh, M):
+    """Backward of the bidirectional attention (causal = 0): dq, dk, dv, dE against the fp64 oracle's autograd, with
+    and without padded keys; the P^T / dS^T workspaces start as garbage (every tile is written before it is read)."""
+    q, k, v, E, dO, pad = attn_case(B, H, L, dh, M, seed=400 + L)
+    for use_pad in (None, pad):
+        got = run_attn(ops, dtype, q, k, v, E, dO, use_pad, causal=False)
+        ref = ref_attn(q, k, v, E, dO, use_pad, dtype, causal=False)
+        errs = {n: relerr(got[n], ref[n]) for n in ("O", "lse", "dq", "dk", "dv", "dE")}
+        assert all(e < tol(dtype, 3e-5, 1.5e-2) for e in errs.values()), (errs, use_pad is not None)

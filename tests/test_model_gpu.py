@@ -391,5 +391,38 @@ def test_f6_regression_model_vs_reference_golden(golden_dir, cd):
         worst = max(worst, float((y.double() - torch.from_numpy(z["y_%d" % L]).double()).abs().max()))
     report("F6 regression[%s]: max abs err of tanh outputs %.2e" % (cd, worst))
     assert worst < (2e-5 if cd == "fp32" else 3e-2), worst
-    with pytest.raises(NotImplementedError):
-        model.loss_and_backward(None, None, None)
+
+
+@pytest.mark.parametrize("cd", ["fp32", "bf16"])
+def test_regression_l1_loss_and_grads_vs_oracle(golden_dir, cd):
+    """Training path of MusicRegression: L1 loss and every parameter gradient (bidirectional attention backward,
+    head on position 0) against the oracle's autograd; then one fused Adam step moves the loss down."""
+    from midiemo.models.music_transformer import MusicRegression
+    from midiemo.optim import FusedAdamW
+    V, N, H, d, di, M = 1008, 2, 2, 128, 256, 128
+    shapes = O.regression_param_shapes(V, N, d, di, d // H, M)
+    P = O.regression_seeded_params(shapes, 5)
+    model = MusicRegression(embedding_dim=d, d_inner=di, vocab_size=V, num_layer=N, num_head=H, max_seq=M, dropout=0.0,
+                            pad_token=0, output_size=2, compute_dtype=cd)
+    model.load_state_dict(P, strict=True)
+    model = model.to(DEV).train()
+    g = torch.Generator().manual_seed(9)
+    tok = torch.randint(1, V, (4, 97), generator=g)
+    tgt = torch.rand(4, 2, generator=g) * 2 - 1
+    cfg = O.Cfg(V, N, H, d, di, max_seq=M)
+    loss_ref, _, G = O.regression_loss_and_grads(cfg, {k: v.double() for k, v in P.items()}, tok, tgt.double())
+    model.flat_grads.zero_()
+    loss = model.loss_and_backward(tok.to(DEV), tgt.to(DEV))
+    model.link_grads()
+    assert abs(float(loss) - float(loss_ref)) < (1e-5 if cd == "fp32" else 2e-2)
+    errs = {k: relerr(p.grad, G[k]) for k, p in model.named_parameters() if float(G[k].norm()) > 1e-9}
+    worst = max(errs.values())
+    report("regression grads[%s]: loss %.6f (oracle %.6f), worst grad rel %.2e (%s)" %
+           (cd, float(loss), float(loss_ref), worst, max(errs, key=errs.get)))
+    assert worst < (3e-4 if cd == "fp32" else 8e-2), errs
+    # the key / value biases get exactly-cancelling or tiny gradients like in the language model; everything else learns
+    opt = FusedAdamW(model, lr=2e-5)                       # the first Adam step moves every weight by lr
+    opt.step()
+    model.flat_grads.zero_()
+    loss2 = model.loss_and_backward(tok.to(DEV), tgt.to(DEV), backward=False)
+    assert float(loss2) < float(loss)

@@ -119,3 +119,25 @@ def test_train_cli_real_data_path(tmp_path, capsys, mode):
     run = os.listdir(tmp_path / "out")[0]
     maps = torch.load(tmp_path / "out" / run / "mappings.pt", weights_only=False)
     assert len(maps["tuple2idx"]) == (1017 if mode == "discrete_token" else 1007)      # 12 songs cover all 2 x 5 bins
+
+
+def test_train_cli_regression(tmp_path, capsys):
+    """--regression trains the evaluation model (8 layers as in config.py:128-130) with the L1 loss and logs the
+    reference's val_l1_v / val_l1_a columns."""
+    import csv
+    import train
+    argv = ["--regression", "--conditioning", "none", "--d_model", "128", "--n_head", "2", "--d_inner", "256",
+            "--tgt_len", "96", "--batch_size", "8", "--lr", "2e-4", "--max_step", "40", "--log_step", "20", "--eval_step", "40",
+            "--work_dir", str(tmp_path), "--dropout", "0.0", "--seed", "2"]
+    train.main(argv)
+    out = capsys.readouterr().out
+    assert "Using 8 layers for regression" in out
+    losses = [float(l.split("| loss")[1].split("|")[0]) for l in out.splitlines() if "| loss" in l]
+    assert len(losses) == 2 and all(0 < v < 1.2 for v in losses), losses
+    assert "l1_v" in out and "l1_a" in out
+    run = os.listdir(tmp_path)[0]
+    rows = list(csv.DictReader(open(tmp_path / run / "performance.csv")))
+    assert 0 < float(rows[-1]["val_l1_v"]) < 1.5 and 0 < float(rows[-1]["val_l1_a"]) < 1.5
+    sd = torch.load(tmp_path / run / "model.pt")
+    assert "fc.0.weight" in sd and sd["fc.0.weight"].shape == (2, 128) and "enc_layers.7.rga.E" in sd
+    assert sd["embedding.weight"].shape[0] == 1008                      # 1007 tokens + <CLS>

@@ -79,14 +79,21 @@ def parse_args(argv=None):
     if args.conditioning != "continuous_concat":
         args.d_condition = -1                                  # config.py:120-121
     if args.regression:
-        raise SystemExit("--regression: the evaluation model MusicRegression is available for inference "
-                         "(build_model(regression=True)), but this build has no bidirectional attention backward to train it")
+        args.n_layer = 8                                       # config.py:128-130
+        args.d_condition = -1
+        print("Using 8 layers for regression")
     return args
 
 
 def synthetic_batch(args, V, B, L, seed, device):
-    """SURVEY 8d synthetic inputs for every conditioning mode."""
+    """SURVEY 8d synthetic inputs for every conditioning mode (regression: <CLS> + tokens, the (valence, arousal) target
+    travels in the condition slot as in data/loader.py:166-168,181-182)."""
     g = torch.Generator().manual_seed(seed)
+    if args.regression:
+        tok = torch.randint(2, V - 1, (B, L), generator=g)
+        tok[:, 0] = V - 1                                      # <CLS> is the last symbol of the loader's vocabulary
+        cond = torch.rand(B, 2, generator=g) * 2 - 1
+        return tok.to(device), cond.to(device), None
     if args.conditioning == "continuous_token":
         tok = torch.randint(2, V, (B, L - 1), generator=g)
         inp, tgt = tok[:, :-1], torch.nn.functional.pad(tok[:, 1:], (2, 0), value=0)   # loader.py:55-57,184-187
@@ -142,11 +149,11 @@ def main(argv=None):
         if args.seed > 0:
             _random.seed(args.seed + rank)
             _np.random.seed(args.seed + rank)
-        n_bins = args.n_emotion_bins if args.conditioning == "discrete_token" else None
+        n_bins = args.n_emotion_bins if args.conditioning == "discrete_token" and not args.regression else None
         train_feats, test_feats = preprocess_features(args.feature_file, n_bins=n_bins,
-                                                      conditional=args.conditioning != "none",
+                                                      conditional=args.conditioning != "none" or args.regression,
                                                       use_labeled_only=not args.full_dataset)
-        kw = dict(always_use_discrete_condition=args.always_use_discrete_condition)
+        kw = dict(always_use_discrete_condition=args.always_use_discrete_condition, regression=args.regression)
         train_ds = Loader(args.data_folder, train_feats, args.tgt_len, args.conditioning, **kw)
         test_ds = Loader(args.data_folder, test_feats, args.tgt_len, args.conditioning, **kw)
         if args.conditioning == "discrete_token":
@@ -167,6 +174,9 @@ def main(argv=None):
             print(f"Data loader lengths\nTrain: {len(train_ds)}\nTest: {len(test_ds)}")
     else:
         maps = get_maps(n_emotion_bins=args.n_emotion_bins if args.conditioning == "discrete_token" else 0)
+        if args.regression:                                   # data/loader.py:77-79: <CLS> joins the vocabulary
+            maps["tuple2idx"]["<CLS>"] = len(maps["idx2tuple"])
+            maps["idx2tuple"][len(maps["idx2tuple"])] = "<CLS>"
     V = len(maps["tuple2idx"])
     pad_idx = maps["tuple2idx"]["<PAD>"]
     config = dict(vars(args), vocab_size=V, compute_dtype="fp32" if args.no_amp else "bf16")
@@ -214,8 +224,10 @@ def main(argv=None):
         """collated (input, condition, target) -> device tensors; None when every sample of the batch was rejected."""
         if not batch or not isinstance(batch[0], torch.Tensor) or batch[0].numel() == 0:
             return None
-        x, c, y = batch
-        return x.to(device, non_blocking=True), c.to(device, non_blocking=True), y.to(device, non_blocking=True)
+        x, c = batch[0], batch[1]
+        y = batch[2] if len(batch) > 2 and isinstance(batch[2], torch.Tensor) else None       # regression: no token target
+        return (x.to(device, non_blocking=True), c.to(device, non_blocking=True),
+                y.to(device, non_blocking=True) if y is not None else None)
 
     def real_batches(loader, epochs_counter=None):
         while True:
@@ -249,6 +261,14 @@ def main(argv=None):
                     if b is None:
                         break
                     x, c, y = b
+                if args.regression:                     # train.py:246-254: clamp, L1 per dimension
+                    pred = model(x).clamp(-1.0, 1.0)
+                    nb = float(pred.shape[0])
+                    acc[0] += (pred - c).abs().mean().double() * nb
+                    acc[1] += (pred[:, 0] - c[:, 0]).abs().mean().double() * nb
+                    acc[2] += (pred[:, 1] - c[:, 1]).abs().mean().double() * nb
+                    acc[3] += nb
+                    continue
                 loss, logits = model.loss_and_backward(x, c, y, backward=False, return_logits=True)
                 valid = y.reshape(-1) != pad_idx
                 top5 = logits.reshape(-1, logits.size(-1)).topk(5, dim=-1).indices
@@ -288,8 +308,11 @@ def main(argv=None):
                 x, c, y = next(train_iter)
             last = (micro + 1) % args.accumulate_step == 0
             # every micro-batch contributes grad/accumulate_step (train.py:309); buckets are exchanged on the last one
-            loss = model.loss_and_backward(x, c, y, grad_scale=1.0 / args.accumulate_step,
-                                           bucket_hook=reducer.hook if (last and world > 1) else None)
+            hook = reducer.hook if (last and world > 1) else None
+            if args.regression:                                 # train.py:282-284: L1Loss(model(input), condition)
+                loss = model.loss_and_backward(x, c, grad_scale=1.0 / args.accumulate_step, bucket_hook=hook)
+            else:
+                loss = model.loss_and_backward(x, c, y, grad_scale=1.0 / args.accumulate_step, bucket_hook=hook)
             loss_acc += loss.detach()
             n_acc += 1
             micro += 1
@@ -319,6 +342,12 @@ def main(argv=None):
                 t0 = time.time()
             if step % args.eval_step == 0:
                 v, accs = evaluate()
+                if args.regression:
+                    if rank == 0:
+                        print("| eval at step {:>8d} | valid loss {:7.4f} | l1_v {:.4f} | l1_a {:.4f}".format(step, v, accs[1], accs[5]))
+                    perf_row(epoch=stats["epoch"], step=step, hour=stats["hour"], lr=opt.param_groups[0]["lr"], val_loss=v,
+                             val_l1_v=accs[1], val_l1_a=accs[5])
+                    continue
                 if rank == 0:
                     print("| eval at step {:>8d} | valid loss {:7.4f} | ppl {:9.3f} | top-1 {:.4f} | top-5 {:.4f}".format(
                         step, v, math.exp(min(v, 20)), accs[1], accs[5]))
