@@ -131,7 +131,7 @@ int me_gemm_tn_join(void* stream);
 /* ---- relative global attention ---------------------------------------------
  * qkv  : T [B, L, 3, H, dh]  (token-major output of the fused QKV projection; the kernels read
  *        q / k / v tiles straight from it -- no head-major permute copies)
- * E    : T [M, dh] relative table of the layer;  ET : T [dh, M] its transpose
+ * Epk  : the layer's relative table E (T [M, dh]) packed by me_rga_pack_rel (below)
  * key_pad : uint8 [B, L] or NULL
  * out  : T [B, L, H, dh]   lse : f32 [B, H, L]
  *   logits[l,j] = (q_l.k_j + q_l.E[M-1-(l-j)]) / sqrt(dh),  j<=l and key j not pad
@@ -155,8 +155,9 @@ int me_rga_pack_rel(const void* E, void* Epk, int M, int dh, int dtype, void* st
  * accumulates (+=) dE f32 [M, dh] (natural layout).
  * Workspaces (caller-owned): delta f32 [B,H,L]; PT, dST: T [B*H][Lp*Lp] each (Lp = L rounded
  * up to 32) = P^T and dS^T as contiguous 32x32 tiles [key tile][query tile][32 key][32 q], which must be
- * ZERO-INITIALISED once (only on/below-diagonal tiles are written and read).  The gradient of the relative
- * table is taken from dS^T (dG is dS re-indexed). */
+ * ZERO-INITIALISED once for causal = 1 (only on/below-diagonal tiles are written and read).  The gradient of the
+ * relative table is taken from dS^T (dG is dS re-indexed).  causal: as in me_rga_fwd (autograd of
+ * music_multi.py:211-235 for 1, of music_regression.py's mask = None attention for 0). */
 int me_rga_bwd(const void* qkv, const void* Epk, const uint8_t* key_pad,
                const void* out, const float* lse, const void* dout,
                void* dqkv, float* dE, float* delta_ws, void* PT, void* dST,
