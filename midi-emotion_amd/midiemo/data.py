@@ -8,6 +8,7 @@ run draws the same crops as the reference):
                             matched/unmatched split, last 5 % of the matched files as test split)
   * Loader               -- data/loader.py:15-195 (random bar window with at least `min_n_instruments`, transposition,
                             <START> / arbitrary offset, emotion-token prefix or continuous condition, trim, pad, shift)
+  * LoaderExhaustive     -- data/loader_exhaustive.py:14-173 (whole songs in consecutive chunks, for --exhaustive_eval)
   * filter_collate       -- data/collate.py:37-82 (default collate that drops None samples)
   * transpose, tensor_to_ind_tensor, count_instruments -- data/data_processing.py:224-246, utils.py:143-148, done on
     whole tensors instead of python loops over tokens (same results: tests/test_data_cpu.py pins them to vectors
@@ -209,6 +210,98 @@ class Loader:
         if self.overfit:
             self.one_sample = [input_, condition, target]
         return input_, condition, target
+
+
+class LoaderExhaustive:
+    """Every song of the split cut into consecutive chunks, no randomness (data/loader_exhaustive.py:14-173, used by
+    `--exhaustive_eval`).  Restated as is, including its own path convention: `maps.pt` INSIDE `data_folder` and the song
+    files in `data_folder/lpd_5_full_transposable/`; the discrete-condition tokens and <CLS> are outside the chunk
+    length; a trailing partial chunk is dropped."""
+
+    def __init__(self, data_folder, data, input_len, conditioning, save_input_dir=None, pad=True,
+                 use_start_token=True, use_end_token=False, always_use_discrete_condition=False,
+                 debug=False, overfit=False, regression=False, max_samples=None, use_cls_token=True):
+        self.data_folder = data_folder
+        self.save_input_dir = save_input_dir
+        self.input_len = input_len
+        self.overfit = overfit
+        self.one_sample = None
+        self.conditioning = conditioning
+        self.regression = regression
+        if debug or overfit:
+            data_folder = data_folder + "_debug"
+        self.maps = torch.load(os.path.join(data_folder, "maps.pt"), weights_only=False)
+        self.pad_token = "<PAD>" if pad else None
+        self.start_token = "<START>" if use_start_token else None
+        self.end_token = "<END>" if use_end_token else None
+        self.cls_token = "<CLS>"
+
+        extra = []
+        if conditioning == "continuous_token":
+            self.input_len -= 2
+        elif conditioning == "discrete_token":
+            self.input_len -= 2
+            extra = sorted({s[label] for s in data for label in ("valence", "arousal")})
+        if regression and use_cls_token:
+            extra.append(self.cls_token)
+            self.input_len -= 1
+        chunk_len = self.input_len if regression else self.input_len + 1        # + 1: the shifted target
+        if extra:
+            syms = list(self.maps["idx2tuple"].values()) + extra
+            self.maps["idx2tuple"] = dict(enumerate(syms))
+            self.maps["tuple2idx"] = {s: i for i, s in enumerate(syms)}
+        if max_samples is not None and not debug and not overfit:
+            data = data[:max_samples]
+        index = TupleIndex(self.maps["tuple2idx"])
+        t2i = self.maps["tuple2idx"]
+        tok = lambda sym: torch.tensor([t2i[sym]], dtype=torch.int16)
+
+        chunks = []
+        for rec in data:
+            item = torch.load(os.path.join(data_folder, "lpd_5_full_transposable", rec["file"] + ".pt"), weights_only=False)
+            if conditioning in ("continuous_token", "continuous_concat") or regression:
+                condition = torch.tensor([rec["valence"], rec["arousal"]], dtype=torch.float32)
+            else:
+                condition = torch.tensor([np.nan, np.nan], dtype=torch.float32)
+            song = index(torch.cat([torch.as_tensor(b) for b in item["bars"]], 0))
+            if self.start_token is not None:
+                song = torch.cat((tok(self.start_token), song), 0)
+            cond_tokens = None
+            if conditioning == "discrete_token":
+                cond_tokens = torch.cat((tok(rec["valence"]), tok(rec["arousal"])), 0)
+                if not always_use_discrete_condition:
+                    song = torch.cat((cond_tokens, song), 0)           # once, in front of the song
+            parts = list(torch.split(song, chunk_len))
+            if parts[-1].size(0) != chunk_len:
+                parts.pop(-1)
+            if regression and use_cls_token:
+                parts = [torch.cat((tok(self.cls_token), x), 0) for x in parts]
+            if conditioning == "discrete_token" and always_use_discrete_condition:
+                parts = [torch.cat((cond_tokens, x), 0) for x in parts]     # in front of every chunk
+            chunks += [(x, condition) for x in parts]
+        self.data = chunks
+
+    def get_vocab_len(self):
+        return len(self.maps["tuple2idx"])
+
+    def get_maps(self):
+        return self.maps
+
+    def get_pad_idx(self):
+        return self.maps["tuple2idx"][self.pad_token]
+
+    def __len__(self):
+        return len(self.data)
+
+    def __getitem__(self, idx):
+        chunk, condition = self.data[idx]
+        chunk = chunk.long()
+        if self.regression:
+            return chunk, condition, None
+        target = chunk[1:]
+        if self.conditioning == "continuous_token":
+            target = torch.nn.functional.pad(target, (condition.size(0), 0), value=self.get_pad_idx())
+        return chunk[:-1], condition, target
 
 
 # ----------------------------------------------------------------------------- collate

@@ -33,6 +33,8 @@ sys.modules["torch._six"] = six
 sys.path.insert(0, REF)
 from data.data_processing import get_maps as ref_get_maps         # noqa: E402  (reference)
 from data.loader import Loader as RefLoader                        # noqa: E402  (reference)
+sys.modules.setdefault("tqdm", __import__("tqdm"))
+from data.loader_exhaustive import LoaderExhaustive as RefExhaustive   # noqa: E402  (reference)
 from data.collate import filter_collate as ref_collate             # noqa: E402  (reference)
 from data.preprocess_features import preprocess_features as ref_preprocess   # noqa: E402  (reference)
 
@@ -131,6 +133,31 @@ def main():
             if tag == "concat":
                 b = ref_collate(items[:10])
                 out["collate_x"], out["collate_c"], out["collate_y"] = b[0].numpy(), b[1].numpy(), b[2].numpy()
+        # ---- exhaustive loader: its own path convention (maps.pt inside the folder, songs in lpd_5_full_transposable/)
+        exroot = os.path.join(tmp, "ex")
+        os.makedirs(os.path.join(exroot, "lpd_5_full_transposable"))
+        torch.save(maps, os.path.join(exroot, "maps.pt"))
+        for nm in names:
+            os.symlink(os.path.join(folder, nm + ".pt"), os.path.join(exroot, "lpd_5_full_transposable", nm + ".pt"))
+        ex_cases = {
+            "ex_none": dict(conditioning="none", input_len=64),
+            "ex_concat": dict(conditioning="continuous_concat", input_len=48),
+            "ex_ctoken": dict(conditioning="continuous_token", input_len=40),
+            "ex_dtoken": dict(conditioning="discrete_token", input_len=56),
+            "ex_dtoken_always": dict(conditioning="discrete_token", input_len=24, always_use_discrete_condition=True),
+            "ex_regression": dict(conditioning="none", input_len=32, regression=True),
+        }
+        for tag, kw in ex_cases.items():
+            disc = kw["conditioning"] == "discrete_token"
+            data = [{"file": nm, "valence": val[i % 5] if disc else float(np.round(-0.9 + 0.2 * i, 3)),
+                     "arousal": aro[(2 * i) % 5] if disc else float(np.round(0.8 - 0.17 * i, 3))} for i, nm in enumerate(names)]
+            ds = RefExhaustive(exroot, data, **kw)
+            items = [ds[i] for i in range(len(ds))]
+            meta[tag] = {"kw": kw, "data": data, "n": len(items), "vocab": ds.get_vocab_len()}
+            out[tag + "_x"] = np.stack([x.numpy() for x, _, _ in items])
+            out[tag + "_c"] = np.stack([c.numpy() for _, c, _ in items])
+            if items[0][2] is not None:
+                out[tag + "_y"] = np.stack([y.numpy() for _, _, y in items])
         out["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
         out["song_names"] = np.array(names)
     np.savez_compressed(OUT, **out)

@@ -64,6 +64,7 @@ def test_preprocess_features_matches_reference(fx, tmp_path):
 
 def test_loader_samples_bit_exact_vs_reference(fx, song_dir):
     meta = json.loads(fx["meta_json"].tobytes().decode())
+    meta = {k: v for k, v in meta.items() if not k.startswith("ex_")}
     assert len(meta) == 8
     n_rejected = 0
     for tag, m in meta.items():
@@ -127,3 +128,26 @@ def test_vectorised_token_helpers_match_their_definitions():
         names = ["DRUMS", "GUITAR", "BASS", "PIANO", "STRINGS"][:k]
         rows = [[maps["event2idx"]["ON_" + nm], 60] for nm in names] + [[maps["event2idx"]["TIMESHIFT"], 8]]
         assert D.count_instruments(torch.tensor(rows, dtype=torch.int16), maps) == k
+
+
+def test_exhaustive_loader_bit_exact_vs_reference(fx, song_dir, tmp_path):
+    """LoaderExhaustive (the --exhaustive_eval data path): every chunk of every song, all modes, against the reference."""
+    meta = {k: v for k, v in json.loads(fx["meta_json"].tobytes().decode()).items() if k.startswith("ex_")}
+    assert len(meta) == 6
+    root = tmp_path / "ex"
+    (root / "lpd_5_full_transposable").mkdir(parents=True)
+    maps = vocab.get_maps()
+    maps["transposable_event_inds"] = D.transposable_event_inds(maps)
+    torch.save(maps, str(root / "maps.pt"))
+    for name in fx["song_names"].tolist():
+        os.symlink(os.path.join(song_dir, name + ".pt"), str(root / "lpd_5_full_transposable" / (name + ".pt")))
+    for tag, m in meta.items():
+        ds = D.LoaderExhaustive(str(root), m["data"], **m["kw"])
+        assert len(ds) == m["n"] and ds.get_vocab_len() == m["vocab"], tag
+        items = [ds[i] for i in range(len(ds))]
+        assert np.array_equal(np.stack([x.numpy() for x, _, _ in items]), fx[tag + "_x"]), tag
+        assert np.array_equal(np.stack([c.numpy() for _, c, _ in items]), fx[tag + "_c"], equal_nan=True), tag
+        if tag + "_y" in fx.files:
+            assert np.array_equal(np.stack([y.numpy() for _, _, y in items]), fx[tag + "_y"]), tag
+        else:
+            assert all(y is None for _, _, y in items)

@@ -141,3 +141,25 @@ def test_train_cli_regression(tmp_path, capsys):
     sd = torch.load(tmp_path / run / "model.pt")
     assert "fc.0.weight" in sd and sd["fc.0.weight"].shape == (2, 128) and "enc_layers.7.rga.E" in sd
     assert sd["embedding.weight"].shape[0] == 1008                      # 1007 tokens + <CLS>
+
+
+def test_train_cli_exhaustive_eval(tmp_path, capsys):
+    """--exhaustive_eval: restore a checkpoint, evaluate every chunk of every test song (LoaderExhaustive) and exit."""
+    import train
+    folder, csv_file = _make_song_collection(str(tmp_path / "lpd"), n_songs=40)
+    base = ["--conditioning", "continuous_concat", "--n_layer", "1", "--d_model", "128", "--n_head", "2", "--d_inner", "256",
+            "--d_condition", "32", "--tgt_len", "128", "--batch_size", "4", "--lr", "1e-3", "--work_dir", str(tmp_path / "out"),
+            "--seed", "3", "--num_workers", "0", "--feature_file", csv_file]
+    train.main(base + ["--data_folder", folder, "--max_step", "6", "--log_step", "6", "--eval_step", "1000"])
+    run = os.listdir(tmp_path / "out")[0]
+    capsys.readouterr()
+    # the exhaustive loader's own convention: <root>/maps.pt and <root>/lpd_5_full_transposable/*.pt
+    root = tmp_path / "ex"
+    root.mkdir()
+    os.symlink(folder, str(root / "lpd_5_full_transposable"))
+    os.symlink(os.path.join(os.path.dirname(folder), "maps.pt"), str(root / "maps.pt"))
+    train.main(base + ["--data_folder", str(root), "--exhaustive_eval", "--restart_dir", run])
+    out = capsys.readouterr().out
+    line = [l for l in out.splitlines() if l.startswith("Exhaustive evaluation")]
+    assert len(line) == 1 and "top1" in line[0] and "| step" not in out, out
+    assert 0 < float(line[0].split("Loss:")[1].split(",")[0]) < 8

@@ -74,10 +74,17 @@ def parse_args(argv=None):
     p.add_argument("--full_dataset", action="store_true", help="also train on songs without emotion labels")
     p.add_argument("--always_use_discrete_condition", action="store_true")
     p.add_argument("--num_workers", type=int, default=4)
+    p.add_argument("--exhaustive_eval", action="store_true",
+                   help="evaluate on every chunk of every test song and exit (config.py:106, train.py:448-461); needs "
+                        "--feature_file; --data_folder is then the root that holds maps.pt and lpd_5_full_transposable/")
     p.add_argument("--weight_decay", type=float, default=0.0, help="decoupled decay; 0 == reference Adam")
     args = p.parse_args(argv)
     if args.conditioning != "continuous_concat":
         args.d_condition = -1                                  # config.py:120-121
+    if args.exhaustive_eval:
+        if not args.feature_file:
+            raise SystemExit("--exhaustive_eval needs --feature_file (there is nothing exhaustive about synthetic batches)")
+        args.max_eval_step = 0                                 # config.py:123: the whole test set
     if args.regression:
         args.n_layer = 8                                       # config.py:128-130
         args.d_condition = -1
@@ -154,9 +161,14 @@ def main(argv=None):
                                                       conditional=args.conditioning != "none" or args.regression,
                                                       use_labeled_only=not args.full_dataset)
         kw = dict(always_use_discrete_condition=args.always_use_discrete_condition, regression=args.regression)
-        train_ds = Loader(args.data_folder, train_feats, args.tgt_len, args.conditioning, **kw)
-        test_ds = Loader(args.data_folder, test_feats, args.tgt_len, args.conditioning, **kw)
-        if args.conditioning == "discrete_token":
+        if args.exhaustive_eval:                               # train.py:58-63
+            from midiemo.data import LoaderExhaustive
+            test_ds = LoaderExhaustive(args.data_folder, test_feats, args.tgt_len, args.conditioning, **kw)
+            train_ds = test_ds                                 # never iterated: the run evaluates and exits
+        else:
+            train_ds = Loader(args.data_folder, train_feats, args.tgt_len, args.conditioning, **kw)
+            test_ds = Loader(args.data_folder, test_feats, args.tgt_len, args.conditioning, **kw)
+        if args.conditioning == "discrete_token" and not args.exhaustive_eval:
             # the reference takes the vocabulary from the test split alone (train.py:76-80), which silently assumes that
             # every emotion bin occurs there; use the union of both splits so that small collections train too
             syms = sorted({s[k] for ds in (train_ds, test_ds) for s in ds.data for k in ("valence", "arousal")})
@@ -250,7 +262,7 @@ def main(argv=None):
         """Mean loss and top-1 / top-5 token accuracy over non-PAD targets (train.py:222-275, utils.accuracy)."""
         model.eval()
         acc = torch.zeros(4, device=device, dtype=torch.float64)          # loss-sum, top1, top5, #targets
-        n = min(args.max_eval_step, 8) if test_loader is None else args.max_eval_step
+        n = min(args.max_eval_step, 8) if test_loader is None else (args.max_eval_step if args.max_eval_step > 0 else 1 << 60)
         test_iter = iter(test_loader) if test_loader is not None else None
         with torch.no_grad():
             for i in range(n):
@@ -300,6 +312,17 @@ def main(argv=None):
                 w.writeheader()
             w.writerow({k: kw.get(k, float("nan")) for k in perf_cols})
 
+    if args.exhaustive_eval:                                   # train.py:448-461
+        v, accs = evaluate()
+        if rank == 0:
+            if args.regression:
+                print("Exhaustive evaluation | Loss: {:7.4f}, l1_v: {:7.4f}, l1_a: {:7.4f}".format(v, accs[1], accs[5]))
+            else:
+                print("Exhaustive evaluation | Loss: {:7.4f}, ppl: {:5.2f}, top1: {:7.4f}, top5: {:7.4f}".format(
+                    v, math.exp(min(v, 20)), accs[1], accs[5]))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     try:
         while step < args.max_step:
             if train_iter is None:
