@@ -1007,7 +1007,9 @@ int bwd_launch(const void* qkv, const void* Epk, const uint8_t* key_pad, const v
                                                                    H, M, scale);
     int rc = me_launch_status();
     if (rc) return rc;
-    static const int kv8 = getenv("MIDIEMO_KV8") ? atoi(getenv("MIDIEMO_KV8")) : 1;   // 256-key blocks (16-bit tier): 181 -> 175 us at C2
+    // 256-key blocks (MIDIEMO_KV8=1, 16-bit tier) fetch the Q / dO slabs half as often, but measured over several runs on
+    // one box they are not faster (128-key: 168 / 176 / 173 us, 256-key: 187 / 199 / 172 us at C2): off by default
+    static const int kv8 = getenv("MIDIEMO_KV8") ? atoi(getenv("MIDIEMO_KV8")) : 0;
     bool big = false;
     if constexpr (sizeof(T) == 2) {
         if (kv8 && causal) {
