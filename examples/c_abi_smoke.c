@@ -1,6 +1,7 @@
 /* Plain C consumer of libmidiemo_hip.so: no Python, no torch -- only the HIP runtime for device memory.
- * Builds a tiny bf16 problem, runs me_cast_transpose -> me_gemm_nt (bias + ReLU epilogue) -> me_sumsq on the
- * default stream and checks the results against a host loop.  This is what a non-Python host (the reference is
+ * Builds a tiny bf16 problem, runs me_cast_transpose -> me_gemm_nt (bias + ReLU epilogue) -> me_sumsq and a weight
+ * gradient (me_gemm_tn_acc with a caller-owned workspace sized by me_workspace_bytes) on the default stream and
+ * checks the results against host loops.  This is what a non-Python host (the reference is
  * Python; a C / C++ / Go-cgo / JNI host would look the same) has to do to use the library.
  *   gcc -std=c11 -D__HIP_PLATFORM_AMD__ examples/c_abi_smoke.c -Iinclude -I/opt/rocm/include -Lmidi-emotion_amd/midiemo \
  *       -L/opt/rocm/lib -lmidiemo_hip -lamdhip64 -lm -o c_abi_smoke        (tests/test_c_abi_example.py does this) */
@@ -58,6 +59,41 @@ int main(void) {
         }
     printf("c_abi_smoke: gemm_nt worst rel err %.3e (bf16 output rounding), sumsq %.4f vs %.4f\n", worst, ss, ref_ss);
     if (worst > 5e-3 || fabs(ss - ref_ss) > 1e-3 * ref_ss) { printf("FAILED\n"); return 4; }
+    /* weight gradient dW[N2][K2] += dY[T][N2]^T . X[T][K2] through the caller-owned partial-tile workspace */
+    {
+        enum { T = 4096, N2 = 256, K2 = 256 };
+        float *hY = malloc(sizeof(float) * T * N2), *hX = malloc(sizeof(float) * T * K2), *hG = malloc(sizeof(float) * N2 * K2);
+        for (int i = 0; i < T * N2; ++i) { s = s * 1664525u + 1013904223u; hY[i] = ((int)(s >> 20) % 16 - 8) / 16.f; }
+        for (int i = 0; i < T * K2; ++i) { s = s * 1664525u + 1013904223u; hX[i] = ((int)(s >> 20) % 16 - 8) / 16.f; }
+        float *dY32, *dX32, *dG;
+        void *dY, *dX, *dws = NULL;
+        CK(hipMalloc((void**)&dY32, sizeof(float) * T * N2)); CK(hipMalloc((void**)&dX32, sizeof(float) * T * K2));
+        CK(hipMalloc((void**)&dG, sizeof(float) * N2 * K2)); CK(hipMalloc(&dY, 2 * T * N2)); CK(hipMalloc(&dX, 2 * T * K2));
+        CK(hipMemcpy(dY32, hY, sizeof(float) * T * N2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dX32, hX, sizeof(float) * T * K2, hipMemcpyHostToDevice));
+        CK(hipMemset(dG, 0, sizeof(float) * N2 * K2));
+        ME(me_cast_transpose(dY32, T, N2, dY, N2, NULL, 0, ME_BF16, NULL));
+        ME(me_cast_transpose(dX32, T, K2, dX, K2, NULL, 0, ME_BF16, NULL));
+        const size_t wsb = me_workspace_bytes(ME_WS_GEMM_TN, T, N2, K2, ME_BF16);
+        if (wsb == 0) { printf("expected a workspace requirement for the 256-tile TN kernel\n"); return 7; }
+        CK(hipMalloc(&dws, wsb));
+        if (me_gemm_tn_acc(dY, N2, dX, K2, dG, K2, NULL, T, N2, K2, dws, wsb / 2, ME_BF16, NULL) != ME_ERR_WORKSPACE) {
+            printf("short workspace accepted\n"); return 8;
+        }
+        ME(me_gemm_tn_acc(dY, N2, dX, K2, dG, K2, NULL, T, N2, K2, dws, wsb, ME_BF16, NULL));
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(hG, dG, sizeof(float) * N2 * K2, hipMemcpyDeviceToHost));
+        double w2 = 0.0;
+        for (int n = 0; n < N2; n += 17)
+            for (int k = 0; k < K2; k += 13) {
+                double acc = 0.0;
+                for (int t = 0; t < T; ++t) acc += (double)hY[t * N2 + n] * hX[t * K2 + k];
+                const double err = fabs(hG[n * K2 + k] - acc) / (fabs(acc) + 1.0);
+                if (err > w2) w2 = err;
+            }
+        printf("c_abi_smoke: gemm_tn_acc (workspace %zu bytes) worst rel err %.3e\n", wsb, w2);
+        if (w2 > 1e-4) { printf("FAILED\n"); return 9; }
+    }
     /* error behaviour: bad arguments are reported, not crashed on */
     if (me_gemm_nt(NULL, K, dW, K, dC, N, db, NULL, 0, NULL, 0, M, N, K, 0, ME_BF16, NULL) == ME_OK) { printf("NULL accepted\n"); return 5; }
     if (me_rga_fwd(dA, dW, NULL, dC, dss, 1, 64, 2, 40, 2048, 1, ME_BF16, NULL) == ME_OK) { printf("dh = 40 accepted\n"); return 6; }

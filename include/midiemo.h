@@ -10,7 +10,9 @@
  *
  * Conventions
  *   - all pointers are DEVICE addresses owned by the caller (PyTorch tensors);
- *     the library is stateless, never allocates, never retains a pointer;
+ *     the library is stateless: it never allocates, frees or synchronises, keeps no
+ *     global mutable state and never retains a pointer past the call.  Scratch memory
+ *     is caller-owned: me_workspace_bytes() says how much an entry point needs;
  *   - `stream` is a hipStream_t passed as void*; calls only enqueue work;
  *   - `dtype` selects the activation/weight storage type T of the call:
  *       ME_F32  : exact-f32 MFMA (v_mfma_f32_32x32x2_f32), parity tier
@@ -21,13 +23,14 @@
 #ifndef MIDIEMO_H
 #define MIDIEMO_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 8
+#define ME_ABI_VERSION 9
 
 enum { ME_F32 = 0, ME_BF16 = 1 };
 
@@ -37,7 +40,8 @@ enum {
     ME_ERR_BAD_SHAPE = -2,   /* unsupported head dim, K not chunk-aligned, L > max_seq, ... */
     ME_ERR_ALIGNMENT = -3,   /* pointer / leading dimension not 16-byte aligned */
     ME_ERR_LAUNCH = -4,      /* hipGetLastError() after launch */
-    ME_ERR_NULL = -5
+    ME_ERR_NULL = -5,
+    ME_ERR_WORKSPACE = -6    /* caller workspace too small / misaligned (see me_workspace_bytes) */
 };
 
 /* conditioning modes of the embedding prologue */
@@ -82,8 +86,10 @@ int me_cast_transpose_multi(const me_ct_desc* desc_dev, int n_tensors, int total
  * followed by inverted dropout(p) with the counter-based mask (seed, site 0)
  * (music_multi.py:102).  emb is the f32 master table [V][d-dc]; pe is f32 [>=Lm][d].
  * pos_dev (may be NULL): device int32, added to every row's position for the PE lookup -- the decode step reads
- * its position from device memory so that the whole step is replayable as a HIP graph. */
-int me_embed_fwd(void* out, int dtype, const int64_t* tokens, const float* cond,
+ * its position from device memory so that the whole step is replayable as a HIP graph.
+ * out_lo (T, may be NULL): receives the low-order part v - float(T(v)) of every element: the residual stream of the
+ * bf16 tier is carried as hi + lo (see me_resid_ln_fwd). */
+int me_embed_fwd(void* out, void* out_lo, int dtype, const int64_t* tokens, const float* cond,
                  const float* emb, const float* cw0, const float* cb0,
                  const float* cw1, const float* cb1, const float* pe, const int32_t* pos_dev,
                  int mode, int B, int Ltok, int d_model, int d_cond,
@@ -117,16 +123,22 @@ int me_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                const float* bias, const void* add, int ldadd, const void* gate, int ldgate,
                int M, int N, int K, int flags, int dtype, void* stream);
 
+/* ---- workspace sizes (caller supplies every workspace) -----------------
+ * Bytes of scratch the entry point `op` needs for a call of the given shape and dtype (an upper bound;
+ * 0 = none).  ME_WS_GEMM_TN: me_gemm_tn_acc with (M, N, K) = (T, N, K). */
+enum { ME_WS_GEMM_TN = 1 };
+size_t me_workspace_bytes(int op, int M, int N, int K, int dtype);
+
 /* ---- GEMM  dW[N,K] += A[T,N]^T . B[T,K] ---------------------------------------
  * A = dY (T, lda), B = X (T, ldb), dW f32 (lddw).  If dbias != NULL also
  * dbias[N] += column sums of A.  Replaces the weight/bias gradients of nn.Linear.
- * The token dimension is split over the CUs; partial tiles are summed in a fixed order (bf16, N/K multiples of
- * 256) or by f32 atomics (other shapes).  flags: ME_TN_ASYNC_REDUCE lets that final summation run on a private
- * side stream; dW is then only valid on `stream` after me_gemm_tn_join(stream). */
-#define ME_TN_ASYNC_REDUCE 1
+ * The token dimension is split over the CUs.  ws (16-byte aligned, ws_bytes >=
+ * me_workspace_bytes(ME_WS_GEMM_TN, T, N, K, dtype)) receives the partial tiles, which are then summed in a FIXED
+ * order (bit-reproducible dW); it may be reused by the next call on the same stream.  ws = NULL: the partial tiles
+ * are accumulated with f32 atomics instead (order-dependent rounding, slower); a workspace that is too small is an
+ * error (ME_ERR_WORKSPACE), never a silent fallback. */
 int me_gemm_tn_acc(const void* A, int lda, const void* B, int ldb, float* dW, int lddw,
-                   float* dbias, int T, int N, int K, int flags, int dtype, void* stream);
-int me_gemm_tn_join(void* stream);
+                   float* dbias, int T, int N, int K, void* ws, size_t ws_bytes, int dtype, void* stream);
 
 /* ---- relative global attention ---------------------------------------------
  * qkv  : T [B, L, 3, H, dh]  (token-major output of the fused QKV projection; the kernels read
@@ -166,9 +178,13 @@ int me_rga_bwd(const void* qkv, const void* Epk, const uint8_t* key_pad,
 /* ---- residual + dropout + LayerNorm (post-LN, eps) ---------------------------
  *   s = x + dropout(a) ;  y = LN(s) * gamma + beta          (music_multi.py:128-129,133-134)
  * x, a, y, s_out are T [rows, d]; s_out (pre-norm sum, needed by backward) and
- * stats (f32 [rows][2] = mean, rstd) may be NULL for inference. */
-int me_resid_ln_fwd(const void* x, const void* a, const float* gamma, const float* beta,
-                    void* y, void* s_out, float* stats, int rows, int d, float eps,
+ * stats (f32 [rows][2] = mean, rstd) may be NULL for inference.
+ * Residual stream precision (bf16 tier): under torch.autocast the reference keeps the residual stream and
+ * LayerNorm in fp32 and only rounds the Linear inputs to bf16 (train.py:281).  x_lo / y_lo (T, may be NULL) carry
+ * the low-order half of that stream: the residual input is x + x_lo, y is the bf16 operand of the next GEMM
+ * (= bf16(LN output), exactly what autocast feeds the Linear) and y_lo = bf16(LN output - y). */
+int me_resid_ln_fwd(const void* x, const void* x_lo, const void* a, const float* gamma, const float* beta,
+                    void* y, void* y_lo, void* s_out, float* stats, int rows, int d, float eps,
                     float p_drop, uint64_t seed, uint32_t site, int dtype, void* stream);
 
 /* Backward: given dy (T), s (T), stats, gamma:

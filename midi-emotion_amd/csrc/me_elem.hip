@@ -39,7 +39,7 @@ inline uint32_t thr_of(float p) {
 
 // ------------------------------------------------------------------ embedding prologue
 template <typename T>
-__global__ __launch_bounds__(256) void embed_fwd_kernel(T* __restrict__ out, const int64_t* __restrict__ tokens,
+__global__ __launch_bounds__(256) void embed_fwd_kernel(T* __restrict__ out, T* __restrict__ out_lo, const int64_t* __restrict__ tokens,
                                                         const float* __restrict__ cond, const float* __restrict__ emb,
                                                         const float* __restrict__ cw0, const float* __restrict__ cb0,
                                                         const float* __restrict__ cw1, const float* __restrict__ cb1,
@@ -109,7 +109,15 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(T* __restrict__ out, con
 #pragma unroll
             for (int i = 0; i < CH; ++i) v[i] *= mult[i];
         }
-        st_chunk(out + row * d + col, f_to_chunk<T>(v));
+        const chunk16 hi = f_to_chunk<T>(v);
+        st_chunk(out + row * d + col, hi);
+        if (out_lo) {                                   // low-order part of the residual stream: v - float(T(v))
+            float hf[CH];
+            chunk_to_f<T>(hi, hf);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) hf[i] = v[i] - hf[i];
+            st_chunk(out_lo + row * d + col, f_to_chunk<T>(hf));
+        }
     }
 }
 
@@ -304,9 +312,9 @@ __global__ void key_pad_kernel(uint8_t* __restrict__ kp, const int64_t* __restri
 
 // ------------------------------------------------------------------ residual + dropout + LayerNorm
 template <typename T>
-__global__ __launch_bounds__(256) void resid_ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ a,
+__global__ __launch_bounds__(256) void resid_ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ x_lo, const T* __restrict__ a,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           T* __restrict__ y, T* __restrict__ s_out, float* __restrict__ stats,
+                                                           T* __restrict__ y, T* __restrict__ y_lo, T* __restrict__ s_out, float* __restrict__ stats,
                                                            int rows, int d, float eps, uint32_t thr16, float inv_keep,
                                                            uint64_t seed, uint32_t site) {
     constexpr int CH = ET<T>::CH;
@@ -321,6 +329,12 @@ __global__ __launch_bounds__(256) void resid_ln_fwd_kernel(const T* __restrict__
                 float xv[CH], av[CH];
                 chunk_to_f<T>(ld_chunk(x + row * d + col), xv);
                 chunk_to_f<T>(ld_chunk(a + row * d + col), av);
+                if (x_lo) {                             // residual stream = hi + lo (the reference keeps it in fp32 under autocast)
+                    float lv[CH];
+                    chunk_to_f<T>(ld_chunk(x_lo + row * d + col), lv);
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) xv[i] += lv[i];
+                }
                 if (thr16) {
                     float mult[CH];
                     drop_mult<CH>(mult, seed, site, (uint64_t)row * d + col, thr16, inv_keep);
@@ -353,7 +367,15 @@ __global__ __launch_bounds__(256) void resid_ln_fwd_kernel(const T* __restrict__
                 float o[CH];
 #pragma unroll
                 for (int i = 0; i < CH; ++i) o[i] = (s[c][i] - mean) * rstd * gamma[col + i] + beta[col + i];
-                st_chunk(y + row * d + col, f_to_chunk<T>(o));
+                const chunk16 hi = f_to_chunk<T>(o);
+                st_chunk(y + row * d + col, hi);
+                if (y_lo) {
+                    float hf[CH];
+                    chunk_to_f<T>(hi, hf);
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) hf[i] = o[i] - hf[i];
+                    st_chunk(y_lo + row * d + col, f_to_chunk<T>(hf));
+                }
                 if (s_out) st_chunk(s_out + row * d + col, f_to_chunk<T>(s[c]));
             }
         }
@@ -837,7 +859,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
 
 extern "C" {
 
-int me_embed_fwd(void* out, int dtype, const int64_t* tokens, const float* cond, const float* emb, const float* cw0,
+int me_embed_fwd(void* out, void* out_lo, int dtype, const int64_t* tokens, const float* cond, const float* emb, const float* cw0,
                  const float* cb0, const float* cw1, const float* cb1, const float* pe, const int32_t* pos_dev, int mode, int B, int Ltok,
                  int d, int dc, float p, uint64_t seed, void* stream) {
     me_clear_error();
@@ -846,7 +868,7 @@ int me_embed_fwd(void* out, int dtype, const int64_t* tokens, const float* cond,
     if (mode == ME_COND_TOKEN && (!cond || !cw0 || !cb0 || !cw1 || !cb1)) return ME_ERR_NULL;
     if (mode != ME_COND_CONCAT) dc = 0;
     if (B <= 0 || Ltok < 0 || d <= 0 || d % 8) return ME_ERR_BAD_SHAPE;
-    if (!aligned16(out)) return ME_ERR_ALIGNMENT;
+    if (!aligned16(out) || (out_lo && !aligned16(out_lo))) return ME_ERR_ALIGNMENT;
     const int Lm = Ltok + (mode == ME_COND_TOKEN ? 2 : 0);
     const int64_t rows = (int64_t)B * Lm;
     if (rows == 0) return ME_OK;
@@ -854,7 +876,7 @@ int me_embed_fwd(void* out, int dtype, const int64_t* tokens, const float* cond,
     const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
     hipStream_t st = (hipStream_t)stream;
     ME_DISPATCH(dtype, (embed_fwd_kernel<T><<<(unsigned)((rows + 3) / 4), 256, 0, st>>>(
-                           (T*)out, tokens, cond, emb, cw0, cb0, cw1, cb1, pe, pos_dev, mode, B, Ltok, d, dc, thr, inv_keep, seed)));
+                           (T*)out, (T*)out_lo, tokens, cond, emb, cw0, cb0, cw1, cb1, pe, pos_dev, mode, B, Ltok, d, dc, thr, inv_keep, seed)));
     return me_launch_status();
 }
 
@@ -915,20 +937,23 @@ int me_key_pad_mask(uint8_t* key_pad, const int64_t* tokens, int B, int Ltok, in
     return me_launch_status();
 }
 
-int me_resid_ln_fwd(const void* x, const void* a, const float* gamma, const float* beta, void* y, void* s_out,
-                    float* stats, int rows, int d, float eps, float p, uint64_t seed, uint32_t site, int dtype,
-                    void* stream) {
+int me_resid_ln_fwd(const void* x, const void* x_lo, const void* a, const float* gamma, const float* beta, void* y,
+                    void* y_lo, void* s_out, float* stats, int rows, int d, float eps, float p, uint64_t seed,
+                    uint32_t site, int dtype, void* stream) {
     me_clear_error();
     if (!x || !a || !gamma || !beta || !y) return ME_ERR_NULL;
     if (rows <= 0) return ME_OK;
     const int ch = dtype == ME_F32 ? 4 : 8;
     if (d <= 0 || d % ch || d > 64 * MAXC * ch) return ME_ERR_BAD_SHAPE;
-    if (!aligned16(x) || !aligned16(a) || !aligned16(y) || (s_out && !aligned16(s_out))) return ME_ERR_ALIGNMENT;
+    if (!aligned16(x) || !aligned16(a) || !aligned16(y) || (s_out && !aligned16(s_out)) || (x_lo && !aligned16(x_lo)) ||
+        (y_lo && !aligned16(y_lo)))
+        return ME_ERR_ALIGNMENT;
     const uint32_t thr = thr_of(p);
     const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
     hipStream_t st = (hipStream_t)stream;
     ME_DISPATCH(dtype, (resid_ln_fwd_kernel<T><<<row_grid(rows, 8192), 256, 0, st>>>(
-                           (const T*)x, (const T*)a, gamma, beta, (T*)y, (T*)s_out, stats, rows, d, eps, thr, inv_keep, seed, site)));
+                           (const T*)x, (const T*)x_lo, (const T*)a, gamma, beta, (T*)y, (T*)y_lo, (T*)s_out, stats, rows, d, eps, thr,
+                           inv_keep, seed, site)));
     return me_launch_status();
 }
 

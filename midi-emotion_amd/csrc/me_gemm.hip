@@ -1,11 +1,11 @@
 // GEMM kernels of the midiemo hot path (gfx950).
 //   me_gemm_nt      C[M,N]  = A[M,K] . B[N,K]^T (+bias, relu, +add, relu-gate)
-//   me_gemm_tn_acc  dW[N,K] += A[T,N]^T . B[T,K]   (f32 atomics, split over T)
+//   me_gemm_tn_acc  dW[N,K] += A[T,N]^T . B[T,K]   (split over T; partial tiles through a CALLER-owned workspace)
 //   me_cast_transpose, me_gemv_small
-// Block tile 128x128, 4 waves (2x2), each wave 64x64 = 2x2 macro-atoms of 32x32.
-// Operands are staged global -> registers -> LDS (register prefetch of the next
-// K-slab overlaps the MFMA work of the current one); LDS rows are padded by one
-// 16-byte chunk so that the ds_read_b128 fragment reads are bank-conflict free.
+// bf16 shapes of the train step run the persistent 256x256 kernels (gemm_nt256_kernel, gemm_tn256_kernel: 8 waves,
+// 64-deep slabs, register-staged operand feed, one raw barrier per slab); everything else (f32 tier, ragged shapes)
+// the generic 128x128 kernels (4 waves of 64x64, register-staged double buffer, padded LDS rows).
+// The library never allocates, frees or synchronises: workspaces come from the caller (me_workspace_bytes).
 #include <stdlib.h>
 
 #include "me_common.h"
@@ -1040,28 +1040,9 @@ int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int 
     return me_launch_status();
 }
 
-// Partial-tile workspaces of gemm_tn256_kernel, cached per caller stream (launches on one stream are ordered).
-// With ME_TN_ASYNC_REDUCE two buffers alternate and the reduce runs on a private side stream.
-struct TnCache {
-    hipStream_t st;
-    bool used;
-    float* p[2];
-    size_t bytes[2];
-    int flip;
-    hipStream_t side;
-    hipEvent_t ev_main, ev_red[2];
-    bool pending;
-};
-static TnCache g_tn_cache[8] = {};
-static TnCache* tn_cache_slot(hipStream_t st) {
-    for (int c = 0; c < 8; ++c) if (g_tn_cache[c].used && g_tn_cache[c].st == st) return &g_tn_cache[c];
-    for (int c = 0; c < 8; ++c) if (!g_tn_cache[c].used) { g_tn_cache[c].used = true; g_tn_cache[c].st = st; return &g_tn_cache[c]; }
-    return nullptr;
-}
-
 template <typename T>
 int gemm_tn_launch(const void* A, int lda, const void* B, int ldb, float* dW, int lddw, float* dbias, int Tn, int N,
-                   int K, int flags, hipStream_t st) {
+                   int K, void* ws_caller, size_t ws_bytes, hipStream_t st) {
     constexpr int CH = ET<T>::CH;
     if (Tn <= 0 || N <= 0 || K <= 0) return ME_ERR_BAD_SHAPE;
     if (lda % CH || ldb % CH || K % CH) return ME_ERR_BAD_SHAPE;
@@ -1094,51 +1075,17 @@ int gemm_tn_launch(const void* A, int lda, const void* B, int ldb, float* dW, in
             tp = ((tp + TN256_BT - 1) / TN256_BT) * TN256_BT;
             ns = (Tn + tp - 1) / tp;
             const int grid256 = ((tn2 * tk2 * ns + 7) / 8) * 8;
-            // workspace for the partial tiles (256 KB per block), cached per stream: launches on one stream are
-            // ordered, so the buffer is free again when the next weight gradient starts
+            // partial tiles (256 KB per block) go to the caller's workspace and are summed in a fixed order by
+            // tn256_reduce_kernel; without a workspace the blocks accumulate with f32 atomics (order-dependent sum)
             const size_t need = (size_t)grid256 * 32 * 512 * 16;
             float* ws = nullptr;
-            static const bool tn_atomics = getenv("MIDIEMO_TN_ATOMICS") != nullptr;
-            TnCache* c = nullptr;
-            const bool async = (flags & ME_TN_ASYNC_REDUCE) != 0;
-            int buf = 0;
-            if (!tn_atomics && ns > 1) {
-                c = tn_cache_slot(st);
-                if (c) {
-                    buf = async ? (c->flip ^= 1) : 0;
-                    if (async && !c->side) {
-                        if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
-                            hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming) != hipSuccess ||
-                            hipEventCreateWithFlags(&c->ev_red[0], hipEventDisableTiming) != hipSuccess ||
-                            hipEventCreateWithFlags(&c->ev_red[1], hipEventDisableTiming) != hipSuccess) {
-                            (void)hipGetLastError();
-                            return ME_ERR_LAUNCH;
-                        }
-                    }
-                    if (c->bytes[buf] < need) {
-                        if (c->p[buf]) { (void)hipDeviceSynchronize(); (void)hipFree(c->p[buf]); c->p[buf] = nullptr; }
-                        const size_t want = need < ((size_t)80 << 20) ? ((size_t)80 << 20) : need;
-                        if (hipMalloc(&c->p[buf], want) == hipSuccess) c->bytes[buf] = want;
-                        else { c->p[buf] = nullptr; c->bytes[buf] = 0; (void)hipGetLastError(); }
-                    }
-                    ws = c->p[buf];
-                }
+            if (ws_caller && ns > 1) {
+                if (ws_bytes < need || !aligned16(ws_caller)) return ME_ERR_WORKSPACE;
+                ws = reinterpret_cast<float*>(ws_caller);
             }
-            // the reduce that last read this workspace buffer must be done before the partial tiles are overwritten
-            if (ws && async) (void)hipStreamWaitEvent(st, c->ev_red[buf], 0);
             gemm_tn256_kernel<<<grid256, 512, TN256_LDS, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, dW, lddw, dbias, Tn, N,
                                                              K, tp, tn2, tk2, ns, ws);
-            if (ws && async) {
-                // the reduce has no consumer until the caller joins (me_gemm_tn_join): it runs on a side stream under
-                // whatever the caller enqueues next
-                (void)hipEventRecord(c->ev_main, st);
-                (void)hipStreamWaitEvent(c->side, c->ev_main, 0);
-                tn256_reduce_kernel<<<dim3(tn2 * tk2, 32), 512, 0, c->side>>>(ws, dW, lddw, tn2, tk2, ns, N);
-                (void)hipEventRecord(c->ev_red[buf], c->side);
-                c->pending = true;
-            } else if (ws) {
-                tn256_reduce_kernel<<<dim3(tn2 * tk2, 32), 512, 0, st>>>(ws, dW, lddw, tn2, tk2, ns, N);
-            }
+            if (ws) tn256_reduce_kernel<<<dim3(tn2 * tk2, 32), 512, 0, st>>>(ws, dW, lddw, tn2, tk2, ns, N);
             return me_launch_status();
         }
         const int npairs8 = ((tn * nsplit + 7) / 8) * 8;
@@ -1184,28 +1131,35 @@ int me_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
     return ME_ERR_BAD_DTYPE;
 }
 
+// bytes of partial-tile workspace gemm_tn_launch<bf16> needs for (T, N, K); 0 = the shape runs a kernel without one
+static size_t tn_ws_bytes(int Tn, int N, int K, int lda_min) {
+    const int n256 = ((N + 255) / 256) * 256;
+    (void)lda_min;
+    if (K % 256 != 0 || Tn < 2048) return 0;
+    const int tn2 = n256 / 256, tk2 = K / 256;
+    int ns = 256 / (tn2 * tk2);
+    if (ns < 1) ns = 1;
+    int tp = (Tn + ns - 1) / ns;
+    tp = ((tp + TN256_BT - 1) / TN256_BT) * TN256_BT;
+    ns = (Tn + tp - 1) / tp;
+    if (ns <= 1) return 0;
+    const int grid256 = ((tn2 * tk2 * ns + 7) / 8) * 8;
+    return (size_t)grid256 * 32 * 512 * 16;
+}
+
+size_t me_workspace_bytes(int op, int M, int N, int K, int dtype) {
+    if (op == ME_WS_GEMM_TN) return dtype == ME_BF16 ? tn_ws_bytes(M, N, K, 0) : 0;
+    return 0;
+}
+
 int me_gemm_tn_acc(const void* A, int lda, const void* B, int ldb, float* dW, int lddw, float* dbias, int T, int N,
-                   int K, int flags, int dtype, void* stream) {
+                   int K, void* ws, size_t ws_bytes, int dtype, void* stream) {
     me_clear_error();
     if (!A || !B || !dW) return ME_ERR_NULL;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == ME_F32) return gemm_tn_launch<float>(A, lda, B, ldb, dW, lddw, dbias, T, N, K, flags, st);
-    if (dtype == ME_BF16) return gemm_tn_launch<bf16_t>(A, lda, B, ldb, dW, lddw, dbias, T, N, K, flags, st);
+    if (dtype == ME_F32) return gemm_tn_launch<float>(A, lda, B, ldb, dW, lddw, dbias, T, N, K, ws, ws_bytes, st);
+    if (dtype == ME_BF16) return gemm_tn_launch<bf16_t>(A, lda, B, ldb, dW, lddw, dbias, T, N, K, ws, ws_bytes, st);
     return ME_ERR_BAD_DTYPE;
-}
-
-int me_gemm_tn_join(void* stream) {
-    me_clear_error();
-    hipStream_t st = (hipStream_t)stream;
-    for (int c = 0; c < 8; ++c) {
-        TnCache& t = g_tn_cache[c];
-        if (t.used && t.st == st && t.pending) {
-            (void)hipStreamWaitEvent(st, t.ev_red[0], 0);
-            (void)hipStreamWaitEvent(st, t.ev_red[1], 0);
-            t.pending = false;
-        }
-    }
-    return me_launch_status();
 }
 
 int me_cast_transpose(const float* src, int rows, int cols, void* dst, int ld_dst, void* dstT, int ld_dstT,

@@ -12,10 +12,11 @@ LIB_PATH = os.environ.get("MIDIEMO_LIB") or os.path.join(HERE, "libmidiemo_hip.s
 ME_F32, ME_BF16 = 0, 1
 ME_COND_NONE, ME_COND_CONCAT, ME_COND_TOKEN = 0, 1, 2
 ME_EPI_RELU, ME_EPI_OUT_F32, ME_EPI_RELU_BWD = 1, 2, 4
-ABI_VERSION = 8
+ME_WS_GEMM_TN = 1
+ABI_VERSION = 9
 
 ERRORS = {0: "ME_OK", -1: "ME_ERR_BAD_DTYPE", -2: "ME_ERR_BAD_SHAPE", -3: "ME_ERR_ALIGNMENT",
-          -4: "ME_ERR_LAUNCH", -5: "ME_ERR_NULL"}
+          -4: "ME_ERR_LAUNCH", -5: "ME_ERR_NULL", -6: "ME_ERR_WORKSPACE"}
 
 _p, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 _i64, _u64, _u32 = ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint32
@@ -25,16 +26,16 @@ SIGNATURES = {
     "me_abi_version": [],
     "me_cast_transpose": [_p, _i, _i, _p, _i, _p, _i, _i, _p],
     "me_cast_transpose_multi": [_p, _i, _i, _i, _p],
-    "me_embed_fwd": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _u64, _p],
+    "me_embed_fwd": [_p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _u64, _p],
     "me_embed_bwd": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _p],
     "me_key_pad_mask": [_p, _p, _i, _i, _i, _i, _p],
     "me_gemm_nt": [_p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
-    "me_gemm_tn_acc": [_p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p],
-    "me_gemm_tn_join": [_p],
+    "me_workspace_bytes": [_i, _i, _i, _i, _i],
+    "me_gemm_tn_acc": [_p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _p, ctypes.c_size_t, _i, _p],
     "me_rga_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "me_rga_pack_rel": [_p, _p, _i, _i, _i, _p],
     "me_rga_bwd": [_p] * 11 + [_i, _i, _i, _i, _i, _i, _i, _i, _p],
-    "me_resid_ln_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _f, _u64, _u32, _i, _p],
+    "me_resid_ln_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _f, _u64, _u32, _i, _p],
     "me_resid_ln_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _u64, _u32, _i, _p],
     "me_ce_fwd": [_p, _i, _p, _p, _p, _p, _i, _i, _i, _p],
     "me_ce_bwd": [_p, _i, _p, _p, _p, _i, _p, _f, _i, _i, _i, _i, _p],
@@ -66,7 +67,7 @@ def load():
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.argtypes = args
-        fn.restype = ctypes.c_int
+        fn.restype = ctypes.c_size_t if name == "me_workspace_bytes" else ctypes.c_int
     v = lib.me_abi_version()
     if v != ABI_VERSION:
         raise RuntimeError("libmidiemo_hip.so ABI %d != binding ABI %d" % (v, ABI_VERSION))

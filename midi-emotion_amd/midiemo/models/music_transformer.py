@@ -119,8 +119,8 @@ class MusicTransformerHIP(nn.Module):
         if max_seq % 32:
             raise ValueError("max_seq must be a multiple of 32")
         self.compute_dtype = _DTYPES[compute_dtype] if isinstance(compute_dtype, str) else compute_dtype
-        self.overlap_wgrad = os.environ.get("MIDIEMO_OVERLAP_WGRAD") is not None   # opt-in: measured +0.5 % only
-        self.async_wgrad_reduce = os.environ.get("MIDIEMO_ASYNC_WGRAD_REDUCE") is not None   # opt-in: measured 1.5 % SLOWER
+        # residual stream carried as bf16 hi + lo (f32-class precision, like autocast's fp32 stream); 0 = round it to bf16
+        self.resid_lo = os.environ.get("MIDIEMO_RESID_LO", "1") != "0"
 
         self.embedding = _Emb(vocab_size, embedding_dim - d_condition)
         if self.token_conditioning:
@@ -267,8 +267,18 @@ class MusicTransformerHIP(nn.Module):
         self._dirty = True
 
     # ------------------------------------------------------------------ prepared (cast / transposed) weights
+    def _param_versions(self):
+        """Sum of the version counters of the flat buffer and of every nn.Parameter view.  `p.data = flat[...]` views
+        do NOT share flat's counter, so an in-place update made through a parameter (torch.optim step, p.copy_(),
+        EMA, manual re-init) bumps only p._version: both have to be watched."""
+        v = self._flat._version
+        for g in self._param_order():
+            for _, p in g:
+                v += p._version
+        return v
+
     def _refresh_weights(self):
-        ver = self._flat._version
+        ver = self._param_versions()
         if self._prep is not None and not self._dirty and ver == self._prep_version:
             return
         dt = self.compute_dtype
@@ -337,6 +347,10 @@ class MusicTransformerHIP(nn.Module):
         ws.key_pad = e(B, Lm, dtype=torch.uint8)
         nl = N if save else 1
         ws.h = [e(T, d) for _ in range(N + 1 if save else 2)]
+        # bf16 tier: low-order half of the residual stream (h, o1), so that the stream itself is ~f32 like the
+        # reference's under autocast while the GEMMs still read the bf16 "hi" tensors (me_resid_ln_fwd x_lo / y_lo)
+        lo = self.resid_lo and dt != torch.float32
+        ws.hlo = [e(T, d) if lo else None for _ in range(2)]
         ws.layers = []
         for _ in range(nl):
             L = _Workspace()
@@ -401,13 +415,14 @@ class MusicTransformerHIP(nn.Module):
                                  self.num_layer, self.max_seq)
         T = B * Lm
         ws = self._workspace(B, Lm, save)
+        ws.stamp = getattr(ws, "stamp", 0) + 1     # a saved-activation workspace is overwritten by every forward that uses it
         self._refresh_weights()
         f = self._flat
         shift = Lm - Ltok
         ops.key_pad_mask(ws.key_pad, tokens, B, Ltok, shift, self.pad_token)
         cw0, cb0, cw1, cb1 = self._cond_params(f)
         ops.embed_fwd(ws.h[0], tokens, cond, self._pview(f, "embedding.weight"), cw0, cb0, cw1, cb1, self._pe,
-                      self._mode(), B, Ltok, d, self.d_condition, p_drop, seed)
+                      self._mode(), B, Ltok, d, self.d_condition, p_drop, seed, out_lo=ws.hlo[0])
         nh = len(ws.h)
         for i in range(N):
             W = self._prep["layers"][i]
@@ -420,12 +435,12 @@ class MusicTransformerHIP(nn.Module):
                         causal=self.causal)             # bidirectional (mask=None in the reference): no pad mask either
             ops.gemm_nt(Lw.att, W["Wo"], ws.tmp, bias=self._pview(f, p + "rga.fc.bias"), M=T, N=d, K=d, dtype=dt)
             ops.resid_ln_fwd(x, ws.tmp, self._pview(f, p + "layernorm1.weight"), self._pview(f, p + "layernorm1.bias"),
-                             Lw.o1, Lw.s1, Lw.st1, T, d, self.LN_EPS, p_drop, seed, 1 + 2 * i)
+                             Lw.o1, Lw.s1, Lw.st1, T, d, self.LN_EPS, p_drop, seed, 1 + 2 * i, x_lo=ws.hlo[0], y_lo=ws.hlo[1])
             ops.gemm_nt(Lw.o1, W["W1"], Lw.hid, bias=self._pview(f, p + "FFN_pre.bias"), M=T, N=di, K=d,
                         flags=ops.ME_EPI_RELU, dtype=dt)
             ops.gemm_nt(Lw.hid, W["W2"], ws.tmp, bias=self._pview(f, p + "FFN_suf.bias"), M=T, N=d, K=di, dtype=dt)
             ops.resid_ln_fwd(Lw.o1, ws.tmp, self._pview(f, p + "layernorm2.weight"), self._pview(f, p + "layernorm2.bias"),
-                             y, Lw.s2, Lw.st2, T, d, self.LN_EPS, p_drop, seed, 2 + 2 * i)
+                             y, Lw.s2, Lw.st2, T, d, self.LN_EPS, p_drop, seed, 2 + 2 * i, x_lo=ws.hlo[1], y_lo=ws.hlo[0])
         hN = ws.h[N % nh if not save else N]
         out = logits_out if logits_out is not None else ws.logits
         ops.gemm_nt(hN, self._prep["head"]["Wf"], out, bias=self._pview(f, self._HEAD_B), M=T, N=V, K=d,
@@ -444,44 +459,19 @@ class MusicTransformerHIP(nn.Module):
         head = self._prep["head"]
         gv = lambda name: self._pview(gflat, name)
         hN = ws.h[N]
-        # Weight gradients (dY^T X, split-K atomics into gflat) depend on nothing downstream, so they CAN be forked
-        # onto a side stream (MIDIEMO_OVERLAP_WGRAD=1).  Measured on MI355X: 13.71 vs 13.78 ms/step -- every kernel
-        # of the chain already fills all 256 CUs, only tails overlap -- so it is off by default.  The only hazard is
-        # the dY buffer being recycled: each buffer role has an event, waited for before the NEXT layer rewrites it.
-        main = torch.cuda.current_stream()
-        side = self._side_stream() if self.overlap_wgrad else None
-        done = {}
-
-        # optionally the final summation of each weight gradient's partial tiles runs on the library's side stream,
-        # joined before a bucket is handed to the all-reduce and at the end (measured: 11.47 vs 11.30 ms/step -- the
-        # memory-bound reduce competes with the next kernel instead of hiding under it; off by default)
-        tn_flags = ops.ME_TN_ASYNC_REDUCE if self.async_wgrad_reduce else 0
+        # Weight gradients (dY^T X) run in line on the caller's stream: forking them onto a side stream measured
+        # +0.5 % (every kernel of the chain already fills all 256 CUs) and an asynchronous partial-tile reduce
+        # measured 1.5 % slower -- both experiments were removed with the library-owned workspace (round 2).
+        tnws = self._tn_workspace(T)
 
         def wgrad(role, dY, X, gW, gb, **kw):
-            kw["flags"] = tn_flags
-            if side is None:
-                ops.gemm_tn_acc(dY, X, gW, gb, **kw)
-                return
-            ev = torch.cuda.Event()
-            ev.record(main)
-            side.wait_event(ev)
-            with torch.cuda.stream(side):
-                ops.gemm_tn_acc(dY, X, gW, gb, **kw)
-            fin = torch.cuda.Event()
-            fin.record(side)
-            done[role] = fin
+            ops.gemm_tn_acc(dY, X, gW, gb, ws=tnws, **kw)
 
-        def reuse(role):                                   # main stream is about to overwrite this role's buffer
-            ev = done.pop(role, None)
-            if ev is not None:
-                main.wait_event(ev)
+        def reuse(role):
+            pass
 
         def join():
-            if side is not None:
-                main.wait_stream(side)
-                done.clear()
-            if tn_flags:
-                ops.gemm_tn_join()
+            pass
 
         wgrad("dlogits", ws.dlogits, hN, gv(self._HEAD_W), gv(self._HEAD_B), T=T, N=V, K=d, dtype=dt)
         ops.gemm_nt(ws.dlogits, head["WfT"], ws.dA, M=T, N=d, K=ldv, dtype=dt)
@@ -530,10 +520,18 @@ class MusicTransformerHIP(nn.Module):
         if bucket_hook:
             bucket_hook(0)
 
-    def _side_stream(self):
-        if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self._flat.device)
-        return self._side
+    def _tn_workspace(self, T):
+        """Caller-owned partial-tile workspace of the weight-gradient GEMMs (me_workspace_bytes):
+        one buffer sized for the largest (T, N, K) of the step, reused by every launch on the stream."""
+        d, di, V = self.embedding_dim, self.d_inner, self.head_size
+        shapes = [(3 * d, d), (d, d), (di, d), (d, di), (V, d)]
+        need = max(ops.workspace_bytes(ops.ME_WS_GEMM_TN, T, n, k, self.compute_dtype) for n, k in shapes)
+        if need == 0:
+            return None
+        buf = getattr(self, "_tnws", None)
+        if buf is None or buf.numel() < need or buf.device != self._flat.device:
+            buf = self._tnws = torch.empty(need, dtype=torch.uint8, device=self._flat.device)
+        return buf
 
     # ------------------------------------------------------------------ public API
     def _next_seed(self):
@@ -592,16 +590,17 @@ class _EngineFn(torch.autograd.Function):
         out = torch.empty(B * Lm, V, dtype=torch.float32, device=model._flat.device)
         ws = model._forward_impl(tokens, cond, B, Ltok, Lm, True, p_drop, seed, out)
         ctx.model, ctx.ws, ctx.args = model, ws, (tokens, cond, B, Ltok, Lm, p_drop, seed)
-        ctx.stamp = model._fwd_count
+        ctx.stamp = ws.stamp
         return out.view(B, Lm, V)
 
     @staticmethod
     def backward(ctx, dlogits):
         model, ws = ctx.model, ctx.ws
         tokens, cond, B, Ltok, Lm, p_drop, seed = ctx.args
-        if ctx.stamp != model._fwd_count:
-            raise RuntimeError("backward() after another forward() of the same shape: activations of the "
-                               "HIP engine live in a shared workspace (one forward in flight per shape)")
+        if ctx.stamp != ws.stamp:
+            raise RuntimeError("backward() after another grad-enabled forward() of the same (batch, length): the "
+                               "activations of the HIP engine live in one workspace per shape (one forward in flight "
+                               "per shape; no-grad / eval forwards and other shapes use their own workspaces)")
         V = model.head_size
         ws.dlogits[:, :V].copy_(dlogits.reshape(B * Lm, V))
         gbuf = torch.zeros_like(model._gflat)

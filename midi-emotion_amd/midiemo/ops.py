@@ -7,7 +7,7 @@ import torch
 
 from . import _lib
 from ._lib import (ME_BF16, ME_COND_CONCAT, ME_COND_NONE, ME_COND_TOKEN, ME_EPI_OUT_F32, ME_EPI_RELU,
-                   ME_EPI_RELU_BWD, ME_F32, check)
+                   ME_EPI_RELU_BWD, ME_F32, ME_WS_GEMM_TN, check)
 
 DTYPE_CODE = {torch.float32: ME_F32, torch.bfloat16: ME_BF16}
 
@@ -67,8 +67,8 @@ def make_ct_desc(items, device):
     return t, len(items), tiles
 
 
-def embed_fwd(out, tokens, cond, emb, cw0, cb0, cw1, cb1, pe, mode, B, Ltok, d, dc, p, seed, pos_dev=None):
-    check(lib().me_embed_fwd(_ptr(out), _code(out.dtype), _ptr(tokens), _ptr(cond), _ptr(emb), _ptr(cw0), _ptr(cb0),
+def embed_fwd(out, tokens, cond, emb, cw0, cb0, cw1, cb1, pe, mode, B, Ltok, d, dc, p, seed, pos_dev=None, out_lo=None):
+    check(lib().me_embed_fwd(_ptr(out), _ptr(out_lo), _code(out.dtype), _ptr(tokens), _ptr(cond), _ptr(emb), _ptr(cw0), _ptr(cb0),
                              _ptr(cw1), _ptr(cb1), _ptr(pe), _ptr(pos_dev), mode, B, Ltok, d, dc, float(p), int(seed), _stream()),
           "me_embed_fwd")
 
@@ -96,23 +96,21 @@ def gemm_nt(A, B, C, bias=None, add=None, gate=None, M=None, N=None, K=None, fla
                            M, N, K, flags, _code(dtype), _stream()), "me_gemm_nt")
 
 
-ME_TN_ASYNC_REDUCE = 1
+def workspace_bytes(op, M, N, K, dtype):
+    """me_workspace_bytes: scratch bytes the entry point `op` needs for this shape (0 = none)."""
+    return int(lib().me_workspace_bytes(int(op), int(M), int(N), int(K), _code(dtype)))
 
 
-def gemm_tn_join():
-    """Make the current stream wait for every asynchronous weight-gradient summation issued on its behalf."""
-    check(lib().me_gemm_tn_join(_stream()), "me_gemm_tn_join")
-
-
-def gemm_tn_acc(A, B, dW, dbias=None, T=None, N=None, K=None, dtype=None, flags=0):
-    """dW[N,K] += A[T,N]^T . B[T,K] ; dbias[N] += colsum(A).  flags=ME_TN_ASYNC_REDUCE: dW is only valid after
-    gemm_tn_join() on the same stream."""
+def gemm_tn_acc(A, B, dW, dbias=None, T=None, N=None, K=None, dtype=None, ws=None):
+    """dW[N,K] += A[T,N]^T . B[T,K] ; dbias[N] += colsum(A).  ws: caller-owned uint8 workspace of at least
+    workspace_bytes(ME_WS_GEMM_TN, T, N, K, dtype) bytes (deterministic summation); None -> f32 atomics."""
     dtype = dtype or A.dtype
     T = A.shape[0] if T is None else T
     N = A.shape[1] if N is None else N
     K = B.shape[1] if K is None else K
     check(lib().me_gemm_tn_acc(_ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(dW), dW.stride(0), _ptr(dbias),
-                               T, N, K, int(flags), _code(dtype), _stream()), "me_gemm_tn_acc")
+                               T, N, K, _ptr(ws), ws.numel() * ws.element_size() if ws is not None else 0,
+                               _code(dtype), _stream()), "me_gemm_tn_acc")
 
 
 def rel_pack_numel(M, dh):
@@ -142,8 +140,8 @@ def rga_bwd(qkv, Epk, key_pad, out, lse, dout, dqkv, dE, delta_ws, PT, dST, B, L
                            _code(qkv.dtype), _stream()), "me_rga_bwd")
 
 
-def resid_ln_fwd(x, a, gamma, beta, y, s_out, stats, rows, d, eps, p, seed, site):
-    check(lib().me_resid_ln_fwd(_ptr(x), _ptr(a), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(s_out), _ptr(stats), rows, d,
+def resid_ln_fwd(x, a, gamma, beta, y, s_out, stats, rows, d, eps, p, seed, site, x_lo=None, y_lo=None):
+    check(lib().me_resid_ln_fwd(_ptr(x), _ptr(x_lo), _ptr(a), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(y_lo), _ptr(s_out), _ptr(stats), rows, d,
                                 float(eps), float(p), int(seed), int(site), _code(x.dtype), _stream()), "me_resid_ln_fwd")
 
 

@@ -191,6 +191,19 @@ def make_f3():
     rows = np.sort(rs.choice(1024, 32, replace=False))
     rec = {"rows": rows, "logits_rows": lg.detach()[:, rows].numpy().astype(np.float32),
            "loss": np.array(loss.item()), "weight_seed": np.array(31), "batch_seed": np.array(1234)}
+    # The reference's OWN reduced-precision error on this very batch: the same module under torch.autocast(bfloat16)
+    # (train.py:281 wraps the model call in autocast; on this CPU-only container the bf16 CPU autocast is what can run).
+    # The bf16 tier of the HIP path is gated on being at least this close to the fp32 logits.
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        lg_ac = model(inp, cond)
+    lg_ac = lg_ac.float()
+    ref32 = lg.detach().double()
+    rec["autocast_bf16_logits_rows"] = lg_ac[:, rows].numpy().astype(np.float32)
+    rec["autocast_bf16_rel_l2_all"] = np.array(float((lg_ac.double() - ref32).norm() / ref32.norm()))
+    rec["autocast_bf16_rel_l2_rows"] = np.array(float((lg_ac.double()[:, rows] - ref32[:, rows]).norm() / ref32[:, rows].norm()))
+    rec["autocast_bf16_max_abs"] = np.array(float((lg_ac.double() - ref32).abs().max()))
+    print("F3 reference bf16-autocast rel-L2 vs its fp32 logits: all %.3e, stored rows %.3e, max abs %.3e" %
+          (rec["autocast_bf16_rel_l2_all"], rec["autocast_bf16_rel_l2_rows"], rec["autocast_bf16_max_abs"]))
     for k, p in model.named_parameters():
         rec[f"gradnorm/{k}"] = np.array(np.sqrt((p.grad.double() ** 2).sum().item()))
     np.savez_compressed(os.path.join(OUT, "f3_cfg2.npz"), **rec)

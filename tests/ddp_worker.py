@@ -1,0 +1,80 @@
+"""Worker of tests/test_ddp_gpu.py: one data-parallel rank running REAL train steps of the HIP engine
+(loss_and_backward with bucket_hook=GradAllReducer.hook -> finish -> FusedAdamW.step(grad_scale=1/world)), every rank on
+cuda:0 (1-GPU boxes).  Rank 0 writes the averaged flat gradient of step 1 and the parameters after the last step."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "midi-emotion_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+CFG = dict(vocab_size=1007, n_layer=2, n_head=2, d_model=128, d_inner=256, dropout=0.0, d_condition=32,
+           conditioning="continuous_concat")
+B, L, STEPS = 2, 96, 3
+
+
+def micro_batch(step, micro, rank, device):
+    g = torch.Generator().manual_seed(9000 + 131 * step + 17 * micro + rank)
+    tok = torch.randint(2, CFG["vocab_size"], (B, L + 1), generator=g)
+    cond = torch.rand(B, 2, generator=g) * 2 - 1
+    return tok[:, :-1].contiguous().to(device), cond.to(device), tok[:, 1:].contiguous().to(device)
+
+
+def build(compute_dtype, device):
+    from midiemo.models.build_model import build_model
+    torch.manual_seed(7)
+    model, _ = build_model(dict(CFG, compute_dtype=compute_dtype))
+    return model.to(device).train()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--policy", required=True)
+    ap.add_argument("--accumulate", type=int, default=1)
+    ap.add_argument("--backend", default="gloo")
+    ap.add_argument("--compute_dtype", default="fp32")
+    ap.add_argument("--out", required=True)
+    a = ap.parse_args()
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    if a.backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(a.backend)
+    from midiemo.ddp import GradAllReducer, broadcast_params
+    from midiemo.optim import FusedAdamW
+    model = build(a.compute_dtype, dev)
+    if rank != 0:
+        with torch.no_grad():
+            model.flat_params.add_(0.01 * rank)             # the broadcast has to repair this
+        model.mark_params_changed()
+    broadcast_params(model.flat_params)
+    model.mark_params_changed()
+    opt = FusedAdamW(model, lr=2e-5, clip=1.0)          # same as the reference run in test_ddp_gpu.py
+    red = GradAllReducer(lambda: model.flat_grads, model.bucket_ranges(), policy=a.policy)
+    g1 = None
+    for step in range(STEPS):
+        for micro in range(a.accumulate):
+            x, c, y = micro_batch(step, micro, rank, dev)
+            last = micro + 1 == a.accumulate
+            model.loss_and_backward(x, c, y, grad_scale=1.0 / a.accumulate, bucket_hook=red.hook if last else None)
+        red.finish()
+        if step == 0:
+            g1 = (model.flat_grads * red.grad_scale).clone()
+        opt.step(grad_scale=red.grad_scale)
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save({"g1": g1.cpu(), "params": model.flat_params.detach().cpu().clone()}, a.out)
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "done")
+
+
+if __name__ == "__main__":
+    main()

@@ -21,14 +21,14 @@ def test_library_exports_every_declared_symbol():
     build()
     lib = _lib.load()
     hdr = open(os.path.join(ROOT, "include", "midiemo.h")).read()
-    declared = set(re.findall(r"\bint\s+(me_\w+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(?:int|size_t)\s+(me_\w+)\s*\(", hdr))
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.me_abi_version() == _lib.ABI_VERSION
     # prototypes: same number of parameters in the header and in the binding
     for name in declared:
-        m = re.search(r"\bint\s+%s\s*\(([^;]*?)\)\s*;" % name, hdr, re.S)
+        m = re.search(r"\b(?:int|size_t)\s+%s\s*\(([^;]*?)\)\s*;" % name, hdr, re.S)
         args = [a for a in m.group(1).split(",") if a.strip() and a.strip() != "void"]
         assert len(args) == len(_lib.SIGNATURES[name]), name
 

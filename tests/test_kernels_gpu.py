@@ -129,25 +129,58 @@ def test_gemm_tn_acc(ops, dtype, T, N, K):
     refb = db0.double() + A[:, :N].double().sum(0)
     dW = dW0.clone().to(DEV)
     db = db0.clone().to(DEV)
-    ops.gemm_tn_acc(A.to(DEV), B.to(DEV), dW, db, T=T, N=N, K=K)
+    need = ops.workspace_bytes(ops.ME_WS_GEMM_TN, T, N, K, dtype)
+    ws = torch.empty(need, dtype=torch.uint8, device=DEV) if need else None
+    ops.gemm_tn_acc(A.to(DEV), B.to(DEV), dW, db, T=T, N=N, K=K, ws=ws)
     assert relerr(dW, ref) < tol(dtype, 2e-5, 2e-5), relerr(dW, ref)   # inputs already rounded -> f32 accumulate
     assert relerr(db, refb) < 2e-5, relerr(db, refb)
 
 
-def test_gemm_tn_acc_async_reduce_then_join(ops):
-    """ME_TN_ASYNC_REDUCE: the partial-tile summation runs on the library's side stream; after me_gemm_tn_join the
-    result on the caller's stream equals the synchronous one (two back-to-back launches alternate workspaces)."""
+def test_gemm_tn_acc_caller_workspace(ops):
+    """SURVEY 8b ownership: the partial-tile workspace is the caller's (me_workspace_bytes).  With it the summation
+    order is fixed -> bit-identical results across launches that reuse the buffer; without it the kernel falls back to
+    f32 atomics (same value up to rounding order); a buffer that is too small is an error, not a silent fallback."""
     T, N, K = 8192, 512, 256
     A = rnd(T, N, seed=21).to(torch.bfloat16).to(DEV)
     B = rnd(T, K, seed=22).to(torch.bfloat16).to(DEV)
-    want = torch.zeros(N, K, device=DEV)
-    ops.gemm_tn_acc(A, B, want, None, T=T, N=N, K=K)
+    need = ops.workspace_bytes(ops.ME_WS_GEMM_TN, T, N, K, torch.bfloat16)
+    assert need > 0 and ops.workspace_bytes(ops.ME_WS_GEMM_TN, T, N, K, torch.float32) == 0
+    ws = torch.empty(need, dtype=torch.uint8, device=DEV)
     got = [torch.zeros(N, K, device=DEV) for _ in range(3)]
     for g in got:
-        ops.gemm_tn_acc(A, B, g, None, T=T, N=N, K=K, flags=ops.ME_TN_ASYNC_REDUCE)
-    ops.gemm_tn_join()
-    for g in got:
-        assert torch.equal(g, want)                      # fixed summation order: bit-identical
+        ops.gemm_tn_acc(A, B, g, None, T=T, N=N, K=K, ws=ws)
+    for g in got[1:]:
+        assert torch.equal(g, got[0])                    # fixed summation order: bit-identical
+    atom = torch.zeros(N, K, device=DEV)
+    ops.gemm_tn_acc(A, B, atom, None, T=T, N=N, K=K, ws=None)
+    ref = A.double().t() @ B.double()
+    assert relerr(got[0], ref) < 2e-5 and relerr(atom, ref) < 2e-5
+    with pytest.raises(RuntimeError, match="ME_ERR_WORKSPACE"):
+        ops.gemm_tn_acc(A, B, atom, None, T=T, N=N, K=K, ws=ws[:need // 2])
+
+
+def test_resid_ln_fwd_hi_lo_residual_stream(ops):
+    """bf16 tier: the residual stream travels as hi + lo (me_resid_ln_fwd x_lo / y_lo).  y must be exactly
+    bf16(LN(x_hi + x_lo + a)) computed in f32, and y + y_lo must carry ~16 mantissa bits of it."""
+    rows, d = 300, 512
+    x = rnd(rows, d, seed=51).float() * 3
+    a = rnd(rows, d, seed=52).to(torch.bfloat16)
+    gamma, beta = rnd(d, seed=53).float(), rnd(d, seed=54).float()
+    x_hi = x.to(torch.bfloat16)
+    x_lo = (x - x_hi.float()).to(torch.bfloat16)
+    xs = x_hi.double() + x_lo.double() + a.double()
+    ref = torch.nn.functional.layer_norm(xs, (d,), gamma.double(), beta.double(), 1e-6)
+    y = torch.empty(rows, d, dtype=torch.bfloat16, device=DEV)
+    y_lo = torch.empty_like(y)
+    ops.resid_ln_fwd(x_hi.to(DEV), a.to(DEV), gamma.to(DEV), beta.to(DEV), y, None, None, rows, d, 1e-6, 0.0, 0, 1,
+                     x_lo=x_lo.to(DEV), y_lo=y_lo)
+    assert relerr(y, ref) < 3e-3                                        # one bf16 rounding
+    assert relerr(y.double() + y_lo.double(), ref) < 2e-5               # hi + lo: f32-class
+    assert (y.float().cpu() - ref.float().to(torch.bfloat16).float()).abs().max() <= 2.0 ** -6   # ulp-level agreement with bf16(ref)
+    y2 = torch.empty_like(y)                                            # without lo the input rounding is visible
+    ops.resid_ln_fwd(x_hi.to(DEV), a.to(DEV), gamma.to(DEV), beta.to(DEV), y2, None, None, rows, d, 1e-6, 0.0, 0, 1)
+    ref_hi = torch.nn.functional.layer_norm(x_hi.double() + a.double(), (d,), gamma.double(), beta.double(), 1e-6)
+    assert relerr(y2, ref_hi) < 3e-3
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -2,8 +2,9 @@
 the oracle and the golden fixtures captured from the reference.
 
 Tolerances: f32 tier -- logits rel-L2 <= 1e-4 (north_star gate is 1e-3), grads rel-L2 <= 2e-4;
-bf16 tier -- logits rel-L2 <= 1.2e-2 on the tiny random models, <= 8e-3 on the headline model
-(the reference's own bf16-autocast error on the headline model is 3.8e-3)."""
+bf16 tier -- DERIVED, not hand-picked: the HIP error against the fp32 reference must not exceed the reference's own
+bf16-autocast error on the same batch (fixture F3 stores it for the headline model: 3.77e-3 on the stored rows; for
+config 4 the oracle is run under torch.autocast(bfloat16) on the host next to its fp32 run)."""
 import os
 
 import numpy as np
@@ -200,6 +201,105 @@ def test_max_seq_discrete_token_config4_shape():
         model(torch.zeros(1, 2049, dtype=torch.long, device=DEV), cond.to(DEV))          # L > max_seq is rejected
 
 
+def test_config4_bf16_discrete_token_L2048():
+    """BASELINE config 4 in ITS OWN dtype and size: discrete_token (V = 1017, the two emotion-bin tokens in front),
+    6 layers d512 8 heads d_inner 2048, L = 2048 = max_seq, bf16 storage.  Logits, loss and every parameter gradient
+    against the oracle's fp32 run; thresholds = what the oracle itself loses under torch.autocast(bfloat16) on the same
+    batch (logits: not above it; gradients: within 1.5x of it per tensor -- the HIP path rounds dS / dP to bf16 where
+    autocast's backward keeps some fp32 intermediates).  Exercises the 256-tile bf16 GEMMs, Frag<bf16> transpose reads
+    and 64 key tiles per query block at the longest sequence the model accepts."""
+    cfg = O.Cfg(1017, 6, 8, 512, 2048, conditioning="discrete_token")
+    P = O.seeded_params(cfg, 2)
+    tok, cond, tgt = O.synthetic_batch(cfg, 1, 2048, seed=3)
+    tok[0, 0], tok[0, 1] = 1007 + 3, 1012 + 1                          # valence / arousal bin tokens (loader.py:158-164)
+    tgt[0, 0] = tok[0, 1]
+    tok[0, -21:] = 0
+    tgt[0, -22:] = 0
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    loss_ref, lg_ref, G = O.loss_and_grads(cfg, P, tok, cond, tgt)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        loss_ac, lg_ac, G_ac = O.loss_and_grads(cfg, P, tok, cond, tgt)
+    ok_rows = torch.arange(2048 - 21)                                  # logits of PAD positions are compared as well below
+    ac_logit = relerr(lg_ac.float(), lg_ref)
+    model = make_model(cfg, P, "bf16").train()
+    loss = model.loss_and_backward(tok.to(DEV), cond.to(DEV), tgt.to(DEV))
+    model.link_grads()
+    with torch.no_grad():
+        lg = model.eval()(tok.to(DEV), cond.to(DEV))
+    e = relerr(lg, lg_ref)
+    report("config 4 (discrete_token V1017 6L d512 8H L2048, bf16): logits rel %.3e (oracle under bf16 autocast %.3e), "
+           "loss %.5f vs %.5f" % (e, ac_logit, loss.item(), loss_ref.item()))
+    assert e <= ac_logit, (e, ac_logit)
+    assert abs(loss.item() - loss_ref.item()) <= max(2 * abs(loss_ac.item() - loss_ref.item()), 2e-3)
+    bad, worst = {}, (0.0, None)
+    for k, p in model.named_parameters():
+        if k.endswith("Wk.bias"):
+            continue
+        eg, ea = relerr(p.grad, G[k]), relerr(G_ac[k], G[k])
+        if eg / max(ea, 1e-12) > worst[0]:
+            worst = (eg / max(ea, 1e-12), k)
+        if eg > 1.5 * ea + 1e-6:
+            bad[k] = (eg, ea)
+    report("config 4 bf16 gradients: worst ratio to the oracle's autocast error %.2f (%s)" % worst)
+    assert not bad, bad
+    del ok_rows
+
+
+def test_forward_follows_torch_optimizer_updates():
+    """the INTEGRATION.md 2a pattern -- loss.backward() + a torch.optim optimiser -- updates the
+    parameters through the nn.Parameter views, which does not bump the flat buffer's version counter.  The prepared
+    (cast / transposed / packed) weights must be refreshed anyway: logits after the step must match the oracle run
+    with the stepped parameters, in both tiers."""
+    cfg = O.Cfg(1007, 2, 2, 128, 256, d_condition=32, conditioning="continuous_concat")
+    for cd, tol in (("fp32", 1e-4), ("bf16", 1.2e-2)):
+        P = O.seeded_params(cfg, 11)
+        model = make_model(cfg, P, cd).train()
+        tok, cond, tgt = O.synthetic_batch(cfg, 2, 64, seed=4)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+        lg0 = model(tok.to(DEV), cond.to(DEV))
+        loss = torch.nn.functional.cross_entropy(lg0.reshape(-1, 1007), tgt.to(DEV).reshape(-1), ignore_index=0)
+        loss.backward()
+        opt.step()
+        with torch.no_grad():
+            lg1 = model(tok.to(DEV), cond.to(DEV))
+        P1 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        lg_ref = O.forward(cfg, P1, tok, cond)
+        moved = relerr(lg1, lg0.detach())
+        assert moved > 1e-2, moved                                  # lr 1e-2: the logits must move visibly
+        assert relerr(lg1, lg_ref) < tol, (cd, relerr(lg1, lg_ref))
+        with torch.no_grad():                                      # p.copy_() / manual re-init through a parameter
+            model.fc.weight.mul_(0.5)
+            lg2 = model(tok.to(DEV), cond.to(DEV))
+        P2 = dict(P1)
+        P2["fc.weight"] = P1["fc.weight"] * 0.5
+        assert relerr(lg2, O.forward(cfg, P2, tok, cond)) < tol
+
+
+def test_backward_survives_eval_forward_and_other_shapes():
+    """an eval / no-grad forward or a forward of another (B, L) between forward and backward uses
+    its own workspace and must not invalidate the pending backward; only a second grad-enabled forward of the SAME
+    shape does (and raises)."""
+    cfg = O.Cfg(1007, 2, 2, 128, 256, d_condition=32, conditioning="continuous_concat")
+    P = O.seeded_params(cfg, 12)
+    model = make_model(cfg, P, "fp32").train()
+    tok, cond, tgt = O.synthetic_batch(cfg, 2, 48, seed=5)
+    tok2, cond2, _ = O.synthetic_batch(cfg, 3, 32, seed=6)
+    _, _, G = O.loss_and_grads(cfg, P, tok, cond, tgt)
+    lg = model(tok.to(DEV), cond.to(DEV))
+    with torch.no_grad():
+        model(tok.to(DEV), cond.to(DEV))                            # logging-style forward, same shape, no grad
+    lgo = model(tok2.to(DEV), cond2.to(DEV))                        # another shape, grad enabled
+    loss = torch.nn.functional.cross_entropy(lg.reshape(-1, 1007), tgt.to(DEV).reshape(-1), ignore_index=0)
+    loss.backward()
+    worst = max(relerr(p.grad, G[k]) for k, p in model.named_parameters() if not k.endswith("Wk.bias"))
+    assert worst < 2e-4, worst
+    del lgo
+    lg_a = model(tok.to(DEV), cond.to(DEV))
+    model(tok.to(DEV), cond.to(DEV))                                # second grad-enabled forward of the same shape
+    with pytest.raises(RuntimeError, match="one forward in flight"):
+        lg_a.sum().backward()
+
+
 @pytest.mark.parametrize("cd", ["fp32", "bf16"])
 def test_head_dim_48_like_published_checkpoints(cd):
     """The reference's published models are d768 / 16 heads (head dim 48).  Same geometry, small: d = 96, 2 heads;
@@ -278,8 +378,14 @@ def test_f3_headline_model_logits(golden_dir, cd):
     with torch.no_grad():
         lg = model(inp.to(DEV), cond.to(DEV))
     e = relerr(lg[:, z["rows"]], z["logits_rows"])
-    report("cfg2 (6L d512 h8 L1024 B2) logits rel-L2 vs reference fp32, compute=%s: %.3e" % (cd, e))
-    assert e < (1e-4 if cd == "fp32" else 8e-3), e
+    ref_bf16 = float(z["autocast_bf16_rel_l2_rows"])       # the reference's own bf16-autocast error on these rows
+    report("cfg2 (6L d512 h8 L1024 B2) logits rel-L2 vs reference fp32, compute=%s: %.3e "
+           "(reference under bf16 autocast: %.3e)" % (cd, e, ref_bf16))
+    assert e < (1e-4 if cd == "fp32" else ref_bf16), (e, ref_bf16)
+    if cd == "bf16":                                        # and it is no further from the autocast logits than fp32 is
+        e_ac = relerr(lg[:, z["rows"]], z["autocast_bf16_logits_rows"])
+        report("cfg2 bf16 logits vs the reference's bf16-autocast logits: %.3e" % e_ac)
+        assert e_ac < 1.5 * ref_bf16, e_ac
     loss = model.loss_and_backward(inp.to(DEV), cond.to(DEV), tgt.to(DEV))
     assert abs(loss.item() - float(z["loss"])) < (5e-5 if cd == "fp32" else 5e-3)
     model.link_grads()
