@@ -75,10 +75,11 @@ def test_two_ranks_one_gpu_rccl_backend(tmp_path):
     support: if the communicator refuses it the test is skipped (the driver's multi-GPU run covers RCCL)."""
     r, out = run_workers(tmp_path, "window", 1, "nccl", "fp32", 29561)
     if r.returncode != 0:
-        msg = r.stdout[-2000:] + r.stderr[-2000:]
-        if "uplicate GPU" in msg or "invalid usage" in msg or "NCCL" in msg or "ncclInvalidUsage" in msg:
-            pytest.skip("RCCL refuses two ranks on one device: " + msg[-300:].replace("\n", " "))
-        assert False, msg
+        msg = r.stdout + r.stderr
+        if "Duplicate GPU detected" in msg or "ncclInvalidUsage" in msg:
+            # measured on the MI355X boxes (RCCL 2.26.6): "Duplicate GPU detected : rank 1 and rank 0 both on CUDA device"
+            pytest.skip("RCCL refuses two ranks on one device (ncclInvalidUsage: Duplicate GPU detected)")
+        assert False, msg[-4000:]
     got = torch.load(out)
     g1, params, p0, keep = single_rank_reference(2, 1, "fp32")
     assert rel(got["g1"][keep], g1[keep]) <= 1e-5 and rel(got["params"][keep], params[keep]) <= 1e-4
