@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 9
+#define ME_ABI_VERSION 10
 
 enum { ME_F32 = 0, ME_BF16 = 1 };
 
@@ -221,19 +221,44 @@ int me_adamw_step(float* p, float* g, float* m, float* v, int64_t n, const float
                   float weight_decay, float bias_corr1, float bias_corr2, int zero_grad,
                   void* stream);
 
-/* ---- KV-cached decode (generate.py:92-122 with the model call made incremental) ---
- * One new position `t` per sequence.  qkv_new: T [B, 3, H, dh] for the new token;
- * kcache/vcache: T [B, H, Mc, dh] (position-major); writes k,v at position t, then
- *   out[b,h,:] = softmax_j<=t( (q.k_j + q.E[M-1-(t-j)])/sqrt(dh) ) . v_j   (pad keys masked)
- * out: T [B, H, dh].  t_dev (may be NULL): device int32 that overrides `t` (graph replay). */
-int me_rga_decode_step(const void* qkv_new, void* kcache, void* vcache, const void* E,
-                       const uint8_t* key_pad, int ld_pad, void* out, int B, int H, int dh,
-                       int M, int Mc, int t, const int32_t* t_dev, int dtype, void* stream);
+/* ---- KV-cached decode step (generate.py:92-122 with the model call made incremental) --------------------
+ * One new position `t` for each of Mr <= 8 sequences; the reference recomputes the whole window for every token
+ * (generate.py:99-119).  Five kernels per layer (me_dec_qkv, me_dec_attn, me_dec_proj_resid, me_dec_ln_proj,
+ * me_dec_proj_resid) + me_dec_ln_proj for the head; every position-dependent quantity can come from device memory
+ * (t_dev, may be NULL) so that the whole step is replayable as one HIP graph.  The residual stream (pre-norm sums,
+ * LayerNorm outputs) is f32 [Mr][d]; projection operands are rounded to T exactly where the training forward rounds
+ * them; q, k, v and the caches are T.  kcache / vcache: T [Mr][H][Mc][dh] (position-major per head).
+ *
+ * me_dec_qkv: x = LayerNorm(s_in; gamma, beta, eps) (s_in f32 [Mr][d] = the previous layer's second pre-norm sum,
+ *   music_multi.py:133-134), or x = x_hi + x_lo (T [Mr][d], x_lo may be NULL) when s_in == NULL (first layer: the
+ *   embedding).  x is written to x_out (f32, residual of the attention block); q | k | v = T(x).Wqkv^T + bqkv
+ *   (music_multi.py:196-209); q -> q_out T [Mr][d], k / v -> the caches at position t (t_dev overrides t). */
+int me_dec_qkv(const float* s_in, const float* gamma, const float* beta, float eps, const void* x_hi, const void* x_lo,
+               const void* Wqkv, const float* bqkv, float* x_out, void* q_out, void* kcache, void* vcache,
+               int Mr, int d, int H, int dh, int Mc, int t, const int32_t* t_dev, int dtype, void* stream);
 
-/* Small-M projection y[Mr,N] = x[Mr,K].W[N,K]^T + bias (Mr <= 8), optional ReLU;
- * weight-streaming kernel for the decode step (HBM-bound). */
-int me_gemv_small(const void* x, int ldx, const void* W, int ldw, const float* bias,
-                  void* y, int ldy, int Mr, int N, int K, int flags, int dtype, void* stream);
+/* me_dec_attn: for every (sequence, head) and each of nsplit key ranges of [0, t]:
+ *   s_j = q.(K[j] + E[M-1-(t-j)]) / sqrt(dh)  (pad keys masked; music_multi.py:211-231 for a single query row),
+ *   part[seq*H + head][split] = (max_j s_j, sum_j exp(s_j - max), sum_j exp(s_j - max) V[j])  -- f32 [dh + 2].
+ * E: T [M][dh] natural layout.  grid = Mr*H x nsplit blocks; one key per 8-lane group, 16-byte coalesced K / V / E
+ * reads.  The splits are combined by the prologue of me_dec_proj_resid. */
+int me_dec_attn(const void* q, const void* kcache, const void* vcache, const void* E, const uint8_t* key_pad, int ld_pad,
+                float* part, int nsplit, int Mr, int H, int dh, int M, int Mc, int t, const int32_t* t_dev, int dtype,
+                void* stream);
+
+/* me_dec_proj_resid: out f32 [Mr][N] = resid f32 [Mr][N] + bias + T(x).W^T with
+ *   x = softmax-combine of the attention partials (part != NULL; K = H*dh; replaces the head merge + self.fc of
+ *       music_multi.py:233-237 and the residual add of :128), or
+ *   x = x_T (T [Mr][ldx]; part == NULL: FFN_suf + residual, music_multi.py:132-133). */
+int me_dec_proj_resid(const float* part, int nsplit, int H, int dh, const void* x_T, int ldx, const void* W, int ldw,
+                      const float* bias, const float* resid, float* out, int Mr, int N, int K, int dtype, void* stream);
+
+/* me_dec_ln_proj: x = LayerNorm(s_in; gamma, beta, eps) -> x_out (f32, may be NULL); y = T(x).W^T + bias,
+ *   flags & ME_EPI_RELU: ReLU (FFN_pre, music_multi.py:129-131); flags & ME_EPI_OUT_F32: y is f32 [Mr][ldy] (the
+ *   vocabulary head, music_multi.py:106), else T [Mr][ldy]. */
+int me_dec_ln_proj(const float* s_in, const float* gamma, const float* beta, float eps, const void* W, int ldw,
+                   const float* bias, float* x_out, void* y, int ldy, int Mr, int N, int K, int flags, int dtype,
+                   void* stream);
 
 /* Greedy pick for generate(top_k=1): logits f32 [B, ld]; NaN -> 0, ids in
  * special[0..n_special) -> -inf, argmax -> out_ids[B] (generate.py:122-136,166-183). */
@@ -252,7 +277,7 @@ int me_sample_topk_topp(const float* logits, int ld, int V, const int32_t* speci
                         int32_t* n_choices, float* dbg_p, int32_t* dbg_i, int B, void* stream);
 
 /* Device-side decode bookkeeping: history[b][*pos] = tok[b] (int64 [B][ld_hist]); *pos += 1.
- * With me_embed_fwd(pos_dev) and me_rga_decode_step(t_dev) a greedy decode step has no host-side state
+ * With me_embed_fwd(pos_dev) and the t_dev arguments of me_dec_* a greedy decode step has no host-side state
  * (the token loop of generate.py:99-189 for top_k = 1) and can be captured once and replayed. */
 int me_decode_commit(const int64_t* tok, int64_t* history, int ld_hist, int32_t* pos, int B, void* stream);
 

@@ -881,76 +881,6 @@ __global__ __launch_bounds__(256) void rga_bwd_e_kernel(const T* __restrict__ dS
 }
 
 // =====================================================================================
-// cached decode step: one query (position t) per (b, head) against t+1 cached keys
-// =====================================================================================
-template <typename T, int DH>
-__global__ __launch_bounds__(256) void rga_decode_kernel(const T* __restrict__ qkv_new, T* __restrict__ kcache,
-                                                         T* __restrict__ vcache, const T* __restrict__ E,
-                                                         const uint8_t* __restrict__ key_pad, int ld_pad,
-                                                         T* __restrict__ out, int H, int M, int Mc, int t_host, const int32_t* __restrict__ t_dev,
-                                                         float scale) {
-    const int t = t_dev ? min(*t_dev, min(Mc, M) - 1) : t_host;   // device-side position: the launch is replayable in a HIP graph
-    __shared__ float qs[DH];
-    __shared__ float ps[2048 + 8];
-    __shared__ float red[256];
-    __shared__ float osum[256 / DH > 0 ? 256 : 256];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int bh = blockIdx.x, b = bh / H, head = bh % H;
-    const int dm = H * DH;
-    const T* qn = qkv_new + (size_t)b * 3 * dm + head * DH;
-    T* kc = kcache + (size_t)bh * Mc * DH;
-    T* vc = vcache + (size_t)bh * Mc * DH;
-    if (tid < DH) {
-        qs[tid] = ET<T>::to_f(qn[tid]);
-        kc[(size_t)t * DH + tid] = qn[dm + tid];
-        vc[(size_t)t * DH + tid] = qn[2 * dm + tid];
-    }
-    __syncthreads();
-    // scores
-    float mx = -INFINITY;
-    for (int j = tid; j <= t; j += 256) {
-        const T* kr = (j == t) ? (qn + dm) : (kc + (size_t)j * DH);
-        const T* er = E + (size_t)(M - 1 - (t - j)) * DH;
-        float s = 0.f;
-#pragma unroll 8
-        for (int d = 0; d < DH; ++d) s += qs[d] * (ET<T>::to_f(kr[d]) + ET<T>::to_f(er[d]));
-        s *= scale;
-        if (key_pad && key_pad[(size_t)b * ld_pad + j]) s = -INFINITY;
-        ps[j] = s;
-        mx = fmaxf(mx, s);
-    }
-    mx = wave_max(mx);
-    if (lane == 0) red[wid] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    const float m_safe = mx == -INFINITY ? 0.f : mx;
-    float sm = 0.f;
-    for (int j = tid; j <= t; j += 256) { const float p = expf(ps[j] - m_safe); ps[j] = p; sm += p; }
-    sm = wave_sum(sm);
-    __syncthreads();
-    if (lane == 0) red[wid] = sm;
-    __syncthreads();
-    const float inv = 1.f / (red[0] + red[1] + red[2] + red[3]);
-    // out[d] = sum_j p_j v[j][d] : thread (d, group) strides j
-    constexpr int NG = 256 / DH;
-    const int d = tid % DH, grp = tid / DH;
-    float acc = 0.f;
-    for (int j = grp; grp < NG && j <= t; j += NG) {          // 256 % DH threads (DH = 48: 16) sit this part out
-        const T* vr = (j == t) ? (qn + 2 * dm) : (vc + (size_t)j * DH);
-        acc += ps[j] * ET<T>::to_f(vr[d]);
-    }
-    osum[tid] = acc;
-    __syncthreads();
-    if (tid < DH) {
-        float s = 0.f;
-#pragma unroll
-        for (int g2 = 0; g2 < NG; ++g2) s += osum[g2 * DH + tid];
-        out[(size_t)b * dm + head * DH + tid] = ET<T>::from_f(s * inv);
-    }
-}
-
-
-// =====================================================================================
 // relative table E [M][DH] -> packed fragment images (what rga_fwd / rga_bwd_q load with one 16-byte chunk per lane)
 // =====================================================================================
 // block eb (32 rows of E), PK elements:   image kk < KA      : lane (a, h) holds E[32 eb + a][16 kk + 8 h + 0..7]
@@ -1038,15 +968,6 @@ int bwd_launch(const void* qkv, const void* Epk, const uint8_t* key_pad, const v
     return me_launch_status();
 }
 
-template <typename T, int DH>
-int dec_launch(const void* qkv_new, void* kc, void* vc, const void* E, const uint8_t* key_pad, int ld_pad, void* out, int B,
-               int H, int M, int Mc, int t, const int32_t* t_dev, hipStream_t st) {
-    const float scale = 1.f / sqrtf((float)DH);
-    rga_decode_kernel<T, DH><<<B * H, 256, 0, st>>>((const T*)qkv_new, (T*)kc, (T*)vc, (const T*)E, key_pad, ld_pad, (T*)out, H, M,
-                                                   Mc, t, t_dev, scale);
-    return me_launch_status();
-}
-
 }  // namespace
 
 #define ME_ATTN_DISPATCH(CALL)                                                   \
@@ -1094,17 +1015,6 @@ int me_rga_bwd(const void* qkv, const void* Epk, const uint8_t* key_pad, const v
     hipStream_t st = (hipStream_t)stream;
     ME_ATTN_DISPATCH((bwd_launch<T, DH>(qkv, Epk, key_pad, out, lse, dout, dqkv, dE, delta_ws, PT, dST, B, L, Lp, H, M,
                                         causal, st)))
-}
-
-int me_rga_decode_step(const void* qkv_new, void* kcache, void* vcache, const void* E, const uint8_t* key_pad, int ld_pad,
-                       void* out, int B, int H, int dh, int M, int Mc, int t, const int32_t* t_dev, int dtype,
-                       void* stream) {
-    me_clear_error();
-    if (!qkv_new || !kcache || !vcache || !E || !out) return ME_ERR_NULL;
-    if (B <= 0 || H <= 0 || (t_dev && Mc > 2048)) return ME_ERR_BAD_SHAPE;
-    if (!t_dev && (t < 0 || t >= Mc || t >= M || t >= 2048)) return ME_ERR_BAD_SHAPE;
-    hipStream_t st = (hipStream_t)stream;
-    ME_ATTN_DISPATCH((dec_launch<T, DH>(qkv_new, kcache, vcache, E, key_pad, ld_pad, out, B, H, M, Mc, t, t_dev, st)))
 }
 
 }  // extern "C"

@@ -1,7 +1,7 @@
 // GEMM kernels of the midiemo hot path (gfx950).
 //   me_gemm_nt      C[M,N]  = A[M,K] . B[N,K]^T (+bias, relu, +add, relu-gate)
 //   me_gemm_tn_acc  dW[N,K] += A[T,N]^T . B[T,K]   (split over T; partial tiles through a CALLER-owned workspace)
-//   me_cast_transpose, me_gemv_small
+//   me_cast_transpose, me_cast_transpose_multi
 // bf16 shapes of the train step run the persistent 256x256 kernels (gemm_nt256_kernel, gemm_tn256_kernel: 8 waves,
 // 64-deep slabs, register-staged operand feed, one raw barrier per slab); everything else (f32 tier, ragged shapes)
 // the generic 128x128 kernels (4 waves of 64x64, register-staged double buffer, padded LDS rows).
@@ -958,44 +958,6 @@ __global__ __launch_bounds__(256) void cast_transpose_multi_kernel(const me_ct_d
     }
 }
 
-// y[m][n] = sum_k x[m][k] W[n][k] + bias[n], m < MR (<= 8).  One wave per output
-// column n; the W row is streamed once with 16-byte loads, x rows come from L1/L2.
-template <typename T, int MR>
-__global__ __launch_bounds__(256) void gemv_small_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ W,
-                                                         int ldw, const float* __restrict__ bias, void* __restrict__ yv,
-                                                         int ldy, int N, int K, int flags) {
-    constexpr int CH = ET<T>::CH;
-    const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= N) return;
-    float acc[MR];
-#pragma unroll
-    for (int m = 0; m < MR; ++m) acc[m] = 0.f;
-    for (int k = lane * CH; k < K; k += 64 * CH) {
-        chunk16 w = ld_chunk(W + (size_t)n * ldw + k);
-        const T* we = reinterpret_cast<const T*>(&w);
-#pragma unroll
-        for (int m = 0; m < MR; ++m) {
-            chunk16 xv = ld_chunk(x + (size_t)m * ldx + k);
-            const T* xe = reinterpret_cast<const T*>(&xv);
-#pragma unroll
-            for (int e = 0; e < CH; ++e) acc[m] = fmaf(ET<T>::to_f(we[e]), ET<T>::to_f(xe[e]), acc[m]);
-        }
-    }
-#pragma unroll
-    for (int m = 0; m < MR; ++m) acc[m] = wave_sum(acc[m]);
-    if (lane == 0) {
-        const float bv = bias ? bias[n] : 0.f;
-#pragma unroll
-        for (int m = 0; m < MR; ++m) {
-            float v = acc[m] + bv;
-            if (flags & ME_EPI_RELU) v = fmaxf(v, 0.f);
-            if (flags & ME_EPI_OUT_F32) reinterpret_cast<float*>(yv)[(size_t)m * ldy + n] = v;
-            else reinterpret_cast<T*>(yv)[(size_t)m * ldy + n] = ET<T>::from_f(v);
-        }
-    }
-}
-
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static const bool g_disable_nt256 = getenv("MIDIEMO_NO_NT256") != nullptr;
 
@@ -1096,25 +1058,6 @@ int gemm_tn_launch(const void* A, int lda, const void* B, int ldb, float* dW, in
     return me_launch_status();
 }
 
-template <typename T>
-int gemv_launch(const void* x, int ldx, const void* W, int ldw, const float* bias, void* y, int ldy, int Mr, int N,
-                int K, int flags, hipStream_t st) {
-    constexpr int CH = ET<T>::CH;
-    if (Mr < 1 || Mr > 8 || K % CH || ldx % CH || ldw % CH) return ME_ERR_BAD_SHAPE;
-    if (!aligned16(x) || !aligned16(W)) return ME_ERR_ALIGNMENT;
-    dim3 grid((N + 3) / 4);
-#define ME_GEMV_CASE(MR)                                                                                         \
-    case MR:                                                                                                     \
-        gemv_small_kernel<T, MR><<<grid, 256, 0, st>>>((const T*)x, ldx, (const T*)W, ldw, bias, y, ldy, N, K, flags); \
-        break;
-    switch (Mr) {
-        ME_GEMV_CASE(1) ME_GEMV_CASE(2) ME_GEMV_CASE(3) ME_GEMV_CASE(4)
-        ME_GEMV_CASE(5) ME_GEMV_CASE(6) ME_GEMV_CASE(7) ME_GEMV_CASE(8)
-    }
-#undef ME_GEMV_CASE
-    return me_launch_status();
-}
-
 }  // namespace
 
 extern "C" {
@@ -1187,16 +1130,6 @@ int me_cast_transpose_multi(const me_ct_desc* desc_dev, int n_tensors, int total
     else if (dtype == ME_BF16) cast_transpose_multi_kernel<bf16_t><<<total_tiles, 256, 0, st>>>(desc_dev, n_tensors);
     else return ME_ERR_BAD_DTYPE;
     return me_launch_status();
-}
-
-int me_gemv_small(const void* x, int ldx, const void* W, int ldw, const float* bias, void* y, int ldy, int Mr, int N,
-                  int K, int flags, int dtype, void* stream) {
-    me_clear_error();
-    if (!x || !W || !y) return ME_ERR_NULL;
-    hipStream_t st = (hipStream_t)stream;
-    if (dtype == ME_F32) return gemv_launch<float>(x, ldx, W, ldw, bias, y, ldy, Mr, N, K, flags, st);
-    if (dtype == ME_BF16) return gemv_launch<bf16_t>(x, ldx, W, ldw, bias, y, ldy, Mr, N, K, flags, st);
-    return ME_ERR_BAD_DTYPE;
 }
 
 }  // extern "C"

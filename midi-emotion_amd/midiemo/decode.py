@@ -5,13 +5,16 @@ The reference recomputes the whole window for every new token
 depend on later tokens nor on the sequence length (prefix invariance, SURVEY 8a
 A15 -- pinned by tests), the model call can be made incremental: per layer the
 new token's k, v are appended to a cache [B, H, max_seq, dh] and a single-query
-relative-global-attention step runs against it (me_rga_decode_step; the relative
-row needed for key j is E[M-1-(t-j)]).
+relative-global-attention step runs against it (the relative row needed for key
+j is E[M-1-(t-j)]).
 
-Small-batch projections use the weight-streaming me_gemv_small kernel (decode
-is HBM/latency bound: the bf16 weights, 41 MB at the headline model, are read
-once per step).  Everything stays on the device; one step issues ~8 kernels
-per layer on the current stream.
+A step is HBM / latency bound (41 MB of bf16 weights + the K / V cache are
+streamed once, the arithmetic is negligible), so what counts is the number of
+dependent kernels and how widely each one spreads its stream.  Per layer five
+fused kernels of csrc/me_decode.hip: {LayerNorm2 of the previous layer + q|k|v
+projection + cache append}, {key-split attention}, {combine + Wo + residual},
+{LayerNorm1 + FFN_pre + ReLU}, {FFN_suf + residual}; then {LayerNorm2 +
+vocabulary head}.  The residual stream stays f32 on the device ([B, d] buffers).
 
 Cache validity: the cache is only valid while absolute positions are stable.
 Once the reference's sliding window starts dropping the oldest token every
@@ -20,9 +23,13 @@ position shifts by one (generate.py:101-103 + music_multi.py:163) and
 embedding; in both cases the caller falls back to full recompute (exact
 reference semantics) -- see generate.py.
 """
+import os
+
 import torch
 
 from . import ops
+
+ROWS = 8            # sequences per kernel call (me_dec_*: Mr <= 8); larger batches run in row chunks
 
 
 class DecodeSession:
@@ -36,11 +43,18 @@ class DecodeSession:
         d, di, H, dh, V = m.embedding_dim, m.d_inner, m.num_head, m.dh, m.vocab_size
         B = self.B
         e = lambda *s, dtype=dt: torch.empty(*s, dtype=dtype, device=dev)
+        f32 = torch.float32
         self.kc = [torch.zeros(B, H, m.max_seq, dh, dtype=dt, device=dev) for _ in range(m.num_layer)]
         self.vc = [torch.zeros(B, H, m.max_seq, dh, dtype=dt, device=dev) for _ in range(m.num_layer)]
-        self.x, self.y = e(B, d), e(B, d)
-        self.qkv, self.att, self.tmp, self.o1, self.hid = e(B, 3 * d), e(B, d), e(B, d), e(B, d), e(B, di)
-        self.logits = e(B, V, dtype=torch.float32)
+        self.x = e(B, d)                                      # embedding of the new token (hi)
+        self.xlo = e(B, d) if dt != f32 else None              # ... and its low-order half (bf16 tier)
+        self.q, self.hid = e(B, d), e(B, di)
+        self.xres, self.o1res = e(B, d, dtype=f32), e(B, d, dtype=f32)     # f32 residual inputs (LayerNorm outputs)
+        self.s1, self.s2 = e(B, d, dtype=f32), e(B, d, dtype=f32)           # f32 pre-norm sums
+        # key splits of the attention: B*H*nsplit blocks should cover the chip (256 CUs)
+        self.nsplit = int(os.environ.get("MIDIEMO_DEC_NSPLIT", "0")) or max(1, min(16, 256 // max(1, min(B, ROWS) * H)))
+        self.part = e(B * H, self.nsplit, dh + 2, dtype=f32)
+        self.logits = e(B, V, dtype=f32)
         self.t = 0                      # next model position to be written
         self._pos_dev = None            # device-side position: set while a step is issued for graph capture / replay
         self._graph = None
@@ -49,33 +63,41 @@ class DecodeSession:
     def reset(self):
         self.t = 0
 
-    # -------------------------------------------------------------- projections
-    def _proj(self, x, W, bias, y, N, K, flags=0):
-        if self.B <= 8:
-            ops.gemv_small(x, W, bias, y, self.B, N, K, flags=flags, dtype=self.m.compute_dtype)
-        else:
-            ops.gemm_nt(x, W, y, bias=bias, M=self.B, N=N, K=K, flags=flags, dtype=self.m.compute_dtype)
-
-    def _layers_and_head(self):
+    def _layers_and_head(self, x_hi=None, x_lo=None):
+        """One position through all layers and the head; the first layer's input is x_hi (+ x_lo) [B, d] in T."""
         m, B, t = self.m, self.B, self.t
         d, di, H, dh, V, M = m.embedding_dim, m.d_inner, m.num_head, m.dh, m.vocab_size, m.max_seq
-        f = m.flat_params
-        x, y = self.x, self.y
-        for i in range(m.num_layer):
-            W = m._prep["layers"][i]
-            p = f"enc_layers.{i}."
-            self._proj(x, W["Wqkv"], W["bqkv"], self.qkv, 3 * d, d)
-            ops.rga_decode_step(self.qkv, self.kc[i], self.vc[i], W["E"], None, 0, self.att, B, H, dh, M, M, t,
-                                t_dev=self._pos_dev)
-            self._proj(self.att, W["Wo"], m._pview(f, p + "rga.fc.bias"), self.tmp, d, d)
-            ops.resid_ln_fwd(x, self.tmp, m._pview(f, p + "layernorm1.weight"), m._pview(f, p + "layernorm1.bias"),
-                             self.o1, None, None, B, d, m.LN_EPS, 0.0, 0, 0)
-            self._proj(self.o1, W["W1"], m._pview(f, p + "FFN_pre.bias"), self.hid, di, d, flags=ops.ME_EPI_RELU)
-            self._proj(self.hid, W["W2"], m._pview(f, p + "FFN_suf.bias"), self.tmp, d, di)
-            ops.resid_ln_fwd(self.o1, self.tmp, m._pview(f, p + "layernorm2.weight"), m._pview(f, p + "layernorm2.bias"),
-                             y, None, None, B, d, m.LN_EPS, 0.0, 0, 0)
-            x, y = y, x
-        self._proj(x, m._prep["head"]["Wf"], m._pview(f, "fc.bias"), self.logits, V, d, flags=ops.ME_EPI_OUT_F32)
+        f, dt, eps, ns = m.flat_params, m.compute_dtype, m.LN_EPS, self.nsplit
+        x_hi = self.x if x_hi is None else x_hi
+        x_lo = self.xlo if x_lo is None and x_hi is self.x else x_lo
+        pv = lambda name: m._pview(f, name)
+        for r0 in range(0, B, ROWS):                          # row chunks (Mr <= 8 per kernel call)
+            r1 = min(B, r0 + ROWS)
+            Mr = r1 - r0
+            part = self.part[r0 * H:r1 * H]
+            for i in range(m.num_layer):
+                W = m._prep["layers"][i]
+                p = f"enc_layers.{i}."
+                if i == 0:
+                    ops.dec_qkv(None, None, None, eps, x_hi[r0:r1], x_lo[r0:r1] if x_lo is not None else None, W["Wqkv"],
+                                W["bqkv"], self.xres[r0:r1], self.q[r0:r1], self.kc[i][r0:r1], self.vc[i][r0:r1], Mr, d, H, dh,
+                                M, t, self._pos_dev, dt)
+                else:
+                    pp = f"enc_layers.{i - 1}."
+                    ops.dec_qkv(self.s2[r0:r1], pv(pp + "layernorm2.weight"), pv(pp + "layernorm2.bias"), eps, None, None,
+                                W["Wqkv"], W["bqkv"], self.xres[r0:r1], self.q[r0:r1], self.kc[i][r0:r1], self.vc[i][r0:r1],
+                                Mr, d, H, dh, M, t, self._pos_dev, dt)
+                ops.dec_attn(self.q[r0:r1], self.kc[i][r0:r1], self.vc[i][r0:r1], W["E"], None, 0, part, ns, Mr, H, dh, M, M,
+                             t, self._pos_dev, dt)
+                ops.dec_proj_resid(part, ns, H, dh, None, W["Wo"], pv(p + "rga.fc.bias"), self.xres[r0:r1], self.s1[r0:r1],
+                                   Mr, d, d, dt)
+                ops.dec_ln_proj(self.s1[r0:r1], pv(p + "layernorm1.weight"), pv(p + "layernorm1.bias"), eps, W["W1"],
+                                pv(p + "FFN_pre.bias"), self.o1res[r0:r1], self.hid[r0:r1], Mr, di, d, ops.ME_EPI_RELU, dt)
+                ops.dec_proj_resid(None, 0, 0, 0, self.hid[r0:r1], W["W2"], pv(p + "FFN_suf.bias"), self.o1res[r0:r1],
+                                   self.s2[r0:r1], Mr, d, di, dt)
+            pl = f"enc_layers.{m.num_layer - 1}."
+            ops.dec_ln_proj(self.s2[r0:r1], pv(pl + "layernorm2.weight"), pv(pl + "layernorm2.bias"), eps,
+                            m._prep["head"]["Wf"], pv(m._HEAD_B), None, self.logits[r0:r1], Mr, V, d, ops.ME_EPI_OUT_F32, dt)
         if self._pos_dev is None:
             self.t += 1
         return self.logits
@@ -94,11 +116,14 @@ class DecodeSession:
         cw0, cb0, cw1, cb1 = m._cond_params(f)
         d = m.embedding_dim
         both = torch.empty(self.B, 2, d, dtype=m.compute_dtype, device=f.device)
+        both_lo = torch.empty_like(both) if self.xlo is not None else None
         dummy = torch.zeros(self.B, 1, dtype=torch.int64, device=f.device)
         ops.embed_fwd(both, dummy, cond, m._pview(f, "embedding.weight"), cw0, cb0, cw1, cb1, m._pe,
-                      ops.ME_COND_TOKEN, self.B, 0, d, 0, 0.0, 0)
+                      ops.ME_COND_TOKEN, self.B, 0, d, 0, 0.0, 0, out_lo=both_lo)
         for s in range(2):
             self.x.copy_(both[:, s])
+            if both_lo is not None:
+                self.xlo.copy_(both_lo[:, s])
             self._layers_and_head()
 
     def step(self, tokens, cond=None):
@@ -120,19 +145,19 @@ class DecodeSession:
             cond = cond.to(device=f.device, dtype=torch.float32).contiguous()
             cw0, cb0, _, _ = m._cond_params(f)
             ops.embed_fwd(self.x, tokens, cond, m._pview(f, "embedding.weight"), cw0, cb0, None, None, pe_t,
-                          ops.ME_COND_CONCAT, self.B, 1, d, m.d_condition, 0.0, 0, pos_dev=pos_dev)
+                          ops.ME_COND_CONCAT, self.B, 1, d, m.d_condition, 0.0, 0, pos_dev=pos_dev, out_lo=self.xlo)
         else:
             ops.embed_fwd(self.x, tokens, None, m._pview(f, "embedding.weight"), None, None, None, None, pe_t,
-                          ops.ME_COND_NONE, self.B, 1, d, 0, 0.0, 0, pos_dev=pos_dev)
+                          ops.ME_COND_NONE, self.B, 1, d, 0, 0.0, 0, pos_dev=pos_dev, out_lo=self.xlo)
         return self._layers_and_head()
 
     # -------------------------------------------------------------- device-resident greedy loop
     def greedy_run(self, tokens, n_steps, cond=None, special=None, use_graph=True):
         """Feed `tokens` (int64 [B]) at the next position, then keep feeding the arg-max token back for n_steps
         steps in total, entirely on the device (generate.py:99-189 with top_k = 1): the position lives in device
-        memory (me_embed_fwd pos_dev, me_rga_decode_step t_dev), me_greedy_pick writes the next input token and
+        memory (me_embed_fwd pos_dev, the t_dev argument of me_dec_qkv / me_dec_attn), me_greedy_pick writes the next input token and
         me_decode_commit appends it to a history buffer and advances the position.  The step is captured once as a
-        HIP graph and replayed, so a token costs one graph launch instead of ~45 kernel launches from Python.
+        HIP graph and replayed, so a token costs one graph launch instead of ~35 kernel launches from Python.
         Returns the generated ids int64 [B, n_steps] (on the device)."""
         m = self.m
         dev = m.flat_params.device

@@ -175,15 +175,26 @@ def adamw_step(p, g, m, v, sumsq_t, clip, grad_scale, lr, beta1, beta2, eps, wei
           "me_adamw_step")
 
 
-def rga_decode_step(qkv_new, kcache, vcache, E, key_pad, ld_pad, out, B, H, dh, M, Mc, t, t_dev=None):
-    check(lib().me_rga_decode_step(_ptr(qkv_new), _ptr(kcache), _ptr(vcache), _ptr(E), _ptr(key_pad), ld_pad,
-                                   _ptr(out), B, H, dh, M, Mc, t, _ptr(t_dev), _code(qkv_new.dtype), _stream()), "me_rga_decode_step")
+def dec_qkv(s_in, gamma, beta, eps, x_hi, x_lo, Wqkv, bqkv, x_out, q_out, kcache, vcache, Mr, d, H, dh, Mc, t, t_dev, dtype):
+    check(lib().me_dec_qkv(_ptr(s_in), _ptr(gamma), _ptr(beta), float(eps), _ptr(x_hi), _ptr(x_lo), _ptr(Wqkv), _ptr(bqkv),
+                           _ptr(x_out), _ptr(q_out), _ptr(kcache), _ptr(vcache), Mr, d, H, dh, Mc, int(t), _ptr(t_dev),
+                           _code(dtype), _stream()), "me_dec_qkv")
 
 
-def gemv_small(x, W, bias, y, Mr, N, K, flags=0, dtype=None):
-    dtype = dtype or x.dtype
-    check(lib().me_gemv_small(_ptr(x), x.stride(0), _ptr(W), W.stride(0), _ptr(bias), _ptr(y), y.stride(0), Mr, N, K,
-                              flags, _code(dtype), _stream()), "me_gemv_small")
+def dec_attn(q, kcache, vcache, E, key_pad, ld_pad, part, nsplit, Mr, H, dh, M, Mc, t, t_dev, dtype):
+    check(lib().me_dec_attn(_ptr(q), _ptr(kcache), _ptr(vcache), _ptr(E), _ptr(key_pad), ld_pad, _ptr(part), nsplit, Mr, H,
+                            dh, M, Mc, int(t), _ptr(t_dev), _code(dtype), _stream()), "me_dec_attn")
+
+
+def dec_proj_resid(part, nsplit, H, dh, x_T, W, bias, resid, out, Mr, N, K, dtype):
+    check(lib().me_dec_proj_resid(_ptr(part), nsplit, H, dh, _ptr(x_T), x_T.stride(0) if x_T is not None else 0, _ptr(W),
+                                  W.stride(0), _ptr(bias), _ptr(resid), _ptr(out), Mr, N, K, _code(dtype), _stream()),
+          "me_dec_proj_resid")
+
+
+def dec_ln_proj(s_in, gamma, beta, eps, W, bias, x_out, y, Mr, N, K, flags, dtype):
+    check(lib().me_dec_ln_proj(_ptr(s_in), _ptr(gamma), _ptr(beta), float(eps), _ptr(W), W.stride(0), _ptr(bias), _ptr(x_out),
+                               _ptr(y), y.stride(0), Mr, N, K, int(flags), _code(dtype), _stream()), "me_dec_ln_proj")
 
 
 def sample_topk_topp(logits, V, special, temp, top_k, top_p, u, out_ids, n_choices=None, dbg_p=None, dbg_i=None):

@@ -173,3 +173,77 @@ def test_fused_sampling_tail_matches_torch_path(top_k, top_p):
             cand.add(int(di[b, pos - 1]))
         assert int(out[b]) in cand and dp[b, (di[b] == int(out[b])).nonzero()[0, 0]] > 0
     assert int(out[2]) == 100                             # the peaked row always picks its peak
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# BASELINE config 5 at its real size: headline model (6L d512 8H), 4 (valence, arousal) pairs, 2048 positions = max_seq
+# ----------------------------------------------------------------------------------------------------------------------
+def _cfg5_model(cd):
+    from midiemo.models.build_model import build_model
+    torch.manual_seed(0)
+    model, _ = build_model(dict(vocab_size=1007, n_layer=6, n_head=8, d_model=512, d_inner=2048, d_condition=128,
+                                conditioning="continuous_concat", dropout=0.1, compute_dtype=cd))
+    return model.cuda().eval()
+
+
+COND5 = [[-0.8, -0.8], [-0.8, 0.8], [0.8, -0.8], [0.8, 0.8]]           # train.py:361-366
+
+
+def test_config5_cache_equals_full_recompute_at_length():
+    """Cache vs full recompute on the 6L d512 model at t in {0, 511, 1023, 2046, 2047} (the last two: the final key split
+    is ragged and t = max_seq - 1 is the clamp boundary of the device-side position).  f32 tier: the cached logits equal
+    the full forward's last row to rounding.  bf16 tier: both are compared with the f32 full forward -- the cached path
+    may not be further from it than 1.5x the bf16 full forward is (its own error, measured in the same test)."""
+    from midiemo.decode import DecodeSession
+    g = torch.Generator().manual_seed(11)
+    toks = torch.randint(2, 1007, (4, 2048), generator=g).cuda()
+    cond = torch.tensor(COND5, device="cuda")
+    probes = [0, 511, 1023, 2046, 2047]
+    got, full = {}, {}
+    for cd in ("fp32", "bf16"):
+        model = _cfg5_model(cd)
+        with torch.no_grad():
+            sess = DecodeSession(model, 4)
+            for t in range(2048):
+                lg = sess.step(toks[:, t], cond)
+                if t in probes:
+                    got[cd, t] = lg.clone()
+            for t in probes:
+                full[cd, t] = model(toks[:, :t + 1], cond)[:, -1].clone()
+        del sess, model
+        torch.cuda.empty_cache()
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    for t in probes:
+        e32 = rel(got["fp32", t], full["fp32", t])
+        e_dec, e_full = rel(got["bf16", t], full["fp32", t]), rel(full["bf16", t], full["fp32", t])
+        print("config 5 t=%d: f32 cache vs full %.2e; bf16 cache vs f32 %.2e (bf16 full forward vs f32 %.2e)" % (t, e32, e_dec, e_full))
+        assert e32 < 1e-4, (t, e32)
+        assert e_dec <= 1.5 * e_full + 5e-4, (t, e_dec, e_full)
+
+
+@pytest.mark.parametrize("cd", ["fp32", "bf16"])
+def test_config5_full_length_greedy_graph_equals_eager(cd):
+    """2048-token device-resident greedy loop (HIP-graph replay, position in device memory) == eager step() +
+    greedy_pick ids on the headline model: same kernels, same arithmetic -> bit-identical ids, all 2048 positions."""
+    from midiemo import ops
+    from midiemo.decode import DecodeSession
+    from midiemo.vocab import get_maps, special_token_ids
+    model = _cfg5_model(cd)
+    cond = torch.tensor(COND5, device="cuda")
+    special = torch.tensor(special_token_ids(get_maps()), dtype=torch.int32, device="cuda")
+    tok0 = torch.full((4,), 1, dtype=torch.long, device="cuda")           # <START>
+    with torch.no_grad():
+        ref = DecodeSession(model, 4)
+        tok, picked, want = tok0.clone(), torch.empty(4, dtype=torch.long, device="cuda"), []
+        for _ in range(2048):
+            lg = ref.step(tok, cond)
+            ops.greedy_pick(lg, 1007, special, picked, 4)
+            tok = picked.clone()
+            want.append(tok)
+        want = torch.stack(want, 1)
+        sess = DecodeSession(model, 4)
+        got = sess.greedy_run(tok0, 2048, cond, special, use_graph=True)
+    assert sess.t == 2048 and got.shape == (4, 2048)
+    assert torch.equal(got, want), int((got != want).sum())
+    with pytest.raises(RuntimeError):
+        sess.greedy_run(got[:, -1], 1, cond, special)                      # position 2048 does not exist

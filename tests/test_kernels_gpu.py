@@ -194,17 +194,85 @@ def test_cast_transpose(ops, dtype):
     assert (dst[:, 1007:] == 0).all() and (dstT[:, 70:] == 0).all()
 
 
+def _ln_ref(s, gamma, beta, dtype):
+    x = torch.nn.functional.layer_norm(s.double(), (s.shape[1],), gamma.double(), beta.double(), 1e-6)
+    return x, x.float().to(dtype).double()                      # f32-class LN output, and the T-rounded GEMV operand
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("Mr", [1, 4, 7])
-def test_gemv_small(ops, dtype, Mr):
+def test_dec_ln_proj(ops, dtype, Mr):
+    """me_dec_ln_proj: LayerNorm prologue + projection (+ ReLU, T output) / (f32 logits), x_out = the f32 LN rows."""
     N, K = 1007, 512
-    x = rnd(Mr, K, seed=14).to(dtype)
+    s_in = rnd(Mr, K, seed=14).float() * 2
+    gamma, beta = rnd(K, seed=17).float() + 1.5, rnd(K, seed=18).float()
     W = rnd(N, K, seed=15).to(dtype)
     bias = rnd(N, seed=16).float()
-    ref = x.double() @ W.double().t() + bias.double()
-    y = torch.empty(Mr, N, dtype=torch.float32, device=DEV)
-    ops.gemv_small(x.to(DEV), W.to(DEV), bias.to(DEV), y, Mr, N, K, flags=ops.ME_EPI_OUT_F32)
-    assert relerr(y, ref) < 1e-5
+    x, xr = _ln_ref(s_in, gamma, beta, dtype)
+    ref = xr @ W.double().t() + bias.double()
+    y = torch.full((Mr, N), 9.0, dtype=torch.float32, device=DEV)
+    xo = torch.zeros(Mr, K, dtype=torch.float32, device=DEV)
+    ops.dec_ln_proj(s_in.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-6, W.to(DEV), bias.to(DEV), xo, y, Mr, N, K,
+                    ops.ME_EPI_OUT_F32, dtype)
+    assert relerr(y, ref) < tol(dtype, 1e-5, 2e-3), relerr(y, ref)     # bf16: an LN output on a rounding boundary may round the other way
+    assert relerr(xo, x) < 1e-5
+    yt = torch.zeros(Mr, N + 8, dtype=dtype, device=DEV)
+    ops.dec_ln_proj(s_in.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-6, W.to(DEV), bias.to(DEV), None, yt, Mr, N, K,
+                    ops.ME_EPI_RELU, dtype)
+    assert relerr(yt[:, :N], torch.relu(ref)) < tol(dtype, 1e-5, 6e-3)
+    assert (yt[:, N:] == 0).all()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Mr,N,K", [(4, 512, 2048), (3, 96, 768), (8, 768, 3072)])
+def test_dec_proj_resid_plain(ops, dtype, Mr, N, K):
+    """me_dec_proj_resid without attention partials: out = resid + bias + x_T . W^T (FFN_suf + residual)."""
+    x = rnd(Mr, K, seed=24).to(dtype)
+    W = rnd(N, K, seed=25).to(dtype)
+    bias, resid = rnd(N, seed=26).float(), rnd(Mr, N, seed=27).float()
+    ref = resid.double() + bias.double() + x.double() @ W.double().t()
+    out = torch.zeros(Mr, N, dtype=torch.float32, device=DEV)
+    ops.dec_proj_resid(None, 0, 0, 0, x.to(DEV), W.to(DEV), bias.to(DEV), resid.to(DEV), out, Mr, N, K, dtype)
+    assert relerr(out, ref) < 2e-5, relerr(out, ref)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_dec_qkv_ln_prologue_and_cache_append(ops, dtype):
+    """me_dec_qkv: (LayerNorm | hi + lo) -> q|k|v projection; q to its buffer, k / v appended at position t of the
+    [Mr, H, Mc, dh] caches (host t and device t_dev), nothing else in the caches touched."""
+    Mr, H, dh, Mc = 3, 4, 32, 40
+    d = H * dh
+    s_in = rnd(Mr, d, seed=31).float() * 2
+    gamma, beta = rnd(d, seed=32).float() + 1.5, rnd(d, seed=33).float()
+    W = rnd(3 * d, d, seed=34).to(dtype)
+    bias = rnd(3 * d, seed=35).float()
+    x, xr = _ln_ref(s_in, gamma, beta, dtype)
+    ref = (xr @ W.double().t() + bias.double()).float().to(dtype)
+    for t, use_dev in ((5, False), (17, True)):
+        kc = torch.full((Mr, H, Mc, dh), 7.0, dtype=dtype, device=DEV)
+        vc = torch.full((Mr, H, Mc, dh), -7.0, dtype=dtype, device=DEV)
+        q = torch.zeros(Mr, d, dtype=dtype, device=DEV)
+        xo = torch.zeros(Mr, d, dtype=torch.float32, device=DEV)
+        t_dev = torch.tensor([t], dtype=torch.int32, device=DEV) if use_dev else None
+        ops.dec_qkv(s_in.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-6, None, None, W.to(DEV), bias.to(DEV), xo, q, kc, vc, Mr, d, H,
+                    dh, Mc, 0 if use_dev else t, t_dev, dtype)
+        assert relerr(q, ref[:, :d]) < tol(dtype, 1e-5, 6e-3)
+        assert relerr(kc[:, :, t].reshape(Mr, d), ref[:, d:2 * d]) < tol(dtype, 1e-5, 6e-3)
+        assert relerr(vc[:, :, t].reshape(Mr, d), ref[:, 2 * d:]) < tol(dtype, 1e-5, 6e-3)
+        keep = torch.ones(Mc, dtype=torch.bool)
+        keep[t] = False
+        assert (kc[:, :, keep] == 7.0).all() and (vc[:, :, keep] == -7.0).all()
+        assert relerr(xo, x) < 1e-5
+    # first layer: x = hi + lo
+    xf = rnd(Mr, d, seed=36).float()
+    hi = xf.to(dtype)
+    lo = (xf - hi.float()).to(dtype)
+    ref2 = ((hi.double() + lo.double()).float().to(dtype).double() @ W.double().t() + bias.double())
+    ops.dec_qkv(None, None, None, 1e-6, hi.to(DEV), lo.to(DEV) if dtype != torch.float32 else None, W.to(DEV), bias.to(DEV), xo, q,
+                kc, vc, Mr, d, H, dh, Mc, 3, None, dtype)
+    assert relerr(q, ref2[:, :d]) < tol(dtype, 1e-5, 6e-3)
+    assert relerr(xo, hi.double() + (lo.double() if dtype != torch.float32 else 0)) < 1e-6
+
 
 
 # ------------------------------------------------------------------ residual + LayerNorm
@@ -476,21 +544,59 @@ def test_rga_prefix_invariance(ops):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("dh", [64, 48])
-def test_rga_decode_step_matches_full(ops, dtype, dh):
+@pytest.mark.parametrize("dh,nsplit", [(64, 1), (64, 8), (48, 3), (32, 5)])
+def test_dec_attn_matches_full(ops, dtype, dh, nsplit):
+    """me_dec_attn (key-split partials) + the combine prologue of me_dec_proj_resid == row t of the full attention,
+    for every t (short ranges, empty splits, ragged last split).  The combine is read back through an identity
+    projection (W = I, no bias, zero residual)."""
     B, H, L, M = 3, 2, 45, 2048
     q, k, v, E, dO, pad = attn_case(B, H, L, dh, M, seed=77, pad_rows=False)
     ref = ref_attn(q, k, v, E, dO, None, dtype)["O"]            # [B,H,L,dh]
     Ed = E.to(dtype).to(DEV).contiguous()
     Mc = 64
+    d = H * dh
     kc = torch.zeros(B, H, Mc, dh, dtype=dtype, device=DEV)
     vc = torch.zeros_like(kc)
-    out = torch.empty(B, H, dh, dtype=dtype, device=DEV)
+    part = torch.zeros(B * H, nsplit, dh + 2, dtype=torch.float32, device=DEV)
+    eye = torch.eye(d, dtype=dtype, device=DEV)
+    zero = torch.zeros(B, d, dtype=torch.float32, device=DEV)
+    out = torch.empty(B, d, dtype=torch.float32, device=DEV)
+    t_dev = torch.zeros(1, dtype=torch.int32, device=DEV)
     for t in range(L):
-        qkv_new = torch.stack([q[:, :, t], k[:, :, t], v[:, :, t]], dim=1).contiguous().to(dtype).to(DEV)  # [B,3,H,dh]
-        ops.rga_decode_step(qkv_new, kc, vc, Ed, None, 0, out, B, H, dh, M, Mc, t)
-        e = relerr(out, ref[:, :, t])
+        kc[:, :, t] = k[:, :, t].to(dtype).to(DEV)
+        vc[:, :, t] = v[:, :, t].to(dtype).to(DEV)
+        qt = q[:, :, t].reshape(B, d).contiguous().to(dtype).to(DEV)
+        if t % 2:
+            ops.dec_attn(qt, kc, vc, Ed, None, 0, part, nsplit, B, H, dh, M, Mc, t, None, dtype)
+        else:                                                   # position from device memory (graph replay path)
+            t_dev.fill_(t)
+            ops.dec_attn(qt, kc, vc, Ed, None, 0, part, nsplit, B, H, dh, M, Mc, 0, t_dev, dtype)
+        ops.dec_proj_resid(part, nsplit, H, dh, None, eye, None, zero, out, B, d, d, dtype)
+        e = relerr(out.view(B, H, dh), ref[:, :, t])
         assert e < tol(dtype, 2e-5, 1.5e-2), (t, e)
+
+
+def test_dec_attn_pad_keys_and_fully_masked_row(ops):
+    """Padded keys are excluded; a query whose every key is padded yields NaN like the reference's softmax."""
+    B, H, dh, M, Mc, t, ns = 2, 2, 64, 2048, 32, 11, 4
+    q, k, v, E, dO, _ = attn_case(B, H, t + 1, dh, M, seed=5, pad_rows=False)
+    pad = torch.zeros(B, t + 1, dtype=torch.uint8)
+    pad[0, 3:6] = 1
+    pad[1, :] = 1
+    ref = ref_attn(q, k, v, E, dO, pad.bool(), torch.float32)["O"]
+    kc = torch.zeros(B, H, Mc, dh, device=DEV)
+    vc = torch.zeros_like(kc)
+    kc[:, :, :t + 1] = k.to(DEV)
+    vc[:, :, :t + 1] = v.to(DEV)
+    d = H * dh
+    part = torch.zeros(B * H, ns, dh + 2, device=DEV)
+    out = torch.empty(B, d, device=DEV)
+    ops.dec_attn(q[:, :, t].reshape(B, d).contiguous().to(DEV), kc, vc, E.to(DEV), pad.to(DEV), t + 1, part, ns, B, H, dh, M, Mc, t,
+                 None, torch.float32)
+    ops.dec_proj_resid(part, ns, H, dh, None, torch.eye(d, device=DEV), None, torch.zeros(B, d, device=DEV), out, B, d, d,
+                       torch.float32)
+    assert relerr(out[0].view(H, dh), ref[0, :, t]) < 2e-5
+    assert torch.isnan(out[1]).all()
 
 
 @pytest.mark.gpu
