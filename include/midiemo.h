@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 10
+#define ME_ABI_VERSION 11
 
 enum { ME_F32 = 0, ME_BF16 = 1 };
 
@@ -237,10 +237,20 @@ int me_dec_qkv(const float* s_in, const float* gamma, const float* beta, float e
                const void* Wqkv, const float* bqkv, float* x_out, void* q_out, void* kcache, void* vcache,
                int Mr, int d, int H, int dh, int Mc, int t, const int32_t* t_dev, int dtype, void* stream);
 
+/* me_dec_embed_qkv: me_dec_qkv for the first layer with the embedding prologue of me_embed_fwd folded in (one
+ *   position, modes NONE / CONCAT; for ME_COND_TOKEN the two condition slots go through me_dec_qkv(x_hi, x_lo)):
+ *   x = emb[token] * sqrt(d - d_cond) | (cw . cond + cb) + pe[t]   (music_multi.py:89-101), f32, no dropout.
+ *   tokens int64 [Mr]; cond f32 [Mr][2]; emb f32 [V][d - d_cond]; cw f32 [d_cond][2], cb f32 [d_cond] (d_cond <= 0:
+ *   unused); pe f32 [>= t + 1][d]. */
+int me_dec_embed_qkv(const int64_t* tokens, const float* cond, const float* emb, const float* cw, const float* cb,
+                     const float* pe, int d_cond, const void* Wqkv, const float* bqkv, float* x_out, void* q_out,
+                     void* kcache, void* vcache, int Mr, int d, int H, int dh, int Mc, int t, const int32_t* t_dev,
+                     int dtype, void* stream);
+
 /* me_dec_attn: for every (sequence, head) and each of nsplit key ranges of [0, t]:
  *   s_j = q.(K[j] + E[M-1-(t-j)]) / sqrt(dh)  (pad keys masked; music_multi.py:211-231 for a single query row),
  *   part[seq*H + head][split] = (max_j s_j, sum_j exp(s_j - max), sum_j exp(s_j - max) V[j])  -- f32 [dh + 2].
- * E: T [M][dh] natural layout.  grid = Mr*H x nsplit blocks; one key per 8-lane group, 16-byte coalesced K / V / E
+ * E: T [M][dh] natural layout.  nsplit <= 8.  grid = Mr*H x nsplit blocks; one key per 8-lane group, 16-byte coalesced K / V / E
  * reads.  The splits are combined by the prologue of me_dec_proj_resid. */
 int me_dec_attn(const void* q, const void* kcache, const void* vcache, const void* E, const uint8_t* key_pad, int ld_pad,
                 float* part, int nsplit, int Mr, int H, int dh, int M, int Mc, int t, const int32_t* t_dev, int dtype,
@@ -280,6 +290,11 @@ int me_sample_topk_topp(const float* logits, int ld, int V, const int32_t* speci
  * With me_embed_fwd(pos_dev) and the t_dev arguments of me_dec_* a greedy decode step has no host-side state
  * (the token loop of generate.py:99-189 for top_k = 1) and can be captured once and replayed. */
 int me_decode_commit(const int64_t* tok, int64_t* history, int ld_hist, int32_t* pos, int B, void* stream);
+
+/* me_greedy_pick followed by me_decode_commit of the picked ids in one launch (one block, a wave per sequence):
+ * out_ids[b] = pick ; history[b][*pos] = pick ; *pos += 1. */
+int me_greedy_pick_commit(const float* logits, int ld, int V, const int32_t* special, int n_special, int64_t* out_ids,
+                          int64_t* history, int ld_hist, int32_t* pos, int B, void* stream);
 
 #ifdef __cplusplus
 }

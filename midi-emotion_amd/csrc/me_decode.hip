@@ -25,7 +25,7 @@
 
 namespace {
 
-enum { PRO_LN = 0, PRO_HILO = 1, PRO_ATTN = 2, PRO_PLAIN = 3 };
+enum { PRO_LN = 0, PRO_HILO = 1, PRO_ATTN = 2, PRO_PLAIN = 3, PRO_EMBED = 4 };
 enum { EPI_QKV = 0, EPI_RESID = 1, EPI_T = 2, EPI_F32 = 3 };
 
 struct DecArgs {
@@ -39,6 +39,13 @@ struct DecArgs {
     int ldx;
     const float* part;      // PRO_ATTN: f32 [Mr*H][nsplit][dh + 2] = (max, sum, o[dh])
     int nsplit, H, dh;
+    const int64_t* tokens;  // PRO_EMBED: one token per row; cond f32 [Mr][2]; emb f32 [V][K - dc]; cw f32 [dc][2]; cb f32 [dc]; pe f32 [>= t + 1][K]
+    const float* cond;
+    const float* emb;
+    const float* cw;
+    const float* cb;
+    const float* pe;
+    int dc;
     float* x_out;           // f32 [Mr][K] (may be NULL): the prologue's unrounded result (residual of a later kernel)
     // projection
     const void* W;          // T [N][ldw]
@@ -57,6 +64,11 @@ struct DecArgs {
 };
 
 template <typename T> ME_DEV float round_to(float x) { return ET<T>::to_f(ET<T>::from_f(x)); }
+template <typename T> ME_DEV void chunk_to_f32(const chunk16& c, float* f) {
+    const T* e = reinterpret_cast<const T*>(&c);
+#pragma unroll
+    for (int i = 0; i < ET<T>::CH; ++i) f[i] = ET<T>::to_f(e[i]);
+}
 
 // sum over the G lanes (G = 4, 8, 16) of an aligned lane group; every lane receives the total
 template <int G> ME_DEV float group_sum(float v) {
@@ -70,144 +82,322 @@ template <int G> ME_DEV float group_sum(float v) {
 // ---------------------------------------------------------------------------------------------------------
 // y = epilogue( T(prologue(...)) . W^T + bias ).  Block = 4 waves, wave = CW output columns, lanes walk the contraction
 // dimension in 16-byte chunks (K = 512 bf16: one chunk per lane and column), MR rows share every weight chunk.
+// Latency is the whole cost of such a kernel, so the weight chunks (they depend on nothing) are requested FIRST, the
+// prologue runs under their flight, and every prologue issues all of its own loads before it consumes any
+// (measured with per-element load -> use loops: 34 us for the FFN_suf projection, 16 us for the combine prologue).
 // ---------------------------------------------------------------------------------------------------------
-template <typename T, int PRO, int EPI, int MR, int CW>
+constexpr int DEC_NSMAX = 8;        // key splits the combine prologue unrolls over
+
+// Sum NV per-lane values over the 64 lanes.  v_permlane32_swap / v_permlane16_swap exchange one half of a register
+// pair, so each swap + add halves the number of live values (NV -> NV/2 -> NV/4) while summing lane pairs (l, l + 32)
+// and (l, l + 16); the remaining NV/4 values are summed inside the 16-lane rows with four DPP adds each.  Result: every
+// lane of row r = lane >> 4 holds, in v[i] (i < NV/4), the total of input value i + (NV/4) * r.  2.5 NV instructions
+// instead of ~12 NV for NV independent wave reductions.  Inline asm: through __builtin_amdgcn_permlane{32,16}_swap hipcc
+// (ROCm 7.2) folds the two results of a swap into one register (it emitted v_add v2, v3, v3 after v_permlane32_swap v3, v2).
+template <int NV> ME_DEV void reduce_scatter64(float* v) {
+    static_assert(NV % 4 == 0, "NV must be a multiple of 4");
+#pragma unroll
+    for (int i = 0; i < NV / 2; ++i) {
+        float x = v[i], y = v[i + NV / 2];
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+        v[i] = x + y;
+    }
+#pragma unroll
+    for (int i = 0; i < NV / 4; ++i) {
+        float x = v[i], y = v[i + NV / 4];
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+        v[i] = x + y;
+    }
+#pragma unroll
+    for (int i = 0; i < NV / 4; ++i) {
+        v[i] += dpp_move<0xB1>(v[i]);
+        v[i] += dpp_move<0x4E>(v[i]);
+        v[i] += dpp_move<0x141>(v[i]);
+        v[i] += dpp_move<0x140>(v[i]);
+    }
+}
+
+template <typename T, int MR, int CW>
+ME_DEV void dec_fma_chunks(float (&acc)[CW][MR], const chunk16 (&w)[CW], bool ok, const float* xs, int K, int chc) {
+    constexpr int CH = ET<T>::CH;
+    float wf[CW][CH];
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+        const T* we = reinterpret_cast<const T*>(&w[c]);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) wf[c][i] = ok ? ET<T>::to_f(we[i]) : 0.f;
+    }
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        float xv[CH];
+#pragma unroll
+        for (int q4 = 0; q4 < CH / 4; ++q4) {
+            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(&xs[m * K + chc * CH + 4 * q4]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xv[4 * q4 + i] = v[i];
+        }
+#pragma unroll
+        for (int c = 0; c < CW; ++c)
+#pragma unroll
+            for (int i = 0; i < CH; ++i) acc[c][m] = fmaf(wf[c][i], xv[i], acc[c][m]);
+    }
+}
+
+// KS = false: every wave owns CW columns and the whole contraction (4 CW columns per block).
+// KS = true : the block owns CW columns, wave w contracts over the w-th quarter of K and the four partial results meet in
+//             LDS -- long rows (FFN_suf: K = 2048) then spread over as many blocks as the short ones: a cold weight
+//             stream is fetched fastest when every CU pulls a few KB (measured: 64 blocks x 32 KB 9.7 us, L2-hot 4.4 us).
+template <typename T, int PRO, int EPI, int MR, int CW, bool KS>
 __global__ __launch_bounds__(256) void dec_gemv_kernel(const DecArgs a) {
     constexpr int CH = ET<T>::CH;
+    constexpr int PF = KS ? 2 : 4;                                      // chunk positions per lane requested before the prologue
     extern __shared__ __attribute__((aligned(16))) float xs[];          // [MR][K]: the projection's input rows (T-rounded values)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int K = a.K, Mr = a.Mr;
+    const int nch_all = K / CH;
+    const int kq = KS ? (nch_all + 3) / 4 : 0;                          // chunks per wave quarter
+    const int ch_lo = KS ? wid * kq : 0;
+    const int nch = KS ? max(0, min(kq, nch_all - ch_lo)) : nch_all;    // chunk positions of this wave: [ch_lo, ch_lo + nch)
+    const T* W = reinterpret_cast<const T*>(a.W) + (size_t)ch_lo * CH;
+    const float* xw = xs + ch_lo * CH;                                  // this wave's slice of every input row
+    const int n0 = KS ? blockIdx.x * CW : (blockIdx.x * 4 + wid) * CW;
+
+    // ---- weight chunks of this wave's columns: in flight during the whole prologue
+    chunk16 wp[PF][CW];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int ch = lane + 64 * u, chc = ch < nch ? ch : 0;
+        if (64 * u < nch) {                                             // wave-uniform: no loads for positions past the row
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                const int n = min(n0 + c, a.N - 1);                     // clamped: results of columns >= N are never stored
+                wp[u][c] = ld_chunk(W + (size_t)n * a.ldw + (size_t)chc * CH);
+            }
+        }
+    }
 
     // ---- prologue: input rows into LDS
     if constexpr (PRO == PRO_LN) {
+        // one wave per row, the row stays in registers (K <= 1024): mean, centred variance, normalise
+        constexpr int NV = 4;
         for (int m = wid; m < MR; m += 4) {
-            if (m >= Mr) { for (int k = lane; k < K; k += 64) xs[m * K + k] = 0.f; continue; }
-            const float* s = a.s_in + (size_t)m * K;
-            float sum = 0.f;
-            for (int k = lane * 4; k < K; k += 256) {
-                const f32x4_t v = *reinterpret_cast<const f32x4_t*>(s + k);
-                *reinterpret_cast<f32x4_t*>(&xs[m * K + k]) = v;
-                sum += v[0] + v[1] + v[2] + v[3];
+            f32x4_t v[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int k = lane * 4 + 256 * i;
+                v[i] = (m < Mr && k < K) ? *reinterpret_cast<const f32x4_t*>(a.s_in + (size_t)m * K + k) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
             }
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
             const float mean = wave_sum(sum) / K;
             float vs = 0.f;
-            for (int k = lane * 4; k < K; k += 256) {
-                const f32x4_t v = *reinterpret_cast<const f32x4_t*>(&xs[m * K + k]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { const float d_ = v[i] - mean; vs += d_ * d_; }
+            for (int i = 0; i < NV; ++i) {
+                if (lane * 4 + 256 * i < K) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float d_ = v[i][e] - mean; vs += d_ * d_; }
+                }
             }
             const float rstd = rsqrtf(wave_sum(vs) / K + a.eps);
-            for (int k = lane * 4; k < K; k += 256) {
-                f32x4_t v = *reinterpret_cast<const f32x4_t*>(&xs[m * K + k]);
-                const f32x4_t g = *reinterpret_cast<const f32x4_t*>(a.gamma + k);
-                const f32x4_t be = *reinterpret_cast<const f32x4_t*>(a.beta + k);
-                f32x4_t o, r;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { o[i] = (v[i] - mean) * rstd * g[i] + be[i]; r[i] = round_to<T>(o[i]); }
-                if (a.x_out && blockIdx.x == 0) *reinterpret_cast<f32x4_t*>(a.x_out + (size_t)m * K + k) = o;
-                *reinterpret_cast<f32x4_t*>(&xs[m * K + k]) = r;
+            for (int i = 0; i < NV; ++i) {
+                const int k = lane * 4 + 256 * i;
+                if (k < K) {
+                    f32x4_t o = {0.f, 0.f, 0.f, 0.f}, r = o;
+                    if (m < Mr) {
+                        const f32x4_t g = *reinterpret_cast<const f32x4_t*>(a.gamma + k);
+                        const f32x4_t be = *reinterpret_cast<const f32x4_t*>(a.beta + k);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { o[e] = (v[i][e] - mean) * rstd * g[e] + be[e]; r[e] = round_to<T>(o[e]); }
+                        if (a.x_out && blockIdx.x == 0) *reinterpret_cast<f32x4_t*>(a.x_out + (size_t)m * K + k) = o;
+                    }
+                    *reinterpret_cast<f32x4_t*>(&xs[m * K + k]) = r;
+                }
             }
         }
     } else if constexpr (PRO == PRO_HILO || PRO == PRO_PLAIN) {
+        // 16-byte chunks, four per thread in flight
         const T* hi = reinterpret_cast<const T*>(a.x_hi);
         const T* lo = reinterpret_cast<const T*>(a.x_lo);
-        for (int idx = tid; idx < MR * K; idx += 256) {
-            const int m = idx / K, k = idx % K;
-            float v = 0.f;
-            if (m < Mr) {
-                v = ET<T>::to_f(hi[(size_t)m * a.ldx + k]);
-                if (PRO == PRO_HILO && lo) v += ET<T>::to_f(lo[(size_t)m * a.ldx + k]);
-                if (a.x_out && blockIdx.x == 0) a.x_out[(size_t)m * K + k] = v;
+        const int total = MR * nch_all;
+        for (int i0 = tid; i0 < total; i0 += 256 * 4) {
+            chunk16 h4[4], l4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + 256 * u, total - 1), m = min(i / nch_all, Mr - 1), c = i % nch_all;
+                h4[u] = ld_chunk(hi + (size_t)m * a.ldx + c * CH);
+                if (PRO == PRO_HILO && lo) l4[u] = ld_chunk(lo + (size_t)m * a.ldx + c * CH);
             }
-            xs[idx] = round_to<T>(v);
-        }
-    } else {    // PRO_ATTN: combine the key-split partials of every (row, head)
-        const int dh = a.dh, ns = a.nsplit, rec = dh + 2;
-        for (int idx = tid; idx < MR * K; idx += 256) {
-            const int m = idx / K, k = idx % K;
-            float v = 0.f;
-            if (m < Mr) {
-                const int h = k / dh, dd = k % dh;
-                const float* p = a.part + (size_t)(m * a.H + h) * ns * rec;
-                float mx = -INFINITY;
-                for (int s = 0; s < ns; ++s) mx = fmaxf(mx, p[s * rec]);
-                const float msafe = mx == -INFINITY ? 0.f : mx;
-                float l = 0.f, o = 0.f;
-                for (int s = 0; s < ns; ++s) {
-                    const float w = ET<T>::fexp(p[s * rec] - msafe);          // exp(-inf) = 0 for empty / fully masked splits
-                    l += w * p[s * rec + 1];
-                    o += w * p[s * rec + 2 + dd];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + 256 * u;
+                if (i < total) {
+                    const int m = i / nch_all, c = i % nch_all;
+                    float v[CH], r[CH];
+                    chunk_to_f32<T>(h4[u], v);
+                    if (PRO == PRO_HILO && lo) {
+                        float l[CH];
+                        chunk_to_f32<T>(l4[u], l);
+#pragma unroll
+                        for (int e = 0; e < CH; ++e) v[e] += l[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) { if (m >= Mr) v[e] = 0.f; r[e] = round_to<T>(v[e]); }
+#pragma unroll
+                    for (int q4 = 0; q4 < CH / 4; ++q4) {
+                        *reinterpret_cast<f32x4_t*>(&xs[m * K + c * CH + 4 * q4]) = (f32x4_t){r[4 * q4], r[4 * q4 + 1], r[4 * q4 + 2], r[4 * q4 + 3]};
+                        if (a.x_out && blockIdx.x == 0 && m < Mr)
+                            *reinterpret_cast<f32x4_t*>(a.x_out + (size_t)m * K + c * CH + 4 * q4) = (f32x4_t){v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]};
+                    }
                 }
-                v = o / l;                                                   // every key masked: 0 / 0 = NaN like the reference's softmax
-                if (a.x_out && blockIdx.x == 0) a.x_out[(size_t)m * K + k] = v;
             }
-            xs[idx] = round_to<T>(v);
+        }
+    } else if constexpr (PRO == PRO_EMBED) {
+        // embedding prologue of the first layer (music_multi.py:89-101 for one position): token row * sqrt(d - dc) |
+        // condition projection, + sinusoid row of position t; f32 throughout (no hi / lo round trip through memory)
+        const int dc = a.dc, de = K - dc;
+        const int t = a.t_dev ? min(*a.t_dev, a.Mc - 1) : a.t;
+        const float sq = sqrtf((float)de);
+        for (int i = tid; i < MR * (K / 4); i += 256) {
+            const int m = i / (K / 4), k = (i % (K / 4)) * 4;
+            f32x4_t v = {0.f, 0.f, 0.f, 0.f}, r = v;
+            if (m < Mr) {
+                const f32x4_t p4 = *reinterpret_cast<const f32x4_t*>(a.pe + (size_t)t * K + k);
+                if (k < de) {
+                    const f32x4_t e4 = *reinterpret_cast<const f32x4_t*>(a.emb + (size_t)a.tokens[m] * de + k);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = e4[e] * sq + p4[e];
+                } else {
+                    const float c0 = a.cond[m * 2], c1 = a.cond[m * 2 + 1];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = a.cw[(k - de + e) * 2] * c0 + a.cw[(k - de + e) * 2 + 1] * c1 + a.cb[k - de + e] + p4[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = round_to<T>(v[e]);
+                if (a.x_out && blockIdx.x == 0) *reinterpret_cast<f32x4_t*>(a.x_out + (size_t)m * K + k) = v;
+            }
+            *reinterpret_cast<f32x4_t*>(&xs[m * K + k]) = r;
+        }
+    } else {    // PRO_ATTN: softmax-combine the key-split partials of every (row, head)
+        const int dh = a.dh, ns = a.nsplit, rec = dh + 2, nmh = Mr * a.H;
+        float* wn = xs + MR * K;                                        // [nmh][DEC_NSMAX] normalised split weights
+        if (tid < nmh) {
+            const float* p = a.part + (size_t)tid * ns * rec;
+            float ms[DEC_NSMAX], ls[DEC_NSMAX];
+#pragma unroll
+            for (int s_ = 0; s_ < DEC_NSMAX; ++s_) {
+                const int sc = min(s_, ns - 1);
+                ms[s_] = p[sc * rec];
+                ls[s_] = p[sc * rec + 1];
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int s_ = 0; s_ < DEC_NSMAX; ++s_) if (s_ < ns) mx = fmaxf(mx, ms[s_]);
+            const float msafe = mx == -INFINITY ? 0.f : mx;
+            float l = 0.f, w[DEC_NSMAX];
+#pragma unroll
+            for (int s_ = 0; s_ < DEC_NSMAX; ++s_) {
+                w[s_] = s_ < ns ? ET<T>::fexp(ms[s_] - msafe) : 0.f;    // exp(-inf) = 0 for empty / fully masked splits
+                l += w[s_] * ls[s_];
+            }
+            const float inv = 1.f / l;                                  // every key masked: 0 * inf = NaN like the reference's softmax
+#pragma unroll
+            for (int s_ = 0; s_ < DEC_NSMAX; ++s_) wn[tid * DEC_NSMAX + s_] = w[s_] * inv;
+        }
+        __syncthreads();
+        // 4 consecutive head-dim elements per thread and pass, two passes in flight: 2 x DEC_NSMAX independent 16-byte loads
+        const int ng = MR * K / 4;
+        for (int g0 = tid; g0 < ng; g0 += 512) {
+            f32x4_t o[2][DEC_NSMAX];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int gi = min(g0 + 256 * u, ng - 1), m = min(gi / (K / 4), Mr - 1), k = (gi % (K / 4)) * 4;
+                const float* p = a.part + (size_t)(m * a.H + k / dh) * ns * rec + 2 + k % dh;
+#pragma unroll
+                for (int s_ = 0; s_ < DEC_NSMAX; ++s_) {
+                    const float* ps_ = p + min(s_, ns - 1) * rec;                  // rec = dh + 2 floats: 8-byte aligned rows
+                    const float2 lo2 = *reinterpret_cast<const float2*>(ps_), hi2 = *reinterpret_cast<const float2*>(ps_ + 2);
+                    o[u][s_] = (f32x4_t){lo2.x, lo2.y, hi2.x, hi2.y};
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int gi = g0 + 256 * u;
+                if (gi < ng) {
+                    const int m = gi / (K / 4), k = (gi % (K / 4)) * 4;
+                    f32x4_t v = {0.f, 0.f, 0.f, 0.f}, r = v;
+                    if (m < Mr) {
+                        const int mh = m * a.H + k / dh;
+#pragma unroll
+                        for (int s_ = 0; s_ < DEC_NSMAX; ++s_) {
+                            const float w = s_ < ns ? wn[mh * DEC_NSMAX + s_] : 0.f;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = s_ < ns ? fmaf(w, o[u][s_][e], v[e]) : v[e];
+                        }
+                        if (a.x_out && blockIdx.x == 0) *reinterpret_cast<f32x4_t*>(a.x_out + (size_t)m * K + k) = v;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) r[e] = round_to<T>(v[e]);
+                    *reinterpret_cast<f32x4_t*>(&xs[m * K + k]) = r;
+                }
+            }
         }
     }
     __syncthreads();
 
-    // ---- projection: CW columns per wave
-    const int n0 = (blockIdx.x * 4 + wid) * CW;
+    // ---- projection
     if (n0 >= a.N) return;
-    const T* W = reinterpret_cast<const T*>(a.W);
-    const int nch = K / CH;
     float acc[CW][MR];
 #pragma unroll
     for (int c = 0; c < CW; ++c)
 #pragma unroll
         for (int m = 0; m < MR; ++m) acc[c][m] = 0.f;
-    constexpr int U = 2;                                    // chunk positions per lane in flight (x CW columns)
-    for (int ch0 = lane; ch0 < nch; ch0 += 64 * U) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int ch = lane + 64 * u;
+        if (64 * u < nch) dec_fma_chunks<T, MR, CW>(acc, wp[u], ch < nch, xw, K, ch < nch ? ch : 0);
+    }
+    constexpr int U = 2;                                    // further chunk positions: two in flight
+    for (int ch0 = lane + 64 * PF; ch0 < nch; ch0 += 64 * U) {
         chunk16 w[U][CW];
-        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ch = ch0 + 64 * u, chc = ch < nch ? ch : ch0;
+#pragma unroll
+            for (int c = 0; c < CW; ++c) w[u][c] = ld_chunk(W + (size_t)min(n0 + c, a.N - 1) * a.ldw + (size_t)chc * CH);
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int ch = ch0 + 64 * u;
-            ok[u] = ch < nch;
-            const int chc = ok[u] ? ch : ch0;
-#pragma unroll
-            for (int c = 0; c < CW; ++c) {
-                const int n = min(n0 + c, a.N - 1);         // clamped: results of columns >= N are never stored
-                w[u][c] = ld_chunk(W + (size_t)n * a.ldw + (size_t)chc * CH);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int chc = ok[u] ? ch0 + 64 * u : ch0;
-            float wf[CW][CH];
-#pragma unroll
-            for (int c = 0; c < CW; ++c) {
-                const T* we = reinterpret_cast<const T*>(&w[u][c]);
-#pragma unroll
-                for (int i = 0; i < CH; ++i) wf[c][i] = ok[u] ? ET<T>::to_f(we[i]) : 0.f;
-            }
-#pragma unroll
-            for (int m = 0; m < MR; ++m) {
-                float xv[CH];
-#pragma unroll
-                for (int q4 = 0; q4 < CH / 4; ++q4) {
-                    const f32x4_t v = *reinterpret_cast<const f32x4_t*>(&xs[m * K + chc * CH + 4 * q4]);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) xv[4 * q4 + i] = v[i];
-                }
-#pragma unroll
-                for (int c = 0; c < CW; ++c)
-#pragma unroll
-                    for (int i = 0; i < CH; ++i) acc[c][m] = fmaf(wf[c][i], xv[i], acc[c][m]);
-            }
+            dec_fma_chunks<T, MR, CW>(acc, w[u], ch < nch, xw, K, ch < nch ? ch : ch0);
         }
     }
-    // ---- reduce over the lanes; lane c * MR + m keeps output (column c, row m)
-    float mine = 0.f;
+    // ---- reduce over the lanes: lane (row r = lane >> 4, i = lane & 15 < NV/4) ends up with output i + (NV/4) r
+    constexpr int NV = CW * MR;
+    float red[NV];
 #pragma unroll
     for (int c = 0; c < CW; ++c)
 #pragma unroll
-        for (int m = 0; m < MR; ++m) {
-            const float tot = wave_sum(acc[c][m]);
-            if (lane == c * MR + m) mine = tot;
+        for (int m = 0; m < MR; ++m) red[c * MR + m] = acc[c][m];
+    reduce_scatter64<NV>(red);
+    float mine = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV / 4; ++i) if ((lane & 15) == i) mine = red[i];
+    if constexpr (KS) {                                     // the four K quarters meet in LDS (xs is dead: every wave passed the barrier)
+        __syncthreads();
+        float* ks = xs;                                     // [4 waves][NV]
+        if ((lane & 15) < NV / 4) ks[wid * NV + (lane & 15) + (NV / 4) * (lane >> 4)] = mine;
+        __syncthreads();
+        if (wid != 0) return;
+        if ((lane & 15) < NV / 4) {
+            const int o_ = (lane & 15) + (NV / 4) * (lane >> 4);
+            mine = (ks[o_] + ks[NV + o_]) + (ks[2 * NV + o_] + ks[3 * NV + o_]);
         }
-    if (lane >= CW * MR) return;
-    const int c = lane / MR, m = lane % MR, n = n0 + c;
+    }
+    if ((lane & 15) >= NV / 4) return;
+    const int oidx = (lane & 15) + (NV / 4) * (lane >> 4);
+    const int c = oidx / MR, m = oidx % MR, n = n0 + c;
     if (n >= a.N || m >= Mr) return;
     float v = mine + (a.bias ? a.bias[n] : 0.f);
     if (a.relu) v = fmaxf(v, 0.f);
@@ -272,8 +462,10 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const T* __restrict__ q, 
     const T* er = E + (size_t)(M - 1 - t) * DH;              // relative row of key j: E[M-1-(t-j)] = er + j * DH
     const uint8_t* kp = key_pad ? key_pad + (size_t)b * ld_pad : nullptr;
 
-    // ---- pass 1: scores of the range into LDS, running maximum
+    // ---- pass 1: scores of the range into LDS, running maximum.  The V rows of the first round (the only round up to
+    //      KPI * U = 128 keys per split at dh = 64 bf16) are requested together with K and E: one memory latency less.
     float mx = -INFINITY;
+    chunk16 v0[U];
     for (int jb = j0 + wid * KPW; jb < j1; jb += KPI * U) {
         chunk16 kk[U], ee[U];
 #pragma unroll
@@ -281,6 +473,10 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const T* __restrict__ q, 
             const int jc = min(jb + u * KPI + kslot, j1 - 1);
             kk[u] = ld_chunk(kc + (size_t)jc * DH + cc * CH);
             ee[u] = ld_chunk(er + (size_t)jc * DH + cc * CH);
+        }
+        if (jb == j0 + wid * KPW) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) v0[u] = ld_chunk(vc + (size_t)min(jb + u * KPI + kslot, j1 - 1) * DH + cc * CH);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -310,10 +506,15 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const T* __restrict__ q, 
     for (int i = 0; i < CH; ++i) o[i] = 0.f;
     for (int jb = j0 + wid * KPW; jb < j1; jb += KPI * U) {
         chunk16 vv[U];
+        if (jb == j0 + wid * KPW) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int jc = min(jb + u * KPI + kslot, j1 - 1);
-            vv[u] = ld_chunk(vc + (size_t)jc * DH + cc * CH);
+            for (int u = 0; u < U; ++u) vv[u] = v0[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int jc = min(jb + u * KPI + kslot, j1 - 1);
+                vv[u] = ld_chunk(vc + (size_t)jc * DH + cc * CH);
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -345,23 +546,57 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const T* __restrict__ q, 
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+template <typename T, int PRO, int EPI, int MR, int CW, bool KS>
+int gemv_launch3(const DecArgs& a, size_t lds, hipStream_t st) {
+    const unsigned grid = (unsigned)(KS ? (a.N + CW - 1) / CW : (a.N + 4 * CW - 1) / (4 * CW));
+    if (lds > 48 * 1024) {                                  // FFN_suf rows of the published 145 M model (8 x 3072 f32)
+        static bool done = false;                           // idempotent attribute: a benign race at worst
+        if (!done) { (void)hipFuncSetAttribute((const void*)dec_gemv_kernel<T, PRO, EPI, MR, CW, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); done = true; }
+    }
+    dec_gemv_kernel<T, PRO, EPI, MR, CW, KS><<<grid, 256, lds, st>>>(a);
+    return me_launch_status();
+}
+
+template <typename T, int PRO, int EPI, int MR>
+int gemv_launch2(const DecArgs& a, size_t lds, hipStream_t st) {
+    // Geometry: a cold weight stream arrives fastest when (nearly) every CU pulls a few KB, so the number of columns per
+    // wave (4, 2 or 1) is the largest that still gives >= 192 blocks; rows of >= 256 chunks (FFN_suf) are additionally
+    // split over the four waves of a block.  MIDIEMO_DEC_CW / MIDIEMO_DEC_KS override (experiments).
+    static const int cw_env = getenv("MIDIEMO_DEC_CW") ? atoi(getenv("MIDIEMO_DEC_CW")) : 0;
+    static const int ks_env = getenv("MIDIEMO_DEC_KS") ? atoi(getenv("MIDIEMO_DEC_KS")) : -1;
+    constexpr int CH = ET<T>::CH;
+    bool ks = PRO == PRO_PLAIN && a.K / CH >= 256;
+    if (ks_env >= 0) ks = PRO == PRO_PLAIN && ks_env != 0;
+    const int per_cw1 = ks ? a.N : (a.N + 3) / 4;           // blocks with one column per wave (per block when split over K)
+    int cw = per_cw1 >= 4 * 192 ? 4 : (per_cw1 >= 2 * 192 ? 2 : 1);
+    if (cw_env == 1 || cw_env == 2 || cw_env == 4) cw = cw_env;
+    if constexpr (PRO == PRO_PLAIN) {
+        if (ks) {
+            if (cw == 4) return gemv_launch3<T, PRO, EPI, MR, 4, true>(a, lds, st);
+            if (cw == 2) return gemv_launch3<T, PRO, EPI, MR, 2, true>(a, lds, st);
+            return gemv_launch3<T, PRO, EPI, MR, 1, true>(a, lds, st);
+        }
+    }
+    if (cw == 4) return gemv_launch3<T, PRO, EPI, MR, 4, false>(a, lds, st);
+    if (cw == 2) return gemv_launch3<T, PRO, EPI, MR, 2, false>(a, lds, st);
+    return gemv_launch3<T, PRO, EPI, MR, 1, false>(a, lds, st);
+}
+
 template <typename T, int PRO, int EPI>
 int gemv_launch(const DecArgs& a, hipStream_t st) {
-    constexpr int CH = ET<T>::CH, CW = 4;
+    constexpr int CH = ET<T>::CH;
     if (a.Mr < 1 || a.Mr > 8 || a.N <= 0 || a.K <= 0 || a.K % CH || a.K % 4 || a.ldw % CH) return ME_ERR_BAD_SHAPE;
+    if (PRO == PRO_LN && a.K > 1024) return ME_ERR_BAD_SHAPE;               // the LayerNorm prologue keeps a row in registers
+    if (PRO == PRO_EMBED && (a.dc < 0 || a.dc >= a.K || a.dc % 4 || (a.K - a.dc) % 4)) return ME_ERR_BAD_SHAPE;
+    if (PRO == PRO_ATTN && (a.nsplit > DEC_NSMAX || a.dh % 4)) return ME_ERR_BAD_SHAPE;
+    if ((PRO == PRO_HILO || PRO == PRO_PLAIN) && (a.ldx % CH || !aligned16(a.x_hi) || (a.x_lo && !aligned16(a.x_lo)))) return ME_ERR_ALIGNMENT;
     if (!a.W || !aligned16(a.W)) return a.W ? ME_ERR_ALIGNMENT : ME_ERR_NULL;
     const int mr = a.Mr <= 4 ? 4 : 8;
-    const size_t lds = (size_t)mr * a.K * sizeof(float);
+    size_t lds = (size_t)mr * a.K * sizeof(float);
+    if (PRO == PRO_ATTN) lds += (size_t)a.Mr * a.H * DEC_NSMAX * sizeof(float);
     if (lds > 96 * 1024) return ME_ERR_BAD_SHAPE;
-    const unsigned grid = (unsigned)((a.N + 4 * CW - 1) / (4 * CW));
-    if (mr == 4) {
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)dec_gemv_kernel<T, PRO, EPI, 4, CW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        dec_gemv_kernel<T, PRO, EPI, 4, CW><<<grid, 256, lds, st>>>(a);
-    } else {
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)dec_gemv_kernel<T, PRO, EPI, 8, CW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        dec_gemv_kernel<T, PRO, EPI, 8, CW><<<grid, 256, lds, st>>>(a);
-    }
-    return me_launch_status();
+    if (mr == 4) return gemv_launch2<T, PRO, EPI, 4>(a, lds, st);
+    return gemv_launch2<T, PRO, EPI, 8>(a, lds, st);
 }
 
 template <typename T, int DH>
@@ -400,12 +635,28 @@ int me_dec_qkv(const float* s_in, const float* gamma, const float* beta, float e
     ME_DEC_T((gemv_launch<T, PRO_HILO, EPI_QKV>(a, st)))
 }
 
+int me_dec_embed_qkv(const int64_t* tokens, const float* cond, const float* emb, const float* cw, const float* cb,
+                     const float* pe, int d_cond, const void* Wqkv, const float* bqkv, float* x_out, void* q_out, void* kcache,
+                     void* vcache, int Mr, int d, int H, int dh, int Mc, int t, const int32_t* t_dev, int dtype, void* stream) {
+    me_clear_error();
+    if (!tokens || !emb || !pe || !Wqkv || !q_out || !kcache || !vcache) return ME_ERR_NULL;
+    if (d_cond > 0 && (!cond || !cw || !cb)) return ME_ERR_NULL;
+    if (H <= 0 || dh <= 0 || H * dh != d || Mc <= 0) return ME_ERR_BAD_SHAPE;
+    if (!t_dev && (t < 0 || t >= Mc)) return ME_ERR_BAD_SHAPE;
+    DecArgs a = {};
+    a.tokens = tokens; a.cond = cond; a.emb = emb; a.cw = cw; a.cb = cb; a.pe = pe; a.dc = d_cond > 0 ? d_cond : 0; a.x_out = x_out;
+    a.W = Wqkv; a.ldw = d; a.bias = bqkv; a.Mr = Mr; a.N = 3 * d; a.K = d; a.y = q_out; a.ldy = d; a.kcache = kcache;
+    a.vcache = vcache; a.Mc = Mc; a.t = t; a.t_dev = t_dev; a.H = H; a.dh = dh;
+    hipStream_t st = (hipStream_t)stream;
+    ME_DEC_T((gemv_launch<T, PRO_EMBED, EPI_QKV>(a, st)))
+}
+
 int me_dec_attn(const void* q, const void* kcache, const void* vcache, const void* E, const uint8_t* key_pad, int ld_pad,
                 float* part, int nsplit, int Mr, int H, int dh, int M, int Mc, int t, const int32_t* t_dev, int dtype,
                 void* stream) {
     me_clear_error();
     if (!q || !kcache || !vcache || !E || !part) return ME_ERR_NULL;
-    if (Mr <= 0 || H <= 0 || nsplit <= 0 || nsplit > 64 || Mc <= 0 || M <= 0) return ME_ERR_BAD_SHAPE;
+    if (Mr <= 0 || H <= 0 || nsplit <= 0 || nsplit > DEC_NSMAX || Mc <= 0 || M <= 0) return ME_ERR_BAD_SHAPE;
     if (!t_dev && (t < 0 || t >= Mc || t >= M)) return ME_ERR_BAD_SHAPE;
     if ((Mc + nsplit - 1) / nsplit + 64 > 2048 + 64) return ME_ERR_BAD_SHAPE;       // the score buffer holds 2048 keys per split
     if (!aligned16(q) || !aligned16(kcache) || !aligned16(vcache) || !aligned16(E)) return ME_ERR_ALIGNMENT;

@@ -698,6 +698,47 @@ __global__ __launch_bounds__(256) void greedy_pick_kernel(const float* __restric
     if (threadIdx.x == 0) out_ids[blockIdx.x] = bi[0] == 0x7fffffff ? 0 : bi[0];
 }
 
+// The same pick for all B rows in ONE block (wave per row), followed by the decode bookkeeping of
+// decode_commit_kernel: history[b][*pos] = id ; *pos += 1 -- one launch instead of two at the end of a greedy step.
+__global__ __launch_bounds__(256) void greedy_pick_commit_kernel(const float* __restrict__ logits, int ld, int V,
+                                                                 const int32_t* __restrict__ special, int n_special,
+                                                                 int64_t* __restrict__ out_ids, int64_t* __restrict__ history,
+                                                                 int ld_hist, int32_t* __restrict__ pos, int B) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int p = *pos;
+    for (int b = wid; b < B; b += 4) {
+        const float* lg = logits + (int64_t)b * ld;
+        float best = -INFINITY;
+        int besti = 0x7fffffff;
+        for (int j0 = lane; j0 < V; j0 += 64 * 16) {             // 16 independent loads in flight (V <= 1024: one round)
+            float vals[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) vals[u] = lg[min(j0 + 64 * u, V - 1)];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int j = j0 + 64 * u;
+                float v = vals[u];
+                if (v != v) v = 0.f;
+                for (int s = 0; s < n_special; ++s) if (special[s] == j) v = -INFINITY;
+                if (j < V && (v > best || (v == best && j < besti))) { best = v; besti = j; }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o);
+            const int oi = __shfl_xor(besti, o);
+            if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+        }
+        if (lane == 0) {
+            const int64_t id = besti == 0x7fffffff ? 0 : besti;
+            out_ids[b] = id;
+            if (p < ld_hist) history[(size_t)b * ld_hist + p] = id;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *pos = p + 1;
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline int row_grid(int64_t rows, int cap) { int64_t g = (rows + 3) / 4; return (int)(g < 1 ? 1 : (g > cap ? cap : g)); }
 
@@ -1060,6 +1101,15 @@ int me_decode_commit(const int64_t* tok, int64_t* history, int ld_hist, int32_t*
     if (!tok || !history || !pos) return ME_ERR_NULL;
     if (B <= 0 || B > 1024 || ld_hist <= 0) return ME_ERR_BAD_SHAPE;
     decode_commit_kernel<<<1, ((B + 63) / 64) * 64, 0, (hipStream_t)stream>>>(tok, history, ld_hist, pos, B);
+    return me_launch_status();
+}
+
+int me_greedy_pick_commit(const float* logits, int ld, int V, const int32_t* special, int n_special, int64_t* out_ids,
+                          int64_t* history, int ld_hist, int32_t* pos, int B, void* stream) {
+    me_clear_error();
+    if (!logits || !out_ids || !history || !pos || (n_special > 0 && !special)) return ME_ERR_NULL;
+    if (B <= 0) return ME_OK;
+    greedy_pick_commit_kernel<<<1, 256, 0, (hipStream_t)stream>>>(logits, ld, V, special, n_special, out_ids, history, ld_hist, pos, B);
     return me_launch_status();
 }
 

@@ -13,7 +13,7 @@ ME_F32, ME_BF16 = 0, 1
 ME_COND_NONE, ME_COND_CONCAT, ME_COND_TOKEN = 0, 1, 2
 ME_EPI_RELU, ME_EPI_OUT_F32, ME_EPI_RELU_BWD = 1, 2, 4
 ME_WS_GEMM_TN = 1
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 ERRORS = {0: "ME_OK", -1: "ME_ERR_BAD_DTYPE", -2: "ME_ERR_BAD_SHAPE", -3: "ME_ERR_ALIGNMENT",
           -4: "ME_ERR_LAUNCH", -5: "ME_ERR_NULL", -6: "ME_ERR_WORKSPACE"}
@@ -42,12 +42,14 @@ SIGNATURES = {
     "me_sumsq": [_p, _i64, _p, _p],
     "me_adamw_step": [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _p],
     "me_dec_qkv": [_p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p],
+    "me_dec_embed_qkv": [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p],
     "me_dec_attn": [_p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p],
     "me_dec_proj_resid": [_p, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p],
     "me_dec_ln_proj": [_p, _p, _p, _f, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "me_greedy_pick": [_p, _i, _i, _p, _i, _p, _i, _p],
     "me_sample_topk_topp": [_p, _i, _i, _p, _i, _p, _i, _f, _p, _p, _p, _p, _p, _i, _p],
     "me_decode_commit": [_p, _p, _i, _p, _i, _p],
+    "me_greedy_pick_commit": [_p, _i, _i, _p, _i, _p, _p, _i, _p, _i, _p],
 }
 
 _lib = None

@@ -46,13 +46,12 @@ class DecodeSession:
         f32 = torch.float32
         self.kc = [torch.zeros(B, H, m.max_seq, dh, dtype=dt, device=dev) for _ in range(m.num_layer)]
         self.vc = [torch.zeros(B, H, m.max_seq, dh, dtype=dt, device=dev) for _ in range(m.num_layer)]
-        self.x = e(B, d)                                      # embedding of the new token (hi)
-        self.xlo = e(B, d) if dt != f32 else None              # ... and its low-order half (bf16 tier)
+        self.xlo = dt != f32                                   # bf16 tier: condition slots are fed as hi + lo rows
         self.q, self.hid = e(B, d), e(B, di)
         self.xres, self.o1res = e(B, d, dtype=f32), e(B, d, dtype=f32)     # f32 residual inputs (LayerNorm outputs)
         self.s1, self.s2 = e(B, d, dtype=f32), e(B, d, dtype=f32)           # f32 pre-norm sums
         # key splits of the attention: B*H*nsplit blocks should cover the chip (256 CUs)
-        self.nsplit = int(os.environ.get("MIDIEMO_DEC_NSPLIT", "0")) or max(1, min(16, 256 // max(1, min(B, ROWS) * H)))
+        self.nsplit = int(os.environ.get("MIDIEMO_DEC_NSPLIT", "0")) or max(1, min(8, 256 // max(1, min(B, ROWS) * H)))
         self.part = e(B * H, self.nsplit, dh + 2, dtype=f32)
         self.logits = e(B, V, dtype=f32)
         self.t = 0                      # next model position to be written
@@ -63,14 +62,17 @@ class DecodeSession:
     def reset(self):
         self.t = 0
 
-    def _layers_and_head(self, x_hi=None, x_lo=None):
-        """One position through all layers and the head; the first layer's input is x_hi (+ x_lo) [B, d] in T."""
+    def _layers_and_head(self, tokens=None, cond=None, x_hi=None, x_lo=None):
+        """One position through all layers and the head.  The first layer's input is either the embedding of `tokens`
+        (int64 [B, 1], computed inside the first kernel: me_dec_embed_qkv) or the rows x_hi (+ x_lo) [B, d] in T."""
         m, B, t = self.m, self.B, self.t
         d, di, H, dh, V, M = m.embedding_dim, m.d_inner, m.num_head, m.dh, m.vocab_size, m.max_seq
         f, dt, eps, ns = m.flat_params, m.compute_dtype, m.LN_EPS, self.nsplit
-        x_hi = self.x if x_hi is None else x_hi
-        x_lo = self.xlo if x_lo is None and x_hi is self.x else x_lo
         pv = lambda name: m._pview(f, name)
+        if tokens is not None and m.d_condition > 0:
+            cw, cb = pv("fc_condition.weight"), pv("fc_condition.bias")
+        else:
+            cw = cb = None
         for r0 in range(0, B, ROWS):                          # row chunks (Mr <= 8 per kernel call)
             r1 = min(B, r0 + ROWS)
             Mr = r1 - r0
@@ -78,7 +80,11 @@ class DecodeSession:
             for i in range(m.num_layer):
                 W = m._prep["layers"][i]
                 p = f"enc_layers.{i}."
-                if i == 0:
+                if i == 0 and tokens is not None:
+                    ops.dec_embed_qkv(tokens[r0:r1], cond[r0:r1] if cw is not None else None, pv("embedding.weight"), cw, cb,
+                                      m._pe, m.d_condition, W["Wqkv"], W["bqkv"], self.xres[r0:r1], self.q[r0:r1],
+                                      self.kc[i][r0:r1], self.vc[i][r0:r1], Mr, d, H, dh, M, t, self._pos_dev, dt)
+                elif i == 0:
                     ops.dec_qkv(None, None, None, eps, x_hi[r0:r1], x_lo[r0:r1] if x_lo is not None else None, W["Wqkv"],
                                 W["bqkv"], self.xres[r0:r1], self.q[r0:r1], self.kc[i][r0:r1], self.vc[i][r0:r1], Mr, d, H, dh,
                                 M, t, self._pos_dev, dt)
@@ -116,15 +122,12 @@ class DecodeSession:
         cw0, cb0, cw1, cb1 = m._cond_params(f)
         d = m.embedding_dim
         both = torch.empty(self.B, 2, d, dtype=m.compute_dtype, device=f.device)
-        both_lo = torch.empty_like(both) if self.xlo is not None else None
+        both_lo = torch.empty_like(both) if self.xlo else None
         dummy = torch.zeros(self.B, 1, dtype=torch.int64, device=f.device)
         ops.embed_fwd(both, dummy, cond, m._pview(f, "embedding.weight"), cw0, cb0, cw1, cb1, m._pe,
                       ops.ME_COND_TOKEN, self.B, 0, d, 0, 0.0, 0, out_lo=both_lo)
         for s in range(2):
-            self.x.copy_(both[:, s])
-            if both_lo is not None:
-                self.xlo.copy_(both_lo[:, s])
-            self._layers_and_head()
+            self._layers_and_head(x_hi=both[:, s].contiguous(), x_lo=both_lo[:, s].contiguous() if both_lo is not None else None)
 
     def step(self, tokens, cond=None):
         """Feed one token per sequence (int64 [B]) at the next position; returns logits f32 [B, V]
@@ -134,22 +137,13 @@ class DecodeSession:
             raise RuntimeError("decode position %d exceeds max_seq %d" % (self.t, m.max_seq))
         f = m.flat_params
         tokens = tokens.to(device=f.device, dtype=torch.int64).reshape(self.B, 1).contiguous()
-        d = m.embedding_dim
-        return self._embed_and_run(tokens, cond, m._pe[self.t:], None)
+        return self._embed_and_run(tokens, cond)
 
-    def _embed_and_run(self, tokens, cond, pe_t, pos_dev):
+    def _embed_and_run(self, tokens, cond):
         m = self.m
-        f = m.flat_params
-        d = m.embedding_dim
         if m.d_condition > 0:
-            cond = cond.to(device=f.device, dtype=torch.float32).contiguous()
-            cw0, cb0, _, _ = m._cond_params(f)
-            ops.embed_fwd(self.x, tokens, cond, m._pview(f, "embedding.weight"), cw0, cb0, None, None, pe_t,
-                          ops.ME_COND_CONCAT, self.B, 1, d, m.d_condition, 0.0, 0, pos_dev=pos_dev, out_lo=self.xlo)
-        else:
-            ops.embed_fwd(self.x, tokens, None, m._pview(f, "embedding.weight"), None, None, None, None, pe_t,
-                          ops.ME_COND_NONE, self.B, 1, d, 0, 0.0, 0, pos_dev=pos_dev, out_lo=self.xlo)
-        return self._layers_and_head()
+            cond = cond.to(device=m.flat_params.device, dtype=torch.float32).contiguous()
+        return self._layers_and_head(tokens=tokens, cond=cond)
 
     # -------------------------------------------------------------- device-resident greedy loop
     def greedy_run(self, tokens, n_steps, cond=None, special=None, use_graph=True):
@@ -181,9 +175,8 @@ class DecodeSession:
         def one_step():
             self._pos_dev = self._pos
             try:
-                self._embed_and_run(self._tok, self._cond if m.d_condition > 0 else None, m._pe, self._pos)
-                ops.greedy_pick(self.logits, m.vocab_size, self._special, self._tok, self.B)
-                ops.decode_commit(self._tok, self._hist, self._pos, self.B)
+                self._embed_and_run(self._tok, self._cond if m.d_condition > 0 else None)
+                ops.greedy_pick_commit(self.logits, m.vocab_size, self._special, self._tok, self._hist, self._pos, self.B)
             finally:
                 self._pos_dev = None
 

@@ -181,6 +181,12 @@ def dec_qkv(s_in, gamma, beta, eps, x_hi, x_lo, Wqkv, bqkv, x_out, q_out, kcache
                            _code(dtype), _stream()), "me_dec_qkv")
 
 
+def dec_embed_qkv(tokens, cond, emb, cw, cb, pe, d_cond, Wqkv, bqkv, x_out, q_out, kcache, vcache, Mr, d, H, dh, Mc, t, t_dev, dtype):
+    check(lib().me_dec_embed_qkv(_ptr(tokens), _ptr(cond), _ptr(emb), _ptr(cw), _ptr(cb), _ptr(pe), int(d_cond), _ptr(Wqkv),
+                                 _ptr(bqkv), _ptr(x_out), _ptr(q_out), _ptr(kcache), _ptr(vcache), Mr, d, H, dh, Mc, int(t),
+                                 _ptr(t_dev), _code(dtype), _stream()), "me_dec_embed_qkv")
+
+
 def dec_attn(q, kcache, vcache, E, key_pad, ld_pad, part, nsplit, Mr, H, dh, M, Mc, t, t_dev, dtype):
     check(lib().me_dec_attn(_ptr(q), _ptr(kcache), _ptr(vcache), _ptr(E), _ptr(key_pad), ld_pad, _ptr(part), nsplit, Mr, H,
                             dh, M, Mc, int(t), _ptr(t_dev), _code(dtype), _stream()), "me_dec_attn")
@@ -207,6 +213,12 @@ def sample_topk_topp(logits, V, special, temp, top_k, top_p, u, out_ids, n_choic
 
 def decode_commit(tok, history, pos, B):
     check(lib().me_decode_commit(_ptr(tok), _ptr(history), history.stride(0), _ptr(pos), B, _stream()), "me_decode_commit")
+
+
+def greedy_pick_commit(logits, V, special, out_ids, history, pos, B):
+    check(lib().me_greedy_pick_commit(_ptr(logits), logits.stride(0), V, _ptr(special),
+                                      special.numel() if special is not None else 0, _ptr(out_ids), _ptr(history),
+                                      history.stride(0), _ptr(pos), B, _stream()), "me_greedy_pick_commit")
 
 
 def greedy_pick(logits, V, special, out_ids, B):

@@ -586,13 +586,13 @@ def test_dec_attn_pad_keys_and_fully_masked_row(ops):
     ref = ref_attn(q, k, v, E, dO, pad.bool(), torch.float32)["O"]
     kc = torch.zeros(B, H, Mc, dh, device=DEV)
     vc = torch.zeros_like(kc)
-    kc[:, :, :t + 1] = k.to(DEV)
-    vc[:, :, :t + 1] = v.to(DEV)
+    kc[:, :, :t + 1] = k.float().to(DEV)
+    vc[:, :, :t + 1] = v.float().to(DEV)
     d = H * dh
     part = torch.zeros(B * H, ns, dh + 2, device=DEV)
     out = torch.empty(B, d, device=DEV)
-    ops.dec_attn(q[:, :, t].reshape(B, d).contiguous().to(DEV), kc, vc, E.to(DEV), pad.to(DEV), t + 1, part, ns, B, H, dh, M, Mc, t,
-                 None, torch.float32)
+    ops.dec_attn(q[:, :, t].reshape(B, d).contiguous().float().to(DEV), kc, vc, E.float().to(DEV), pad.to(DEV), t + 1, part, ns, B, H,
+                 dh, M, Mc, t, None, torch.float32)
     ops.dec_proj_resid(part, ns, H, dh, None, torch.eye(d, device=DEV), None, torch.zeros(B, d, device=DEV), out, B, d, d,
                        torch.float32)
     assert relerr(out[0].view(H, dh), ref[0, :, t]) < 2e-5
