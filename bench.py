@@ -10,7 +10,12 @@ f32 accumulate, synthetic tokens in [2, V), weights random-init.  Weak scaling: 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0.  `roofline` is the dominant kernel family
+Prints ONE JSON line on rank 0.  `value` = tokens / wall time of the K timed steps (barrier + synchronize on both
+sides, max over ranks); `median_ms_per_step` = median of the per-step HIP-event durations inside that region.
+`decode` (N = 1 only) = BASELINE config 5: KV-cached greedy decode, 4 (valence, arousal) pairs x 2048 tokens, tok/s,
+p50 / p90 device step latency and the HBM roofline fraction of a step at context 1024.  `hbm_kernels` = GB/s of every
+HBM-bound kernel of the train step from in-run HIP events.  `extra.config4` = discrete_token V1017 L2048 B16 train step.
+`roofline` is the dominant kernel family
 (the NT GEMM gemm_nt256_kernel<bf16>: every nn.Linear forward and dX product): algorithmic FLOPs of its launches /
 their HIP-event durations, measured on the launch stream in instrumented steps after the
 timed region.  `cpu_baseline` is the oracle (oracle/ref_model.py, a port) timed on the
@@ -86,6 +91,142 @@ def cpu_baseline(c, L, budget_s=25.0):
                       % (B, L, len(times), max(1, len(times) - 1))}
 
 
+def source_hash():
+    """sha256 over the kernel sources: ties profiles/hbm_traffic.json (a PMC pass) to the code it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    cs = os.path.join(ROOT, "midi-emotion_amd", "csrc")
+    for n in sorted(os.listdir(cs)):
+        if n.endswith((".hip", ".h")):
+            h.update(open(os.path.join(cs, n), "rb").read())
+    return h.hexdigest()
+
+
+def decode_bytes(c, t, B, elt=2):
+    """algorithmic HBM bytes of one decode step at context length t (weights once + K/V/E rows read + k/v written)."""
+    d, di, V, N, H = c["d_model"], c["d_inner"], c["vocab_size"], c["n_layer"], c["n_head"]
+    dh = d // H
+    weights = elt * (N * (3 * d * d + d * d + 2 * d * di) + V * d)
+    return weights + N * t * dh * elt + B * N * 2 * t * d * elt + B * N * 2 * d * elt
+
+
+def decode_bench(cd, gen_len=2048):
+    """BASELINE config 5: KV-cached greedy decode (generate.py --topk 1), B = 4 conditions, gen_len tokens, one GPU."""
+    from midiemo.decode import DecodeSession
+    from midiemo.models.build_model import build_model
+    from midiemo.vocab import get_maps, special_token_ids
+    torch.manual_seed(0)
+    model, _ = build_model(dict(CFG, compute_dtype=cd))
+    model = model.cuda().eval()
+    B = 4
+    cond = torch.tensor([[-0.8, -0.8], [-0.8, 0.8], [0.8, -0.8], [0.8, 0.8]], device="cuda")      # train.py:361-366
+    specials = torch.tensor(special_token_ids(get_maps()), dtype=torch.int32, device="cuda")
+    tok0 = torch.full((B,), 1, dtype=torch.long, device="cuda")                                   # <START>
+    sess = DecodeSession(model, B)
+    with torch.no_grad():
+        sess.greedy_run(tok0, 8, cond, specials)                 # graph capture + warm-up
+        sess.reset()
+        torch.cuda.synchronize()
+        evs = []
+        e0 = torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        ids = sess.greedy_run(tok0, gen_len, cond, specials, step_events=evs)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+    lat = [a.elapsed_time(b) for a, b in zip([e0] + evs[:-1], evs)]      # ms per step on the device
+    lat_sorted = sorted(lat)
+    pct = lambda q: lat_sorted[min(len(lat_sorted) - 1, int(q * len(lat_sorted)))]
+    mid = lat[gen_len // 2 - 32: gen_len // 2 + 32] if gen_len >= 128 else lat
+    t_mid = gen_len // 2
+    l_mid = sorted(mid)[len(mid) // 2] * 1e-3
+    elt = 2 if cd == "bf16" else 4
+    by = decode_bytes(CFG, t_mid, B, elt)
+    del sess, model
+    torch.cuda.empty_cache()
+    return {"dtype": cd, "batch": B, "gen_len": gen_len, "tokens_per_s": round(B * gen_len / wall, 1),
+            "step_ms_p50": round(pct(0.5), 4), "step_ms_p90": round(pct(0.9), 4), "step_ms_mean_wall": round(1e3 * wall / gen_len, 4),
+            "launches_per_step": 32, "replay": "one HIP graph per token, position in device memory",
+            "roofline": {"bound": "hbm", "context": t_mid, "bytes_per_step": by, "step_ms": round(l_mid * 1e3, 4),
+                         "achieved": round(by / l_mid / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": round(by / l_mid / 1e9 / PEAK_HBM_GBS, 4)},
+            "ids_checksum": int(ids.sum().item())}
+
+
+def decode_cpu_baseline(budget_s=12.0):
+    """The oracle's restatement of the reference's decode loop (full-window recompute per token, no cache) on the host
+    cores, on a bounded prefix: B = 4, as many tokens as fit the budget (the cost per token grows with the prefix)."""
+    from oracle import ref_model as O
+    c = CFG
+    cfg = O.Cfg(c["vocab_size"], c["n_layer"], c["n_head"], c["d_model"], c["d_inner"], d_condition=c["d_condition"],
+                conditioning=c["conditioning"])
+    P = O.seeded_params(cfg, 0)
+    conds = torch.tensor([[-0.8, -0.8], [-0.8, 0.8], [0.8, -0.8], [0.8, 0.8]])
+    n, t0 = 0, time.perf_counter()
+    with torch.no_grad():
+        for n_try in (8, 16, 32, 64):
+            t1 = time.perf_counter()
+            O.greedy_decode(cfg, P, conds, n_try, 2048)
+            dt, n = time.perf_counter() - t1, n_try
+            if time.perf_counter() - t0 + 2.5 * dt > budget_s:
+                break
+    return {"value": round(4 * n / dt, 2), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle greedy decode, full recompute per token (generate.py:99-119), f32, B=4, first %d tokens" % n}
+
+
+class OpProbe:
+    """HIP-event timing of the HBM-bound kernels of a train step (SURVEY 8d asks for their GB/s): every launch of the
+    wrapped ops is bracketed by events on the launch stream; bytes = the algorithmic bytes of the call."""
+
+    def __init__(self, ops, model, B, L):
+        self.ops, self.rec, self.orig = ops, {}, {}
+        d, V = model.embedding_dim, model.head_size
+        T = B * L
+        es = 2 if model.compute_dtype == torch.bfloat16 else 4
+        lo = es if (model.resid_lo and es == 2) else 0
+        n = model.flat_params.numel()
+        ldv = ((V + 63) // 64) * 64
+        self.bytes = {
+            "resid_ln_fwd": T * d * (es + lo + es + es + lo + es) + T * 8,        # x(+lo), a in; y(+lo), s out; stats
+            "resid_ln_bwd": T * d * 4 * es + T * 8,                               # dy, s in; dx, da out
+            "ce_fwd": T * ldv * 4 + T * 12,
+            "ce_bwd": T * ldv * 4 + T * ldv * es + T * 12,
+            "embed_fwd": T * d * (es + lo) + T * (d - model.d_condition) * 4 + T * d * 4,   # out(+lo); table rows; PE
+            "embed_bwd": T * d * es,
+            "sumsq": n * 4,
+            "adamw_step": n * 4 * 7,                                               # p, g, m, v in; p, m, v (+ zeroed g) out
+        }
+
+    def __enter__(self):
+        for name in self.bytes:
+            orig = getattr(self.ops, name)
+            self.orig[name] = orig
+
+            def wrapped(*a, _o=orig, _n=name, **k):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = _o(*a, **k)
+                e1.record()
+                self.rec.setdefault(_n, []).append((e0, e1))
+                return r
+            setattr(self.ops, name, wrapped)
+        return self
+
+    def __exit__(self, *a):
+        for name, orig in self.orig.items():
+            setattr(self.ops, name, orig)
+
+    def table(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, evs in self.rec.items():
+            us = sorted(1e3 * a.elapsed_time(b) for a, b in evs)
+            med = us[len(us) // 2]
+            out[name] = {"launches": len(evs), "us": round(med, 2), "MB": round(self.bytes[name] / 1e6, 1),
+                         "GBps": round(self.bytes[name] / med / 1e3, 1), "frac_of_8TBps": round(self.bytes[name] / med / 1e3 / PEAK_HBM_GBS, 3)}
+        return out
+
+
 class GemmProbe:
     """HIP-event timing of every NT-GEMM launch (me_gemm_nt; events recorded on the launch stream).
     At the bench shapes all of them run gemm_nt256_kernel<bf16>."""
@@ -117,16 +258,55 @@ class GemmProbe:
         return flops, ms, len(self.rec)
 
 
+def config4_bench(steps=8, warmup=3):
+    """BASELINE config 4 as a sub-measurement: discrete_token (V = 1017), same 6L d512 model, L = 2048, B = 16, bf16,
+    full train step; synthetic tokens with the two emotion-bin tokens in front."""
+    from midiemo.models.build_model import build_model
+    from midiemo.optim import FusedAdamW
+    c = dict(CFG, vocab_size=1017, conditioning="discrete_token", d_condition=-1)
+    torch.manual_seed(0)
+    model, _ = build_model(dict(c, compute_dtype="bf16"))
+    model = model.cuda().train()
+    opt = FusedAdamW(model, lr=2e-5, clip=1.0)
+    B, L = 16, 2048
+    g = torch.Generator().manual_seed(4321)
+    tok = torch.randint(2, 1007, (B, L + 1), generator=g)
+    tok[:, 0] = torch.randint(1007, 1012, (B,), generator=g)
+    tok[:, 1] = torch.randint(1012, 1017, (B,), generator=g)
+    x, y = tok[:, :-1].contiguous().cuda(), tok[:, 1:].contiguous().cuda()
+    for _ in range(warmup):
+        model.loss_and_backward(x, None, y)
+        opt.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = model.loss_and_backward(x, None, y)
+        opt.step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    d, di, V = c["d_model"], c["d_inner"], 1017
+    fpt = 3 * (c["n_layer"] * (8 * d * d + 4 * d * di + 3 * (2 * d * (L + 1) // 2)) + 2 * d * V)
+    tps = B * L * steps / el
+    res = {"workload": "discrete_token V1017 6L d512 8H, seq 2048, batch 16, bf16, fwd+CE+bwd+clip+AdamW, dropout 0.1",
+           "tokens_per_s": round(tps, 1), "ms_per_step": round(1e3 * el / steps, 3), "steps": steps,
+           "step_tflops_algorithmic": round(tps * fpt / 1e12, 2), "final_loss": round(float(loss.item()), 4)}
+    del model, opt
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)       # SURVEY 8d: >= 50 timed steps after >= 10 warm-up (the driver passes its own)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=BATCH, help="sequences per GPU (weak scaling)")
     ap.add_argument("--seq", type=int, default=SEQ)
     ap.add_argument("--compute_dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_probe", action="store_true")
+    ap.add_argument("--no_decode", action="store_true")
+    ap.add_argument("--no_extra", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -185,21 +365,25 @@ def main():
         step(i)
     fence()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     t0 = time.perf_counter()
     e0.record()
     loss = None
     for i in range(args.steps):
         loss = step(args.warmup + i)
+        step_ev[i].record()                    # one timing event per step (no sync): median of the per-step device times
     e1.record()
     fence()
     elapsed = time.perf_counter() - t0
+    per_step = sorted(a.elapsed_time(b) for a, b in zip([e0] + step_ev[:-1], step_ev))
+    median_ms = per_step[len(per_step) // 2]
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     final_loss = float(loss.item())
 
-    probe = None
+    probe, hbm_table = None, None
     if not args.no_probe:
         # every rank runs the instrumented steps (they contain the gradient all-reduce); only rank 0 times its GEMMs
         if rank == 0:
@@ -207,7 +391,13 @@ def main():
                 for i in range(3):
                     step(i)
                 probe = gp.summary()
+            with OpProbe(ops, model, B, L) as op_probe:
+                for i in range(3):
+                    step(i)
+                hbm_table = op_probe.table()
         else:
+            for i in range(3):
+                step(i)
             for i in range(3):
                 step(i)
     fence()
@@ -219,7 +409,8 @@ def main():
         out = {
             "metric": "MIDI tokens/sec training (B32 seq1024 d512 6L)", "value": round(tps, 1), "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "median_ms_per_step": round(median_ms, 3),
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.compute_dtype, "data": "synthetic",
             "config": {"workload": "continuous_concat 6L d512 8H d_inner2048 d_cond128 V1007, seq %d, batch %d/GPU, "
                                    "fwd+CE+bwd+clip+AdamW, dropout 0.1" % (L, B),
@@ -232,25 +423,40 @@ def main():
             # HBM bytes/launch of the same kernel: PMC counters need their own rocprofv3 pass (guide section
             # "HBM traffic"), so the committed summary of that pass over this exact command is quoted here --
             # only for the workload it was collected on.
-            traffic = None
+            traffic, traffic_note = None, "no PMC pass committed for this workload"
             tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")
             if args.compute_dtype == "bf16" and (B, L) == (32, 1024) and os.path.exists(tj):
                 tjd = json.load(open(tj))
                 k = tjd.get("gemm_nt256_kernel") or tjd.get("gemm_nt256_kernel<false>")
-                if k:
+                if tjd.get("_source_sha256") != source_hash():
+                    traffic_note = "profiles/hbm_traffic.json was measured on other kernel sources (hash mismatch): not quoted"
+                elif k:
                     traffic = int(round((k["read_MB"] + k["write_MB"]) * 1e6))
+                    traffic_note = "HBM bytes per launch (rocprofv3 PMC passes FETCH_SIZE x2 + WRITE_SIZE, %s)" % tjd.get("_profile", "profiles/")
             ach = flops / (ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": ("gemm_nt256_kernel<bf16>" if args.compute_dtype == "bf16" else "gemm_nt_kernel<float>"),
                                "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS if args.compute_dtype == "bf16" else 157.3,
                                "unit": "TFLOP/s",
                                "frac": round(ach / (PEAK_BF16_TFLOPS if args.compute_dtype == "bf16" else 157.3), 4),
-                               "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC pass, profiles/r01_f_hbm_traffic.txt)",
+                               "traffic": traffic, "traffic_unit": traffic_note,
                                "algorithmic_bytes_per_launch": int(gp.alg_bytes), "launches_per_step": n // 3,
                                "avg_launch_us": round(1000.0 * ms / n, 2),
                                "gemm_nt_ms_per_step": round(ms / 3, 3),
                                "step_frac_of_peak": round(tps * fpt / 1e12 / world / PEAK_BF16_TFLOPS, 4)}
+        if hbm_table is not None:
+            out["hbm_kernels"] = hbm_table
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(CFG, L)
+        if world == 1 and not args.no_extra:
+            out["extra"] = {"config4": config4_bench()}
+        if world == 1 and not args.no_decode:
+            del model, opt
+            torch.cuda.empty_cache()
+            dec = decode_bench("bf16")
+            dec["fp32"] = {k: v for k, v in decode_bench("fp32").items() if k in ("tokens_per_s", "step_ms_p50", "step_ms_p90", "roofline")}
+            if not args.no_cpu_baseline:
+                dec["cpu_baseline"] = decode_cpu_baseline()
+            out["decode"] = dec
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

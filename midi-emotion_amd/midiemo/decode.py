@@ -146,7 +146,7 @@ class DecodeSession:
         return self._layers_and_head(tokens=tokens, cond=cond)
 
     # -------------------------------------------------------------- device-resident greedy loop
-    def greedy_run(self, tokens, n_steps, cond=None, special=None, use_graph=True):
+    def greedy_run(self, tokens, n_steps, cond=None, special=None, use_graph=True, step_events=None):
         """Feed `tokens` (int64 [B]) at the next position, then keep feeding the arg-max token back for n_steps
         steps in total, entirely on the device (generate.py:99-189 with top_k = 1): the position lives in device
         memory (me_embed_fwd pos_dev, the t_dev argument of me_dec_qkv / me_dec_attn), me_greedy_pick writes the next input token and
@@ -194,5 +194,9 @@ class DecodeSession:
                 self._graph.replay()
             else:
                 one_step()
+            if step_events is not None:                     # per-step device latency (bench.py): one timing event per step
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                step_events.append(ev)
         self.t = t0 + n_steps
         return self._hist[:, t0:t0 + n_steps]

@@ -55,8 +55,16 @@ def main():
     for k, n, rd, wr in rows:
         print("%-42s %9d %12.1f %12.1f" % (k, n, rd, wr))
     if jpath:
-        json.dump({k: {"launches": n, "read_MB": round(rd, 1), "write_MB": round(wr, 1)} for k, n, rd, wr in rows},
-                  open(jpath, "w"), indent=1)
+        import hashlib, os
+        cs = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "midi-emotion_amd", "csrc")
+        h = hashlib.sha256()
+        for n_ in sorted(os.listdir(cs)):
+            if n_.endswith((".hip", ".h")):
+                h.update(open(os.path.join(cs, n_), "rb").read())
+        d = {k: {"launches": n, "read_MB": round(rd, 1), "write_MB": round(wr, 1)} for k, n, rd, wr in rows}
+        d["_source_sha256"] = h.hexdigest()          # bench.py quotes roofline.traffic only for the sources it was measured on
+        d["_profile"] = os.environ.get("PROFILE_TAG", "profiles/")
+        json.dump(d, open(jpath, "w"), indent=1)
 
 
 if __name__ == "__main__":
