@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 11
+#define ME_ABI_VERSION 12
 
 enum { ME_F32 = 0, ME_BF16 = 1 };
 
@@ -126,7 +126,11 @@ int me_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
 /* ---- workspace sizes (caller supplies every workspace) -----------------
  * Bytes of scratch the entry point `op` needs for a call of the given shape and dtype (an upper bound;
  * 0 = none).  ME_WS_GEMM_TN: me_gemm_tn_acc with (M, N, K) = (T, N, K). */
-enum { ME_WS_GEMM_TN = 1 };
+enum {
+    ME_WS_GEMM_TN = 1,   /* me_gemm_tn_acc partial tiles: (M, N, K) = (T, N, K) */
+    ME_WS_RGA_PT = 2,    /* me_rga_bwd PT workspace:  (M, N, K) = (B*H, Lp, causal) */
+    ME_WS_RGA_DGT = 3    /* me_rga_bwd dGT workspace: (M, N, K) = (B*H, Lp, unused) */
+};
 size_t me_workspace_bytes(int op, int M, int N, int K, int dtype);
 
 /* ---- GEMM  dW[N,K] += A[T,N]^T . B[T,K] ---------------------------------------
@@ -151,8 +155,7 @@ int me_gemm_tn_acc(const void* A, int lda, const void* B, int ldb, float* dW, in
  * mask, softmax, PV, head merge).  dh in {32, 48, 64}; M % 32 == 0; L <= M.  Epk = me_rga_pack_rel(E).
  * causal = 1: the language model (generate_mask: key <= q and not padded).  causal = 0: the bidirectional attention of
  * MusicRegression (models/music_regression.py:79, mask = None): all keys, relative term only for key <= q (the
- * reference's skewing leaves zeros above the diagonal); me_rga_bwd takes the same flag (causal = 0 writes and reads
- * every tile of the P^T / dS^T workspaces, so they need not be zero-initialised for it). */
+ * reference's skewing leaves zeros above the diagonal); me_rga_bwd takes the same flag. */
 int me_rga_fwd(const void* qkv, const void* Epk, const uint8_t* key_pad, void* out, float* lse,
                int B, int L, int H, int dh, int M, int causal, int dtype, void* stream);
 
@@ -165,14 +168,17 @@ int me_rga_pack_rel(const void* E, void* Epk, int M, int dh, int dtype, void* st
 
 /* Backward of me_rga_fwd.  dout: T [B,L,H,dh].  Writes dqkv (T, same layout as qkv),
  * accumulates (+=) dE f32 [M, dh] (natural layout).
- * Workspaces (caller-owned): delta f32 [B,H,L]; PT, dST: T [B*H][Lp*Lp] each (Lp = L rounded
- * up to 32) = P^T and dS^T as contiguous 32x32 tiles [key tile][query tile][32 key][32 q], which must be
- * ZERO-INITIALISED once for causal = 1 (only on/below-diagonal tiles are written and read).  The gradient of the
- * relative table is taken from dS^T (dG is dS re-indexed).  causal: as in me_rga_fwd (autograd of
- * music_multi.py:211-235 for 1, of music_regression.py's mask = None attention for 0). */
+ * Workspaces (caller-owned, sizes from me_workspace_bytes, 16-byte aligned, contents need NOT be initialised: every
+ * tile is written before it is read in every call): delta f32 [B,H,L];
+ *   PT  : T, per (batch, head) the 32 x 32 tiles of P^T -- the packed lower triangle (key tile, query tile >= key tile)
+ *         for causal = 1, the full square for causal = 0          (ME_WS_RGA_PT, Lp = L rounded up to 32);
+ *   dGT : T, per (batch, head) the tiles (query tile qt, step t <= qt) of the skewed dS (rows = rows of the relative
+ *         table, columns = queries): what dE is contracted from       (ME_WS_RGA_DGT).
+ * dK / dV recompute dS from P^T (dS = P o (V dO^T - delta) / sqrt(dh)); dS itself is never stored.
+ * causal: as in me_rga_fwd (autograd of music_multi.py:211-235 for 1, of music_regression.py's mask = None attention for 0). */
 int me_rga_bwd(const void* qkv, const void* Epk, const uint8_t* key_pad,
                const void* out, const float* lse, const void* dout,
-               void* dqkv, float* dE, float* delta_ws, void* PT, void* dST,
+               void* dqkv, float* dE, float* delta_ws, void* PT, void* dGT,
                int B, int L, int Lp, int H, int dh, int M, int causal, int dtype, void* stream);
 
 /* ---- residual + dropout + LayerNorm (post-LN, eps) ---------------------------

@@ -23,14 +23,16 @@
 // LDS tiles with the hardware transpose read (frag_load_tr, me_common.h): no transposed copies in
 // memory, no LDS scatter.
 //
-// Backward.  The query-owned kernel recomputes P, forms dS, accumulates dQ (key part and
-// relative part) and MATERIALISES, for the current layer only, P^T, dS^T ([bh][key][q]) and
-// the skewed dG^T ([bh][c][q], c = E-row - (M - Lp)) in the compute type.  dK/dV and dE are
-// then plain streaming tile products (contraction over q) that read those once:
-//     dV = P^T dO,  dK = dS^T Q            (rga_bwd_kv_kernel, key-owned, HBM-bound)
-//     dE[e] += sum_bh dG^T[bh][e] Q^T      (rga_bwd_e_kernel, E-row-owned, HBM-bound)
-// Only tiles on/below the diagonal are ever written or read; the workspaces must be
-// zero-initialised once (rows q >= L and the unreachable corner stay zero).
+// Backward.  The query-owned kernel recomputes P, forms dS, accumulates dQ (key part and relative part) and
+// MATERIALISES, for the current layer only, two tensors in the compute type as contiguous 32 x 32 tiles:
+//     P^T  [bh][key tile][query tile >= key tile]   (packed lower triangle; full square for the bidirectional variant)
+//     dG^T [bh][query tile qt][step t <= qt]        (the skewed dS of E block eb0(qt) + t: rows = E row, columns = query)
+// Every tile of both is written by exactly one wave in every call: no zero-initialisation contract.
+//     dV = P^T dO,  dS^T = P^T o (V dO^T - delta) / sqrt(dh),  dK = dS^T Q   (rga_bwd_kv_kernel, key-owned: streams P^T once,
+//                                                                          recomputes dS from it -- no exp, no skew)
+//     dE[e] += sum_{bh, q} dG^T[e][q] Q[q]                                 (rga_bwd_e_kernel, E-row-owned: plain tile stream)
+// Round 1 also materialised dS^T (the key-owned kernel read it, the E kernel re-read it as sheared bands): 2.33 GB of HBM
+// traffic per layer at the headline shape against 1.2 GB now.
 #include "me_common.h"
 #include <type_traits>
 
@@ -115,17 +117,14 @@ ME_DEV void row_frags(Frag<T>* f, const T* rowptr, bool valid, int h) {
     }
 }
 
-// P^T / dS^T workspace of one (b, head): element offset of the 32-query row segment (key, query tile qt).
-// Layout 2 (default): [key tile][query tile][32 key][32 q], every tile 32 x 32 contiguous; 0: plain [key][q] rows;
-// 1: query-tile-major [Lp/32 qt][Lp key][32 q].  Measured in the train step (q / kv kernels, us): 0: 319 / 188, 1: 303 / 178, 2: 298 / 173.
-#ifndef ME_WS_LAYOUT
-#define ME_WS_LAYOUT 2
-#endif
-ME_DEV size_t ws_row(int key, int qt, int Lp) {
-    if (ME_WS_LAYOUT == 0) return (size_t)key * Lp + qt * 32;
-    if (ME_WS_LAYOUT == 1) return ((size_t)qt * Lp + key) * 32;
-    return (((size_t)(key >> 5) * (Lp >> 5) + qt) * 32 + (key & 31)) * 32;
+// Workspace tiles of one (b, head); every tile is a contiguous 32 x 32 block of T (1024 elements).
+//   P^T : causal: packed lower triangle, tile (kt, qt >= kt); bidirectional: full square (kt, qt)
+//   dG^T: tile (qt, t <= qt)
+ME_DEV size_t pt_tile(int kt, int qt, int nq, bool causal) {
+    return causal ? (size_t)kt * nq - (size_t)kt * (kt - 1) / 2 + (qt - kt) : (size_t)kt * nq + qt;
 }
+ME_DEV size_t pt_tiles(int nq, bool causal) { return causal ? (size_t)nq * (nq + 1) / 2 : (size_t)nq * nq; }
+ME_DEV size_t dg_tile(int qt, int t) { return (size_t)qt * (qt + 1) / 2 + t; }
 
 // v_exp_f32 without the denormal-range fix-up of exp2f (arguments here are <= 0: tiny results may flush to 0)
 ME_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -215,6 +214,11 @@ __global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ q
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq)
             *reinterpret_cast<f32x4_t*>(gs + 8 * gq + 4 * h) = (f32x4_t){g[4 * gq], g[4 * gq + 1], g[4 * gq + 2], g[4 * gq + 3]};
+        // halo: columns 64..66 of a ring row mirror columns 0..2, so that the 4-element groups of the skewed read never have
+        // to wrap inside a group (one base address per group instead of an add / and / shift per element).  Branch-free:
+        // lanes that do not own columns 0..3 of slot 0 rewrite their own first quad in place.
+        float* hs = &Gs[wid][a * LDG2] + (((eb & 1) | h) ? (eb & 1) * 32 + 4 * h : 64);
+        *reinterpret_cast<f32x4_t*>(hs) = (f32x4_t){g[0], g[1], g[2], g[3]};
     };
 
     // E rows of block eb as A-operand fragments: one contiguous 1 KB image per contraction atom (me_rga_pack_rel);
@@ -261,14 +265,24 @@ __global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ q
             }
             uint32_t pbits = 0;
             if (key_pad) pbits = __builtin_amdgcn_readfirstlane((uint32_t)__ballot(lane < 32 && Ps[buf][a] != 0));
-            // band element m (0..62) of this tile sits at ring column ((eb_lo & 1) * 32 + m) & 63
+            // band element m (0..62) of this tile sits at ring column ((eb_lo & 1) * 32 + m) & 63; the lane's 16 elements
+            // are four groups of 4 consecutive columns (a group may run into the halo columns 64..66, never wraps)
             const float* grow = &Gs[wid][a * LDG2];
             const int t0 = (eb_lo & 1) * 32 + 31 - a + 4 * h;
+            float gv[16];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const float* gp = grow + ((t0 + 8 * gq) & 63);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gv[4 * gq + i] = gp[i];
+            }
+            // the running maximum is kept in RAW logit units (before the scale / log2e factor c2 > 0): the exponent is
+            // one fma per element, exp2(s * c2 - m * c2)
             float mt = -INFINITY;
             if (!diag && !upper && pbits == 0u && k0 + 32 <= L) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    s[r] = (s[r] + grow[(t0 + (r & 3) + 8 * (r >> 2)) & 63]) * c2;
+                    s[r] += gv[r];
                     mt = fmaxf(mt, s[r]);
                 }
             } else {
@@ -276,12 +290,8 @@ __global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ q
                 for (int r = 0; r < 16; ++r) {
                     const int bk = (r & 3) + 8 * (r >> 2) + 4 * h, key = k0 + bk;
                     const bool masked = (CAUSAL && key > q) || key >= L || ((pbits >> bk) & 1u);
-                    float v = -INFINITY;
-                    if (!masked) {
-                        float g = 0.f;
-                        if (CAUSAL || (!upper && key <= q)) g = grow[(t0 + (r & 3) + 8 * (r >> 2)) & 63];
-                        v = (s[r] + g) * c2;
-                    }
+                    const float g = (CAUSAL || (!upper && key <= q)) ? gv[r] : 0.f;
+                    const float v = masked ? -INFINITY : s[r] + g;
                     s[r] = v;
                     mt = fmaxf(mt, v);
                 }
@@ -289,10 +299,11 @@ __global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ q
             mt = half_max(mt);
             const float m_new = fmaxf(m_run, mt);
             const float m_safe = m_new == -INFINITY ? 0.f : m_new;
-            const float alpha = fast_exp2(m_run - m_safe);
+            const float alpha = fast_exp2((m_run - m_safe) * c2);
+            const float nm = -m_safe * c2;
             float rs = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = fast_exp2(s[r] - m_safe); rs += s[r]; }
+            for (int r = 0; r < 16; ++r) { s[r] = fast_exp2(fmaf(s[r], c2, nm)); rs += s[r]; }
             l_run = l_run * alpha + rs;
             if (__any(m_new != m_run)) {                 // running maxima settle quickly: most steps skip the rescale
 #pragma unroll
@@ -328,7 +339,7 @@ __global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ q
     if (!wave_on || q >= L) return;
     const float l_tot = half_sum(l_run);
     const float inv = 1.f / l_tot;
-    if (h == 0) lse[((size_t)b * H + head) * L + q] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
+    if (h == 0) lse[((size_t)b * H + head) * L + q] = (m_run * c2 + log2f(l_tot)) * 0.6931471805599453f;
     T* op = out + ((size_t)b * L + q) * dm + head * DH;
 #pragma unroll
     for (int i = 0; i < C::DB; ++i)
@@ -349,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
     const T* __restrict__ qkv, const T* __restrict__ Epk,
     const uint8_t* __restrict__ key_pad, const T* __restrict__ out, const float* __restrict__ lse,
     const T* __restrict__ dout, T* __restrict__ dqkv, float* __restrict__ delta_ws, T* __restrict__ PT,
-    T* __restrict__ dST, int B, int L, int Lp, int H, int M, float scale) {
+    T* __restrict__ dGT, int B, int L, int Lp, int H, int M, float scale) {
     using C = ACfg<T, DH>;
     constexpr int LDR = 72;                         // dG ring row (elements of T): 64-column ring + 8
     __shared__ __attribute__((aligned(16))) T Ks[2][32 * C::LDN];      // natural K tile: 16-byte fragment reads (S) and transpose reads (dQ)
@@ -428,6 +439,11 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq)
             *reinterpret_cast<f32x4_t*>(gs + 8 * gq + 4 * h) = (f32x4_t){g[4 * gq], g[4 * gq + 1], g[4 * gq + 2], g[4 * gq + 3]};
+        // halo: columns 64..66 of a ring row mirror columns 0..2, so that the 4-element groups of the skewed read never have
+        // to wrap inside a group (one base address per group instead of an add / and / shift per element).  Branch-free:
+        // lanes that do not own columns 0..3 of slot 0 rewrite their own first quad in place.
+        float* hs = &Gs[wid][a * LDG2] + (((eb & 1) | h) ? (eb & 1) * 32 + 4 * h : 64);
+        *reinterpret_cast<f32x4_t*>(hs) = (f32x4_t){g[0], g[1], g[2], g[3]};
     };
     // packed relative table (me_rga_pack_rel): every fragment is one contiguous 1 KB image
     auto e_frags = [&](Frag<T>* f, int eb) __attribute__((always_inline)) {      // E rows of block eb: A operand of G^T = E . Q^T
@@ -450,7 +466,9 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
         g_block(ef, eb0);
         if (my_last_kt > 0) e_frags(ef, eb0 + 1);
     }
-    const size_t ws_bh = (size_t)bh * Lp * Lp;
+    const int nq32 = Lp >> 5;
+    T* const ptb = PT + (size_t)bh * pt_tiles(nq32, CAUSAL) * 1024;
+    T* const dgb = dGT + (size_t)bh * pt_tiles(nq32, true) * 1024;
     sstore(0);
     if (nkt > 1) gload(1);
     __syncthreads();
@@ -496,7 +514,11 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
             for (int r0 = 0; r0 < 16; r0 += 8) {                 // two batches of 8 ring reads (register budget)
                 float gv[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) gv[j] = grow[(t0 + ((r0 + j) & 3) + 8 * ((r0 + j) >> 2)) & 63];
+                for (int gq = 0; gq < 2; ++gq) {             // group bases: a group may run into the halo columns, never wraps
+                    const float* gp = grow + ((t0 + 2 * r0 + 8 * gq) & 63);     // r0 = 0 / 8: register quads 0,1 / 2,3 = columns +0,+8 / +16,+24
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gv[4 * gq + i] = gp[i];
+                }
                 if (plain) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
@@ -526,9 +548,9 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
                     drow[(t0 + (r & 3) + 8 * (r >> 2)) & 63] = ET<T>::from_f(rel ? s[r] : 0.f);
                 }
             }
-            // ---- materialise P^T, dS^T tiles [key][q]: transpose through the (now dead) lo slot of the G
-            //      ring so that the tiles leave as 16-byte row-contiguous stores.  Rows key >= L and
-            //      columns q >= L carry exact zeros (masked), consistent with the zero-initialised workspace.
+            // ---- materialise the P^T tile [key][q]: transpose through the (now dead) lo slot of the G ring so that
+            //      the tile leaves as 16-byte row-contiguous stores.  Rows key >= L and columns q >= L carry exact
+            //      zeros (masked).
             // staging = the 32 dead lo columns of every ring row (row stride LDG2 floats)
             T* stg = reinterpret_cast<T*>(&Gs[wid][(eb_lo & 1) * 32]);
             constexpr int LDX = LDG2 * (int)(sizeof(float) / sizeof(T));   // staging row stride in elements of T
@@ -537,10 +559,10 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
 #pragma unroll
                 for (int it = 0; it < 32 * CPRX / 64; ++it) {
                     const int c = it * 64 + lane, row = c / CPRX, cc = (c % CPRX) * C::CH;
-                    st_chunk(gdst + (size_t)row * (ME_WS_LAYOUT == 0 ? Lp : 32) + cc, ld_chunk(&stg[row * LDX + cc]));
+                    st_chunk(gdst + (size_t)row * 32 + cc, ld_chunk(&stg[row * LDX + cc]));
                 }
             };
-            const size_t tile_off = ws_bh + ws_row(k0, q0 >> 5, Lp);
+            T* const pt_dst = ptb + pt_tile(kt, q0 >> 5, nq32, CAUSAL) * 1024;
             if constexpr (MAIN && ME_ABL != 8)      // issued BEFORE the tile stores: in-order vmcnt then never makes the next step wait for them
                 e_frags(ef, min(eb_lo + 2, (M >> 5) - 1));          // clamped: unused past the diagonal
             if constexpr (sizeof(T) == 2) {
@@ -572,22 +594,17 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
                         chunk16 c;
                         reinterpret_cast<v4s*>(&c)[0] = x[0];
                         reinterpret_cast<v4s*>(&c)[1] = x[1];
-                        st_chunk(gdst + (size_t)(kh * 16 + l16) * (ME_WS_LAYOUT == 0 ? Lp : 32) + 8 * gidx, c);
+                        st_chunk(gdst + (size_t)(kh * 16 + l16) * 32 + 8 * gidx, c);
                     }
                 };
                 if (ME_ABL != 1) {
                     put_tile(dp);
-                    flush_tr(PT + tile_off);
-                    put_tile(s);
-                    flush_tr(dST + tile_off);
+                    flush_tr(pt_dst);
                 }
             } else if (ME_ABL != 1) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * h) * LDX + a] = ET<T>::from_f(dp[r]);
-                flush_tile(PT + tile_off);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * h) * LDX + a] = ET<T>::from_f(s[r]);
-                flush_tile(dST + tile_off);
+                flush_tile(pt_dst);
             }
             // ---- dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
 #pragma unroll
@@ -600,15 +617,44 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
                     mma32(dq[i], kf, dsf);
                 }
             }
-            // ---- the lo block of dG is complete now: relative part of dQ and flush of dG^T
-            if (!upper)
+            // ---- the lo block of dG is complete now: relative part of dQ, and the block leaves as the dG^T tile
+            //      (qt, t = kt) [E row m][query]: the ring rows [q][m] are read back transposed (16-bit tier:
+            //      ds_read_b64_tr_b16, two 16-byte stores per lane) -- the E kernel streams these tiles as they are.
+            if (!upper) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                Frag<T> dgf;
-                const T* dlo = drow + (eb_lo & 1) * 32;
-                frag_load(dgf, dlo + 16 * t + 8 * h);
+                for (int t = 0; t < 2; ++t) {
+                    Frag<T> dgf;
+                    const T* dlo = drow + (eb_lo & 1) * 32;
+                    frag_load(dgf, dlo + 16 * t + 8 * h);
 #pragma unroll
-                for (int i = 0; i < C::DB; ++i) { if (ME_ABL != 3) mma32(dq[i], etf[i][t], dgf); }
+                    for (int i = 0; i < C::DB; ++i) { if (ME_ABL != 3) mma32(dq[i], etf[i][t], dgf); }
+                }
+                T* const dg_dst = dgb + dg_tile(q0 >> 5, kt) * 1024;
+                const T* ring = &Ds[wid][(eb_lo & 1) * 32];                  // lo block: ring rows q, 32 columns m, row stride LDR
+                if constexpr (ME_ABL == 9) {
+                } else if constexpr (sizeof(T) == 2) {
+                    typedef short v4s __attribute__((ext_vector_type(4)));
+                    const int gidx = lane >> 4, l16 = lane & 15;
+#pragma unroll
+                    for (int kh = 0; kh < 2; ++kh) {
+                        v4s x[2];
+#pragma unroll
+                        for (int s_ = 0; s_ < 2; ++s_) {
+                            const T* src = ring + (8 * gidx + 4 * s_ + (l16 >> 2)) * LDR + kh * 16 + 4 * (l16 & 3);
+                            x[s_] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)src);
+                        }
+                        chunk16 c;
+                        reinterpret_cast<v4s*>(&c)[0] = x[0];
+                        reinterpret_cast<v4s*>(&c)[1] = x[1];
+                        st_chunk(dg_dst + (size_t)(kh * 16 + l16) * 32 + 8 * gidx, c);     // row m = 16 kh + l16, queries 8 gidx .. + 7
+                    }
+                } else {
+#pragma unroll
+                    for (int it = 0; it < 16; ++it) {
+                        const int idx = it * 64 + lane, m = idx >> 5, qq = idx & 31;
+                        dg_dst[idx] = ring[qq * LDR + m];
+                    }
+                }
             }
         }
         if constexpr (MAIN) {
@@ -636,23 +682,25 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
 }
 
 // =====================================================================================
-// backward 2/3 (key-owned, streaming):  dV[key] = sum_q P^T[key][q] dO[q],  dK[key] = sum_q dS^T[key][q] Q[q]
+// backward 2/3 (key-owned):  dV[key] = sum_q P^T[key][q] dO[q],  dK[key] = sum_q dS^T[key][q] Q[q]
 // =====================================================================================
-// Block = 128 keys (4 waves x 32) x DH.  Every step stages a 32-query slab: P^T, dS^T tiles
-// [128 key][32 q] and dO^T, Q^T tiles [DH][32 q]; all four are contraction-contiguous, so the
-// fragments are plain 16-byte LDS reads.  The materialised tensors are read exactly once:
-// the kernel is HBM-bound (2 x Lp^2/2 elements per (b, head)).
-template <typename T, int DH, int NWK, bool CAUSAL = true>
-__global__ __launch_bounds__(NWK * 64) void rga_bwd_kv_kernel(const T* __restrict__ PT, const T* __restrict__ dST,
-                                                              const T* __restrict__ qkv, const T* __restrict__ dout,
-                                                              T* __restrict__ dqkv, int B, int L, int Lp, int H) {
-    // NWK waves x 32 keys per block.  8 waves (256 keys): the Q / dO slabs every block streams are fetched half as often
-    constexpr int CH = ET<T>::CH, LDP = 32 + CH, DB = ACfg<T, DH>::DB, LDV = ACfg<T, DH>::LDV;
-    constexpr int KB = NWK * 32, NTHR = NWK * 64;
+// Block = 128 keys (4 waves x 32) x DH.  Every step stages a 32-query slab: the P^T tiles [128 key][32 q], the dO and Q
+// slabs [32 q][DH] and -delta / sqrt(dh) of the 32 queries.  dS^T is NOT read from memory: with the wave's V rows resident
+// in registers, dP^T = V dO^T is KA macro-atoms and dS = P o (dP - delta) / sqrt(dh) a multiply-add per element (no
+// exponential, no relative-term skew: P already contains both) -- P^T is the only O(L^2) tensor this kernel streams.
+// dP is accumulated as dP[q][key] (lane = key column), so that its registers carry the same (key, 8 queries) elements
+// as the P^T fragment read with the accumulator's k-map; all contraction-over-q operands use that map.
+template <typename T, int DH, bool CAUSAL = true>
+__global__ __launch_bounds__(256) void rga_bwd_kv_kernel(const T* __restrict__ PT, const T* __restrict__ qkv,
+                                                         const T* __restrict__ dout, const float* __restrict__ delta_ws,
+                                                         T* __restrict__ dqkv, int B, int L, int Lp, int H, float scale) {
+    using C = ACfg<T, DH>;
+    constexpr int CH = ET<T>::CH, LDP = 32 + CH, DB = C::DB, LDV = C::LDV, KA = C::KA;
+    constexpr int KB = 128;
     __shared__ __attribute__((aligned(16))) T Pt[2][KB * LDP];
-    __shared__ __attribute__((aligned(16))) T St[2][KB * LDP];
-    __shared__ __attribute__((aligned(16))) T Os[2][32 * LDV];         // natural dO / Q slabs [32 q][DH], transpose-read
+    __shared__ __attribute__((aligned(16))) T Os[2][32 * LDV];         // natural dO / Q slabs [32 q][DH]
     __shared__ __attribute__((aligned(16))) T Qs[2][32 * LDV];
+    __shared__ __attribute__((aligned(16))) float Dl[2][32];           // -delta[q] / sqrt(dh)
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, a = lane & 31, h = lane >> 5;
     const int BH = B * H;
@@ -662,50 +710,54 @@ __global__ __launch_bounds__(NWK * 64) void rga_bwd_kv_kernel(const T* __restric
     const size_t ldq = (size_t)3 * dm;
     const int k0 = kb * KB + wid * 32;
     const bool wave_on = k0 < L;
-    const int nqt = (L + 31) / 32;
-    const int qs0 = CAUSAL ? kb * NWK : 0;                          // bidirectional: every query tile contributes
-    const int rows_valid = min(KB, Lp - kb * KB);
-    const T* pt_ = PT + (size_t)bh * Lp * Lp;
-    const T* st_ = dST + (size_t)bh * Lp * Lp;
+    const int nqt = (L + 31) / 32, nq32 = Lp >> 5;
+    const int qs0 = CAUSAL ? kb * 4 : 0;                            // bidirectional: every query tile contributes
+    const T* ptb = PT + (size_t)bh * pt_tiles(nq32, CAUSAL) * 1024;
     const T* q_ = qkv + (size_t)b * L * ldq + head * DH;
     const T* o_ = dout + (size_t)b * L * dm + head * DH;
+    const float* dl_ = delta_ws + (size_t)bh * L;
+
+    Frag<T> vf[KA];                                                 // V rows of this wave's 32 keys (B operand of dP)
+    row_frags<T, DH>(vf, q_ + 2 * dm + (size_t)(k0 + a) * ldq, wave_on && k0 + a < L, h);
 
     f32x16_t dk[DB], dv[DB];
 #pragma unroll
     for (int i = 0; i < DB; ++i) { acc_zero(dk[i]); acc_zero(dv[i]); }
 
-    constexpr int CPRP = 32 / CH, NPTP = KB * CPRP / NTHR;              // P^T / dS^T tile [KB][32]: chunks per thread
-    constexpr int CPRQ = DH / CH, NCHQ = 32 * CPRQ, NPTQ = (NCHQ + NTHR - 1) / NTHR;   // Q / dO slab [32][DH]
-    chunk16 rp[NPTP], rs[NPTP], ro[NPTQ], rq[NPTQ];
+    constexpr int CPRP = 32 / CH, NPTP = KB * CPRP / 256;              // P^T tiles [128][32]: chunks per thread
+    constexpr int CPRQ = DH / CH, NCHQ = 32 * CPRQ, NPTQ = (NCHQ + 255) / 256;   // Q / dO slab [32][DH]
+    chunk16 rp[NPTP], ro[NPTQ], rq[NPTQ];
+    float rd = 0.f;
     auto gload = [&](int qs) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NPTP; ++i) {
-            const int c = tid + i * NTHR, row = c / CPRP, cc = (c % CPRP) * CH;
-            const size_t o = ws_row(kb * KB + min(row, rows_valid - 1), qs, Lp) + cc;
-            rp[i] = row < rows_valid ? ld_chunk(pt_ + o) : zero_chunk();
-            rs[i] = row < rows_valid ? ld_chunk(st_ + o) : zero_chunk();
+            const int c = tid + i * 256, row = c / CPRP, cc = (c % CPRP) * CH;
+            const int kt = min(kb * 4 + (row >> 5), nq32 - 1);
+            // tiles above the diagonal do not exist in the packed triangle: clamped to the diagonal tile (never used)
+            rp[i] = ld_chunk(ptb + pt_tile(kt, CAUSAL ? max(qs, kt) : qs, nq32, CAUSAL) * 1024 + (row & 31) * 32 + cc);
         }
         const int qv = L - qs * 32;
 #pragma unroll
         for (int i = 0; i < NPTQ; ++i) {
-            const int c = tid + i * NTHR, row = c / CPRQ, cc = (c % CPRQ) * CH;
+            const int c = tid + i * 256, row = c / CPRQ, cc = (c % CPRQ) * CH;
             const bool ok = c < NCHQ && row < qv;
             ro[i] = ok ? ld_chunk(o_ + ((size_t)qs * 32 + row) * dm + cc) : zero_chunk();
             rq[i] = ok ? ld_chunk(q_ + ((size_t)qs * 32 + row) * ldq + cc) : zero_chunk();
         }
+        rd = dl_[min(qs * 32 + (tid & 31), L - 1)];
     };
     auto sstore = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NPTP; ++i) {
-            const int c = tid + i * NTHR, row = c / CPRP, cc = (c % CPRP) * CH;
+            const int c = tid + i * 256, row = c / CPRP, cc = (c % CPRP) * CH;
             st_chunk(&Pt[buf][row * LDP + cc], rp[i]);
-            st_chunk(&St[buf][row * LDP + cc], rs[i]);
         }
 #pragma unroll
         for (int i = 0; i < NPTQ; ++i) {
-            const int c = tid + i * NTHR, row = c / CPRQ, cc = (c % CPRQ) * CH;
+            const int c = tid + i * 256, row = c / CPRQ, cc = (c % CPRQ) * CH;
             if (c < NCHQ) { st_chunk(&Os[buf][row * LDV + cc], ro[i]); st_chunk(&Qs[buf][row * LDV + cc], rq[i]); }
         }
+        if (tid < 32) Dl[buf][tid] = -rd * scale;
     };
     gload(qs0);
     sstore(0);
@@ -714,16 +766,31 @@ __global__ __launch_bounds__(NWK * 64) void rga_bwd_kv_kernel(const T* __restric
     for (int qs = qs0; qs < nqt; ++qs) {
         const int buf = (qs - qs0) & 1;
         if (wave_on && (!CAUSAL || qs * 32 + 31 >= k0)) {
+            f32x16_t dp; acc_zero(dp);                              // dP[q][key] = dO[q] . V[key]
+#pragma unroll
+            for (int kk = 0; kk < KA; ++kk) {
+                Frag<T> of;
+                frag_load(of, &Os[buf][a * LDV + kk * 16 + h * 8]);
+                mma32(dp, of, vf[kk]);
+            }
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
+                // accumulator registers 8t .. 8t+7 of lane (key a, h) = queries 16t + 4h + {0..3} and 16t + 8 + 4h + {0..3}
+                const int qa = 16 * t + 4 * h, qb_ = qa + 8;
                 Frag<T> pf, sf;
-                frag_load(pf, &Pt[buf][(wid * 32 + a) * LDP + 16 * t + 8 * h]);
-                frag_load(sf, &St[buf][(wid * 32 + a) * LDP + 16 * t + 8 * h]);
+                frag_load_4x2(pf, &Pt[buf][(wid * 32 + a) * LDP + qa], &Pt[buf][(wid * 32 + a) * LDP + qb_]);
+                const f32x4_t da = *reinterpret_cast<const f32x4_t*>(&Dl[buf][qa]);
+                const f32x4_t db_ = *reinterpret_cast<const f32x4_t*>(&Dl[buf][qb_]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float nd = e < 4 ? da[e] : db_[e - 4];
+                    frag_set(sf, e, frag_get(pf, e) * fmaf(dp[8 * t + e], scale, nd));
+                }
 #pragma unroll
                 for (int i = 0; i < DB; ++i) {
                     Frag<T> of, qf;
-                    frag_load_tr(of, Os[buf], LDV, 16 * t + 8 * h, 16 * t + 8 * h + 4, i * 32, lane);     // dO^T[d][q]
-                    frag_load_tr(qf, Qs[buf], LDV, 16 * t + 8 * h, 16 * t + 8 * h + 4, i * 32, lane);     // Q^T[d][q]
+                    frag_load_tr(of, Os[buf], LDV, qa, qb_, i * 32, lane);     // dO^T[d][q], accumulator k-map
+                    frag_load_tr(qf, Qs[buf], LDV, qa, qb_, i * 32, lane);     // Q^T[d][q]
                     mma32(dv[i], pf, of);
                     mma32(dk[i], sf, qf);
                 }
@@ -733,7 +800,7 @@ __global__ __launch_bounds__(NWK * 64) void rga_bwd_kv_kernel(const T* __restric
             sstore(buf ^ 1);
             if (qs + 2 < nqt) gload(qs + 2);
         }
-        block_sync_lds();               // LDS hand-over only: prefetch loads / tile stores stay in flight
+        block_sync_lds();               // LDS hand-over only: prefetch loads stay in flight
     }
     if (!wave_on) return;
 #pragma unroll
@@ -750,22 +817,20 @@ __global__ __launch_bounds__(NWK * 64) void rga_bwd_kv_kernel(const T* __restric
 }
 
 // =====================================================================================
-// backward 3/3 (E-row-owned, streaming):  dE[e][d] += sum_{bh, q} dG^T[bh][c(e)][q] Q^T[bh][d][q]
+// backward 3/3 (E-row-owned, streaming):  dE[e][d] += sum_{bh, q} dG^T[bh][e][q] Q[bh][q][d]
 // =====================================================================================
-// dG is dS re-indexed: dG^T[c][q] = dS^T[key][q] with key = c - (Lp - 1) + q (c = e - (M - Lp)).  The kernel
-// therefore reads the dS^T workspace the query kernel writes for dK anyway and applies the shear while
-// staging: a [128 c][32 q] operand tile is the band of 159 dS^T rows key = kb + kk (kb = c0 - Lp + 1 + 32 qs)
-// with element (kk, qq) landing at tile row kk - qq.  The band arrives as natural 16-byte row chunks and is
-// scattered element-wise into LDS (the kernel is HBM bound with 4 MFMAs per step, the extra LDS stores are
-// free) -- this removed the separate dG^T workspace: 268 MB written and read per layer.
+// The query kernel left dG^T as tiles (query tile qt, step t) = E block cb = Lp/32 - 1 - qt + t (relative to row
+// M - Lp), rows = E row, columns = query: a [128 c][32 q] operand tile of column-block group gx and query slab qs is
+// the four consecutive tiles t0 .. t0 + 3, t0 = 4 gx - (Lp/32 - 1) + qs (8 KB contiguous where they exist; tiles with
+// t < 0 or t > qs do not exist and count as zero).  Plain 16-byte chunk traffic: the kernel is HBM bound.
 // Block = 128 rows c (4 waves x 32) x DH, one split of the (b, head) range; register accumulation over
 // (bh, q) and one atomic flush per block.  Column block cb only receives queries
 // q >= 32*(Lp/32 - 1 - cb); earlier slabs are skipped.
 template <typename T, int DH>
-__global__ __launch_bounds__(256) void rga_bwd_e_kernel(const T* __restrict__ dST, const T* __restrict__ qkv,
+__global__ __launch_bounds__(256) void rga_bwd_e_kernel(const T* __restrict__ dGT, const T* __restrict__ qkv,
                                                         float* __restrict__ dE, int B, int L, int Lp, int H, int M) {
     constexpr int CH = ET<T>::CH, LDP = 32 + CH, DB = ACfg<T, DH>::DB, LDV = ACfg<T, DH>::LDV;
-    __shared__ __attribute__((aligned(16))) T Gt[2][(128 + 16) * LDP];  // + 16 dump rows: out-of-tile band elements are stored there, not branched around
+    __shared__ __attribute__((aligned(16))) T Gt[2][128 * LDP];
     __shared__ __attribute__((aligned(16))) T Qs[2][32 * LDV];         // natural Q slab [32 q][DH], transpose-read
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, a = lane & 31, h = lane >> 5;
@@ -803,24 +868,23 @@ __global__ __launch_bounds__(256) void rga_bwd_e_kernel(const T* __restrict__ dS
 #pragma unroll
     for (int i = 0; i < DB; ++i) acc_zero(acc[i]);
 
-    using BandT = TileT<T, 160, 32>;                    // 159 band rows (+1 pad) x 32 queries, CPR chunks per row
-    chunk16 rg[BandT::NPT], rq[TileT<T, 32, DH>::NPT];
-    bool rgv[BandT::NPT];                               // band row inside the workspace?  applied when the chunk is sheared into LDS
+    using GT = TileT<T, 128, 32>;                       // four dG^T tiles [32 c][32 q]
+    chunk16 rg[GT::NPT], rq[TileT<T, 32, DH>::NPT];
+    bool rgv[GT::NPT];                                  // tile exists?  applied when the chunk is stored into LDS
     const int dm = H * DH;
     const size_t ldq = (size_t)3 * dm;
-    // No branch encloses a global load or an LDS store in the steady state: rows are clamped, invalid band rows
-    // are zeroed by a select at shear time and out-of-tile elements go to dump rows (exact s_waitcnt bookkeeping,
-    // no exec-mask branch per element).
+    const size_t dg_bh = pt_tiles(ncb, true) * 1024;
+    // No branch encloses a global load or an LDS store in the steady state: tile indices are clamped, non-existent
+    // tiles are zeroed by a select when they are stored (exact s_waitcnt bookkeeping).
     auto gload = [&](int s) __attribute__((always_inline)) {
         const int bh = bh_lo + s / nq, qs = qs0 + s % nq;
-        const int kb = c0 - Lp + 1 + qs * 32;            // key of tile element (row 0, column 0)
-        const T* src = dST + (size_t)bh * Lp * Lp;
+        const T* src = dGT + (size_t)bh * dg_bh;
 #pragma unroll
-        for (int i = 0; i < BandT::NPT; ++i) {
-            const int c = min(tid + i * 256, BandT::NCH - 1), kk = c / BandT::CPR, cc = (c % BandT::CPR) * CH;
-            const int key = kb + kk;
-            rgv[i] = kk < 159 && key >= 0 && key < Lp;
-            rg[i] = ld_chunk(src + ws_row(min(max(key, 0), Lp - 1), qs, Lp) + cc);
+        for (int i = 0; i < GT::NPT; ++i) {
+            const int c = tid + i * 256, row = c / GT::CPR, cc = (c % GT::CPR) * CH;
+            const int cb = gx * 4 + (row >> 5), t = cb - (ncb - 1) + qs;
+            rgv[i] = cb < ncb && t >= 0 && t <= qs;
+            rg[i] = ld_chunk(src + dg_tile(qs, min(max(t, 0), qs)) * 1024 + (row & 31) * 32 + cc);
         }
         const T* qsrc = qkv + ((size_t)(bh / H) * L + qs * 32) * ldq + (bh % H) * DH;
         using QT = TileT<T, 32, DH>;
@@ -831,17 +895,10 @@ __global__ __launch_bounds__(256) void rga_bwd_e_kernel(const T* __restrict__ dS
         }
     };
     auto sstore = [&](int buf) __attribute__((always_inline)) {
-        // shear: band element (kk, qq) -> tile row kk - qq; every tile element is written exactly once per step
 #pragma unroll
-        for (int i = 0; i < BandT::NPT; ++i) {
-            const int c = tid + i * 256, kk = c / BandT::CPR, cc = (c % BandT::CPR) * CH;
-            const T* v = reinterpret_cast<const T*>(&rg[i]);
-#pragma unroll
-            for (int e = 0; e < CH; ++e) {
-                const int cl = kk - cc - e;
-                const int row = (cl >= 0 && cl < 128) ? cl : 128 + (kk & 15);     // threads past the band (kk >= 160) land in the dump rows too
-                Gt[buf][row * LDP + cc + e] = rgv[i] ? v[e] : ET<T>::from_f(0.f);
-            }
+        for (int i = 0; i < GT::NPT; ++i) {
+            const int c = tid + i * 256, row = c / GT::CPR, cc = (c % GT::CPR) * CH;
+            st_chunk(&Gt[buf][row * LDP + cc], rgv[i] ? rg[i] : zero_chunk());
         }
         tile_sstore<T, 32, DH, LDV>(rq, Qs[buf], tid);
     };
@@ -923,39 +980,26 @@ int fwd_launch(const void* qkv, const void* Epk, const uint8_t* key_pad, void* o
 
 template <typename T, int DH>
 int bwd_launch(const void* qkv, const void* Epk, const uint8_t* key_pad, const void* out, const float* lse,
-               const void* dout, void* dqkv, float* dE, float* delta_ws, void* PT, void* dST, int B, int L,
+               const void* dout, void* dqkv, float* dE, float* delta_ws, void* PT, void* dGT, int B, int L,
                int Lp, int H, int M, int causal, hipStream_t st) {
     const int nqb = (L + 127) / 128;
     const float scale = 1.f / sqrtf((float)DH);
     if (causal)
         rga_bwd_q_kernel<T, DH, true><<<B * H * nqb, 256, 0, st>>>((const T*)qkv, (const T*)Epk, key_pad, (const T*)out, lse,
-                                                                  (const T*)dout, (T*)dqkv, delta_ws, (T*)PT, (T*)dST, B, L, Lp,
+                                                                  (const T*)dout, (T*)dqkv, delta_ws, (T*)PT, (T*)dGT, B, L, Lp,
                                                                   H, M, scale);
     else
         rga_bwd_q_kernel<T, DH, false><<<B * H * nqb, 256, 0, st>>>((const T*)qkv, (const T*)Epk, key_pad, (const T*)out, lse,
-                                                                   (const T*)dout, (T*)dqkv, delta_ws, (T*)PT, (T*)dST, B, L, Lp,
+                                                                   (const T*)dout, (T*)dqkv, delta_ws, (T*)PT, (T*)dGT, B, L, Lp,
                                                                    H, M, scale);
     int rc = me_launch_status();
     if (rc) return rc;
-    // 256-key blocks (MIDIEMO_KV8=1, 16-bit tier) fetch the Q / dO slabs half as often, but measured over several runs on
-    // one box they are not faster (128-key: 168 / 176 / 173 us, 256-key: 187 / 199 / 172 us at C2): off by default
-    static const int kv8 = getenv("MIDIEMO_KV8") ? atoi(getenv("MIDIEMO_KV8")) : 0;
-    bool big = false;
-    if constexpr (sizeof(T) == 2) {
-        if (kv8 && causal) {
-            big = true;
-            rga_bwd_kv_kernel<T, DH, 8, true><<<B * H * ((L + 255) / 256), 512, 0, st>>>((const T*)PT, (const T*)dST, (const T*)qkv,
-                                                                                        (const T*)dout, (T*)dqkv, B, L, Lp, H);
-        }
-    }
-    if (!big) {
-        if (causal)
-            rga_bwd_kv_kernel<T, DH, 4, true><<<B * H * nqb, 256, 0, st>>>((const T*)PT, (const T*)dST, (const T*)qkv, (const T*)dout,
-                                                                          (T*)dqkv, B, L, Lp, H);
-        else
-            rga_bwd_kv_kernel<T, DH, 4, false><<<B * H * nqb, 256, 0, st>>>((const T*)PT, (const T*)dST, (const T*)qkv, (const T*)dout,
-                                                                           (T*)dqkv, B, L, Lp, H);
-    }
+    if (causal)
+        rga_bwd_kv_kernel<T, DH, true><<<B * H * nqb, 256, 0, st>>>((const T*)PT, (const T*)qkv, (const T*)dout, delta_ws, (T*)dqkv,
+                                                                   B, L, Lp, H, scale);
+    else
+        rga_bwd_kv_kernel<T, DH, false><<<B * H * nqb, 256, 0, st>>>((const T*)PT, (const T*)qkv, (const T*)dout, delta_ws, (T*)dqkv,
+                                                                    B, L, Lp, H, scale);
     rc = me_launch_status();
     if (rc) return rc;
     const int ngx = (Lp + 127) / 128;
@@ -964,7 +1008,7 @@ int bwd_launch(const void* qkv, const void* Epk, const uint8_t* key_pad, const v
     int eblocks = 1536;
     if (eblocks > ngx * B * H) eblocks = ngx * B * H;
     if (eblocks < ngx) eblocks = ngx;
-    rga_bwd_e_kernel<T, DH><<<eblocks, 256, 0, st>>>((const T*)dST, (const T*)qkv, dE, B, L, Lp, H, M);
+    rga_bwd_e_kernel<T, DH><<<eblocks, 256, 0, st>>>((const T*)dGT, (const T*)qkv, dE, B, L, Lp, H, M);
     return me_launch_status();
 }
 
@@ -1004,16 +1048,16 @@ int me_rga_fwd(const void* qkv, const void* Epk, const uint8_t* key_pad, void* o
 }
 
 int me_rga_bwd(const void* qkv, const void* Epk, const uint8_t* key_pad, const void* out, const float* lse,
-               const void* dout, void* dqkv, float* dE, float* delta_ws, void* PT, void* dST, int B, int L,
+               const void* dout, void* dqkv, float* dE, float* delta_ws, void* PT, void* dGT, int B, int L,
                int Lp, int H, int dh, int M, int causal, int dtype, void* stream) {
     me_clear_error();
-    if (!qkv || !Epk || !out || !lse || !dout || !dqkv || !dE || !delta_ws || !PT || !dST) return ME_ERR_NULL;
+    if (!qkv || !Epk || !out || !lse || !dout || !dqkv || !dE || !delta_ws || !PT || !dGT) return ME_ERR_NULL;
     if (B <= 0 || L <= 0 || H <= 0 || L > M || (M & 31) || (Lp & 31) || Lp < L || Lp > M) return ME_ERR_BAD_SHAPE;
     if (!aligned16(qkv) || !aligned16(Epk) || !aligned16(out) || !aligned16(dout) || !aligned16(dqkv) ||
-        !aligned16(PT) || !aligned16(dST))
+        !aligned16(PT) || !aligned16(dGT))
         return ME_ERR_ALIGNMENT;
     hipStream_t st = (hipStream_t)stream;
-    ME_ATTN_DISPATCH((bwd_launch<T, DH>(qkv, Epk, key_pad, out, lse, dout, dqkv, dE, delta_ws, PT, dST, B, L, Lp, H, M,
+    ME_ATTN_DISPATCH((bwd_launch<T, DH>(qkv, Epk, key_pad, out, lse, dout, dqkv, dE, delta_ws, PT, dGT, B, L, Lp, H, M,
                                         causal, st)))
 }
 

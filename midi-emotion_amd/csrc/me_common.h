@@ -101,6 +101,8 @@ ME_DEV void frag_zero(Frag<bf16_t>& f) { f.v = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0
 ME_DEV void frag_zero(Frag<float>& f) { f.lo = (f32x4_t){0, 0, 0, 0}; f.hi = f.lo; }
 ME_DEV void frag_set(Frag<bf16_t>& f, int e, float x) { f.v[e] = (bf16_t)x; }
 ME_DEV void frag_set(Frag<float>& f, int e, float x) { if (e < 4) f.lo[e] = x; else f.hi[e - 4] = x; }
+ME_DEV float frag_get(const Frag<bf16_t>& f, int e) { return (float)f.v[e]; }
+ME_DEV float frag_get(const Frag<float>& f, int e) { return e < 4 ? f.lo[e] : f.hi[e - 4]; }
 
 // accumulator registers [8*t .. 8*t+7] -> operand fragment (k map = c_row of those registers)
 ME_DEV void frag_from_acc(Frag<bf16_t>& f, const f32x16_t& a, int t) {

@@ -1092,6 +1092,13 @@ static size_t tn_ws_bytes(int Tn, int N, int K, int lda_min) {
 
 size_t me_workspace_bytes(int op, int M, int N, int K, int dtype) {
     if (op == ME_WS_GEMM_TN) return dtype == ME_BF16 ? tn_ws_bytes(M, N, K, 0) : 0;
+    if (op == ME_WS_RGA_PT || op == ME_WS_RGA_DGT) {
+        // 32 x 32 tiles of the compute type per (batch, head): M = B*H, N = Lp (multiple of 32), K = causal flag
+        if (M <= 0 || N <= 0 || (N & 31)) return 0;
+        const size_t nq = (size_t)N / 32, es = dtype == ME_BF16 ? 2 : 4;
+        const size_t tiles = (op == ME_WS_RGA_DGT || K) ? nq * (nq + 1) / 2 : nq * nq;
+        return (size_t)M * tiles * 1024 * es;
+    }
     return 0;
 }
 

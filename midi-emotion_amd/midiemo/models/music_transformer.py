@@ -372,10 +372,9 @@ class MusicTransformerHIP(nn.Module):
             ws.dA, ws.dB, ws.dC, ws.dC2 = e(T, d), e(T, d), e(T, d), e(T, d)
             ws.dhid, ws.dqkv = e(T, di), e(T, 3 * d)
             ws.delta = e(B, H, Lm, dtype=torch.float32)
-            # materialised P^T, dS^T, dG^T of the layer being differentiated (zero-initialised once:
-            # only on/below-diagonal tiles are ever written or read)
-            ws.PT = torch.zeros(B * H, Lp, Lp, dtype=dt, device=dev)
-            ws.dST = torch.zeros(B * H, Lp, Lp, dtype=dt, device=dev)
+            # tiles of P^T and of the skewed dS (dG^T) of the layer being differentiated (me_workspace_bytes; no
+            # initialisation contract: every tile is written before it is read)
+            ws.PT, ws.dGT = ops.rga_bwd_workspaces(B, H, Lp, dt, dev, causal=self.causal)
         self._ws[key] = ws
         return ws
 
@@ -503,7 +502,7 @@ class MusicTransformerHIP(nn.Module):
             if bucket_hook:
                 bucket_hook(-1)            # comm window: ~0.5 ms of attention-backward kernels follow (ddp.GradAllReducer)
             ops.rga_bwd(Lw.qkv, W["Epk"], ws.key_pad if self.causal else None, Lw.att, Lw.lse, ws.dA, ws.dqkv,
-                        gv(p + "rga.E"), ws.delta, ws.PT, ws.dST, B, Lm, ws.Lp, H, dh, M, causal=self.causal)
+                        gv(p + "rga.E"), ws.delta, ws.PT, ws.dGT, B, Lm, ws.Lp, H, dh, M, causal=self.causal)
             o, _, _ = self._slices[p + "rga.Wq.weight"]
             ob, _, _ = self._slices[p + "rga.Wq.bias"]
             wgrad("dqkv", ws.dqkv, x, gflat[o:o + 3 * d * d].view(3 * d, d), gflat[ob:ob + 3 * d], T=T, N=3 * d, K=d,

@@ -7,7 +7,7 @@ import torch
 
 from . import _lib
 from ._lib import (ME_BF16, ME_COND_CONCAT, ME_COND_NONE, ME_COND_TOKEN, ME_EPI_OUT_F32, ME_EPI_RELU,
-                   ME_EPI_RELU_BWD, ME_F32, ME_WS_GEMM_TN, check)
+                   ME_EPI_RELU_BWD, ME_F32, ME_WS_GEMM_TN, ME_WS_RGA_DGT, ME_WS_RGA_PT, check)
 
 DTYPE_CODE = {torch.float32: ME_F32, torch.bfloat16: ME_BF16}
 
@@ -134,9 +134,21 @@ def rga_fwd(qkv, Epk, key_pad, out, lse, B, L, H, dh, M, causal=True):
                            _code(qkv.dtype), _stream()), "me_rga_fwd")
 
 
-def rga_bwd(qkv, Epk, key_pad, out, lse, dout, dqkv, dE, delta_ws, PT, dST, B, L, Lp, H, dh, M, causal=True):
+def rga_bwd_workspaces(B, H, Lp, dtype, device, causal=True):
+    """(PT, dGT): uninitialised tile workspaces of me_rga_bwd, sized by me_workspace_bytes."""
+    es = torch.empty(0, dtype=dtype).element_size()
+    n_pt = workspace_bytes(ME_WS_RGA_PT, B * H, Lp, 1 if causal else 0, dtype) // es
+    n_dg = workspace_bytes(ME_WS_RGA_DGT, B * H, Lp, 0, dtype) // es
+    return torch.empty(n_pt, dtype=dtype, device=device), torch.empty(n_dg, dtype=dtype, device=device)
+
+
+def rga_bwd(qkv, Epk, key_pad, out, lse, dout, dqkv, dE, delta_ws, PT, dGT, B, L, Lp, H, dh, M, causal=True):
+    es = PT.element_size()
+    if (PT.numel() * es < workspace_bytes(ME_WS_RGA_PT, B * H, Lp, 1 if causal else 0, qkv.dtype) or
+            dGT.numel() * es < workspace_bytes(ME_WS_RGA_DGT, B * H, Lp, 0, qkv.dtype)):
+        raise RuntimeError("rga_bwd: PT / dGT workspace smaller than me_workspace_bytes")
     check(lib().me_rga_bwd(_ptr(qkv), _ptr(Epk), _ptr(key_pad), _ptr(out), _ptr(lse), _ptr(dout), _ptr(dqkv),
-                           _ptr(dE), _ptr(delta_ws), _ptr(PT), _ptr(dST), B, L, Lp, H, dh, M, 1 if causal else 0,
+                           _ptr(dE), _ptr(delta_ws), _ptr(PT), _ptr(dGT), B, L, Lp, H, dh, M, 1 if causal else 0,
                            _code(qkv.dtype), _stream()), "me_rga_bwd")
 
 

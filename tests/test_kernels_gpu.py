@@ -470,8 +470,10 @@ def run_attn(ops, dtype, q, k, v, E, dO, pad, backward=True, causal=True):
         dqkv = torch.full_like(qkv, float("nan"))
         dE = torch.zeros(M, dh, dtype=torch.float32, device=DEV)
         delta = torch.empty(B, H, L, dtype=torch.float32, device=DEV)
-        PT, dST = (torch.zeros(B * H, Lp, Lp, dtype=dtype, device=DEV) for _ in range(2))
-        ops.rga_bwd(qkv, Epk, kp, out, lse, dout, dqkv, dE, delta, PT, dST, B, L, Lp, H, dh, M, causal=causal)
+        PT, dGT = ops.rga_bwd_workspaces(B, H, Lp, dtype, DEV, causal=causal)
+        PT.fill_(float("nan"))                          # no initialisation contract: every tile read was written in the same call
+        dGT.fill_(float("nan"))
+        ops.rga_bwd(qkv, Epk, kp, out, lse, dout, dqkv, dE, delta, PT, dGT, B, L, Lp, H, dh, M, causal=causal)
         g = dqkv.float().cpu().permute(2, 0, 3, 1, 4)   # [3,B,H,L,dh]
         res.update(dq=g[0], dk=g[1], dv=g[2], dE=dE.cpu())
     return res

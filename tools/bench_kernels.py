@@ -45,7 +45,7 @@ def main():
         dqkv = torch.empty_like(qkv)
         dE = torch.zeros(M, dh, device=dev)
         delta = torch.empty(B, H, L, device=dev)
-        PT, dST = (torch.zeros(B * H, Lp, Lp, device=dev, dtype=dt) for _ in range(2))
+        PT, dST = ops.rga_bwd_workspaces(B, H, Lp, dt, dev)
         kp = torch.zeros(B, L, dtype=torch.uint8, device=dev)
         flop = 3 * 2 * B * H * dh * L * (L + 1) / 2
         t = timeit(lambda: ops.rga_fwd(qkv, Epk, kp, out, lse, B, L, H, dh, M), a.iters)
@@ -66,7 +66,7 @@ def main():
         dqkv2 = torch.empty_like(qkv)
         delta = torch.empty(B, H, L, device=dev)
         kp = torch.zeros(B, L, dtype=torch.uint8, device=dev)
-        PT, dST = (torch.zeros(B * H, Lp, Lp, device=dev, dtype=dt) for _ in range(2))
+        PT, dST = ops.rga_bwd_workspaces(B, H, Lp, dt, dev)
         dE = torch.zeros(M, dh, device=dev)
         t = timeit(lambda: ops.rga_bwd(qkv, Epk, kp, out, lse, dout, dqkv, dE, delta, PT, dST, B, L, Lp, H, dh, M), a.iters)
         print("rga_bwd one call, workspace %4d MB x3      %9.1f us" % (PT.numel() * 2 // 2**20, t))
@@ -106,7 +106,9 @@ def main():
             X = torch.randn(T, K_, device=dev).to(dt)
             dW = torch.zeros(N_, K_, device=dev)
             db = torch.zeros(N_, device=dev)
-            t = timeit(lambda: ops.gemm_tn_acc(A, X, dW, db), a.iters)
+            need = ops.workspace_bytes(ops.ME_WS_GEMM_TN, T, N_, K_, dt)
+            ws = torch.empty(need, dtype=torch.uint8, device=dev) if need else None
+            t = timeit(lambda: ops.gemm_tn_acc(A, X, dW, db, ws=ws), a.iters)
             print("gemm_tn %-5s T%d N%d K%d %9.1f us  %7.1f TF" % (tag, T, N_, K_, t, 2.0 * T * N_ * K_ / t / 1e6))
             if "blaslt" in a.what:
                 At = A.t()
