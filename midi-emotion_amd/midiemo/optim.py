@@ -51,6 +51,29 @@ class FusedAdamW:
         return {"m": self.m, "v": self.v, "step": self.step_count, "lr": self.param_groups[0]["lr"]}
 
     def load_state_dict(self, sd):
+        """Own format ({"m", "v", "step", "lr"}) or a torch.optim.Adam state_dict as the reference writes it
+        (train.py:403: {"state": {i: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [...]}): the per-parameter
+        moments are copied into the flat buffers in the optimiser's parameter order (= model.parameters())."""
+        if "state" in sd and "param_groups" in sd:
+            params = list(self.model.parameters())
+            idx = [i for g in sd["param_groups"] for i in g["params"]]
+            if len(idx) != len(params):
+                raise ValueError("torch Adam state has %d parameters, the model %d" % (len(idx), len(params)))
+            names = {id(p): n for n, p in self.model.named_parameters()}
+            step = 0
+            for i, p in zip(idx, params):
+                st = sd["state"].get(i)
+                if st is None:
+                    continue
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError("torch Adam state of parameter %d has shape %s, %s has %s" %
+                                     (i, tuple(st["exp_avg"].shape), names[id(p)], tuple(p.shape)))
+                self.model._pview(self.m, names[id(p)]).copy_(st["exp_avg"])
+                self.model._pview(self.v, names[id(p)]).copy_(st["exp_avg_sq"])
+                step = max(step, int(st["step"]))
+            self.step_count = step
+            self.param_groups[0]["lr"] = sd["param_groups"][0].get("lr", self.lr)
+            return
         self.m.copy_(sd["m"])
         self.v.copy_(sd["v"])
         self.step_count = int(sd["step"])

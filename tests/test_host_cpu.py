@@ -182,3 +182,64 @@ def test_midi_writer_round_trip_and_reference_semantics():
     assert tracks["drums"]["notes"] == [(tk(0.4), tk(1.504), 36, VELOCITIES["DRUMS"])]
     assert tracks["strings"]["notes"] == [(tk(0.504), tk(1.504), 72, VELOCITIES["STRINGS"])]
     assert tracks["guitar"]["notes"] == [] and tracks["bass"]["notes"] == []
+
+
+def test_lr_schedules_follow_torch_schedulers():
+    """train.py's LRSchedule (reference train.py:128-139,326-333,433-434): `cyclic` and `dev_perf` must produce exactly the
+    learning rates of torch's CyclicLR / ReduceLROnPlateau (the classes the reference constructs), `constant` must leave a
+    restored lr alone, warm-up is linear in the step."""
+    sys.path.insert(0, ROOT)
+    import train
+
+    class Opt:
+        def __init__(self, lr):
+            self.param_groups = [{"lr": lr}]
+
+    # cyclic: base = lr_min (config.py:145-146 sets lr = lr_min), warm-up 3 steps, then one scheduler.step() per step
+    a = train.parse_args(["--scheduler", "cyclic", "--lr_min", "1e-5", "--lr_max", "1e-3", "--warmup_step", "3"])
+    assert a.lr == 1e-5
+    opt = Opt(a.lr)
+    s = train.LRSchedule(a, opt)
+    ref_opt = torch.optim.SGD([torch.zeros(1, requires_grad=True)], lr=a.lr)
+    ref = torch.optim.lr_scheduler.CyclicLR(ref_opt, a.lr_min, a.lr_max, cycle_momentum=False)
+    got, want = [], []
+    for step in range(1, 40):
+        s.on_step(step)
+        got.append(opt.param_groups[0]["lr"])
+        if step <= a.warmup_step:
+            want.append(a.lr * step / a.warmup_step)
+        else:
+            ref_opt.step()
+            ref.step()
+            want.append(ref_opt.param_groups[0]["lr"])
+    assert got == pytest.approx(want, rel=1e-12)
+    assert got[-1] > got[5] > a.lr_min                       # the triangle is rising (step_size_up = 2000)
+
+    # dev_perf: stepped with the validation loss at evaluations only
+    a = train.parse_args(["--scheduler", "dev_perf", "--lr", "1e-3", "--decay_rate", "0.5", "--patience", "1", "--lr_min", "2e-4"])
+    opt = Opt(a.lr)
+    s = train.LRSchedule(a, opt)
+    ref_opt = torch.optim.SGD([torch.zeros(1, requires_grad=True)], lr=a.lr)
+    ref = torch.optim.lr_scheduler.ReduceLROnPlateau(ref_opt, factor=0.5, patience=1, min_lr=2e-4)
+    for step, v in enumerate([3.0, 2.5, 2.6, 2.7, 2.8, 2.9, 3.0, 3.1, 3.2], 1):
+        s.on_step(step)                                      # no per-step effect
+        s.on_eval(v)
+        ref.step(v)
+        assert opt.param_groups[0]["lr"] == ref_opt.param_groups[0]["lr"]
+    assert opt.param_groups[0]["lr"] == pytest.approx(2.5e-4) or opt.param_groups[0]["lr"] == pytest.approx(2e-4)
+
+    # constant: a restored learning rate survives (only --overwrite_lr changes it)
+    a = train.parse_args(["--scheduler", "constant", "--lr", "2e-5"])
+    opt = Opt(7e-6)
+    s = train.LRSchedule(a, opt)
+    for step in range(1, 5):
+        s.on_step(step)
+    assert opt.param_groups[0]["lr"] == 7e-6
+    # cosine / inv_sqrt closed forms with warm-up
+    a = train.parse_args(["--scheduler", "cosine", "--lr", "1e-3", "--warmup_step", "10", "--max_step", "100"])
+    opt = Opt(a.lr)
+    s = train.LRSchedule(a, opt)
+    s.on_step(5)
+    assert opt.param_groups[0]["lr"] == pytest.approx(5e-4)
+    s.on_step(100)
+    assert opt.param_groups[0]["lr"] == pytest.approx(0.0, abs=1e-12)

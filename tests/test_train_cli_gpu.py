@@ -163,3 +163,71 @@ def test_train_cli_exhaustive_eval(tmp_path, capsys):
     line = [l for l in out.splitlines() if l.startswith("Exhaustive evaluation")]
     assert len(line) == 1 and "top1" in line[0] and "| step" not in out, out
     assert 0 < float(line[0].split("Loss:")[1].split(",")[0]) < 8
+
+
+def test_restart_writes_a_fresh_dir_and_accepts_reference_optimizer_state(tmp_path, capsys):
+    """a restart must not overwrite the checkpoint it resumes from; stats.pt and optimizer.pt are
+    restored independently; an optimizer.pt in the REFERENCE's format (torch.optim.Adam state_dict, train.py:403) is
+    converted into the fused optimiser's flat moments; a checkpoint built for another vocabulary is refused."""
+    import time
+    import train
+    from midiemo.models.build_model import build_model
+    from midiemo.optim import FusedAdamW
+    argv = ["--conditioning", "none", "--n_layer", "1", "--d_model", "64", "--n_head", "2", "--d_inner", "128",
+            "--tgt_len", "64", "--batch_size", "2", "--lr", "1e-3", "--log_step", "5", "--eval_step", "1000",
+            "--gen_step", "1000", "--work_dir", str(tmp_path), "--dropout", "0.0", "--seed", "1"]
+    train.main(argv + ["--max_step", "5"])
+    run = os.listdir(tmp_path)[0]
+    before = {f: os.path.getmtime(tmp_path / run / f) for f in os.listdir(tmp_path / run)}
+    # replace optimizer.pt by a reference-format torch.optim.Adam state_dict with recognisable moments
+    cfg = torch.load(tmp_path / run / "model_config.pt")
+    model, _ = build_model(None, load_config_dict=cfg)
+    tadam = torch.optim.Adam(model.parameters(), lr=3e-4)
+    for i, p in enumerate(model.parameters()):
+        p.grad = torch.full_like(p, 0.01 * (i + 1))
+    tadam.step()
+    torch.save(tadam.state_dict(), tmp_path / run / "optimizer.pt")
+    model = model.cuda()
+    opt = FusedAdamW(model)
+    opt.load_state_dict(torch.load(tmp_path / run / "optimizer.pt", map_location="cuda"))
+    assert opt.step_count == 1 and opt.param_groups[0]["lr"] == 3e-4
+    for i, (n, p) in enumerate(model.named_parameters()):
+        assert torch.allclose(model._pview(opt.m, n), torch.full_like(p, 0.1 * 0.01 * (i + 1)), rtol=1e-5), n
+        assert torch.allclose(model._pview(opt.v, n), torch.full_like(p, 0.001 * (0.01 * (i + 1)) ** 2), rtol=1e-5), n
+    before["optimizer.pt"] = os.path.getmtime(tmp_path / run / "optimizer.pt")
+    capsys.readouterr()
+    time.sleep(1.1)                                         # work_dir names have one-second resolution
+    train.main(argv + ["--max_step", "10", "--restart_dir", run])
+    out = capsys.readouterr().out
+    assert "step       10" in out and "not restored" not in out
+    runs = sorted(os.listdir(tmp_path))
+    assert len(runs) == 2
+    new = [r for r in runs if r != run][0]
+    assert {f: os.path.getmtime(tmp_path / run / f) for f in before} == before          # the source checkpoint is untouched
+    assert torch.load(tmp_path / new / "stats.pt")["step"] == 10
+    import csv
+    rows = list(csv.DictReader(open(tmp_path / new / "performance.csv")))
+    assert [int(r["step"]) for r in rows] == [5, 10]                                     # the table continues
+    # constant scheduler: the restored lr (3e-4 from the torch state) is kept, --lr is not re-imposed
+    assert float(rows[-1]["lr"]) == pytest.approx(3e-4)
+    with pytest.raises(SystemExit, match="disagrees"):
+        train.main(argv[:1] + ["discrete_token"] + argv[2:] + ["--max_step", "12", "--restart_dir", run])
+
+
+def test_in_training_sample_generation(tmp_path, capsys):
+    """--gen_step (train.py:335-373): every gen_step steps rank 0 generates the four fixed conditions into
+    <work_dir>/generations/training with the KV-cached decoder, then training continues."""
+    import train
+    argv = ["--conditioning", "continuous_concat", "--n_layer", "1", "--d_model", "64", "--n_head", "2", "--d_inner", "128",
+            "--d_condition", "16", "--tgt_len", "64", "--batch_size", "2", "--lr", "1e-3", "--max_step", "6", "--log_step", "3",
+            "--eval_step", "1000", "--gen_step", "3", "--gen_len", "24", "--work_dir", str(tmp_path), "--seed", "2"]
+    train.main(argv)
+    out = capsys.readouterr().out
+    assert "step        6" in out
+    run = os.listdir(tmp_path)[0]
+    gen = tmp_path / run / "generations" / "training"
+    files = os.listdir(gen) if os.path.isdir(gen) else []
+    mids = [f for f in files if f.endswith(".mid")]
+    # 2 generation rounds (steps 3 and 6) x 4 conditions; a sample without any instrument is reported, not saved
+    assert len(mids) + out.count("not saving") == 8, (files, out[-500:])
+    assert all(f.startswith(("3_", "6_")) for f in mids) and mids, mids

@@ -17,7 +17,12 @@ defined in SURVEY 8d.  One process per GPU: launch with
 Deviations from the reference, on purpose: bf16 (no GradScaler) instead of fp16 autocast;
 `loss.item()` is only read every --log_step (the reference syncs every step, train.py:308);
 schedulers `cosine`/`inv_sqrt` are implemented (the reference never constructs them,
-train.py:129 tests for '--').
+train.py:129 tests for '--'); `cyclic` and `dev_perf` drive torch's own CyclicLR / ReduceLROnPlateau on a shadow
+optimiser and copy its learning rate into the fused optimiser (train.py:132-139).  The reference also calls
+`scheduler.step()` without a metric on every step past the warm-up (train.py:333), which raises for ReduceLROnPlateau;
+here `dev_perf` is stepped with the validation loss at every evaluation only (train.py:433-434), the part that works.
+A restart writes into a fresh time-stamped work_dir (never into the checkpoint it resumes from) and carries
+performance.csv over, like the reference (train.py:173,118).
 """
 import argparse
 import math
@@ -47,8 +52,17 @@ def parse_args(argv=None):
     p.add_argument("--tgt_len", type=int, default=1216)
     p.add_argument("--dropout", type=float, default=0.1)
     p.add_argument("--lr", type=float, default=2e-5)
-    p.add_argument("--scheduler", default="constant", choices=["cosine", "inv_sqrt", "constant"])
+    p.add_argument("--scheduler", default="constant", choices=["cosine", "inv_sqrt", "dev_perf", "constant", "cyclic"])
+    p.add_argument("--lr_min", type=float, default=5e-6, help="minimum learning rate (cyclic base / dev_perf floor)")
+    p.add_argument("--lr_max", type=float, default=5e-3, help="maximum learning rate for the cyclic scheduler")
+    p.add_argument("--decay_rate", type=float, default=0.5, help="ReduceLROnPlateau factor (dev_perf)")
+    p.add_argument("--patience", type=int, default=10, help="ReduceLROnPlateau patience in evaluations (dev_perf)")
     p.add_argument("--warmup_step", type=int, default=0)
+    p.add_argument("--gen_step", type=int, default=8000, help="generation interval (train.py:335-373)")
+    p.add_argument("--gen_len", type=int, default=2048)
+    p.add_argument("--max_gen_input_len", type=int, default=-1)
+    p.add_argument("--temp_note", type=float, default=1.2)
+    p.add_argument("--temp_rest", type=float, default=1.2)
     p.add_argument("--clip", type=float, default=1.0)
     p.add_argument("--batch_size", type=int, default=4, help="sequences per GPU")
     p.add_argument("--accumulate_step", type=int, default=1)
@@ -81,6 +95,8 @@ def parse_args(argv=None):
     args = p.parse_args(argv)
     if args.conditioning != "continuous_concat":
         args.d_condition = -1                                  # config.py:120-121
+    if args.scheduler == "cyclic":
+        args.lr = args.lr_min                                  # config.py:145-146
     if args.exhaustive_eval:
         if not args.feature_file:
             raise SystemExit("--exhaustive_eval needs --feature_file (there is nothing exhaustive about synthetic batches)")
@@ -118,14 +134,50 @@ def synthetic_batch(args, V, B, L, seed, device):
 
 
 def lr_at(args, step):
-    """Warm-up (train.py:327-331) then the schedule."""
-    if args.scheduler == "constant":
-        return args.lr
+    """Closed-form schedules: warm-up (train.py:327-331) then cosine / inv_sqrt."""
     if args.warmup_step > 0 and step <= args.warmup_step:
         return args.lr * step / args.warmup_step
     if args.scheduler == "cosine":
         return 0.5 * args.lr * (1 + math.cos(math.pi * min(1.0, step / max(1, args.max_step))))
     return args.lr / math.sqrt(max(1.0, step / max(1, args.warmup_step)))      # inv_sqrt
+
+
+class LRSchedule:
+    """Learning-rate policy of the run (train.py:128-139,326-333,433-434), applied to FusedAdamW.param_groups[0]['lr'].
+    constant: the optimiser's lr is never touched (a restored checkpoint keeps its lr unless --overwrite_lr);
+    cosine / inv_sqrt: closed form (lr_at); cyclic / dev_perf: torch's CyclicLR / ReduceLROnPlateau run on a shadow
+    SGD optimiser with one parameter, so the sequence of learning rates is torch's own."""
+
+    def __init__(self, args, opt):
+        self.args, self.opt, self.shadow, self.sched = args, opt, None, None
+        if args.scheduler in ("cyclic", "dev_perf"):
+            self.shadow = torch.optim.SGD([torch.zeros(1, requires_grad=True)], lr=opt.param_groups[0]["lr"])
+            if args.scheduler == "cyclic":
+                self.sched = torch.optim.lr_scheduler.CyclicLR(self.shadow, args.lr_min, args.lr_max, cycle_momentum=False)
+            else:
+                self.sched = torch.optim.lr_scheduler.ReduceLROnPlateau(self.shadow, factor=args.decay_rate,
+                                                                        patience=args.patience, min_lr=args.lr_min)
+
+    def _copy(self):
+        self.opt.param_groups[0]["lr"] = self.shadow.param_groups[0]["lr"]
+
+    def on_step(self, step):
+        a = self.args
+        if a.scheduler == "constant":
+            return
+        if a.scheduler in ("cosine", "inv_sqrt"):
+            self.opt.param_groups[0]["lr"] = lr_at(a, step)
+        elif a.warmup_step > 0 and step <= a.warmup_step:
+            self.opt.param_groups[0]["lr"] = a.lr * step / a.warmup_step
+        elif a.scheduler == "cyclic":
+            self.shadow.step()                       # keeps torch's "optimizer.step() before scheduler.step()" order
+            self.sched.step()
+            self._copy()
+
+    def on_eval(self, val_loss):
+        if self.args.scheduler == "dev_perf":
+            self.sched.step(val_loss)
+            self._copy()
 
 
 def main(argv=None):
@@ -193,12 +245,22 @@ def main(argv=None):
     pad_idx = maps["tuple2idx"]["<PAD>"]
     config = dict(vars(args), vocab_size=V, compute_dtype="fp32" if args.no_amp else "bf16")
     work_dir = os.path.join(args.work_dir, ("DEBUG_" if args.debug else "") + time.strftime("%Y%m%d-%H%M%S"))
+    base_dir, n_try = work_dir, 0
+    while os.path.exists(work_dir):                           # one-second names: never reuse (or restart into) an existing run
+        n_try += 1
+        work_dir = "%s-%d" % (base_dir, n_try)
     restart = os.path.join(args.work_dir, args.restart_dir) if args.restart_dir else None
     if restart:
         config = torch.load(os.path.join(restart, "model_config.pt"))
+        # the kernels index the embedding / CE tables with the token ids unchecked: a checkpoint whose vocabulary or
+        # conditioning differs from what this command line builds would read out of bounds -- refuse instead
+        want = {"vocab_size": V, "conditioning": args.conditioning, "regression": bool(args.regression)}
+        bad = {k: (config.get(k), v) for k, v in want.items() if k in config and config.get(k) != v}
+        if bad:
+            raise SystemExit("restart: model_config.pt disagrees with the command line (saved, requested): %s" % bad)
         model, _ = build_model(None, load_config_dict=config)
         model.load_state_dict(torch.load(os.path.join(restart, "model.pt"), map_location="cpu"))
-        work_dir = restart
+        # work_dir stays the fresh time-stamped directory (train.py:173-180 writes there, never into restart_dir)
     else:
         model, config = build_model(config)
     model = model.to(device).train()
@@ -208,13 +270,24 @@ def main(argv=None):
     opt = FusedAdamW(model, lr=args.lr, clip=args.clip, weight_decay=args.weight_decay)
     stats = {"step": 0, "hour": 0.0, "epoch": 0, "sample": 0}
     if restart:
+        # optimizer.pt and stats.pt are restored independently, each tolerating absence (train.py:187-211)
         try:
             opt.load_state_dict(torch.load(os.path.join(restart, "optimizer.pt"), map_location=device))
-            stats = torch.load(os.path.join(restart, "stats.pt"))
-        except Exception as e:                                  # reference tolerates missing files (train.py:187-211)
-            print("optimizer/stats not restored:", e)
+        except FileNotFoundError:
+            print("Optimizer was not saved. Start from scratch.")
+        except Exception as e:
+            print("optimizer state not restored (%s: %s); moments start from zero" % (type(e).__name__, e))
+        try:
+            stats = dict(stats, **torch.load(os.path.join(restart, "stats.pt")))
+        except Exception as e:
+            print("stats.pt not restored (%s); step / hour / epoch start from zero" % type(e).__name__)
         if args.overwrite_lr:
             opt.param_groups[0]["lr"] = args.lr
+        if rank == 0 and not args.debug and os.path.exists(os.path.join(restart, "performance.csv")):
+            os.makedirs(work_dir, exist_ok=True)                # train.py:173,118: the resumed run continues the table
+            import shutil
+            shutil.copy(os.path.join(restart, "performance.csv"), os.path.join(work_dir, "performance.csv"))
+    sched = LRSchedule(args, opt)
     reducer = GradAllReducer(lambda: model.flat_grads, model.bucket_ranges())
     if rank == 0 and not args.debug:
         os.makedirs(work_dir, exist_ok=True)
@@ -312,6 +385,25 @@ def main(argv=None):
                 w.writeheader()
             w.writerow({k: kw.get(k, float("nan")) for k in perf_cols})
 
+    def generate_samples(step_no):
+        """In-training sample generation with the fixed condition set (train.py:335-373)."""
+        from generate import generate
+        max_input_len = args.max_gen_input_len if args.max_gen_input_len > 0 else args.tgt_len
+        primers, disc, cont = [["<START>"]], None, None
+        if args.conditioning == "none":
+            primers = [["<START>"] for _ in range(4)]
+        elif args.conditioning == "discrete_token":
+            disc = [["<V-2>", "<A-2>"], ["<V-2>", "<A2>"], ["<V2>", "<A-2>"], ["<V2>", "<A2>"]]
+        else:
+            cont = [[-0.8, -0.8], [-0.8, 0.8], [0.8, -0.8], [0.8, 0.8]]
+        was_training = model.training
+        with torch.no_grad():
+            generate(model, maps, device, os.path.join(work_dir, "generations", "training"), args.conditioning,
+                     debug=args.debug, verbose=False, amp=not args.no_amp, discrete_conditions=disc,
+                     continuous_conditions=cont, min_n_instruments=1, gen_len=args.gen_len, max_input_len=max_input_len,
+                     step=str(step_no), primers=primers, temperatures=[args.temp_note, args.temp_rest])
+        model.train(was_training)
+
     if args.exhaustive_eval:                                   # train.py:448-461
         v, accs = evaluate()
         if rank == 0:
@@ -344,8 +436,10 @@ def main(argv=None):
             micro = 0
             reducer.finish()
             step += 1
-            opt.param_groups[0]["lr"] = lr_at(args, step)
+            sched.on_step(step)
             opt.step(grad_scale=reducer.grad_scale)
+            if step % args.gen_step == 0 and not args.regression and rank == 0:
+                generate_samples(step)
             if step % args.log_step == 0 or step == args.max_step:
                 cur = float(loss_acc.item()) / max(n_acc, 1)                 # the only host sync
                 el = time.time() - t0
@@ -365,6 +459,7 @@ def main(argv=None):
                 t0 = time.time()
             if step % args.eval_step == 0:
                 v, accs = evaluate()
+                sched.on_eval(v)
                 if args.regression:
                     if rank == 0:
                         print("| eval at step {:>8d} | valid loss {:7.4f} | l1_v {:.4f} | l1_a {:.4f}".format(step, v, accs[1], accs[5]))
