@@ -39,6 +39,23 @@ from midiemo.vocab import (emotion_symbols, get_maps, get_n_instruments, ind_lis
                            special_token_ids, timeshift_token_mask)
 
 
+def sampling_temperature(prev_ids, repeat_counts, is_timeshift, temp_note, temp_rest, penalty_coeff):
+    """Per-row temperature of one sampling step (generate.py:138-163): the note temperature right after a TIMESHIFT,
+    else the rest temperature, raised by max(0, log((repeats + 1) / 4) * penalty_coeff) times itself."""
+    dev = prev_ids.device
+    temp = torch.where(is_timeshift[prev_ids], torch.tensor(float(temp_note), device=dev),
+                       torch.tensor(float(temp_rest), device=dev))
+    if penalty_coeff > 0:
+        mult = torch.clamp(torch.log((repeat_counts + 1) / 4) * penalty_coeff, min=0)
+        temp = temp + mult * temp
+    return temp
+
+
+def update_repeat_counts(repeat_counts, n_choices):
+    """generate.py:186-189: a step with at most two choices counts as a repeat, any other halves the counter."""
+    return torch.where(n_choices <= 2, repeat_counts + 1, torch.floor(repeat_counts / 2))
+
+
 def generate(model, maps, device, out_dir, conditioning, short_filename=False,
              penalty_coeff=0.5, discrete_conditions=None, continuous_conditions=None,
              max_input_len=1024, amp=True, step=None,
@@ -150,12 +167,7 @@ def generate(model, maps, device, out_dir, conditioning, short_filename=False,
             # ---- sampling tail (generate.py:122-189) in one launch: NaN->0, specials->-inf, log_softmax, per-row
             # temperature, top-k, nucleus cut, renormalise, draw, n_choices.  The draw is the inverse CDF at a uniform
             # from torch's generator (the reference's torch.multinomial stream itself is not reproducible).
-            prev = gen_inds[0]
-            temp = torch.where(is_timeshift[prev], torch.tensor(temp_note, device=device),
-                               torch.tensor(temp_rest, device=device))           # generate.py:138-150
-            if penalty_coeff > 0:                                 # generate.py:155-160
-                mult = torch.clamp(torch.log((repeat_counts + 1) / 4) * penalty_coeff, min=0)
-                temp = temp + mult * temp
+            temp = sampling_temperature(gen_inds[0], repeat_counts, is_timeshift, temp_note, temp_rest, penalty_coeff)
             lg = output.float()
             lg = lg if lg.is_contiguous() else lg.contiguous()
             if V <= 1024:
@@ -179,7 +191,7 @@ def generate(model, maps, device, out_dir, conditioning, short_filename=False,
                 sampled = torch.multinomial(probs, 1, replacement=True)
                 gen_inds = top_inds.gather(1, sampled).t()
                 n_choices = (probs > 0).sum(-1)
-            repeat_counts = torch.where(n_choices <= 2, repeat_counts + 1, torch.floor(repeat_counts / 2))   # :186-189
+            repeat_counts = update_repeat_counts(repeat_counts, n_choices)
 
     ids = gen_song.cpu()
     redo_primers, redo_discrete, redo_continuous = [], [], []

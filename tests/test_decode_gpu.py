@@ -247,3 +247,35 @@ def test_config5_full_length_greedy_graph_equals_eager(cd):
     assert torch.equal(got, want), int((got != want).sum())
     with pytest.raises(RuntimeError):
         sess.greedy_run(got[:, -1], 1, cond, special)                      # position 2048 does not exist
+
+
+@pytest.mark.parametrize("tag", ["k0p07", "k20p10", "k50p09"])
+def test_sampling_kernel_matches_reference_distribution(golden_dir, tag):
+    """SURVEY 8f #1, device half: for the logits and temperatures of every step of a reference generate() run (fixture
+    f7: captured with spies on torch.topk / torch.multinomial, oracle/make_host_fixtures.py) me_sample_topk_topp must
+    produce the reference's filtered distribution -- same surviving ids, same probabilities, same number of choices."""
+    from midiemo import ops
+    z = np.load(os.path.join(golden_dir, "f7_host.npz"))
+    top_k, top_p, steps, B, k_eff = z[f"samp_{tag}_cfg"]
+    top_k, steps, B, k_eff = int(top_k), int(steps), int(B), int(k_eff)
+    V = z[f"samp_{tag}_logits"].shape[-1]
+    special = torch.from_numpy(z["special_ids"]).cuda()
+    out = torch.empty(B, dtype=torch.long, device="cuda")
+    nch = torch.empty(B, dtype=torch.int32, device="cuda")
+    dp = torch.empty(B, 1024, device="cuda")
+    di = torch.empty(B, 1024, dtype=torch.int32, device="cuda")
+    g = torch.Generator().manual_seed(1)
+    for s in range(steps):
+        lg = torch.zeros(B, 1024)
+        lg[:, :V] = torch.from_numpy(z[f"samp_{tag}_logits"][s])
+        temp = torch.from_numpy(z[f"samp_{tag}_temp"][s]).float()
+        u = torch.rand(B, generator=g)
+        ops.sample_topk_topp(lg.cuda(), V, special, temp.cuda(), top_k, float(top_p), u.cuda(), out, nch, dp, di)
+        probs = torch.from_numpy(z[f"samp_{tag}_probs"][s])                      # [B, k_eff], sorted descending
+        inds = torch.from_numpy(z[f"samp_{tag}_inds"][s]).long()
+        dense_ref = torch.zeros(B, V).scatter_add_(1, inds, probs)
+        dpc, dic = dp.cpu(), di.cpu()
+        dense_got = torch.zeros(B, V).scatter_add_(1, dic.long().clamp(max=V - 1), dpc * (dic < V))
+        assert torch.allclose(dense_got, dense_ref, atol=3e-6, rtol=2e-4), (s, float((dense_got - dense_ref).abs().max()))
+        assert torch.equal(nch.cpu().long(), (probs > 0).sum(-1)), s
+        assert bool(((dense_ref.gather(1, out.cpu()[:, None]) > 0).all())), s     # the draw lands on a surviving id

@@ -243,3 +243,58 @@ def test_lr_schedules_follow_torch_schedulers():
     assert opt.param_groups[0]["lr"] == pytest.approx(5e-4)
     s.on_step(100)
     assert opt.param_groups[0]["lr"] == pytest.approx(0.0, abs=1e-12)
+
+
+def test_midi_notes_match_reference_tuples_to_mid(golden_dir):
+    """SURVEY 8f #3, pinned: fixture f7 holds what the reference's tuples_to_mid (data_processing_reverse.py:12-53)
+    produced for seeded token streams -- every pretty_midi.Instrument(program, is_drum, name) and
+    Note(velocity, pitch, start, end) it constructed (oracle/make_host_fixtures.py).  The build's writer must derive the
+    same notes, programs and velocities from the same ids; the ids -> symbol strings step is pinned by a checksum."""
+    from midiemo.midi_writer import PROGRAMS, VELOCITIES, symbols_to_midi_bytes, symbols_to_notes
+    from midiemo.vocab import get_maps, ind_list_to_str
+    z = np.load(os.path.join(golden_dir, "f7_host.npz"))
+    maps = get_maps()
+    for si in (0, 1):
+        ids = z[f"midi{si}_ids"].tolist()
+        symbols = ind_list_to_str(ids, maps)
+        assert sum((i + 1) * len(s) for i, s in enumerate(symbols)) == int(z[f"midi{si}_symbols_crc"])
+        notes = symbols_to_notes(symbols)
+        assert set(notes) == set(PROGRAMS)
+        total = 0
+        for name, (program, is_drum) in PROGRAMS.items():
+            meta = z[f"midi{si}_{name.lower()}_meta"]
+            assert (int(meta[0]), bool(meta[1])) == (program, is_drum), name
+            ref = z[f"midi{si}_{name.lower()}_notes"]               # rows: velocity, pitch, start, end
+            got = notes[name]
+            assert len(got) == len(ref), (name, len(got), len(ref))
+            for (s0, e0, p0), r in zip(got, ref):
+                assert (VELOCITIES[name], p0) == (int(r[0]), int(r[1])) and abs(s0 - r[2]) < 1e-9 and abs(e0 - r[3]) < 1e-9
+            total += len(got)
+        assert total > 10 * (si + 1)
+        assert len(symbols_to_midi_bytes(symbols)) > 100          # the container itself: test_midi_writer_round_trip_...
+
+
+def test_sampling_temperature_and_repeat_penalty_match_reference(golden_dir):
+    """SURVEY 8f #1, host half: replaying the reference run captured in f7 (tokens drawn and number of surviving choices
+    of every step), generate.sampling_temperature / update_repeat_counts must give the per-row temperatures the
+    reference used at every step (note vs rest temperature after a TIMESHIFT, repeat penalty; generate.py:138-163,186-189)."""
+    sys.path.insert(0, ROOT)
+    import generate as G
+    from midiemo.vocab import get_maps, timeshift_token_mask
+    z = np.load(os.path.join(golden_dir, "f7_host.npz"))
+    maps = get_maps()
+    is_ts = torch.tensor(timeshift_token_mask(maps), dtype=torch.bool)
+    for tag in ("k0p07", "k20p10", "k50p09"):
+        steps, B = int(z[f"samp_{tag}_cfg"][2]), int(z[f"samp_{tag}_cfg"][3])
+        prev = torch.full((B,), maps["tuple2idx"]["<START>"], dtype=torch.long)
+        rc = torch.zeros(B)
+        seen_penalty = False
+        for s in range(steps):
+            temp = G.sampling_temperature(prev, rc, is_ts, 1.2, 0.9, 0.5)
+            np.testing.assert_allclose(temp.numpy(), z[f"samp_{tag}_temp"][s], rtol=2e-5)
+            seen_penalty |= bool((temp > 1.2 + 1e-6).any())
+            n_choices = torch.from_numpy((z[f"samp_{tag}_probs"][s] > 0).sum(-1))
+            rc = G.update_repeat_counts(rc, n_choices)
+            prev = torch.from_numpy(z[f"samp_{tag}_tokens"][s]).long()
+        if tag == "k0p07":
+            assert seen_penalty                              # the peaked rows drive the repeat counter past 3
