@@ -96,7 +96,7 @@ int main(void) {
     }
     /* error behaviour: bad arguments are reported, not crashed on */
     if (me_gemm_nt(NULL, K, dW, K, dC, N, db, NULL, 0, NULL, 0, M, N, K, 0, ME_BF16, NULL) == ME_OK) { printf("NULL accepted\n"); return 5; }
-    if (me_rga_fwd(dA, dW, NULL, dC, dss, 1, 64, 2, 40, 2048, 1, ME_BF16, NULL) == ME_OK) { printf("dh = 40 accepted\n"); return 6; }
+    if (me_rga_fwd(dA, dW, NULL, dC, dss, NULL, NULL, 1, 64, 2, 40, 2048, 1, ME_BF16, NULL) == ME_OK) { printf("dh = 40 accepted\n"); return 6; }
     printf("OK\n");
     return 0;
 }

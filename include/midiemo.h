@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 12
+#define ME_ABI_VERSION 13
 
 enum { ME_F32 = 0, ME_BF16 = 1 };
 
@@ -128,8 +128,9 @@ int me_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
  * 0 = none).  ME_WS_GEMM_TN: me_gemm_tn_acc with (M, N, K) = (T, N, K). */
 enum {
     ME_WS_GEMM_TN = 1,   /* me_gemm_tn_acc partial tiles: (M, N, K) = (T, N, K) */
-    ME_WS_RGA_PT = 2,    /* me_rga_bwd PT workspace:  (M, N, K) = (B*H, Lp, causal) */
-    ME_WS_RGA_DGT = 3    /* me_rga_bwd dGT workspace: (M, N, K) = (B*H, Lp, unused) */
+    ME_WS_RGA_PT = 2,    /* me_rga_fwd / me_rga_bwd PT: (M, N, K) = (B*H, Lp, causal) */
+    ME_WS_RGA_DGT = 3,   /* me_rga_bwd dGT workspace:   (M, N, K) = (B*H, Lp, unused) */
+    ME_WS_RGA_MT = 4     /* me_rga_fwd / me_rga_bwd MT: (M, N, K) = (B*H, Lp, unused) */
 };
 size_t me_workspace_bytes(int op, int M, int N, int K, int dtype);
 
@@ -156,8 +157,16 @@ int me_gemm_tn_acc(const void* A, int lda, const void* B, int ldb, float* dW, in
  * causal = 1: the language model (generate_mask: key <= q and not padded).  causal = 0: the bidirectional attention of
  * MusicRegression (models/music_regression.py:79, mask = None): all keys, relative term only for key <= q (the
  * reference's skewing leaves zeros above the diagonal); me_rga_bwd takes the same flag. */
-int me_rga_fwd(const void* qkv, const void* Epk, const uint8_t* key_pad, void* out, float* lse,
+int me_rga_fwd(const void* qkv, const void* Epk, const uint8_t* key_pad, void* out, float* lse, void* PT, float* MT,
                int B, int L, int H, int dh, int M, int causal, int dtype, void* stream);
+/* PT / MT (both NULL for inference, both given for training): the forward additionally leaves what the backward needs
+ * instead of recomputing the softmax --
+ *   PT : T, per (batch, head) the 32 x 32 tiles [query][key] of the UNNORMALISED probabilities p = exp((s - m_t)) taken
+ *        against the running row maximum m_t at that key tile: the packed lower triangle (key tile, query tile >= key
+ *        tile) for causal = 1, the full square for causal = 0        (bytes: me_workspace_bytes(ME_WS_RGA_PT, B*H, Lp, causal));
+ *   MT : f32 [B*H][Lp/32 key tiles][Lp] the running maxima m_t (raw logit units)   (ME_WS_RGA_MT).
+ * P = p * exp(m_t / sqrt(dh) - lse).  Lp = L rounded up to 32.  No initialisation needed; kept until me_rga_bwd of the
+ * same layer has run. */
 
 /* Packs the relative table E (T [M][dh], music_multi.py:191 self.E) into the fragment images me_rga_fwd / me_rga_bwd
  * read: per block of 32 rows, dh/16 images of the rows themselves (operand of Q.E^T) followed by 2*ceil(dh/32) images
@@ -166,19 +175,15 @@ int me_rga_fwd(const void* qkv, const void* Epk, const uint8_t* key_pad, void* o
  * Call it whenever E changes (the model does it inside its multi-tensor weight refresh, me_ct_desc.mode = 1). */
 int me_rga_pack_rel(const void* E, void* Epk, int M, int dh, int dtype, void* stream);
 
-/* Backward of me_rga_fwd.  dout: T [B,L,H,dh].  Writes dqkv (T, same layout as qkv),
- * accumulates (+=) dE f32 [M, dh] (natural layout).
- * Workspaces (caller-owned, sizes from me_workspace_bytes, 16-byte aligned, contents need NOT be initialised: every
- * tile is written before it is read in every call): delta f32 [B,H,L];
- *   PT  : T, per (batch, head) the 32 x 32 tiles of P^T -- the packed lower triangle (key tile, query tile >= key tile)
- *         for causal = 1, the full square for causal = 0          (ME_WS_RGA_PT, Lp = L rounded up to 32);
+/* Backward of me_rga_fwd.  dout: T [B,L,H,dh].  Writes dqkv (T, same layout as qkv), accumulates (+=) dE f32 [M, dh]
+ * (natural layout).  PT / MT: what me_rga_fwd left for this layer (read only).  Workspaces (caller-owned, 16-byte
+ * aligned, contents need NOT be initialised): delta f32 [B,H,L];
  *   dGT : T, per (batch, head) the tiles (query tile qt, step t <= qt) of the skewed dS (rows = rows of the relative
  *         table, columns = queries): what dE is contracted from       (ME_WS_RGA_DGT).
- * dK / dV recompute dS from P^T (dS = P o (V dO^T - delta) / sqrt(dh)); dS itself is never stored.
+ * Neither S nor dS is stored or recomputed from Q.K^T: dS = P o (V dO^T - delta) / sqrt(dh) with P from PT / MT.
  * causal: as in me_rga_fwd (autograd of music_multi.py:211-235 for 1, of music_regression.py's mask = None attention for 0). */
-int me_rga_bwd(const void* qkv, const void* Epk, const uint8_t* key_pad,
-               const void* out, const float* lse, const void* dout,
-               void* dqkv, float* dE, float* delta_ws, void* PT, void* dGT,
+int me_rga_bwd(const void* qkv, const void* Epk, const void* out, const float* lse, const void* dout,
+               void* dqkv, float* dE, float* delta_ws, const void* PT, const float* MT, void* dGT,
                int B, int L, int Lp, int H, int dh, int M, int causal, int dtype, void* stream);
 
 /* ---- residual + dropout + LayerNorm (post-LN, eps) ---------------------------

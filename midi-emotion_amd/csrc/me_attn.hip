@@ -23,16 +23,17 @@
 // LDS tiles with the hardware transpose read (frag_load_tr, me_common.h): no transposed copies in
 // memory, no LDS scatter.
 //
-// Backward.  The query-owned kernel recomputes P, forms dS, accumulates dQ (key part and relative part) and
-// MATERIALISES, for the current layer only, two tensors in the compute type as contiguous 32 x 32 tiles:
-//     P^T  [bh][key tile][query tile >= key tile]   (packed lower triangle; full square for the bidirectional variant)
-//     dG^T [bh][query tile qt][step t <= qt]        (the skewed dS of E block eb0(qt) + t: rows = E row, columns = query)
-// Every tile of both is written by exactly one wave in every call: no zero-initialisation contract.
-//     dV = P^T dO,  dS^T = P^T o (V dO^T - delta) / sqrt(dh),  dK = dS^T Q   (rga_bwd_kv_kernel, key-owned: streams P^T once,
-//                                                                          recomputes dS from it -- no exp, no skew)
-//     dE[e] += sum_{bh, q} dG^T[e][q] Q[q]                                 (rga_bwd_e_kernel, E-row-owned: plain tile stream)
-// Round 1 also materialised dS^T (the key-owned kernel read it, the E kernel re-read it as sheared bands): 2.33 GB of HBM
-// traffic per layer at the headline shape against 1.2 GB now.
+// Backward.  Nothing of the softmax is recomputed: in training mode the forward leaves, per layer, its unnormalised
+// probability tiles p = exp2((s - m_t) c2) (compute type, natural [q][key] 32 x 32 tiles: the packed lower triangle
+// (key tile, query tile >= key tile), the full square for the bidirectional variant) and the running maxima m_t; the
+// backward kernels rebuild P = p * exp2(m_t c2 - lse log2e).  For the layer being differentiated the query-owned kernel
+// additionally writes dG^T [bh][query tile qt][step t <= qt] (the skewed dS of E block eb0(qt) + t: rows = E row,
+// columns = query).  Every tile is written by exactly one wave before it is read: no zero-initialisation contract.
+//     dQ  = dS (K + E_skewed)             (rga_bwd_q_kernel: P tile read back by the lanes that wrote it)
+//     dV = P^T dO,  dK = dS^T Q           (rga_bwd_kv_kernel, key-owned: streams the P tiles once, dS from P and V dO^T)
+//     dE[e] += sum_{bh, q} dG^T[e][q] Q[q]   (rga_bwd_e_kernel, E-row-owned: plain tile stream)
+// with dS = P o (dP - delta) / sqrt(dh).  Round 1 recomputed S / G / exp in the query kernel and materialised P^T and dS^T
+// there (2.33 GB of HBM traffic per layer at the headline shape); dS^T is never stored now.
 #include "me_common.h"
 #include <type_traits>
 
@@ -72,7 +73,7 @@ ME_DEV void tile_gload(chunk16* r, const T* origin, size_t ld, int rows_valid, i
 #pragma unroll
     for (int i = 0; i < TT::NPT; ++i) {
         const int c = tid + i * 256;
-        if (c < TT::NCH) {
+        if (TT::NCH % 256 == 0 || c < TT::NCH) {
             const int row = c / TT::CPR, cc = (c % TT::CPR) * TT::CH;
             r[i] = row < rows_valid ? ld_chunk(origin + (size_t)row * ld + cc) : zero_chunk();
         }
@@ -94,7 +95,9 @@ ME_DEV void tile_sstore(const chunk16* r, T* S, int tid) {
 #pragma unroll
     for (int i = 0; i < TT::NPT; ++i) {
         const int c = tid + i * 256;
-        if (c < TT::NCH) {
+        // a whole number of 256-chunk rounds: no predicate -- an exec-masked region here splits the step into basic
+        // blocks and the s_waitcnt pass then drains vmcnt to 0 at the loop header (every prefetch latency exposed)
+        if (TT::NCH % 256 == 0 || c < TT::NCH) {
             T* dst = &S[(c / TT::CPR) * LDS_LD + (c % TT::CPR) * TT::CH];
             if constexpr ((LDS_LD * sizeof(T)) % 16 == 0) {
                 st_chunk(dst, r[i]);
@@ -125,6 +128,11 @@ ME_DEV size_t pt_tile(int kt, int qt, int nq, bool causal) {
 }
 ME_DEV size_t pt_tiles(int nq, bool causal) { return causal ? (size_t)nq * (nq + 1) / 2 : (size_t)nq * nq; }
 ME_DEV size_t dg_tile(int qt, int t) { return (size_t)qt * (qt + 1) / 2 + t; }
+// Probability tiles are stored as the forward's REGISTER IMAGE: row q holds its 32 keys in the order the two lanes
+// (q, h = 0 / 1) own them (accumulator registers 0..15 of lane (q, h) = keys 8 g + 4 h + i, g = r / 4, i = r % 4), i.e.
+// key -> position 16 h + 4 g + i.  A lane then writes / reads back 16 contiguous elements (a wave: one contiguous tile,
+// full cache lines) instead of four 8-byte pieces scattered over 32 rows (measured: +80 us per forward launch).
+ME_DEV int p_col(int key) { return ((key >> 2) & 1) * 16 + (key >> 3) * 4 + (key & 3); }
 
 // v_exp_f32 without the denormal-range fix-up of exp2f (arguments here are <= 0: tiny results may flush to 0)
 ME_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -149,10 +157,15 @@ template <> ME_DEV void st4<float>(float* p, float a, float b, float c, float d)
 // CAUSAL = false: the bidirectional variant of MusicRegression (models/music_regression.py:79, mask = None): every key
 // is attended; the relative term exists only for key <= q (the reference's _qe_masking + _skewing leave exact zeros
 // above the diagonal), nothing is masked but keys >= L and padded keys.
-template <typename T, int DH, bool CAUSAL = true>
+// STORE_P (training): every wave also leaves its UNNORMALISED probability tile p = exp2((s - m_t) c2) -- [32 q][32 key]
+// in register-image order (p_col), straight from the registers that feed the P.V product -- and the running maximum m_t it was
+// taken against (raw logit units).  The backward kernels rebuild P = p * exp2(m_t c2 - lse log2e) from them instead of
+// recomputing Q.K^T, the relative term and the exponential (round 2: the query-owned backward kernel was bound by exactly
+// that recomputation).  Rows q >= L of a tile hold garbage: the consumers' factor is 0 there.
+template <typename T, int DH, bool CAUSAL = true, bool STORE_P = false>
 __global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ qkv, const T* __restrict__ Epk, const uint8_t* __restrict__ key_pad,
-                                                      T* __restrict__ out, float* __restrict__ lse, int B, int L, int H, int M,
-                                                      float scale) {
+                                                      T* __restrict__ out, float* __restrict__ lse, T* __restrict__ PT,
+                                                      float* __restrict__ MT, int B, int L, int Lp, int H, int M, float scale) {
     using C = ACfg<T, DH>;
     __shared__ __attribute__((aligned(16))) T Ks[2][32 * C::LDN];
     __shared__ __attribute__((aligned(16))) T Vs[2][32 * C::LDN];      // natural V tile, transpose-read (144-byte rows: 2-way conflicts, but 3 blocks/CU)
@@ -269,31 +282,37 @@ __global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ q
             // are four groups of 4 consecutive columns (a group may run into the halo columns 64..66, never wraps)
             const float* grow = &Gs[wid][a * LDG2];
             const int t0 = (eb_lo & 1) * 32 + 31 - a + 4 * h;
-            float gv[16];
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const float* gp = grow + ((t0 + 8 * gq) & 63);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) gv[4 * gq + i] = gp[i];
-            }
             // the running maximum is kept in RAW logit units (before the scale / log2e factor c2 > 0): the exponent is
-            // one fma per element, exp2(s * c2 - m * c2)
+            // one fma per element, exp2(s * c2 - m * c2).  Two batches of 8 ring reads (register budget: the kernel sits at
+            // the 168 registers of 3 waves per SIMD).
             float mt = -INFINITY;
-            if (!diag && !upper && pbits == 0u && k0 + 32 <= L) {
+            const bool plain = !diag && !upper && pbits == 0u && k0 + 32 <= L;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    s[r] += gv[r];
-                    mt = fmaxf(mt, s[r]);
+            for (int r0 = 0; r0 < 16; r0 += 8) {
+                float gv[8];
+#pragma unroll
+                for (int gq = 0; gq < 2; ++gq) {
+                    const float* gp = grow + ((t0 + 2 * r0 + 8 * gq) & 63);      // register quads r0/4 + gq = columns + 8 (r0/4 + gq)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gv[4 * gq + i] = gp[i];
                 }
-            } else {
+                if (plain) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int bk = (r & 3) + 8 * (r >> 2) + 4 * h, key = k0 + bk;
-                    const bool masked = (CAUSAL && key > q) || key >= L || ((pbits >> bk) & 1u);
-                    const float g = (CAUSAL || (!upper && key <= q)) ? gv[r] : 0.f;
-                    const float v = masked ? -INFINITY : s[r] + g;
-                    s[r] = v;
-                    mt = fmaxf(mt, v);
+                    for (int j = 0; j < 8; ++j) {
+                        s[r0 + j] += gv[j];
+                        mt = fmaxf(mt, s[r0 + j]);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int r = r0 + j;
+                        const int bk = (r & 3) + 8 * (r >> 2) + 4 * h, key = k0 + bk;
+                        const bool masked = (CAUSAL && key > q) || key >= L || ((pbits >> bk) & 1u);
+                        const float g = (CAUSAL || (!upper && key <= q)) ? gv[j] : 0.f;
+                        const float v = masked ? -INFINITY : s[r] + g;
+                        s[r] = v;
+                        mt = fmaxf(mt, v);
+                    }
                 }
             }
             mt = half_max(mt);
@@ -312,9 +331,21 @@ __global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ q
                     for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
             }
             m_run = m_new;
+            T* tile = nullptr;
+            if constexpr (STORE_P) {
+                // wave-uniform tile origin in SGPRs (readfirstlane: the compiler cannot prove tid >> 6 uniform), one lane
+                // offset register: the forward sits exactly at its 168-register budget (3 waves per SIMD)
+                const int nq32 = Lp >> 5;
+                const int qt_u = __builtin_amdgcn_readfirstlane(q0 >> 5);
+                T* tile_u = PT + ((size_t)bh * pt_tiles(nq32, CAUSAL) + pt_tile(kt, qt_u, nq32, CAUSAL)) * 1024;
+                tile = tile_u + (a * 32 + 16 * h);
+                float* mt_u = MT + ((size_t)bh * nq32 + kt) * Lp + qt_u * 32;
+                mt_u[a] = m_safe;                           // both half-waves write the same value: no exec-mask branch
+            }
 #pragma unroll
             for (int t = 0; t < 2; ++t) {                   // O^T[d][q] += V^T[d][key] . P^T[key][q]
                 Frag<T> pf; frag_from_acc(pf, s, t);
+                if constexpr (STORE_P) frag_store(tile + 8 * t, pf);     // registers 8 t .. 8 t + 7 of the lane's image
 #pragma unroll
                 for (int i = 0; i < C::DB; ++i) {
                     Frag<T> vf;                              // V^T[d][key] for the accumulator's key map
@@ -351,23 +382,30 @@ __global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ q
 }
 
 // =====================================================================================
-// backward 1/3 (query-owned): delta, dQ, and the materialised P^T, dS^T, dG^T
+// backward 1/3 (query-owned): delta, dQ (key part + relative part), and the dG^T tiles
 // =====================================================================================
-// CAUSAL = false: backward of the bidirectional forward (MusicRegression): every key tile is visited and written; tiles
-// above the diagonal have no relative term (no G, no dG, no E^T product).
+// P is NOT recomputed: the forward pass left the unnormalised tile p (register image: a lane reads back exactly the
+// 16 contiguous elements of its query row that it wrote) and the running maximum m_t, so P = p * exp2(m_t c2 - lse log2e) is one
+// exponential per lane and step instead of K.Q^T, the E block product, the ring skew and 16 exponentials.  Per key tile
+// and wave: dP^T = V dO^T (KA atoms), dS = P o (dP - delta) / sqrt(dh), dQ^T += K^T dS^T (2 DB atoms), the skewed dS
+// goes through the dG ring (LDS) and gives the relative part dQ^T += E^T dG^T (2 DB atoms) and the dG^T tile for dE.
+// CAUSAL = false: backward of the bidirectional forward (MusicRegression): every key tile is visited; tiles above the
+// diagonal have no relative term (no dG, no E^T product).
+template <typename T> struct PHalf;
+template <> struct PHalf<bf16_t> { typedef bf16x4_t type; };
+template <> struct PHalf<float> { typedef f32x4_t type; };
+
 template <typename T, int DH, bool CAUSAL = true>
 __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
-    const T* __restrict__ qkv, const T* __restrict__ Epk,
-    const uint8_t* __restrict__ key_pad, const T* __restrict__ out, const float* __restrict__ lse,
-    const T* __restrict__ dout, T* __restrict__ dqkv, float* __restrict__ delta_ws, T* __restrict__ PT,
-    T* __restrict__ dGT, int B, int L, int Lp, int H, int M, float scale) {
+    const T* __restrict__ qkv, const T* __restrict__ Epk, const T* __restrict__ out, const float* __restrict__ lse,
+    const T* __restrict__ dout, T* __restrict__ dqkv, float* __restrict__ delta_ws, const T* __restrict__ PT,
+    const float* __restrict__ MT, T* __restrict__ dGT, int B, int L, int Lp, int H, int M, float scale) {
     using C = ACfg<T, DH>;
+    using PH = typename PHalf<T>::type;
     constexpr int LDR = 72;                         // dG ring row (elements of T): 64-column ring + 8
-    __shared__ __attribute__((aligned(16))) T Ks[2][32 * C::LDN];      // natural K tile: 16-byte fragment reads (S) and transpose reads (dQ)
-    __shared__ __attribute__((aligned(16))) T Vs[2][32 * C::LDN];
-    __shared__ __attribute__((aligned(16))) float Gs[4][32 * LDG2];     // per wave: [q][64-column ring]
+    __shared__ __attribute__((aligned(16))) T Ks[2][32 * C::LDN];      // natural K tile: transpose reads (dQ)
+    __shared__ __attribute__((aligned(16))) T Vs[2][32 * C::LDN];      // natural V tile: 16-byte fragment reads (dP)
     __shared__ __attribute__((aligned(16))) T Ds[4][32 * LDR];          // per wave: [q][64-column ring] of dG
-    __shared__ uint32_t Ps[2][32];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, a = lane & 31, h = lane >> 5;
     const int nqb = (L + 127) / 128;
@@ -386,8 +424,7 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
     const int my_last_kt = qb * 4 + wid;
     const float c2 = scale * 1.4426950408889634f;
 
-    Frag<T> qf[C::KA], dof[C::KA];
-    row_frags<T, DH>(qf, qb_ + (size_t)q * ldq, row_on, h);
+    Frag<T> dof[C::KA];
     const size_t orow = ((size_t)b * L + q) * dm + head * DH;
     row_frags<T, DH>(dof, dout + orow, row_on, h);
     float delta = 0.f, lse2 = 0.f;
@@ -409,202 +446,94 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
     for (int i = lane; i < 32 * LDR; i += 64) Ds[wid][i] = ET<T>::from_f(0.f);
 
     chunk16 rk[TileT<T, 32, DH>::NPT], rv[TileT<T, 32, DH>::NPT];
-    uint32_t rp = 0, rpm = 0;
-    // pad flags: always one byte load per thread (a valid dummy row when there is no mask) -- a load under a
-    // branch would make every later vmcnt wait conservative
-    const uint8_t* kp_ = key_pad ? key_pad + (size_t)b * L : reinterpret_cast<const uint8_t*>(lse);
-    const uint32_t kp_on = key_pad ? 0xffu : 0u;
     auto gload = [&](int kt) __attribute__((always_inline)) {
         tile_gload<T, 32, DH>(rk, kb_ + (size_t)kt * 32 * ldq, ldq, L - kt * 32, tid);
         tile_gload<T, 32, DH>(rv, vb_ + (size_t)kt * 32 * ldq, ldq, L - kt * 32, tid);
-        rp = kp_[min(kt * 32 + (tid & 31), L - 1)];
-        rpm = kt * 32 + (tid & 31) < L ? kp_on : 0u;
     };
     auto gload_full = [&](int kt) __attribute__((always_inline)) {       // tile kt entirely below L
         tile_gload_full<T, 32, DH>(rk, kb_ + (size_t)kt * 32 * ldq, ldq, tid);
         tile_gload_full<T, 32, DH>(rv, vb_ + (size_t)kt * 32 * ldq, ldq, tid);
-        rp = kp_[kt * 32 + (tid & 31)];            // masked when it is stored: no early use, no early wait
-        rpm = kp_on;
     };
     auto sstore = [&](int buf) __attribute__((always_inline)) {
         tile_sstore<T, 32, DH, C::LDN>(rk, Ks[buf], tid);
         tile_sstore<T, 32, DH, C::LDN>(rv, Vs[buf], tid);
-        if (tid < 32) Ps[buf][tid] = rp & rpm;
     };
-    auto g_block = [&](const Frag<T>* ef, int eb) {
-        f32x16_t g; acc_zero(g);
-#pragma unroll
-        for (int kk = 0; kk < C::KA; ++kk) mma32(g, ef[kk], qf[kk]);
-        float* gs = &Gs[wid][a * LDG2 + (eb & 1) * 32];
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq)
-            *reinterpret_cast<f32x4_t*>(gs + 8 * gq + 4 * h) = (f32x4_t){g[4 * gq], g[4 * gq + 1], g[4 * gq + 2], g[4 * gq + 3]};
-        // halo: columns 64..66 of a ring row mirror columns 0..2, so that the 4-element groups of the skewed read never have
-        // to wrap inside a group (one base address per group instead of an add / and / shift per element).  Branch-free:
-        // lanes that do not own columns 0..3 of slot 0 rewrite their own first quad in place.
-        float* hs = &Gs[wid][a * LDG2] + (((eb & 1) | h) ? (eb & 1) * 32 + 4 * h : 64);
-        *reinterpret_cast<f32x4_t*>(hs) = (f32x4_t){g[0], g[1], g[2], g[3]};
-    };
-    // packed relative table (me_rga_pack_rel): every fragment is one contiguous 1 KB image
-    auto e_frags = [&](Frag<T>* f, int eb) __attribute__((always_inline)) {      // E rows of block eb: A operand of G^T = E . Q^T
-#pragma unroll
-        for (int kk = 0; kk < C::KA; ++kk) frag_load(f[kk], Epk + (size_t)eb * C::PK + (kk * 64 + lane) * 8);
-    };
-    // E^T of block eb: A operand of dQ^T[d][q] += E^T[d][e] dG^T[e][q], contraction map e = 16 t + 8 h + j on both operands
+    // E^T of block eb (packed relative table): A operand of dQ^T[d][q] += E^T[d][e] dG^T[e][q]
     auto et_frags = [&](Frag<T> (*f)[2], int eb) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < C::DB; ++i)
 #pragma unroll
             for (int t = 0; t < 2; ++t) frag_load(f[i][t], Epk + (size_t)eb * C::PK + C::PK_B + ((i * 2 + t) * 64 + lane) * 8);
     };
-    gload(0);
-    const int eb0 = (M - 32 - q0) >> 5;
-    Frag<T> ef[C::KA];
-    Frag<T> etf[C::DB][2];
-    if (wave_on) {
-        e_frags(ef, eb0);
-        g_block(ef, eb0);
-        if (my_last_kt > 0) e_frags(ef, eb0 + 1);
-    }
+    // the wave's probability tile of step kt (what the forward wrote) and its running maximum: fetched a step ahead
     const int nq32 = Lp >> 5;
-    T* const ptb = PT + (size_t)bh * pt_tiles(nq32, CAUSAL) * 1024;
+    const T* const ptb = PT + (size_t)bh * pt_tiles(nq32, CAUSAL) * 1024 + a * 32 + 16 * h;
+    const float* const mtb = MT + (size_t)bh * nq32 * Lp + min(q, Lp - 1);
     T* const dgb = dGT + (size_t)bh * pt_tiles(nq32, true) * 1024;
+    const int kt_hi = CAUSAL ? min(my_last_kt, nq32 - 1) : nq32 - 1;     // last tile this wave owns (clamp for the prefetch)
+    const int qt = min(q0 >> 5, nq32 - 1);
+    PH pp[4];
+    float mtn = 0.f;
+    auto load_p = [&](int kt) __attribute__((always_inline)) {
+        const int ktc = min(kt, kt_hi);
+        const T* tp = ptb + pt_tile(ktc, qt, nq32, CAUSAL) * 1024;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pp[g] = *reinterpret_cast<const PH*>(tp + 4 * g);      // the lane's own 16 elements, contiguous
+        mtn = mtb[(size_t)ktc * Lp];
+    };
+    gload(0);
+    load_p(0);
+    const int eb0 = (M - 32 - q0) >> 5, eb_max = (M >> 5) - 1;
+    constexpr bool E_AHEAD = sizeof(T) == 2;                            // f32 tier: 64 more registers would spill
+    Frag<T> etn[E_AHEAD ? C::DB : 1][2];                                // E^T images of the NEXT step's block
+    if constexpr (E_AHEAD) et_frags(etn, min(max(eb0, 0), eb_max));
     sstore(0);
     if (nkt > 1) gload(1);
     __syncthreads();
-    // One key tile.  MAIN = every wave of the block is strictly above its diagonal tile and tiles kt + 1,
-    // kt + 2 lie entirely below L: no wave-, tile- or bounds-dependent branch encloses a global load or
-    // store, so the compiler's s_waitcnt bookkeeping stays exact (vmcnt is in order: one conservative
-    // vmcnt(0) exposes the K / V prefetch latency and the tile-store acknowledgements in every step).
+    // One key tile.  MAIN = every wave of the block is strictly above its diagonal tile and tiles kt + 1, kt + 2 lie
+    // entirely below L: no wave-, tile- or bounds-dependent branch encloses a global load or store (exact s_waitcnt
+    // bookkeeping: vmcnt is in order).
     auto step = [&](int kt, auto main_tag) __attribute__((always_inline)) {
         constexpr bool MAIN = decltype(main_tag)::value;
         const int buf = kt & 1;
         if (MAIN || (wave_on && (!CAUSAL || kt <= my_last_kt))) {
             const int k0 = kt * 32;
-            const bool diag = !MAIN && kt == my_last_kt;
             const bool upper = !CAUSAL && !MAIN && kt > my_last_kt;      // bidirectional only: above the diagonal, no relative term
             const int eb_lo = eb0 + kt;
-            if constexpr (MAIN) {
-                g_block(ef, eb_lo + 1);               // the next block's E rows are fetched after the softmax (register budget)
-            } else if (!diag && !upper) {
-                g_block(ef, eb_lo + 1);
-                if (kt + 1 < my_last_kt) e_frags(ef, eb_lo + 2);
-            }
-            if (ME_ABL != 3 && !(MAIN && ME_ABL == 8) && !upper) et_frags(etf, eb_lo);      // E^T block of this step's lo block: in flight during S / dP / softmax
-            f32x16_t s, dp; acc_zero(s); acc_zero(dp);
+            // Everything this step reads from global memory was requested a step ago; the next step's requests go out
+            // first and are pinned there (sched_barrier): left alone, the scheduler sinks them to the end of the step and
+            // the register copies below then wait out their whole latency.
+            PH pc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pc[g] = pp[g];
+            Frag<T> etf[C::DB][2];
+            if constexpr (E_AHEAD) {
+#pragma unroll
+                for (int i = 0; i < C::DB; ++i) { etf[i][0] = etn[i][0]; etf[i][1] = etn[i][1]; }
+            } else if (!upper) et_frags(etf, eb_lo);
+            const float fac = row_on ? fast_exp2(fmaf(mtn, c2, -lse2)) : 0.f;
+            load_p(kt + 1);
+            if constexpr (E_AHEAD) et_frags(etn, min(max(eb_lo + 1, 0), eb_max));
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16_t s, dp; acc_zero(dp);
 #pragma unroll
             for (int kk = 0; kk < C::KA; ++kk) {
-                Frag<T> kf, vf;
-                frag_load(kf, &Ks[buf][a * C::LDN + kk * 16 + h * 8]);
+                Frag<T> vf;
                 frag_load(vf, &Vs[buf][a * C::LDN + kk * 16 + h * 8]);
-                mma32(s, kf, qf[kk]);          // S^T[key][q]
                 mma32(dp, vf, dof[kk]);        // dP^T[key][q] = V[key] . dO[q]
             }
-            uint32_t pbits = 0;
-            if (key_pad) pbits = __builtin_amdgcn_readfirstlane((uint32_t)__ballot(lane < 32 && Ps[buf][a] != 0));
-            // band element m (0..62) of this tile sits at ring column ((eb_lo & 1) * 32 + m) & 63 (G and dG rings)
-            const float* grow = &Gs[wid][a * LDG2];
-            T* drow = &Ds[wid][a * LDR];
-            const int t0 = (eb_lo & 1) * 32 + 31 - a + 4 * h;
-            const bool plain = !diag && !upper && pbits == 0u && k0 + 32 <= L && q0 + 32 <= L;
-            // the 16 ring reads are issued as one batch and every element is computed branch-free: per-element
-            // exec-mask branches serialise the LDS latency (one read -> wait -> exp per basic block)
             const float nds = -delta * scale;
 #pragma unroll
-            for (int r0 = 0; r0 < 16; r0 += 8) {                 // two batches of 8 ring reads (register budget)
-                float gv[8];
-#pragma unroll
-                for (int gq = 0; gq < 2; ++gq) {             // group bases: a group may run into the halo columns, never wraps
-                    const float* gp = grow + ((t0 + 2 * r0 + 8 * gq) & 63);     // r0 = 0 / 8: register quads 0,1 / 2,3 = columns +0,+8 / +16,+24
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) gv[4 * gq + i] = gp[i];
-                }
-                if (plain) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int r = r0 + j;
-                        const float p = fast_exp2(fmaf(s[r] + gv[j], c2, -lse2));
-                        s[r] = p * fmaf(dp[r], scale, nds);
-                        dp[r] = p;
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int r = r0 + j;
-                        const int bk = (r & 3) + 8 * (r >> 2) + 4 * h, key = k0 + bk;
-                        const bool masked = !row_on || (CAUSAL && key > q) || key >= L || ((pbits >> bk) & 1u);
-                        const float gq = (CAUSAL || (!upper && key <= q)) ? gv[j] : 0.f;                   // no relative term above the diagonal
-                        const float p = fast_exp2(masked ? -INFINITY : fmaf(s[r] + gq, c2, -lse2));       // exp2(-inf) = 0
-                        s[r] = masked ? 0.f : p * fmaf(dp[r], scale, nds);
-                        dp[r] = p;
-                    }
-                }
-            }
-            if (ME_ABL != 4 && !upper) {
+            for (int r = 0; r < 16; ++r) s[r] = (ET<T>::to_f(pc[r >> 2][r & 3]) * fac) * fmaf(dp[r], scale, nds);
+            T* drow = &Ds[wid][a * LDR];
+            const int t0 = (eb_lo & 1) * 32 + 31 - a + 4 * h;            // band element m sits at ring column ((eb_lo & 1) * 32 + m) & 63
+            if (!upper) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     // dG collects dS only where the relative term exists (bidirectional diagonal tile: key <= q)
                     const bool rel = CAUSAL || k0 + (r & 3) + 8 * (r >> 2) + 4 * h <= q;
                     drow[(t0 + (r & 3) + 8 * (r >> 2)) & 63] = ET<T>::from_f(rel ? s[r] : 0.f);
                 }
-            }
-            // ---- materialise the P^T tile [key][q]: transpose through the (now dead) lo slot of the G ring so that
-            //      the tile leaves as 16-byte row-contiguous stores.  Rows key >= L and columns q >= L carry exact
-            //      zeros (masked).
-            // staging = the 32 dead lo columns of every ring row (row stride LDG2 floats)
-            T* stg = reinterpret_cast<T*>(&Gs[wid][(eb_lo & 1) * 32]);
-            constexpr int LDX = LDG2 * (int)(sizeof(float) / sizeof(T));   // staging row stride in elements of T
-            constexpr int CPRX = 32 / C::CH;                        // chunks per 32-wide row
-            auto flush_tile = [&](T* gdst) {                        // stg[32][LDX] -> one contiguous [32 key][32 q] tile
-#pragma unroll
-                for (int it = 0; it < 32 * CPRX / 64; ++it) {
-                    const int c = it * 64 + lane, row = c / CPRX, cc = (c % CPRX) * C::CH;
-                    st_chunk(gdst + (size_t)row * 32 + cc, ld_chunk(&stg[row * LDX + cc]));
-                }
-            };
-            T* const pt_dst = ptb + pt_tile(kt, q0 >> 5, nq32, CAUSAL) * 1024;
-            if constexpr (MAIN && ME_ABL != 8)      // issued BEFORE the tile stores: in-order vmcnt then never makes the next step wait for them
-                e_frags(ef, min(eb_lo + 2, (M >> 5) - 1));          // clamped: unused past the diagonal
-            if constexpr (sizeof(T) == 2) {
-                // 16-bit tier: the accumulator rows go to LDS in their NATURAL [q][key] order (4 x ds_write_b64: the lane's
-                // 4 consecutive keys of each register quad) and come back transposed through ds_read_b64_tr_b16 -- 8 LDS
-                // instructions per tile instead of 16 two-byte scatters + 2 reads, and two 16-byte stores that each write 16
-                // complete 64-byte tile rows.  Chunk slot XOR (row >> 3) & 1: the 16-lane write groups hit 16 distinct bank pairs.
-                char* stgb = reinterpret_cast<char*>(stg);
-                constexpr int LDB = LDG2 * 4;                                         // staging row stride (bytes)
-                const int gidx = lane >> 4, l16 = lane & 15;
-                auto put_tile = [&](const f32x16_t& v) __attribute__((always_inline)) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        st4<T>(reinterpret_cast<T*>(stgb + a * LDB + (((2 * g + h) ^ ((a >> 3) & 1)) << 3)), v[4 * g], v[4 * g + 1], v[4 * g + 2],
-                               v[4 * g + 3]);
-                };
-                // lane (group gidx, l16) supplies the chunk (row 8 gidx + 4 s + l16 / 4, keys 16 kh + 4 (l16 % 4) ..) and receives
-                // key 16 kh + l16, queries 8 gidx + 4 s .. + 3: with s = 0, 1 that is 16 contiguous bytes of tile row `key`
-                auto flush_tr = [&](T* gdst) __attribute__((always_inline)) {
-                    typedef short v4s __attribute__((ext_vector_type(4)));
-#pragma unroll
-                    for (int kh = 0; kh < 2; ++kh) {
-                        v4s x[2];
-#pragma unroll
-                        for (int s_ = 0; s_ < 2; ++s_) {
-                            const char* src = stgb + (8 * gidx + 4 * s_ + (l16 >> 2)) * LDB + (((kh * 4 + (l16 & 3)) ^ (gidx & 1)) << 3);
-                            x[s_] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)src);
-                        }
-                        chunk16 c;
-                        reinterpret_cast<v4s*>(&c)[0] = x[0];
-                        reinterpret_cast<v4s*>(&c)[1] = x[1];
-                        st_chunk(gdst + (size_t)(kh * 16 + l16) * 32 + 8 * gidx, c);
-                    }
-                };
-                if (ME_ABL != 1) {
-                    put_tile(dp);
-                    flush_tr(pt_dst);
-                }
-            } else if (ME_ABL != 1) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * h) * LDX + a] = ET<T>::from_f(dp[r]);
-                flush_tile(pt_dst);
             }
             // ---- dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
 #pragma unroll
@@ -627,12 +556,11 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
                     const T* dlo = drow + (eb_lo & 1) * 32;
                     frag_load(dgf, dlo + 16 * t + 8 * h);
 #pragma unroll
-                    for (int i = 0; i < C::DB; ++i) { if (ME_ABL != 3) mma32(dq[i], etf[i][t], dgf); }
+                    for (int i = 0; i < C::DB; ++i) mma32(dq[i], etf[i][t], dgf);
                 }
                 T* const dg_dst = dgb + dg_tile(q0 >> 5, kt) * 1024;
                 const T* ring = &Ds[wid][(eb_lo & 1) * 32];                  // lo block: ring rows q, 32 columns m, row stride LDR
-                if constexpr (ME_ABL == 9) {
-                } else if constexpr (sizeof(T) == 2) {
+                if constexpr (sizeof(T) == 2) {
                     typedef short v4s __attribute__((ext_vector_type(4)));
                     const int gidx = lane >> 4, l16 = lane & 15;
 #pragma unroll
@@ -664,11 +592,12 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
             sstore(buf ^ 1);
             if (kt + 2 < nkt) gload(kt + 2);
         }
-        if (!(MAIN && ME_ABL == 7)) block_sync_lds();               // LDS hand-over only: prefetch loads / tile stores stay in flight
+        block_sync_lds();               // LDS hand-over only: prefetch loads / tile stores stay in flight
     };
     // MAIN steps: all four waves on and off-diagonal (kt < 4 qb), tiles kt + 1, kt + 2 whole (kt + 3 <= L / 32)
     const int nmain = (qb * 128 + 96 < L) ? max(0, min(qb * 4, (L >> 5) - 2)) : 0;
     int kt = 0;
+    vm_drain();                         // loop entry state = nothing in flight: the header's waits are the back edge's exact counts
     for (; kt < nmain; ++kt) step(kt, std::true_type{});
     for (; kt < nkt; ++kt) step(kt, std::false_type{});
     if (!row_on) return;
@@ -682,25 +611,48 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
 }
 
 // =====================================================================================
-// backward 2/3 (key-owned):  dV[key] = sum_q P^T[key][q] dO[q],  dK[key] = sum_q dS^T[key][q] Q[q]
+// backward 2/3 (key-owned):  dV[key] = sum_q P[q][key] dO[q],  dK[key] = sum_q dS[q][key] Q[q]
 // =====================================================================================
-// Block = 128 keys (4 waves x 32) x DH.  Every step stages a 32-query slab: the P^T tiles [128 key][32 q], the dO and Q
-// slabs [32 q][DH] and -delta / sqrt(dh) of the 32 queries.  dS^T is NOT read from memory: with the wave's V rows resident
-// in registers, dP^T = V dO^T is KA macro-atoms and dS = P o (dP - delta) / sqrt(dh) a multiply-add per element (no
-// exponential, no relative-term skew: P already contains both) -- P^T is the only O(L^2) tensor this kernel streams.
+// Block = 128 keys (4 waves x 32) x DH.  Every step stages a 32-query slab: the forward's probability tiles
+// [32 q][32 key] of the four key tiles, the dO and Q slabs [32 q][DH], -delta / sqrt(dh) and, per key tile, the factor
+// exp2(m_t c2 - lse log2e) that normalises the tile (0 for rows q >= L).  Neither S nor dS is read from memory: with the
+// wave's V rows resident in registers dP = dO V^T is KA macro-atoms and dS = P o (dP - delta) / sqrt(dh) a few
+// multiply-adds per element -- the probability tiles are the only O(L^2) tensor this kernel streams.
 // dP is accumulated as dP[q][key] (lane = key column), so that its registers carry the same (key, 8 queries) elements
-// as the P^T fragment read with the accumulator's k-map; all contraction-over-q operands use that map.
+// as the P fragment read (transposed, ds_read_b64_tr_b16) with the accumulator's k-map; all contraction-over-q operands
+// use that map.
+// frag_load_tr for a probability tile in register-image order: the lane's operand column is KEY lane & 31, which sits at
+// position p_col(key) of every row; a 4-key group stays a contiguous 4-element group (key group j -> position group
+// 4 (j & 1) + (j >> 1)), so the 16-bit transpose read only needs the permuted group address.
+ME_DEV void p_frag_tr(Frag<bf16_t>& f, const bf16_t* tile, int ld, int rA, int rB, int lane) {
+    typedef short v4s __attribute__((ext_vector_type(4)));
+    const int l16 = lane & 15, j = (l16 & 3) + 4 * ((lane >> 4) & 1);
+    const bf16_t* p = tile + (l16 >> 2) * ld + 4 * (4 * (j & 1) + (j >> 1));
+    v4s x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p + rA * ld));
+    v4s y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p + rB * ld));
+    f.v = __builtin_shufflevector(__builtin_bit_cast(bf16x4_t, x), __builtin_bit_cast(bf16x4_t, y), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+ME_DEV void p_frag_tr(Frag<float>& f, const float* tile, int ld, int rA, int rB, int lane) {
+    const float* p = tile + p_col(lane & 31);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f.lo[e] = p[(rA + e) * ld]; f.hi[e] = p[(rB + e) * ld]; }
+}
+
 template <typename T, int DH, bool CAUSAL = true>
-__global__ __launch_bounds__(256) void rga_bwd_kv_kernel(const T* __restrict__ PT, const T* __restrict__ qkv,
-                                                         const T* __restrict__ dout, const float* __restrict__ delta_ws,
+__global__ __launch_bounds__(256) void rga_bwd_kv_kernel(const T* __restrict__ PT, const float* __restrict__ MT,
+                                                         const T* __restrict__ qkv, const T* __restrict__ dout,
+                                                         const float* __restrict__ lse, const float* __restrict__ delta_ws,
                                                          T* __restrict__ dqkv, int B, int L, int Lp, int H, float scale) {
     using C = ACfg<T, DH>;
-    constexpr int CH = ET<T>::CH, LDP = 32 + CH, DB = C::DB, LDV = C::LDV, KA = C::KA;
+    // probability tile rows: 64 B (bf16, no padding): the four consecutive rows of a transpose read then sit on the four
+    // 16-bank quarters of the LDS (a 80-byte stride wraps row 3 onto row 0's banks), and the 16-byte tile stores are linear
+    constexpr int CH = ET<T>::CH, LDP = sizeof(T) == 2 ? 32 : 32 + CH, DB = C::DB, LDV = C::LDV, KA = C::KA;
     constexpr int KB = 128;
-    __shared__ __attribute__((aligned(16))) T Pt[2][KB * LDP];
+    __shared__ __attribute__((aligned(16))) T Pt[2][KB * LDP];         // four tiles [32 q][32 key], rows = w * 32 + q
     __shared__ __attribute__((aligned(16))) T Os[2][32 * LDV];         // natural dO / Q slabs [32 q][DH]
     __shared__ __attribute__((aligned(16))) T Qs[2][32 * LDV];
     __shared__ __attribute__((aligned(16))) float Dl[2][32];           // -delta[q] / sqrt(dh)
+    __shared__ __attribute__((aligned(16))) float Fs[2][4 * 32];       // per key tile: exp2(m_t c2 - lse log2e)
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, a = lane & 31, h = lane >> 5;
     const int BH = B * H;
@@ -712,10 +664,13 @@ __global__ __launch_bounds__(256) void rga_bwd_kv_kernel(const T* __restrict__ P
     const bool wave_on = k0 < L;
     const int nqt = (L + 31) / 32, nq32 = Lp >> 5;
     const int qs0 = CAUSAL ? kb * 4 : 0;                            // bidirectional: every query tile contributes
+    const float c2 = scale * 1.4426950408889634f;
     const T* ptb = PT + (size_t)bh * pt_tiles(nq32, CAUSAL) * 1024;
+    const float* mtb = MT + (size_t)bh * nq32 * Lp;
     const T* q_ = qkv + (size_t)b * L * ldq + head * DH;
     const T* o_ = dout + (size_t)b * L * dm + head * DH;
     const float* dl_ = delta_ws + (size_t)bh * L;
+    const float* ls_ = lse + (size_t)bh * L;
 
     Frag<T> vf[KA];                                                 // V rows of this wave's 32 keys (B operand of dP)
     row_frags<T, DH>(vf, q_ + 2 * dm + (size_t)(k0 + a) * ldq, wave_on && k0 + a < L, h);
@@ -724,10 +679,10 @@ __global__ __launch_bounds__(256) void rga_bwd_kv_kernel(const T* __restrict__ P
 #pragma unroll
     for (int i = 0; i < DB; ++i) { acc_zero(dk[i]); acc_zero(dv[i]); }
 
-    constexpr int CPRP = 32 / CH, NPTP = KB * CPRP / 256;              // P^T tiles [128][32]: chunks per thread
+    constexpr int CPRP = 32 / CH, NPTP = KB * CPRP / 256;              // probability tiles: chunks per thread
     constexpr int CPRQ = DH / CH, NCHQ = 32 * CPRQ, NPTQ = (NCHQ + 255) / 256;   // Q / dO slab [32][DH]
     chunk16 rp[NPTP], ro[NPTQ], rq[NPTQ];
-    float rd = 0.f;
+    float rd = 0.f, rl = 0.f, rm = 0.f;
     auto gload = [&](int qs) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NPTP; ++i) {
@@ -744,9 +699,12 @@ __global__ __launch_bounds__(256) void rga_bwd_kv_kernel(const T* __restrict__ P
             ro[i] = ok ? ld_chunk(o_ + ((size_t)qs * 32 + row) * dm + cc) : zero_chunk();
             rq[i] = ok ? ld_chunk(q_ + ((size_t)qs * 32 + row) * ldq + cc) : zero_chunk();
         }
-        rd = dl_[min(qs * 32 + (tid & 31), L - 1)];
+        const int qq = min(qs * 32 + (tid & 31), L - 1);
+        rd = dl_[qq];
+        rl = ls_[qq];
+        rm = mtb[(size_t)min(kb * 4 + ((tid >> 5) & 3), nq32 - 1) * Lp + qs * 32 + (tid & 31)];      // tid < 128: (key tile tid / 32, query tid % 32)
     };
-    auto sstore = [&](int buf) __attribute__((always_inline)) {
+    auto sstore = [&](int buf, int qs) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NPTP; ++i) {
             const int c = tid + i * 256, row = c / CPRP, cc = (c % CPRP) * CH;
@@ -758,9 +716,10 @@ __global__ __launch_bounds__(256) void rga_bwd_kv_kernel(const T* __restrict__ P
             if (c < NCHQ) { st_chunk(&Os[buf][row * LDV + cc], ro[i]); st_chunk(&Qs[buf][row * LDV + cc], rq[i]); }
         }
         if (tid < 32) Dl[buf][tid] = -rd * scale;
+        if (tid < 128) Fs[buf][tid] = qs * 32 + (tid & 31) < L ? fast_exp2(fmaf(rm, c2, -rl * 1.4426950408889634f)) : 0.f;
     };
     gload(qs0);
-    sstore(0);
+    sstore(0, qs0);
     if (qs0 + 1 < nqt) gload(qs0 + 1);
     __syncthreads();
     for (int qs = qs0; qs < nqt; ++qs) {
@@ -777,14 +736,18 @@ __global__ __launch_bounds__(256) void rga_bwd_kv_kernel(const T* __restrict__ P
             for (int t = 0; t < 2; ++t) {
                 // accumulator registers 8t .. 8t+7 of lane (key a, h) = queries 16t + 4h + {0..3} and 16t + 8 + 4h + {0..3}
                 const int qa = 16 * t + 4 * h, qb_ = qa + 8;
-                Frag<T> pf, sf;
-                frag_load_4x2(pf, &Pt[buf][(wid * 32 + a) * LDP + qa], &Pt[buf][(wid * 32 + a) * LDP + qb_]);
+                Frag<T> pr, pf, sf;
+                p_frag_tr(pr, &Pt[buf][wid * 32 * LDP], LDP, qa, qb_, lane);             // p[q][key a], q in the k-map above
                 const f32x4_t da = *reinterpret_cast<const f32x4_t*>(&Dl[buf][qa]);
                 const f32x4_t db_ = *reinterpret_cast<const f32x4_t*>(&Dl[buf][qb_]);
+                const f32x4_t fa = *reinterpret_cast<const f32x4_t*>(&Fs[buf][wid * 32 + qa]);
+                const f32x4_t fb = *reinterpret_cast<const f32x4_t*>(&Fs[buf][wid * 32 + qb_]);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float nd = e < 4 ? da[e] : db_[e - 4];
-                    frag_set(sf, e, frag_get(pf, e) * fmaf(dp[8 * t + e], scale, nd));
+                    const float pn = frag_get(pr, e) * (e < 4 ? fa[e] : fb[e - 4]);      // P = p * exp2(m_t c2 - lse log2e)
+                    frag_set(pf, e, pn);
+                    frag_set(sf, e, pn * fmaf(dp[8 * t + e], scale, nd));
                 }
 #pragma unroll
                 for (int i = 0; i < DB; ++i) {
@@ -797,7 +760,7 @@ __global__ __launch_bounds__(256) void rga_bwd_kv_kernel(const T* __restrict__ P
             }
         }
         if (qs + 1 < nqt) {
-            sstore(buf ^ 1);
+            sstore(buf ^ 1, qs + 1);
             if (qs + 2 < nqt) gload(qs + 2);
         }
         block_sync_lds();               // LDS hand-over only: prefetch loads stay in flight
@@ -967,39 +930,42 @@ int pack_launch(const void* E, void* Epk, int M, hipStream_t st) {
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <typename T, int DH>
-int fwd_launch(const void* qkv, const void* Epk, const uint8_t* key_pad, void* out, float* lse, int B, int L, int H, int M,
-               int causal, hipStream_t st) {
-    const int nqb = (L + 127) / 128;
+int fwd_launch(const void* qkv, const void* Epk, const uint8_t* key_pad, void* out, float* lse, void* PT, float* MT, int B,
+               int L, int H, int M, int causal, hipStream_t st) {
+    const int nqb = (L + 127) / 128, Lp = ((L + 31) / 32) * 32;
     const float scale = 1.f / sqrtf((float)DH);
-    if (causal)
-        rga_fwd_kernel<T, DH, true><<<B * H * nqb, 256, 0, st>>>((const T*)qkv, (const T*)Epk, key_pad, (T*)out, lse, B, L, H, M, scale);
-    else
-        rga_fwd_kernel<T, DH, false><<<B * H * nqb, 256, 0, st>>>((const T*)qkv, (const T*)Epk, key_pad, (T*)out, lse, B, L, H, M, scale);
+    const dim3 grid(B * H * nqb);
+#define ME_FWD(CA, SP) rga_fwd_kernel<T, DH, CA, SP><<<grid, 256, 0, st>>>((const T*)qkv, (const T*)Epk, key_pad, (T*)out, lse, (T*)PT, MT, B, L, Lp, H, M, scale)
+    if (causal) { if (PT) ME_FWD(true, true); else ME_FWD(true, false); }
+    else { if (PT) ME_FWD(false, true); else ME_FWD(false, false); }
+#undef ME_FWD
     return me_launch_status();
 }
 
 template <typename T, int DH>
-int bwd_launch(const void* qkv, const void* Epk, const uint8_t* key_pad, const void* out, const float* lse,
-               const void* dout, void* dqkv, float* dE, float* delta_ws, void* PT, void* dGT, int B, int L,
-               int Lp, int H, int M, int causal, hipStream_t st) {
+int bwd_launch(const void* qkv, const void* Epk, const void* out, const float* lse, const void* dout, void* dqkv, float* dE,
+               float* delta_ws, const void* PT, const float* MT, void* dGT, int B, int L, int Lp, int H, int M, int causal,
+               hipStream_t st) {
+    // One launch of each kernel over the whole batch.  Splitting the batch so that a chunk's probability / dG^T tiles
+    // stay in the 256 MB Infinity Cache between the three kernels was measured and is slower (B = 32 in chunks of
+    // 16 / 8 / 4: 449 / 524 / 898 us against 424 us): these kernels are latency bound, not HBM bound, and smaller
+    // launches leave CUs idle.
     const int nqb = (L + 127) / 128;
     const float scale = 1.f / sqrtf((float)DH);
     if (causal)
-        rga_bwd_q_kernel<T, DH, true><<<B * H * nqb, 256, 0, st>>>((const T*)qkv, (const T*)Epk, key_pad, (const T*)out, lse,
-                                                                  (const T*)dout, (T*)dqkv, delta_ws, (T*)PT, (T*)dGT, B, L, Lp,
-                                                                  H, M, scale);
+        rga_bwd_q_kernel<T, DH, true><<<B * H * nqb, 256, 0, st>>>((const T*)qkv, (const T*)Epk, (const T*)out, lse, (const T*)dout,
+                                                                  (T*)dqkv, delta_ws, (const T*)PT, MT, (T*)dGT, B, L, Lp, H, M, scale);
     else
-        rga_bwd_q_kernel<T, DH, false><<<B * H * nqb, 256, 0, st>>>((const T*)qkv, (const T*)Epk, key_pad, (const T*)out, lse,
-                                                                   (const T*)dout, (T*)dqkv, delta_ws, (T*)PT, (T*)dGT, B, L, Lp,
-                                                                   H, M, scale);
+        rga_bwd_q_kernel<T, DH, false><<<B * H * nqb, 256, 0, st>>>((const T*)qkv, (const T*)Epk, (const T*)out, lse, (const T*)dout,
+                                                                   (T*)dqkv, delta_ws, (const T*)PT, MT, (T*)dGT, B, L, Lp, H, M, scale);
     int rc = me_launch_status();
     if (rc) return rc;
     if (causal)
-        rga_bwd_kv_kernel<T, DH, true><<<B * H * nqb, 256, 0, st>>>((const T*)PT, (const T*)qkv, (const T*)dout, delta_ws, (T*)dqkv,
-                                                                   B, L, Lp, H, scale);
+        rga_bwd_kv_kernel<T, DH, true><<<B * H * nqb, 256, 0, st>>>((const T*)PT, MT, (const T*)qkv, (const T*)dout, lse, delta_ws,
+                                                                   (T*)dqkv, B, L, Lp, H, scale);
     else
-        rga_bwd_kv_kernel<T, DH, false><<<B * H * nqb, 256, 0, st>>>((const T*)PT, (const T*)qkv, (const T*)dout, delta_ws, (T*)dqkv,
-                                                                    B, L, Lp, H, scale);
+        rga_bwd_kv_kernel<T, DH, false><<<B * H * nqb, 256, 0, st>>>((const T*)PT, MT, (const T*)qkv, (const T*)dout, lse, delta_ws,
+                                                                    (T*)dqkv, B, L, Lp, H, scale);
     rc = me_launch_status();
     if (rc) return rc;
     const int ngx = (Lp + 127) / 128;
@@ -1037,28 +1003,27 @@ int me_rga_pack_rel(const void* E, void* Epk, int M, int dh, int dtype, void* st
     ME_ATTN_DISPATCH((pack_launch<T, DH>(E, Epk, M, st)))
 }
 
-int me_rga_fwd(const void* qkv, const void* Epk, const uint8_t* key_pad, void* out, float* lse, int B, int L, int H, int dh,
-               int M, int causal, int dtype, void* stream) {
+int me_rga_fwd(const void* qkv, const void* Epk, const uint8_t* key_pad, void* out, float* lse, void* PT, float* MT, int B,
+               int L, int H, int dh, int M, int causal, int dtype, void* stream) {
     me_clear_error();
-    if (!qkv || !Epk || !out || !lse) return ME_ERR_NULL;
+    if (!qkv || !Epk || !out || !lse || ((PT == nullptr) != (MT == nullptr))) return ME_ERR_NULL;
     if (B <= 0 || L <= 0 || H <= 0 || L > M || (M & 31)) return ME_ERR_BAD_SHAPE;
-    if (!aligned16(qkv) || !aligned16(Epk) || !aligned16(out)) return ME_ERR_ALIGNMENT;
+    if (!aligned16(qkv) || !aligned16(Epk) || !aligned16(out) || !aligned16(PT)) return ME_ERR_ALIGNMENT;
     hipStream_t st = (hipStream_t)stream;
-    ME_ATTN_DISPATCH((fwd_launch<T, DH>(qkv, Epk, key_pad, out, lse, B, L, H, M, causal, st)))
+    ME_ATTN_DISPATCH((fwd_launch<T, DH>(qkv, Epk, key_pad, out, lse, PT, MT, B, L, H, M, causal, st)))
 }
 
-int me_rga_bwd(const void* qkv, const void* Epk, const uint8_t* key_pad, const void* out, const float* lse,
-               const void* dout, void* dqkv, float* dE, float* delta_ws, void* PT, void* dGT, int B, int L,
-               int Lp, int H, int dh, int M, int causal, int dtype, void* stream) {
+int me_rga_bwd(const void* qkv, const void* Epk, const void* out, const float* lse, const void* dout, void* dqkv, float* dE,
+               float* delta_ws, const void* PT, const float* MT, void* dGT, int B, int L, int Lp, int H, int dh, int M,
+               int causal, int dtype, void* stream) {
     me_clear_error();
-    if (!qkv || !Epk || !out || !lse || !dout || !dqkv || !dE || !delta_ws || !PT || !dGT) return ME_ERR_NULL;
-    if (B <= 0 || L <= 0 || H <= 0 || L > M || (M & 31) || (Lp & 31) || Lp < L || Lp > M) return ME_ERR_BAD_SHAPE;
+    if (!qkv || !Epk || !out || !lse || !dout || !dqkv || !dE || !delta_ws || !PT || !MT || !dGT) return ME_ERR_NULL;
+    if (B <= 0 || L <= 0 || H <= 0 || L > M || (M & 31) || Lp != ((L + 31) / 32) * 32 || Lp > M) return ME_ERR_BAD_SHAPE;
     if (!aligned16(qkv) || !aligned16(Epk) || !aligned16(out) || !aligned16(dout) || !aligned16(dqkv) ||
         !aligned16(PT) || !aligned16(dGT))
         return ME_ERR_ALIGNMENT;
     hipStream_t st = (hipStream_t)stream;
-    ME_ATTN_DISPATCH((bwd_launch<T, DH>(qkv, Epk, key_pad, out, lse, dout, dqkv, dE, delta_ws, PT, dGT, B, L, Lp, H, M,
-                                        causal, st)))
+    ME_ATTN_DISPATCH((bwd_launch<T, DH>(qkv, Epk, out, lse, dout, dqkv, dE, delta_ws, PT, MT, dGT, B, L, Lp, H, M, causal, st)))
 }
 
 }  // extern "C"

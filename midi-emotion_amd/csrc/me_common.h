@@ -101,6 +101,18 @@ ME_DEV void frag_zero(Frag<bf16_t>& f) { f.v = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0
 ME_DEV void frag_zero(Frag<float>& f) { f.lo = (f32x4_t){0, 0, 0, 0}; f.hi = f.lo; }
 ME_DEV void frag_set(Frag<bf16_t>& f, int e, float x) { f.v[e] = (bf16_t)x; }
 ME_DEV void frag_set(Frag<float>& f, int e, float x) { if (e < 4) f.lo[e] = x; else f.hi[e - 4] = x; }
+// the 8 elements of a fragment as one 16-byte (bf16) / two 16-byte (f32) stores
+ME_DEV void frag_store(bf16_t* p, const Frag<bf16_t>& f) { *reinterpret_cast<bf16x8_t*>(p) = f.v; }
+ME_DEV void frag_store(float* p, const Frag<float>& f) {
+    *reinterpret_cast<f32x4_t*>(p) = f.lo;
+    *reinterpret_cast<f32x4_t*>(p + 4) = f.hi;
+}
+// elements 4 half .. 4 half + 3 of a fragment as one 8-byte (bf16) / 16-byte (f32) store
+ME_DEV void frag_store_half(bf16_t* p, const Frag<bf16_t>& f, int half) {
+    bf16x4_t v = half ? __builtin_shufflevector(f.v, f.v, 4, 5, 6, 7) : __builtin_shufflevector(f.v, f.v, 0, 1, 2, 3);
+    *reinterpret_cast<bf16x4_t*>(p) = v;
+}
+ME_DEV void frag_store_half(float* p, const Frag<float>& f, int half) { *reinterpret_cast<f32x4_t*>(p) = half ? f.hi : f.lo; }
 ME_DEV float frag_get(const Frag<bf16_t>& f, int e) { return (float)f.v[e]; }
 ME_DEV float frag_get(const Frag<float>& f, int e) { return e < 4 ? f.lo[e] : f.hi[e - 4]; }
 
@@ -132,6 +144,10 @@ ME_DEV void block_sync_lds() {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
+// s_waitcnt vmcnt(0) as a real instruction (the waitcnt pass accounts for it, unlike inline asm).  Placed in a loop's
+// preheader it makes "nothing in flight" the entry state, so the conservative merge of entry and back-edge states at the
+// loop header keeps the back edge's exact counts instead of draining the prefetches every iteration.
+ME_DEV void vm_drain() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 ME_DEV void acc_zero(f32x16_t& a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) a[r] = 0.f;

@@ -1099,6 +1099,7 @@ size_t me_workspace_bytes(int op, int M, int N, int K, int dtype) {
         const size_t tiles = (op == ME_WS_RGA_DGT || K) ? nq * (nq + 1) / 2 : nq * nq;
         return (size_t)M * tiles * 1024 * es;
     }
+    if (op == ME_WS_RGA_MT) return (M > 0 && N > 0 && !(N & 31)) ? (size_t)M * (N / 32) * N * sizeof(float) : 0;
     return 0;
 }
 

@@ -359,8 +359,10 @@ class MusicTransformerHIP(nn.Module):
             if save:
                 L.s1, L.s2 = e(T, d), e(T, d)
                 L.st1, L.st2 = e(T, 2, dtype=torch.float32), e(T, 2, dtype=torch.float32)
+                # what the attention forward leaves for its backward: unnormalised probability tiles + running maxima
+                L.PT, L.MT = ops.rga_saved_buffers(B, H, Lm, dt, dev, causal=self.causal)
             else:
-                L.s1 = L.s2 = L.st1 = L.st2 = None
+                L.s1 = L.s2 = L.st1 = L.st2 = L.PT = L.MT = None
             ws.layers.append(L)
         ws.tmp = e(T, d)
         if save:
@@ -372,9 +374,9 @@ class MusicTransformerHIP(nn.Module):
             ws.dA, ws.dB, ws.dC, ws.dC2 = e(T, d), e(T, d), e(T, d), e(T, d)
             ws.dhid, ws.dqkv = e(T, di), e(T, 3 * d)
             ws.delta = e(B, H, Lm, dtype=torch.float32)
-            # tiles of P^T and of the skewed dS (dG^T) of the layer being differentiated (me_workspace_bytes; no
-            # initialisation contract: every tile is written before it is read)
-            ws.PT, ws.dGT = ops.rga_bwd_workspaces(B, H, Lp, dt, dev, causal=self.causal)
+            # tiles of the skewed dS (dG^T) of the layer being differentiated (me_workspace_bytes; no initialisation
+            # contract: every tile is written before it is read)
+            ws.dGT = ops.rga_bwd_workspace(B, H, Lm, dt, dev)
         self._ws[key] = ws
         return ws
 
@@ -431,7 +433,7 @@ class MusicTransformerHIP(nn.Module):
             p = f"enc_layers.{i}."
             ops.gemm_nt(x, W["Wqkv"], Lw.qkv, bias=W["bqkv"], M=T, N=3 * d, K=d, dtype=dt)
             ops.rga_fwd(Lw.qkv, W["Epk"], ws.key_pad if self.causal else None, Lw.att, Lw.lse, B, Lm, H, dh, M,
-                        causal=self.causal)             # bidirectional (mask=None in the reference): no pad mask either
+                        causal=self.causal, PT=Lw.PT, MT=Lw.MT)   # bidirectional (mask=None in the reference): no pad mask either
             ops.gemm_nt(Lw.att, W["Wo"], ws.tmp, bias=self._pview(f, p + "rga.fc.bias"), M=T, N=d, K=d, dtype=dt)
             ops.resid_ln_fwd(x, ws.tmp, self._pview(f, p + "layernorm1.weight"), self._pview(f, p + "layernorm1.bias"),
                              Lw.o1, Lw.s1, Lw.st1, T, d, self.LN_EPS, p_drop, seed, 1 + 2 * i, x_lo=ws.hlo[0], y_lo=ws.hlo[1])
@@ -501,8 +503,8 @@ class MusicTransformerHIP(nn.Module):
             reuse("dqkv")
             if bucket_hook:
                 bucket_hook(-1)            # comm window: ~0.5 ms of attention-backward kernels follow (ddp.GradAllReducer)
-            ops.rga_bwd(Lw.qkv, W["Epk"], ws.key_pad if self.causal else None, Lw.att, Lw.lse, ws.dA, ws.dqkv,
-                        gv(p + "rga.E"), ws.delta, ws.PT, ws.dGT, B, Lm, ws.Lp, H, dh, M, causal=self.causal)
+            ops.rga_bwd(Lw.qkv, W["Epk"], Lw.att, Lw.lse, ws.dA, ws.dqkv, gv(p + "rga.E"), ws.delta, Lw.PT, Lw.MT, ws.dGT,
+                        B, Lm, ws.Lp, H, dh, M, causal=self.causal)
             o, _, _ = self._slices[p + "rga.Wq.weight"]
             ob, _, _ = self._slices[p + "rga.Wq.bias"]
             wgrad("dqkv", ws.dqkv, x, gflat[o:o + 3 * d * d].view(3 * d, d), gflat[ob:ob + 3 * d], T=T, N=3 * d, K=d,

@@ -7,7 +7,7 @@ import torch
 
 from . import _lib
 from ._lib import (ME_BF16, ME_COND_CONCAT, ME_COND_NONE, ME_COND_TOKEN, ME_EPI_OUT_F32, ME_EPI_RELU,
-                   ME_EPI_RELU_BWD, ME_F32, ME_WS_GEMM_TN, ME_WS_RGA_DGT, ME_WS_RGA_PT, check)
+                   ME_EPI_RELU_BWD, ME_F32, ME_WS_GEMM_TN, ME_WS_RGA_DGT, ME_WS_RGA_MT, ME_WS_RGA_PT, check)
 
 DTYPE_CODE = {torch.float32: ME_F32, torch.bfloat16: ME_BF16}
 
@@ -128,28 +128,38 @@ def rga_pack_rel(E, out=None):
     return out
 
 
-def rga_fwd(qkv, Epk, key_pad, out, lse, B, L, H, dh, M, causal=True):
-    """Epk = rga_pack_rel(E).  causal=False: bidirectional attention of the regression model (forward only)."""
-    check(lib().me_rga_fwd(_ptr(qkv), _ptr(Epk), _ptr(key_pad), _ptr(out), _ptr(lse), B, L, H, dh, M, 1 if causal else 0,
-                           _code(qkv.dtype), _stream()), "me_rga_fwd")
+def rga_fwd(qkv, Epk, key_pad, out, lse, B, L, H, dh, M, causal=True, PT=None, MT=None):
+    """Epk = rga_pack_rel(E).  causal=False: bidirectional attention of the regression model.  PT / MT (rga_saved_buffers):
+    training mode -- the probability tiles and running maxima me_rga_bwd reads."""
+    check(lib().me_rga_fwd(_ptr(qkv), _ptr(Epk), _ptr(key_pad), _ptr(out), _ptr(lse), _ptr(PT), _ptr(MT), B, L, H, dh, M,
+                           1 if causal else 0, _code(qkv.dtype), _stream()), "me_rga_fwd")
 
 
-def rga_bwd_workspaces(B, H, Lp, dtype, device, causal=True):
-    """(PT, dGT): uninitialised tile workspaces of me_rga_bwd, sized by me_workspace_bytes."""
+def rga_saved_buffers(B, H, L, dtype, device, causal=True):
+    """(PT, MT): what a training-mode me_rga_fwd leaves for me_rga_bwd of the same layer (sizes: me_workspace_bytes)."""
+    Lp = ((L + 31) // 32) * 32
     es = torch.empty(0, dtype=dtype).element_size()
     n_pt = workspace_bytes(ME_WS_RGA_PT, B * H, Lp, 1 if causal else 0, dtype) // es
-    n_dg = workspace_bytes(ME_WS_RGA_DGT, B * H, Lp, 0, dtype) // es
-    return torch.empty(n_pt, dtype=dtype, device=device), torch.empty(n_dg, dtype=dtype, device=device)
+    n_mt = workspace_bytes(ME_WS_RGA_MT, B * H, Lp, 0, dtype) // 4
+    return torch.empty(n_pt, dtype=dtype, device=device), torch.empty(n_mt, dtype=torch.float32, device=device)
 
 
-def rga_bwd(qkv, Epk, key_pad, out, lse, dout, dqkv, dE, delta_ws, PT, dGT, B, L, Lp, H, dh, M, causal=True):
+def rga_bwd_workspace(B, H, L, dtype, device):
+    """dGT: uninitialised tile workspace of me_rga_bwd (shared by all layers), sized by me_workspace_bytes."""
+    Lp = ((L + 31) // 32) * 32
+    es = torch.empty(0, dtype=dtype).element_size()
+    return torch.empty(workspace_bytes(ME_WS_RGA_DGT, B * H, Lp, 0, dtype) // es, dtype=dtype, device=device)
+
+
+def rga_bwd(qkv, Epk, out, lse, dout, dqkv, dE, delta_ws, PT, MT, dGT, B, L, Lp, H, dh, M, causal=True):
     es = PT.element_size()
     if (PT.numel() * es < workspace_bytes(ME_WS_RGA_PT, B * H, Lp, 1 if causal else 0, qkv.dtype) or
+            MT.numel() * 4 < workspace_bytes(ME_WS_RGA_MT, B * H, Lp, 0, qkv.dtype) or
             dGT.numel() * es < workspace_bytes(ME_WS_RGA_DGT, B * H, Lp, 0, qkv.dtype)):
-        raise RuntimeError("rga_bwd: PT / dGT workspace smaller than me_workspace_bytes")
-    check(lib().me_rga_bwd(_ptr(qkv), _ptr(Epk), _ptr(key_pad), _ptr(out), _ptr(lse), _ptr(dout), _ptr(dqkv),
-                           _ptr(dE), _ptr(delta_ws), _ptr(PT), _ptr(dGT), B, L, Lp, H, dh, M, 1 if causal else 0,
-                           _code(qkv.dtype), _stream()), "me_rga_bwd")
+        raise RuntimeError("rga_bwd: PT / MT / dGT smaller than me_workspace_bytes")
+    check(lib().me_rga_bwd(_ptr(qkv), _ptr(Epk), _ptr(out), _ptr(lse), _ptr(dout), _ptr(dqkv), _ptr(dE), _ptr(delta_ws),
+                           _ptr(PT), _ptr(MT), _ptr(dGT), B, L, Lp, H, dh, M, 1 if causal else 0, _code(qkv.dtype), _stream()),
+          "me_rga_bwd")
 
 
 def resid_ln_fwd(x, a, gamma, beta, y, s_out, stats, rows, d, eps, p, seed, site, x_lo=None, y_lo=None):

@@ -463,17 +463,26 @@ def run_attn(ops, dtype, q, k, v, E, dO, pad, backward=True, causal=True):
     out = torch.full((B, L, H, dh), float("nan"), dtype=dtype, device=DEV)
     lse = torch.empty(B, H, L, dtype=torch.float32, device=DEV)
     Epk = ops.rga_pack_rel(Ed)
-    ops.rga_fwd(qkv, Epk, kp, out, lse, B, L, H, dh, M, causal=causal)
+    PT = MT = None
+    if backward:                                        # training mode: the forward leaves its probability tiles + running maxima
+        PT, MT = ops.rga_saved_buffers(B, H, L, dtype, DEV, causal=causal)
+        PT.fill_(float("nan"))                          # no initialisation contract: every tile read was written before
+        MT.fill_(float("nan"))
+        out_inf = torch.full_like(out, float("nan"))
+        lse_inf = torch.empty_like(lse)
+        ops.rga_fwd(qkv, Epk, kp, out_inf, lse_inf, B, L, H, dh, M, causal=causal)       # inference mode: same outputs
+    ops.rga_fwd(qkv, Epk, kp, out, lse, B, L, H, dh, M, causal=causal, PT=PT, MT=MT)
+    if backward:
+        assert torch.equal(out.nan_to_num(7.0), out_inf.nan_to_num(7.0)) and torch.equal(lse.nan_to_num(7.0), lse_inf.nan_to_num(7.0))
     res = {"O": out.permute(0, 2, 1, 3).float().cpu(), "lse": lse.cpu()}
     if backward:
         dout = to_tok(dO).contiguous().to(dtype).to(DEV)
         dqkv = torch.full_like(qkv, float("nan"))
         dE = torch.zeros(M, dh, dtype=torch.float32, device=DEV)
         delta = torch.empty(B, H, L, dtype=torch.float32, device=DEV)
-        PT, dGT = ops.rga_bwd_workspaces(B, H, Lp, dtype, DEV, causal=causal)
-        PT.fill_(float("nan"))                          # no initialisation contract: every tile read was written in the same call
+        dGT = ops.rga_bwd_workspace(B, H, L, dtype, DEV)
         dGT.fill_(float("nan"))
-        ops.rga_bwd(qkv, Epk, kp, out, lse, dout, dqkv, dE, delta, PT, dGT, B, L, Lp, H, dh, M, causal=causal)
+        ops.rga_bwd(qkv, Epk, out, lse, dout, dqkv, dE, delta, PT, MT, dGT, B, L, Lp, H, dh, M, causal=causal)
         g = dqkv.float().cpu().permute(2, 0, 3, 1, 4)   # [3,B,H,L,dh]
         res.update(dq=g[0], dk=g[1], dv=g[2], dE=dE.cpu())
     return res

@@ -16,6 +16,7 @@ qkv = torch.randn(B, L, 3, H, dh, device=dev).to(dt); E = torch.randn(M, dh, dev
 out = torch.randn(B, L, H, dh, device=dev).to(dt); lse = torch.randn(B, H, L, device=dev).abs() + 5
 dout = torch.randn(B, L, H, dh, device=dev).to(dt); dqkv = torch.empty_like(qkv); dE = torch.zeros(M, dh, device=dev)
 delta = torch.empty(B, H, L, device=dev); kp = torch.zeros(B, L, dtype=torch.uint8, device=dev)
-PT, dST = ops.rga_bwd_workspaces(B, H, Lp, dt, dev)
-t = timeit(lambda: ops.rga_bwd(qkv, Epk, kp, out, lse, dout, dqkv, dE, delta, PT, dST, B, L, Lp, H, dh, M))
+PT, MT = ops.rga_saved_buffers(B, H, L, dt, dev)
+dST = ops.rga_bwd_workspace(B, H, L, dt, dev)
+t = timeit(lambda: ops.rga_bwd(qkv, Epk, out, lse, dout, dqkv, dE, delta, PT, MT, dST, B, L, Lp, H, dh, M))
 print("%s rga_bwd total %.1f us" % (os.environ.get("TAG", ""), t))

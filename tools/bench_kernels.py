@@ -45,45 +45,17 @@ def main():
         dqkv = torch.empty_like(qkv)
         dE = torch.zeros(M, dh, device=dev)
         delta = torch.empty(B, H, L, device=dev)
-        PT, dST = ops.rga_bwd_workspaces(B, H, Lp, dt, dev)
+        PT, MT = ops.rga_saved_buffers(B, H, L, dt, dev)
+        dST = ops.rga_bwd_workspace(B, H, L, dt, dev)
         kp = torch.zeros(B, L, dtype=torch.uint8, device=dev)
         flop = 3 * 2 * B * H * dh * L * (L + 1) / 2
         t = timeit(lambda: ops.rga_fwd(qkv, Epk, kp, out, lse, B, L, H, dh, M), a.iters)
-        print("rga_fwd          %9.1f us  %7.1f TF (causal-discounted 3 contractions)" % (t, flop / t / 1e6))
-        t = timeit(lambda: ops.rga_bwd(qkv, Epk, kp, out, lse, dout, dqkv, dE, delta, PT, dST, B, L, Lp, H, dh, M),
+        print("rga_fwd (infer)  %9.1f us  %7.1f TF (causal-discounted 3 contractions)" % (t, flop / t / 1e6))
+        t = timeit(lambda: ops.rga_fwd(qkv, Epk, kp, out, lse, B, L, H, dh, M, PT=PT, MT=MT), a.iters)
+        print("rga_fwd (train)  %9.1f us  %7.1f TF" % (t, flop / t / 1e6))
+        t = timeit(lambda: ops.rga_bwd(qkv, Epk, out, lse, dout, dqkv, dE, delta, PT, MT, dST, B, L, Lp, H, dh, M),
                    a.iters)
         print("rga_bwd (3 krn)  %9.1f us  %7.1f TF (2x fwd flops)" % (t, 2 * flop / t / 1e6))
-    if "chunk" in a.what:
-        # attention backward in batch chunks that recycle a small workspace (does it stay in the Infinity Cache?)
-        Lp = ((L + 31) // 32) * 32
-        qkv = torch.randn(B, L, 3, H, dh, device=dev).to(dt)
-        E = torch.randn(M, dh, device=dev).to(dt)
-        Epk = ops.rga_pack_rel(E)
-        out = torch.randn(B, L, H, dh, device=dev).to(dt)
-        lse = torch.randn(B, H, L, device=dev).abs() + 5
-        dout = torch.randn(B, L, H, dh, device=dev).to(dt)
-        dqkv = torch.empty_like(qkv)
-        dqkv2 = torch.empty_like(qkv)
-        delta = torch.empty(B, H, L, device=dev)
-        kp = torch.zeros(B, L, dtype=torch.uint8, device=dev)
-        PT, dST = ops.rga_bwd_workspaces(B, H, Lp, dt, dev)
-        dE = torch.zeros(M, dh, device=dev)
-        t = timeit(lambda: ops.rga_bwd(qkv, Epk, kp, out, lse, dout, dqkv, dE, delta, PT, dST, B, L, Lp, H, dh, M), a.iters)
-        print("rga_bwd one call, workspace %4d MB x3      %9.1f us" % (PT.numel() * 2 // 2**20, t))
-        dE1 = torch.zeros(M, dh, device=dev)
-        ops.rga_bwd(qkv, Epk, kp, out, lse, dout, dqkv, dE1, delta, PT, dST, B, L, Lp, H, dh, M)
-        for Bc in (16, 8, 4, 2, 1):
-            def run(dq, dEx):
-                for b0 in range(0, B, Bc):
-                    ops.rga_bwd(qkv[b0:b0 + Bc], Epk, kp[b0:b0 + Bc], out[b0:b0 + Bc], lse[b0:b0 + Bc], dout[b0:b0 + Bc],
-                                dq[b0:b0 + Bc], dEx, delta[b0:b0 + Bc], PT, dST, Bc, L, Lp, H, dh, M)
-            t = timeit(lambda: run(dqkv2, dE), a.iters)
-            dE2 = torch.zeros(M, dh, device=dev)
-            run(dqkv2, dE2)
-            err = float((dqkv2.float() - dqkv.float()).norm() / dqkv.float().norm())
-            errE = float((dE2 - dE1).norm() / dE1.norm())
-            print("rga_bwd in chunks of %2d sequences (%3d MB x3) %9.1f us   dqkv rel diff %.1e  dE rel diff %.1e" % (
-                Bc, Bc * H * Lp * Lp * 2 // 2**20, t, err, errE))
     if "gemm" in a.what:
         for (M_, N_, K_, tag) in [(T, 1536, 512, "qkv"), (T, 512, 512, "proj"), (T, 2048, 512, "ffn1"),
                                    (T, 512, 2048, "ffn2"), (T, 1007, 512, "head")]:
