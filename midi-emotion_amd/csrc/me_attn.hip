@@ -37,9 +37,6 @@
 #include "me_common.h"
 #include <type_traits>
 
-#ifndef ME_ABL
-#define ME_ABL 0
-#endif
 
 namespace {
 
@@ -128,6 +125,10 @@ ME_DEV size_t pt_tile(int kt, int qt, int nq, bool causal) {
 }
 ME_DEV size_t pt_tiles(int nq, bool causal) { return causal ? (size_t)nq * (nq + 1) / 2 : (size_t)nq * nq; }
 ME_DEV size_t dg_tile(int qt, int t) { return (size_t)qt * (qt + 1) / 2 + t; }
+// A dG^T tile [32 E rows m][32 queries q] is stored as the E kernel's two A-operand fragment images: image t = q / 16,
+// lane (a = m, h = (q / 8) % 2) holds queries 16 t + 8 h .. + 7 contiguously -- consecutive lanes read consecutive 16-byte
+// (bf16) pieces, one contiguous KB per wave load (row-major tiles made every lane its own 64-byte-granule request).
+ME_DEV int dg_pos(int m, int q) { return (q >> 4) * 512 + (m + 32 * ((q >> 3) & 1)) * 8 + (q & 7); }
 // Probability tiles are stored as the forward's REGISTER IMAGE: row q holds its 32 keys in the order the two lanes
 // (q, h = 0 / 1) own them (accumulator registers 0..15 of lane (q, h) = keys 8 g + 4 h + i, g = r / 4, i = r % 4), i.e.
 // key -> position 16 h + 4 g + i.  A lane then writes / reads back 16 contiguous elements (a wave: one contiguous tile,
@@ -574,13 +575,14 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
                         chunk16 c;
                         reinterpret_cast<v4s*>(&c)[0] = x[0];
                         reinterpret_cast<v4s*>(&c)[1] = x[1];
-                        st_chunk(dg_dst + (size_t)(kh * 16 + l16) * 32 + 8 * gidx, c);     // row m = 16 kh + l16, queries 8 gidx .. + 7
+                        // row m = 16 kh + l16, queries 8 gidx .. + 7 -> fragment-image position (dg_pos)
+                        st_chunk(dg_dst + (gidx >> 1) * 512 + (kh * 16 + l16 + 32 * (gidx & 1)) * 8, c);
                     }
                 } else {
 #pragma unroll
                     for (int it = 0; it < 16; ++it) {
                         const int idx = it * 64 + lane, m = idx >> 5, qq = idx & 31;
-                        dg_dst[idx] = ring[qq * LDR + m];
+                        dg_dst[dg_pos(m, qq)] = ring[qq * LDR + m];
                     }
                 }
             }
@@ -792,8 +794,7 @@ __global__ __launch_bounds__(256) void rga_bwd_kv_kernel(const T* __restrict__ P
 template <typename T, int DH>
 __global__ __launch_bounds__(256) void rga_bwd_e_kernel(const T* __restrict__ dGT, const T* __restrict__ qkv,
                                                         float* __restrict__ dE, int B, int L, int Lp, int H, int M) {
-    constexpr int CH = ET<T>::CH, LDP = 32 + CH, DB = ACfg<T, DH>::DB, LDV = ACfg<T, DH>::LDV;
-    __shared__ __attribute__((aligned(16))) T Gt[2][128 * LDP];
+    constexpr int DB = ACfg<T, DH>::DB, LDV = ACfg<T, DH>::LDV;
     __shared__ __attribute__((aligned(16))) T Qs[2][32 * LDV];         // natural Q slab [32 q][DH], transpose-read
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, a = lane & 31, h = lane >> 5;
@@ -816,7 +817,6 @@ __global__ __launch_bounds__(256) void rga_bwd_e_kernel(const T* __restrict__ dG
         }
         if ((int)blockIdx.x >= first) return;             // rounding leftovers
     }
-    const int c0 = gx * 128;
     const int cbw = gx * 4 + wid;
     const bool wave_on = cbw * 32 < Lp;
     const int my_qmin = max(0, ncb - 1 - cbw);
@@ -831,63 +831,81 @@ __global__ __launch_bounds__(256) void rga_bwd_e_kernel(const T* __restrict__ dG
 #pragma unroll
     for (int i = 0; i < DB; ++i) acc_zero(acc[i]);
 
-    using GT = TileT<T, 128, 32>;                       // four dG^T tiles [32 c][32 q]
-    chunk16 rg[GT::NPT], rq[TileT<T, 32, DH>::NPT];
-    bool rgv[GT::NPT];                                  // tile exists?  applied when the chunk is stored into LDS
+    // The wave's dG^T tile of a step is its own A operand, fragment for fragment: lane (a, h) needs row a, queries
+    // 16 t + 8 h .. + 7 -- 16 contiguous bytes (bf16) of the tile image (dg_pos).  It comes straight from global memory into the
+    // registers, RG - 1 steps ahead (a wave reads a whole 2 KB tile with two instructions); only the Q slab, which all
+    // four waves read transposed, goes through LDS.  (Round 1 staged the four tiles through LDS as well: 32 KB per
+    // block = 5 blocks per CU and a second, mostly idle round of blocks; now 12 KB.)
+    // The (bh, qs) cursors advance by increments: no division in the loop (it was ~100 SALU instructions per step).
     const int dm = H * DH;
     const size_t ldq = (size_t)3 * dm;
     const size_t dg_bh = pt_tiles(ncb, true) * 1024;
-    // No branch encloses a global load or an LDS store in the steady state: tile indices are clamped, non-existent
-    // tiles are zeroed by a select when they are stored (exact s_waitcnt bookkeeping).
-    auto gload = [&](int s) __attribute__((always_inline)) {
-        const int bh = bh_lo + s / nq, qs = qs0 + s % nq;
-        const T* src = dGT + (size_t)bh * dg_bh;
-#pragma unroll
-        for (int i = 0; i < GT::NPT; ++i) {
-            const int c = tid + i * 256, row = c / GT::CPR, cc = (c % GT::CPR) * CH;
-            const int cb = gx * 4 + (row >> 5), t = cb - (ncb - 1) + qs;
-            rgv[i] = cb < ncb && t >= 0 && t <= qs;
-            rg[i] = ld_chunk(src + dg_tile(qs, min(max(t, 0), qs)) * 1024 + (row & 31) * 32 + cc);
-        }
-        const T* qsrc = qkv + ((size_t)(bh / H) * L + qs * 32) * ldq + (bh % H) * DH;
+    const int tshift = cbw - (ncb - 1);                 // tile index of the wave at slab qs: t = qs + tshift
+    constexpr int RG = 3;          // ring of dG^T fragment sets: steps s .. s + RG - 1 (RG - 1 loads in flight)
+    Frag<T> gq[RG][2];
+    chunk16 rq[TileT<T, 32, DH>::NPT];
+    int l_bh = bh_lo, l_qs = qs0, l_left = nsteps;      // cursor of the Q slab loads
+    auto qload = [&]() __attribute__((always_inline)) {
+        const T* qsrc = qkv + ((size_t)(l_bh / H) * L + l_qs * 32) * ldq + (l_bh % H) * DH;
         using QT = TileT<T, 32, DH>;
 #pragma unroll
-        for (int i = 0; i < QT::NPT; ++i) {              // rows past L repeat the last row: their dS^T columns are exact zeros
+        for (int i = 0; i < QT::NPT; ++i) {              // rows past L repeat the last row: their dG^T columns are exact zeros
             const int c = min(tid + i * 256, QT::NCH - 1);
-            rq[i] = ld_chunk(qsrc + (size_t)min(c / QT::CPR, L - 1 - qs * 32) * ldq + (c % QT::CPR) * CH);
+            rq[i] = ld_chunk(qsrc + (size_t)min(c / QT::CPR, L - 1 - l_qs * 32) * ldq + (c % QT::CPR) * ET<T>::CH);
         }
     };
-    auto sstore = [&](int buf) __attribute__((always_inline)) {
+    auto advance = [&]() __attribute__((always_inline)) {   // past the last step the cursor stays on it (harmless re-loads)
+        if (l_left > 1) {
+            --l_left;
+            if (++l_qs == nqt) { l_qs = qs0; ++l_bh; }
+        }
+    };
+    // The dG^T stream is the HBM stream (the Q slabs are shared by the 8 row groups through L2): it runs RG - 1 steps
+    // ahead with its own cursor; the Q slab of step s + 2 is fetched while step s is multiplied.
+    int g_bh = bh_lo, g_qs = qs0, g_left = nsteps;      // cursor of the dG^T loads
+    auto gload = [&](Frag<T>* g) __attribute__((always_inline)) {
+        const T* src = dGT + (size_t)g_bh * dg_bh + dg_tile(g_qs, min(max(g_qs + tshift, 0), g_qs)) * 1024 + lane * 8;
+        frag_load(g[0], src);
+        frag_load(g[1], src + 512);
+        if (g_left > 1) {                               // past the last step the cursor stays on it (harmless re-loads)
+            --g_left;
+            if (++g_qs == nqt) { g_qs = qs0; ++g_bh; }
+        }
+    };
+    // prologue: Q slab 0 -> LDS, Q slab 1 -> registers; dG^T of steps 0 .. RG - 2 -> ring
 #pragma unroll
-        for (int i = 0; i < GT::NPT; ++i) {
-            const int c = tid + i * 256, row = c / GT::CPR, cc = (c % GT::CPR) * CH;
-            st_chunk(&Gt[buf][row * LDP + cc], rgv[i] ? rg[i] : zero_chunk());
-        }
-        tile_sstore<T, 32, DH, LDV>(rq, Qs[buf], tid);
-    };
-    gload(0);
-    sstore(0);
-    gload(min(1, nsteps - 1));
+    for (int u = 0; u < RG - 1; ++u) gload(gq[u]);
+    qload(); advance();
+    tile_sstore<T, 32, DH, LDV>(rq, Qs[0], tid);
+    qload(); advance();
     __syncthreads();
-    for (int s = 0; s < nsteps; ++s) {
-        const int buf = s & 1;
-        const int qs = qs0 + s % nq;
-        if (wave_on && qs >= my_qmin) {
+    vm_drain();
+    int c_qs = qs0;                                     // slab of the step being multiplied
+    auto step = [&](int buf, Frag<T>* gcur, Frag<T>* gfar) __attribute__((always_inline)) {
+        gload(gfar);                                    // step s + RG - 1
+        if (wave_on && c_qs >= my_qmin) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                Frag<T> gf;
-                frag_load(gf, &Gt[buf][(wid * 32 + a) * LDP + 16 * t + 8 * h]);
 #pragma unroll
                 for (int i = 0; i < DB; ++i) {
                     Frag<T> qf;
                     frag_load_tr(qf, Qs[buf], LDV, 16 * t + 8 * h, 16 * t + 8 * h + 4, i * 32, lane);     // Q^T[d][q]
-                    mma32(acc[i], gf, qf);
+                    mma32(acc[i], gcur[t], qf);
                 }
             }
         }
-        sstore(buf ^ 1);                            // past the last step: a harmless re-store of the last slab
-        gload(min(s + 2, nsteps - 1));
-        block_sync_lds();               // LDS hand-over only: prefetch loads / tile stores stay in flight
+        tile_sstore<T, 32, DH, LDV>(rq, Qs[buf ^ 1], tid);      // Q slab of step s + 1 (past the last step: a harmless re-store)
+        qload();                                                // Q slab of step s + 2
+        advance();
+        if (++c_qs == nqt) c_qs = qs0;
+        block_sync_lds();               // LDS hand-over only: prefetch loads stay in flight
+    };
+    for (int s = 0; s < nsteps; s += RG) {              // unrolled over the ring so that the fragment indices are static
+#pragma unroll
+        for (int u = 0; u < RG; ++u) {
+            if (s + u >= nsteps) break;
+            step((s + u) & 1, gq[u], gq[(u + RG - 1) % RG]);
+        }
     }
     if (!wave_on) return;
 #pragma unroll
@@ -969,8 +987,8 @@ int bwd_launch(const void* qkv, const void* Epk, const void* out, const float* l
     rc = me_launch_status();
     if (rc) return rc;
     const int ngx = (Lp + 127) / 128;
-    // grid sweep at C2 (us per launch): 512: 131, 768: 118, 1024: 127, 1160: 108, 1536: 106, 2048: 113, 4096: 111 --
-    // ~6 blocks per CU (4 resident): short blocks fill the tail left by the proportional group split
+    // grid sweep at C2 (us per launch, round 2 kernel): 768: 85.8, 1024: 90.8, 1280: 82.5, 1536: 85.4, 2048: 85.2, 4096: 85.9 -- flat:
+    // the launch is bound by the per-step latency chain (Q slab -> LDS -> barrier -> transpose reads -> 4 MFMAs), not by the tail
     int eblocks = 1536;
     if (eblocks > ngx * B * H) eblocks = ngx * B * H;
     if (eblocks < ngx) eblocks = ngx;

@@ -961,6 +961,23 @@ __global__ __launch_bounds__(256) void cast_transpose_multi_kernel(const me_ct_d
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static const bool g_disable_nt256 = getenv("MIDIEMO_NO_NT256") != nullptr;
 
+// CUs the persistent kernels may occupy on the current device: multiProcessorCount minus MIDIEMO_CU_RESERVE (CUs left
+// to a concurrent RCCL kernel when the gradient all-reduce overlaps the backward; default 0).  A query, not a
+// synchronisation; cached per device; 256 (MI355X) when no device is visible (host-only symbol checks).
+static int persistent_cus() {
+    static int cached[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 256; }
+    if (dev >= 0 && dev < 16 && cached[dev]) return cached[dev];
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
+    static const int reserve = getenv("MIDIEMO_CU_RESERVE") ? atoi(getenv("MIDIEMO_CU_RESERVE")) : 0;
+    if (reserve > 0 && reserve < n) n -= reserve;
+    if (n > 8) n &= ~7;                                   // whole blocks per XCD round (tile renumbering)
+    if (dev >= 0 && dev < 16) cached[dev] = n;
+    return n;
+}
+
 template <typename T>
 int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
                    const void* add, int ldadd, const void* gate, int ldgate, int M, int N, int K, int flags,
@@ -980,7 +997,8 @@ int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int 
                 attr_set = true;
             }
             unsigned g256 = (unsigned)(((N + 255) / 256) * ((M + 255) / 256));
-            if (g256 > 256u) g256 = 256u;            // persistent: one block per CU
+            const unsigned ncu = (unsigned)persistent_cus();
+            if (g256 > ncu) g256 = ncu;              // persistent: one block per CU
             // 2 x 4 waves.  The 2 x 2 instantiation (128 x 128 per wave, one wave per SIMD, accumulators in the 256
             // AGPRs) is correct but hipcc spills the 16 prefetch pieces to scratch inside the main loop: 45 TF/s.
             if (flags & ME_EPI_OUT_F32)
@@ -1031,7 +1049,7 @@ int gemm_tn_launch(const void* A, int lda, const void* B, int ldb, float* dW, in
                 attr_set = true;
             }
             const int tn2 = n256 / 256, tk2 = K / 256;
-            int ns = 256 / (tn2 * tk2);
+            int ns = persistent_cus() / (tn2 * tk2);
             if (ns < 1) ns = 1;
             int tp = (Tn + ns - 1) / ns;
             tp = ((tp + TN256_BT - 1) / TN256_BT) * TN256_BT;
@@ -1080,7 +1098,7 @@ static size_t tn_ws_bytes(int Tn, int N, int K, int lda_min) {
     (void)lda_min;
     if (K % 256 != 0 || Tn < 2048) return 0;
     const int tn2 = n256 / 256, tk2 = K / 256;
-    int ns = 256 / (tn2 * tk2);
+    int ns = persistent_cus() / (tn2 * tk2);
     if (ns < 1) ns = 1;
     int tp = (Tn + ns - 1) / ns;
     tp = ((tp + TN256_BT - 1) / TN256_BT) * TN256_BT;
