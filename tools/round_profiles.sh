@@ -1,0 +1,21 @@
+#!/bin/bash
+# End-of-milestone evidence, run on the GPU box from the repo root:  bash tools/round_profiles.sh r02_b
+#   1. rocprofv3 --kernel-trace --stats over the DEFAULT bench.py command  -> <tag>_bench_kernel_stats.txt, <tag>_bench.json
+#   2. two PMC passes (FETCH_SIZE / WRITE_SIZE, counters only) over a short train-only bench -> <tag>_hbm_traffic.txt, hbm_traffic.json
+#   3. kernel trace of 64 eager decode steps at t = 1024                   -> <tag>_decode_kernel_stats.txt
+# Everything lands in gpurun_out/prof/ (copy what is to be judged into profiles/).
+TAG=${1:-rXX}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/prof; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/rp_*
+timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/rp_bench -o p -- python $R/bench.py > /tmp/rp_bench.log 2>&1
+grep "^{\"metric\"" /tmp/rp_bench.log | tail -1 > $OUT/${TAG}_bench.json
+python $R/tools/rocpd_stats.py $(find /tmp/rp_bench -name "*.db" | head -1) > $OUT/${TAG}_bench_kernel_stats.txt 2>&1
+SHORT="--steps 4 --warmup 1 --no_cpu_baseline --no_probe --no_decode --no_extra"
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/rp_f -o p -- python $R/bench.py $SHORT > /tmp/rp_f.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/rp_w -o p -- python $R/bench.py $SHORT > /tmp/rp_w.log 2>&1
+PROFILE_TAG=profiles/${TAG}_hbm_traffic.txt python $R/tools/hbm_traffic.py $(find /tmp/rp_f -name "*.db" | head -1) $(find /tmp/rp_w -name "*.db" | head -1) --json $OUT/hbm_traffic.json > $OUT/${TAG}_hbm_traffic.txt 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/rp_dec -o p -- python $R/tools/prof_decode.py 1024 64 bf16 > /tmp/rp_dec.log 2>&1
+python $R/tools/rocpd_stats.py $(find /tmp/rp_dec -name "*.db" | head -1) 64 > $OUT/${TAG}_decode_kernel_stats.txt 2>&1
+ls -la $OUT; head -12 $OUT/${TAG}_bench_kernel_stats.txt; head -14 $OUT/${TAG}_hbm_traffic.txt; cut -c1-300 $OUT/${TAG}_bench.json
