@@ -189,8 +189,8 @@ class OpProbe:
         self.bytes = {
             "resid_ln_fwd": T * d * (es + lo + es + es + lo + es) + T * 8,        # x(+lo), a in; y(+lo), s out; stats
             "resid_ln_bwd": T * d * 4 * es + T * 8,                               # dy, s in; dx, da out
-            "ce_fwd": T * ldv * 4 + T * 12,
-            "ce_bwd": T * ldv * 4 + T * ldv * es + T * 12,
+            "ce_fwd": T * ldv * es + T * 12,                 # logits in the compute type
+            "ce_bwd": T * ldv * es + T * ldv * es + T * 12,
             "embed_fwd": T * d * (es + lo) + T * (d - model.d_condition) * 4 + T * d * 4,   # out(+lo); table rows; PE
             "embed_bwd": T * d * es,
             "sumsq": n * 4,

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 13
+#define ME_ABI_VERSION 14
 
 enum { ME_F32 = 0, ME_BF16 = 1 };
 
@@ -205,18 +205,20 @@ int me_resid_ln_bwd(const void* dy, const void* s, const float* stats, const flo
                     float p_drop, uint64_t seed, uint32_t site, int dtype, void* stream);
 
 /* ---- cross-entropy head ------------------------------------------------------
- * logits f32 [rows, ld] (V valid columns), target int64 [rows].
+ * logits [rows, ld] (V valid columns) in logits_dtype: ME_F32, or ME_BF16 -- the bf16 tier's head GEMM writes T
+ * logits (what the reference's autocast F.linear produces; no 4-byte logits tensor exists then); target int64 [rows].
+ * The loss arithmetic is f32 either way.
  * me_ce_fwd:  row_lse[r] = logsumexp(logits[r, :V]);
  *             *loss_sum += sum over target != ignore of (row_lse - logit[target]);
  *             *n_valid  += count(target != ignore)          (both f32 device scalars)
  * me_ce_bwd:  dlogits (T [rows, ld_d]) = (exp(logit - row_lse) - onehot) * (target != ignore)
  *             * extra_scale / *n_valid ; columns V..ld_d-1 are written as 0.
  * Replaces CrossEntropyLoss(ignore_index=pad) + its autograd (train.py:124,288-290). */
-int me_ce_fwd(const float* logits, int ld, const int64_t* target, float* row_lse,
-              float* loss_sum, float* n_valid, int rows, int V, int ignore_index, void* stream);
-int me_ce_bwd(const float* logits, int ld, const int64_t* target, const float* row_lse,
+int me_ce_fwd(const void* logits, int ld, const int64_t* target, float* row_lse,
+              float* loss_sum, float* n_valid, int rows, int V, int ignore_index, int logits_dtype, void* stream);
+int me_ce_bwd(const void* logits, int ld, const int64_t* target, const float* row_lse,
               void* dlogits, int ld_d, const float* n_valid, float extra_scale,
-              int rows, int V, int ignore_index, int dtype, void* stream);
+              int rows, int V, int ignore_index, int logits_dtype, int dtype, void* stream);
 
 /* ---- optimiser: global-norm clip + Adam(W) -----------------------------------
  * me_sumsq: *out += sum g[i]^2   (zero *out first; multiple calls accumulate)

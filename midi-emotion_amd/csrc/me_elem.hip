@@ -500,8 +500,10 @@ __global__ __launch_bounds__(NW * 64) void resid_ln_bwd_kernel(const T* __restri
 // atomics per block, and same-address atomics serialise at ~15 ns each -- with 2048 four-wave blocks they were 55 of the
 // kernel's 64 us.
 constexpr int CE_NW = 16;
-template <int CE_Q>
-__global__ __launch_bounds__(CE_NW * 64) void ce_fwd_kernel(const float* __restrict__ logits, int ld,
+// LT = type of the logits: float (f32 tier, MusicRegression) or bf16 (bf16 tier: the head GEMM writes T logits, which is
+// what the reference's autocast F.linear produces as well; the loss arithmetic is f32 either way)
+template <typename LT, int CE_Q>
+__global__ __launch_bounds__(CE_NW * 64) void ce_fwd_kernel(const LT* __restrict__ logits, int ld,
                                                      const int64_t* __restrict__ target, float* __restrict__ row_lse,
                                                      float* __restrict__ loss_sum, float* __restrict__ n_valid, int rows,
                                                      int V, int ignore_index) {
@@ -510,39 +512,47 @@ __global__ __launch_bounds__(CE_NW * 64) void ce_fwd_kernel(const float* __restr
     float bl = 0.f, bn = 0.f;
     const int64_t stride = (int64_t)gridDim.x * CE_NW;
     int64_t row = (int64_t)blockIdx.x * CE_NW + wid;
-    if (V <= 64 * 4 * CE_Q && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0) {
+    constexpr int EP = 16 / sizeof(LT);                                   // logits per 16-byte piece
+    if (V <= 64 * EP * CE_Q && (ld % EP) == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0) {
         // One pass: the row (<= 2048 logits) sits in registers, 16-byte loads.  The next row (and its target) is
         // fetched BEFORE this row's lse is stored and the target logit comes out of the registers: vmcnt is in
         // order, so a load issued after a store cannot be consumed before that store has been acknowledged.
-        f32x4_t nv[CE_Q];
+        chunk16 nv[CE_Q];
         int64_t nt = 0;
         auto fetch = [&](int64_t r) {
             r = r < rows ? r : rows - 1;                  // clamped, not skipped: loads under a branch serialise the loop
-            const float* lg = logits + r * ld;
+            const LT* lg = logits + r * ld;
             nt = target[r];
 #pragma unroll
             for (int q = 0; q < CE_Q; ++q) {
-                const int j = (q * 64 + lane) * 4;
-                // rows are padded to a multiple of 4 floats (ld % 4 == 0), so the 16-byte load is always in bounds for
-                // j < ld; entries at or beyond V are masked after the load
-                nv[q] = j < ld ? *reinterpret_cast<const f32x4_t*>(lg + j) : (f32x4_t){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) nv[q][i] = j + i < V ? nv[q][i] : -INFINITY;
+                const int j = (q * 64 + lane) * EP;
+                // rows are padded to a multiple of 16 bytes (ld % EP == 0), so the 16-byte load is always in bounds for
+                // j < ld (clamped otherwise); entries at or beyond V are masked when the piece is unpacked
+                nv[q] = ld_chunk(lg + (j < ld ? j : 0));
             }
         };
         fetch(row);
         for (; row < rows; row += stride) {
-            f32x4_t v[CE_Q];
+            float v[CE_Q][EP];
             const int64_t t = nt;
 #pragma unroll
-            for (int q = 0; q < CE_Q; ++q) v[q] = nv[q];
+            for (int q = 0; q < CE_Q; ++q) {
+                const int j = (q * 64 + lane) * EP;
+#pragma unroll
+                for (int i = 0; i < EP; ++i) {
+                    float x;
+                    if constexpr (sizeof(LT) == 4) x = reinterpret_cast<const float*>(&nv[q])[i];
+                    else x = (float)reinterpret_cast<const bf16_t*>(&nv[q])[i];
+                    v[q][i] = j + i < V ? x : -INFINITY;
+                }
+            }
             fetch(row + stride);
             float mx = -INFINITY, se = 0.f, tv = 0.f;
 #pragma unroll
             for (int q = 0; q < CE_Q; ++q) {
-                const int j = (q * 64 + lane) * 4;
+                const int j = (q * 64 + lane) * EP;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < EP; ++i) {
                     mx = fmaxf(mx, v[q][i]);
                     tv = (t == j + i) ? v[q][i] : tv;
                 }
@@ -551,7 +561,7 @@ __global__ __launch_bounds__(CE_NW * 64) void ce_fwd_kernel(const float* __restr
 #pragma unroll
             for (int q = 0; q < CE_Q; ++q)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) se += __builtin_amdgcn_exp2f((v[q][i] - mx) * 1.4426950408889634f);   // exp2(-inf) = 0 for the padding
+                for (int i = 0; i < EP; ++i) se += __builtin_amdgcn_exp2f((v[q][i] - mx) * 1.4426950408889634f);   // exp2(-inf) = 0 for the padding
             se = wave_sum(se);
             tv = wave_sum(tv);                                       // the one lane that holds logit[t]
             const float lse = mx + logf(se);
@@ -562,17 +572,17 @@ __global__ __launch_bounds__(CE_NW * 64) void ce_fwd_kernel(const float* __restr
         }
     } else {
         for (; row < rows; row += stride) {
-            const float* lg = logits + row * ld;
+            const LT* lg = logits + row * ld;
             float mx = -INFINITY, se = 0.f;
-            for (int j = lane; j < V; j += 64) mx = fmaxf(mx, lg[j]);
+            for (int j = lane; j < V; j += 64) mx = fmaxf(mx, (float)lg[j]);
             mx = wave_max(mx);
-            for (int j = lane; j < V; j += 64) se += expf(lg[j] - mx);
+            for (int j = lane; j < V; j += 64) se += expf((float)lg[j] - mx);
             se = wave_sum(se);
             const float lse = mx + logf(se);
             if (lane == 0) {
                 if (row_lse) row_lse[row] = lse;
                 const int64_t t = target[row];
-                if (t != ignore_index) { bl += lse - lg[t]; bn += 1.f; }
+                if (t != ignore_index) { bl += lse - (float)lg[t]; bn += 1.f; }
             }
         }
     }
@@ -587,21 +597,41 @@ __global__ __launch_bounds__(CE_NW * 64) void ce_fwd_kernel(const float* __restr
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, int ld,
+template <typename T, typename LT>
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const LT* __restrict__ logits, int ld,
                                                      const int64_t* __restrict__ target, const float* __restrict__ row_lse,
                                                      T* __restrict__ dlogits, int ld_d, const float* __restrict__ n_valid,
                                                      float extra_scale, int rows, int V, int ignore_index) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const float scale = extra_scale / fmaxf(*n_valid, 0.f);   // n_valid == 0 -> inf/nan like torch's 0/0 mean
     for (int64_t row = (int64_t)blockIdx.x * 4 + wid; row < rows; row += (int64_t)gridDim.x * 4) {
-        const float* lg = logits + row * ld;
+        const LT* lg = logits + row * ld;
         const int64_t t = target[row];
         const float lse = row_lse[row];
         const bool valid = t != ignore_index;
+        if constexpr (sizeof(LT) == 2 && sizeof(T) == 2) {
+            // both 16-bit: 8 columns per lane and 16-byte access (2-byte accesses made this kernel issue bound: 37 us
+            // for 133 MB); columns in [V, ld) of the logits are never used, columns in [V, ld_d) are written as 0
+            if ((ld & 7) == 0 && (ld_d & 7) == 0 && ld >= ld_d && ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits)) & 15) == 0) {
+                for (int j = lane * 8; j < ld_d; j += 512) {
+                    const chunk16 c = ld_chunk(lg + j);
+                    chunk16 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float g = 0.f;
+                        if (valid && j + e < V)
+                            g = (__builtin_amdgcn_exp2f(((float)reinterpret_cast<const bf16_t*>(&c)[e] - lse) * 1.4426950408889634f) -
+                                 (j + e == t ? 1.f : 0.f)) * scale;
+                        reinterpret_cast<bf16_t*>(&o)[e] = ET<T>::from_f(g);
+                    }
+                    st_chunk(dlogits + row * ld_d + j, o);
+                }
+                continue;
+            }
+        }
         for (int j = lane; j < ld_d; j += 64) {
             float g = 0.f;
-            if (valid && j < V) g = (expf(lg[j] - lse) - (j == t ? 1.f : 0.f)) * scale;
+            if (valid && j < V) g = (expf((float)lg[j] - lse) - (j == t ? 1.f : 0.f)) * scale;
             dlogits[row * ld_d + j] = ET<T>::from_f(g);
         }
     }
@@ -1030,30 +1060,44 @@ int me_resid_ln_bwd(const void* dy, const void* s, const float* stats, const flo
     return me_launch_status();
 }
 
-int me_ce_fwd(const float* logits, int ld, const int64_t* target, float* row_lse, float* loss_sum, float* n_valid,
-              int rows, int V, int ignore_index, void* stream) {
+int me_ce_fwd(const void* logits, int ld, const int64_t* target, float* row_lse, float* loss_sum, float* n_valid,
+              int rows, int V, int ignore_index, int logits_dtype, void* stream) {
     me_clear_error();
     if (!logits || !target || !loss_sum || !n_valid) return ME_ERR_NULL;
+    if (logits_dtype != ME_F32 && logits_dtype != ME_BF16) return ME_ERR_BAD_DTYPE;
     if (rows <= 0) return ME_OK;
     if (V <= 0 || ld < V) return ME_ERR_BAD_SHAPE;
     const int64_t gb = ((int64_t)rows + CE_NW - 1) / CE_NW;
     const int grid = (int)(gb > 256 ? 256 : gb);
-    if (V <= 1024)
-        ce_fwd_kernel<4><<<grid, CE_NW * 64, 0, (hipStream_t)stream>>>(logits, ld, target, row_lse, loss_sum, n_valid, rows, V, ignore_index);
-    else
-        ce_fwd_kernel<8><<<grid, CE_NW * 64, 0, (hipStream_t)stream>>>(logits, ld, target, row_lse, loss_sum, n_valid, rows, V, ignore_index);
+    hipStream_t st = (hipStream_t)stream;
+    if (logits_dtype == ME_F32) {
+        const float* lg = (const float*)logits;
+        if (V <= 1024) ce_fwd_kernel<float, 4><<<grid, CE_NW * 64, 0, st>>>(lg, ld, target, row_lse, loss_sum, n_valid, rows, V, ignore_index);
+        else ce_fwd_kernel<float, 8><<<grid, CE_NW * 64, 0, st>>>(lg, ld, target, row_lse, loss_sum, n_valid, rows, V, ignore_index);
+    } else {
+        const bf16_t* lg = (const bf16_t*)logits;
+        if (V <= 1024) ce_fwd_kernel<bf16_t, 2><<<grid, CE_NW * 64, 0, st>>>(lg, ld, target, row_lse, loss_sum, n_valid, rows, V, ignore_index);
+        else ce_fwd_kernel<bf16_t, 4><<<grid, CE_NW * 64, 0, st>>>(lg, ld, target, row_lse, loss_sum, n_valid, rows, V, ignore_index);
+    }
     return me_launch_status();
 }
 
-int me_ce_bwd(const float* logits, int ld, const int64_t* target, const float* row_lse, void* dlogits, int ld_d,
-              const float* n_valid, float extra_scale, int rows, int V, int ignore_index, int dtype, void* stream) {
+int me_ce_bwd(const void* logits, int ld, const int64_t* target, const float* row_lse, void* dlogits, int ld_d,
+              const float* n_valid, float extra_scale, int rows, int V, int ignore_index, int logits_dtype, int dtype,
+              void* stream) {
     me_clear_error();
     if (!logits || !target || !row_lse || !dlogits || !n_valid) return ME_ERR_NULL;
+    if (logits_dtype != ME_F32 && logits_dtype != ME_BF16) return ME_ERR_BAD_DTYPE;
     if (rows <= 0) return ME_OK;
     if (V <= 0 || ld < V || ld_d < V) return ME_ERR_BAD_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    ME_DISPATCH(dtype, (ce_bwd_kernel<T><<<row_grid(rows, 8192), 256, 0, st>>>(logits, ld, target, row_lse, (T*)dlogits, ld_d,
-                                                                             n_valid, extra_scale, rows, V, ignore_index)));
+    if (logits_dtype == ME_F32) {
+        ME_DISPATCH(dtype, (ce_bwd_kernel<T, float><<<row_grid(rows, 8192), 256, 0, st>>>((const float*)logits, ld, target, row_lse,
+                                                                                        (T*)dlogits, ld_d, n_valid, extra_scale, rows, V, ignore_index)));
+    } else {
+        ME_DISPATCH(dtype, (ce_bwd_kernel<T, bf16_t><<<row_grid(rows, 8192), 256, 0, st>>>((const bf16_t*)logits, ld, target, row_lse,
+                                                                                         (T*)dlogits, ld_d, n_valid, extra_scale, rows, V, ignore_index)));
+    }
     return me_launch_status();
 }
 

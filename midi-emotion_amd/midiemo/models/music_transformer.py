@@ -95,6 +95,7 @@ class _Workspace:
 
 class MusicTransformerHIP(nn.Module):
     LN_EPS = 1e-6
+    _logits_f32 = False         # workspace logits of the loss path in f32 regardless of the compute type (MusicRegression)
 
     def __init__(self, embedding_dim=None, d_inner=None, d_condition=-1, vocab_size=None, num_layer=None,
                  num_head=None, max_seq=2048, dropout=0.1, pad_token=0, token_conditioning=False,
@@ -367,7 +368,9 @@ class MusicTransformerHIP(nn.Module):
         ws.tmp = e(T, d)
         if save:
             ldv = _round_up(V, 64)
-            ws.logits = e(T, ldv, dtype=torch.float32)
+            # the training loss reads the logits in the compute type (bf16 tier: what the reference's autocast F.linear
+            # produces; the 134 MB f32 logits tensor of round 1 is gone); MusicRegression's tanh head keeps f32
+            ws.logits = e(T, ldv, dtype=torch.float32 if self._logits_f32 else dt)
             ws.row_lse = e(T, dtype=torch.float32)
             ws.dlogits = torch.zeros(T, ldv, dtype=dt, device=dev)
             ws.acc = torch.zeros(2, dtype=torch.float32, device=dev)      # loss_sum, n_valid
@@ -445,7 +448,7 @@ class MusicTransformerHIP(nn.Module):
         hN = ws.h[N % nh if not save else N]
         out = logits_out if logits_out is not None else ws.logits
         ops.gemm_nt(hN, self._prep["head"]["Wf"], out, bias=self._pview(f, self._HEAD_B), M=T, N=V, K=d,
-                    flags=ops.ME_EPI_OUT_F32, dtype=dt)
+                    flags=ops.ME_EPI_OUT_F32 if out.dtype == torch.float32 else 0, dtype=dt)
         return ws
 
     # ------------------------------------------------------------------ engine: backward
@@ -575,8 +578,8 @@ class MusicTransformerHIP(nn.Module):
         if backward:
             ops.ce_bwd(ws.logits, target, ws.row_lse, ws.dlogits, ws.acc[1:2], grad_scale, T, V, self.pad_token)
             self._backward_impl(ws, tokens, cond, B, Ltok, Lm, p_drop, seed, self._gflat, bucket_hook)
-        if return_logits:                                   # f32 [B, Lm, V] view of the workspace (valid until the next call)
-            return loss, ws.logits[:, :V].view(B, Lm, V)
+        if return_logits:                                   # f32 [B, Lm, V] copy of the workspace logits
+            return loss, ws.logits[:, :V].float().view(B, Lm, V)
         return loss
 
 
@@ -644,6 +647,7 @@ class MusicRegression(MusicTransformerHIP):
     graph); training goes through loss_and_backward() (L1 loss, bidirectional attention backward).  With
     `no_mask=False` the reference applies the causal + pad mask of the language model, which is the base class."""
     _HEAD_W, _HEAD_B = "fc.0.weight", "fc.0.bias"
+    _logits_f32 = True
 
     def __init__(self, embedding_dim=None, d_inner=None, vocab_size=None, num_layer=None, num_head=None,
                  max_seq=None, dropout=None, pad_token=None, output_size=None, d_condition=-1, no_mask=True,

@@ -175,13 +175,13 @@ def resid_ln_bwd(dy, s, stats, gamma, dx, da, dgamma, dbeta, rows, d, p, seed, s
 
 def ce_fwd(logits, target, row_lse, loss_sum, n_valid, rows, V, ignore_index):
     check(lib().me_ce_fwd(_ptr(logits), logits.stride(0), _ptr(target), _ptr(row_lse), _ptr(loss_sum), _ptr(n_valid),
-                          rows, V, ignore_index, _stream()), "me_ce_fwd")
+                          rows, V, ignore_index, _code(logits.dtype), _stream()), "me_ce_fwd")
 
 
 def ce_bwd(logits, target, row_lse, dlogits, n_valid, extra_scale, rows, V, ignore_index):
     check(lib().me_ce_bwd(_ptr(logits), logits.stride(0), _ptr(target), _ptr(row_lse), _ptr(dlogits),
                           dlogits.stride(0), _ptr(n_valid), float(extra_scale), rows, V, ignore_index,
-                          _code(dlogits.dtype), _stream()), "me_ce_bwd")
+                          _code(logits.dtype), _code(dlogits.dtype), _stream()), "me_ce_bwd")
 
 
 def sumsq(g, out):

@@ -365,6 +365,33 @@ def test_ce_fwd_bwd(ops, dtype):
     assert (dl[:, V:] == 0).all()
 
 
+@pytest.mark.parametrize("V,ld", [(1007, 1024), (1017, 1024), (97, 128), (2500, 2560)])
+def test_ce_bf16_logits(ops, V, ld):
+    """bf16 tier: the head GEMM writes bf16 logits (me_ce_fwd / me_ce_bwd with logits_dtype = ME_BF16).  The kernels
+    must give exactly the cross-entropy of those rounded logits (f32 arithmetic): compared with fp64 CE of the same
+    bf16 values; padding columns [V, ld) hold garbage and must not leak in."""
+    rows = 203
+    lg = rnd(rows, V, seed=31, scale=4.0).to(torch.bfloat16)
+    tgt = torch.randint(0, V, (rows,), generator=torch.Generator().manual_seed(32))
+    tgt[::7] = 0
+    l64 = lg.double().requires_grad_(True)
+    loss = torch.nn.functional.cross_entropy(l64, tgt, ignore_index=0)
+    loss.backward()
+    lgd = torch.full((rows, ld), 1e4, dtype=torch.bfloat16, device=DEV)        # huge padding: would dominate the lse
+    lgd[:, :V] = lg.to(DEV)
+    row_lse = torch.empty(rows, device=DEV)
+    acc = torch.zeros(2, device=DEV)
+    ops.ce_fwd(lgd, tgt.to(DEV), row_lse, acc[0:1], acc[1:2], rows, V, 0)
+    nvalid = int((tgt != 0).sum())
+    assert abs(acc[1].item() - nvalid) < 1e-3
+    assert abs(acc[0].item() / nvalid - loss.item()) < 2e-5 * abs(loss.item())
+    assert relerr(row_lse, torch.logsumexp(lg.double(), -1)) < 1e-6
+    dl = torch.full((rows, ld), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.ce_bwd(lgd, tgt.to(DEV), row_lse, dl, acc[1:2], 1.0, rows, V, 0)
+    assert relerr(dl[:, :V], l64.grad) < 4e-3
+    assert (dl[:, V:] == 0).all()
+
+
 # ------------------------------------------------------------------ optimiser
 def test_sumsq_and_adamw(ops):
     n = 100003
