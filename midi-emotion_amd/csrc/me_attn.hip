@@ -484,10 +484,7 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
     };
     gload(0);
     load_p(0);
-    const int eb0 = (M - 32 - q0) >> 5, eb_max = (M >> 5) - 1;
-    constexpr bool E_AHEAD = sizeof(T) == 2;                            // f32 tier: 64 more registers would spill
-    Frag<T> etn[E_AHEAD ? C::DB : 1][2];                                // E^T images of the NEXT step's block
-    if constexpr (E_AHEAD) et_frags(etn, min(max(eb0, 0), eb_max));
+    const int eb0 = (M - 32 - q0) >> 5;
     sstore(0);
     if (nkt > 1) gload(1);
     __syncthreads();
@@ -501,20 +498,16 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
             const int k0 = kt * 32;
             const bool upper = !CAUSAL && !MAIN && kt > my_last_kt;      // bidirectional only: above the diagonal, no relative term
             const int eb_lo = eb0 + kt;
-            // Everything this step reads from global memory was requested a step ago; the next step's requests go out
-            // first and are pinned there (sched_barrier): left alone, the scheduler sinks them to the end of the step and
-            // the register copies below then wait out their whole latency.
+            // The next step's probability tile is requested first and pinned there (sched_barrier): left alone, the
+            // scheduler sinks those loads to the end of the step and the register copy below waits out their whole
+            // latency.  (Fetching the E^T images a step ahead as well cost 44 registers and was not faster.)
             PH pc[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) pc[g] = pp[g];
             Frag<T> etf[C::DB][2];
-            if constexpr (E_AHEAD) {
-#pragma unroll
-                for (int i = 0; i < C::DB; ++i) { etf[i][0] = etn[i][0]; etf[i][1] = etn[i][1]; }
-            } else if (!upper) et_frags(etf, eb_lo);
+            if (!upper) et_frags(etf, eb_lo);                            // in flight during dP / dS
             const float fac = row_on ? fast_exp2(fmaf(mtn, c2, -lse2)) : 0.f;
             load_p(kt + 1);
-            if constexpr (E_AHEAD) et_frags(etn, min(max(eb_lo + 1, 0), eb_max));
             __builtin_amdgcn_sched_barrier(0);
             f32x16_t s, dp; acc_zero(dp);
 #pragma unroll
