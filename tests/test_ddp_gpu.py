@@ -83,3 +83,23 @@ def test_two_ranks_one_gpu_rccl_backend(tmp_path):
     got = torch.load(out)
     g1, params, p0, keep = single_rank_reference(2, 1, "fp32")
     assert rel(got["g1"][keep], g1[keep]) <= 1e-5 and rel(got["params"][keep], params[keep]) <= 1e-4
+
+
+def test_bench_two_ranks_on_one_device():
+    """bench.py's N > 1 control flow (rank setup from the launcher's environment, per-rank batches, barrier + max over
+    ranks, rank 0 prints ONE JSON line with the whole-job aggregate) under the driver's own launch line, with both ranks
+    on cuda:0 and gloo instead of RCCL (RCCL refuses two ranks on one device)."""
+    import json
+    env = dict(os.environ, MIDIEMO_BENCH_ONE_DEVICE="1", MIDIEMO_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--no_decode", "--no_extra", "--no_cpu_baseline", "--no_probe"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-3000:]
+    lines = [l for l in out.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, out[-3000:]                      # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 64 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and abs(d["value"] - 64 * 1024 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
