@@ -63,13 +63,15 @@ def main():
                 continue
             A = torch.randn(M_, K_, device=dev).to(dt)
             Bm = torch.randn(N_, K_, device=dev).to(dt)
-            C = torch.empty(M_, N_, device=dev, dtype=dt)
+            ldc = (N_ + 63) // 64 * 64                      # the model pads the logits rows to 64 columns (16-byte row stores)
+            C = torch.empty(M_, ldc, device=dev, dtype=dt)[:, :N_]
             bias = torch.randn(N_, device=dev)
             t = timeit(lambda: ops.gemm_nt(A, Bm, C, bias=bias), a.iters)
             print("gemm_nt %-5s M%d N%d K%d %9.1f us  %7.1f TF" % (tag, M_, N_, K_, t, 2.0 * M_ * N_ * K_ / t / 1e6))
             if "blaslt" in a.what:      # yardstick only: the vendor library on the same shape (no bias)
                 Bt = Bm.t()
-                t = timeit(lambda: torch.matmul(A, Bt, out=C), a.iters)
+                Cb = torch.empty(M_, N_, device=dev, dtype=dt)
+                t = timeit(lambda: torch.matmul(A, Bt, out=Cb), a.iters)
                 print("   torch.matmul (hipBLASLt)      %9.1f us  %7.1f TF" % (t, 2.0 * M_ * N_ * K_ / t / 1e6))
         for (N_, K_, tag) in [(1536, 512, "dWqkv"), (512, 512, "dWo"), (2048, 512, "dW1"), (512, 2048, "dW2")]:
             if a.only and tag not in a.only.split(","):
