@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
     using C = ACfg<T, DH>;
     using PH = typename PHalf<T>::type;
     constexpr int LDR = 72;                         // dG ring row (elements of T): 64-column ring + 8
-    __shared__ __attribute__((aligned(16))) T Ks[2][32 * C::LDN];      // natural K tile: transpose reads (dQ)
+    __shared__ __attribute__((aligned(16))) T Ks[2][32 * C::LDV];      // natural K tile, only read transposed (dQ): the transpose-read row stride
     __shared__ __attribute__((aligned(16))) T Vs[2][32 * C::LDN];      // natural V tile: 16-byte fragment reads (dP)
     __shared__ __attribute__((aligned(16))) T Ds[4][32 * LDR];          // per wave: [q][64-column ring] of dG
 
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
         tile_gload_full<T, 32, DH>(rv, vb_ + (size_t)kt * 32 * ldq, ldq, tid);
     };
     auto sstore = [&](int buf) __attribute__((always_inline)) {
-        tile_sstore<T, 32, DH, C::LDN>(rk, Ks[buf], tid);
+        tile_sstore<T, 32, DH, C::LDV>(rk, Ks[buf], tid);
         tile_sstore<T, 32, DH, C::LDN>(rv, Vs[buf], tid);
     };
     // E^T of block eb (packed relative table): A operand of dQ^T[d][q] += E^T[d][e] dG^T[e][q]
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
 #pragma unroll
                 for (int i = 0; i < C::DB; ++i) {
                     Frag<T> kf;                              // K^T[d][key] for the accumulator's key map
-                    frag_load_tr(kf, Ks[buf], C::LDN, 16 * t + 4 * h, 16 * t + 8 + 4 * h, i * 32, lane);
+                    frag_load_tr(kf, Ks[buf], C::LDV, 16 * t + 4 * h, 16 * t + 8 + 4 * h, i * 32, lane);
                     mma32(dq[i], kf, dsf);
                 }
             }
