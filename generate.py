@@ -62,8 +62,9 @@ def generate(model, maps, device, out_dir, conditioning, short_filename=False,
              gen_len=2048, temperatures=[1.2, 1.2], top_k=-1,
              top_p=0.7, debug=False, varying_condition=None, seed=-1,
              verbose=False, primers=[["<START>"]], min_n_instruments=2,
-             use_cache=True, return_ids=False):
-    """Reference signature (generate.py:20-26) + `use_cache`, `return_ids`.
+             use_cache=True, return_ids=False, device_loop=True):
+    """Reference signature (generate.py:20-26) + `use_cache`, `return_ids`, `device_loop` (sampling loop replayed on
+    the device as one HIP graph per token while the KV cache is valid; False = one Python iteration per token).
     `amp` is accepted for compatibility; the engine's precision is model.compute_dtype."""
     if not debug:
         os.makedirs(out_dir, exist_ok=True)
@@ -139,6 +140,20 @@ def generate(model, maps, device, out_dir, conditioning, short_filename=False,
 
             if cache_ok and T <= max_input_len:
                 # ---- incremental path: absolute positions are stable
+                if (top_k != 1 and V <= 1024 and device_loop and sess is not None and fed == T - 1 and gen_len - i >= 2
+                        and max_input_len - T >= 2):
+                    # ---- the rest of the cache-valid span entirely on the device (DecodeSession.sample_run): the
+                    # uniforms are drawn here, one torch.rand(batch_size) per step exactly like the eager loop below, so
+                    # both paths consume the same random stream and produce the same tokens
+                    n_dev = min(gen_len - i + 1, max_input_len - T + 1)
+                    uni = torch.stack([torch.rand(batch_size, device=device) for _ in range(n_dev)])
+                    ids_dev = sess.sample_run(gen_song[fed], n_dev, conditions_tensor, specials, is_timeshift, repeat_counts,
+                                              temp_note, temp_rest, penalty_coeff, top_k, top_p, uni)      # [B, n_dev]
+                    fed += n_dev
+                    gen_song = torch.cat((gen_song, ids_dev[:, :n_dev - 1].t()), 0)
+                    gen_inds = ids_dev[:, n_dev - 1].clone()[None, :]
+                    i += n_dev - 1
+                    continue
                 if sess is None:
                     sess = DecodeSession(model, batch_size)
                     if conditioning == "continuous_token":

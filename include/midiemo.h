@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 14
+#define ME_ABI_VERSION 15
 
 enum { ME_F32 = 0, ME_BF16 = 1 };
 
@@ -298,6 +298,16 @@ int me_greedy_pick(const float* logits, int ld, int V, const int32_t* special, i
 int me_sample_topk_topp(const float* logits, int ld, int V, const int32_t* special, int n_special,
                         const float* temp, int top_k, float top_p, const float* u, int64_t* out_ids,
                         int32_t* n_choices, float* dbg_p, int32_t* dbg_i, int B, void* stream);
+
+/* One sampled decode step for a device-resident generation loop (HIP-graph replay): me_sample_topk_topp with the
+ * per-row temperature of generate.py:138-163 computed on the device from the token that was just fed (prev_tok,
+ * is_timeshift [V] bytes, repeat_counts [B] f32 in / out: updated as generate.py:186-189 does), and the uniform taken
+ * from row (*pos - pos0) of u_table [steps, u_ld] (drawn in advance by the caller, so the stream of random numbers is
+ * the caller's generator's).  The f32 operations of the temperature are the ones of the torch expression, unfused. */
+int me_sample_step(const float* logits, int ld, int V, const int32_t* special, int n_special, const int64_t* prev_tok,
+                   const uint8_t* is_timeshift, float* repeat_counts, float temp_note, float temp_rest, float penalty_coeff,
+                   int top_k, float top_p, const float* u_table, int u_ld, const int32_t* pos, int pos0, int64_t* out_ids,
+                   int32_t* n_choices, int B, void* stream);
 
 /* Device-side decode bookkeeping: history[b][*pos] = tok[b] (int64 [B][ld_hist]); *pos += 1.
  * With me_embed_fwd(pos_dev) and the t_dev arguments of me_dec_* a greedy decode step has no host-side state

@@ -798,12 +798,26 @@ __global__ void decode_commit_kernel(const int64_t* __restrict__ tok, int64_t* _
 // from the caller's uniform u[b] in [0,1), report n_choices = #(probability > 0).  Descending order comes from
 // a bitonic sort of (value, index) pairs in LDS (ties: lower index first).  dbg_p / dbg_i (optional, [B][1024])
 // receive the final sorted probabilities and their vocabulary ids so tests can compare with the torch path.
+// Step mode (me_sample_step, st != NULL): the per-row temperature of generate.py:138-163 is computed here from the token
+// that was just fed (note temperature right after a TIMESHIFT, else the rest temperature, raised by
+// max(0, log((repeats + 1) / 4) * penalty) times itself -- the same f32 operations, unfused, as the torch expression of
+// generate.py's sampling_temperature()), the uniform comes from row (*pos - pos0) of a table drawn in advance, and the
+// repeat counter is updated (generate.py:186-189) -- so a whole sampled decode step can be replayed as one HIP graph.
+struct SampleStep {
+    const int64_t* prev_tok;        // [B] token fed at this step
+    const uint8_t* is_timeshift;    // [V]
+    float* repeat_counts;           // [B] in / out
+    const int32_t* pos;             // device position counter
+    int pos0, u_ld;
+    float temp_note, temp_rest, penalty;
+};
+
 __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ logits, int ld, int V,
                                                      const int32_t* __restrict__ special, int n_special,
                                                      const float* __restrict__ temp, int top_k, float top_p,
                                                      const float* __restrict__ u, int64_t* __restrict__ out_ids,
                                                      int32_t* __restrict__ n_choices, float* __restrict__ dbg_p,
-                                                     int32_t* __restrict__ dbg_i) {
+                                                     int32_t* __restrict__ dbg_i, SampleStep st) {
     __shared__ float key[1024];
     __shared__ int idx[1024];
     __shared__ float part[256];
@@ -841,7 +855,20 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
     float se = 0.f;
     for (int j = tid; j < 1024; j += 256) se += expf(key[j] - mx);
     se = block_sum(se);
-    const float lse = mx + logf(se), inv_t = 1.f / temp[b];
+    float row_temp, row_u;
+    if (st.prev_tok) {
+        const int64_t pt = st.prev_tok[b];
+        row_temp = (pt >= 0 && pt < V && st.is_timeshift[pt]) ? st.temp_note : st.temp_rest;
+        if (st.penalty > 0.f) {
+            const float mult = fmaxf(__fmul_rn(logf(__fdiv_rn(__fadd_rn(st.repeat_counts[b], 1.f), 4.f)), st.penalty), 0.f);
+            row_temp = __fadd_rn(row_temp, __fmul_rn(mult, row_temp));
+        }
+        row_u = u[(size_t)(st.pos[0] - st.pos0) * st.u_ld + b];
+    } else {
+        row_temp = temp[b];
+        row_u = u[b];
+    }
+    const float lse = mx + logf(se), inv_t = 1.f / row_temp;
     for (int j = tid; j < 1024; j += 256) key[j] = (key[j] - lse) * inv_t;
     __syncthreads();
     // ---- bitonic sort, descending by value, ascending index among equals
@@ -899,7 +926,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
         part[tid] += v;
         __syncthreads();
     }
-    const float target = u[b] * tot2;
+    const float target = row_u * tot2;
     float c0 = part[tid] - loc2;
     int cnt = 0, pick = -1;
 #pragma unroll
@@ -925,6 +952,10 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
         const int pos = s_pick < (1 << 30) ? s_pick : s_last;
         out_ids[b] = idx[pos];
         if (n_choices) n_choices[b] = s_cnt;
+        if (st.prev_tok) {                                  // generate.py:186-189
+            const float rc = st.repeat_counts[b];
+            st.repeat_counts[b] = s_cnt <= 2 ? rc + 1.f : floorf(rc * 0.5f);
+        }
     }
 }
 
@@ -1135,8 +1166,22 @@ int me_sample_topk_topp(const float* logits, int ld, int V, const int32_t* speci
     me_clear_error();
     if (!logits || !temp || !u || !out_ids) return ME_ERR_NULL;
     if (B <= 0 || V <= 0 || V > 1024 || ld < V || (dbg_p && !dbg_i)) return ME_ERR_BAD_SHAPE;
+    SampleStep none = {};
     sample_kernel<<<B, 256, 0, (hipStream_t)stream>>>(logits, ld, V, special, special ? n_special : 0, temp, top_k, top_p, u,
-                                                      out_ids, n_choices, dbg_p, dbg_i);
+                                                      out_ids, n_choices, dbg_p, dbg_i, none);
+    return me_launch_status();
+}
+
+int me_sample_step(const float* logits, int ld, int V, const int32_t* special, int n_special, const int64_t* prev_tok,
+                   const uint8_t* is_timeshift, float* repeat_counts, float temp_note, float temp_rest, float penalty_coeff,
+                   int top_k, float top_p, const float* u_table, int u_ld, const int32_t* pos, int pos0, int64_t* out_ids,
+                   int32_t* n_choices, int B, void* stream) {
+    me_clear_error();
+    if (!logits || !prev_tok || !is_timeshift || !repeat_counts || !u_table || !pos || !out_ids) return ME_ERR_NULL;
+    if (B <= 0 || V <= 0 || V > 1024 || ld < V || u_ld < B) return ME_ERR_BAD_SHAPE;
+    SampleStep st = {prev_tok, is_timeshift, repeat_counts, pos, pos0, u_ld, temp_note, temp_rest, penalty_coeff};
+    sample_kernel<<<B, 256, 0, (hipStream_t)stream>>>(logits, ld, V, special, special ? n_special : 0, nullptr, top_k, top_p,
+                                                      u_table, out_ids, n_choices, nullptr, nullptr, st);
     return me_launch_status();
 }
 

@@ -13,7 +13,7 @@ ME_F32, ME_BF16 = 0, 1
 ME_COND_NONE, ME_COND_CONCAT, ME_COND_TOKEN = 0, 1, 2
 ME_EPI_RELU, ME_EPI_OUT_F32, ME_EPI_RELU_BWD = 1, 2, 4
 ME_WS_GEMM_TN, ME_WS_RGA_PT, ME_WS_RGA_DGT, ME_WS_RGA_MT = 1, 2, 3, 4
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 ERRORS = {0: "ME_OK", -1: "ME_ERR_BAD_DTYPE", -2: "ME_ERR_BAD_SHAPE", -3: "ME_ERR_ALIGNMENT",
           -4: "ME_ERR_LAUNCH", -5: "ME_ERR_NULL", -6: "ME_ERR_WORKSPACE"}
@@ -48,6 +48,7 @@ SIGNATURES = {
     "me_dec_ln_proj": [_p, _p, _p, _f, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "me_greedy_pick": [_p, _i, _i, _p, _i, _p, _i, _p],
     "me_sample_topk_topp": [_p, _i, _i, _p, _i, _p, _i, _f, _p, _p, _p, _p, _p, _i, _p],
+    "me_sample_step": [_p, _i, _i, _p, _i, _p, _p, _p, _f, _f, _f, _i, _f, _p, _i, _p, _i, _p, _p, _i, _p],
     "me_decode_commit": [_p, _p, _i, _p, _i, _p],
     "me_greedy_pick_commit": [_p, _i, _i, _p, _i, _p, _p, _i, _p, _i, _p],
 }

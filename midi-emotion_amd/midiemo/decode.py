@@ -200,3 +200,75 @@ class DecodeSession:
                 step_events.append(ev)
         self.t = t0 + n_steps
         return self._hist[:, t0:t0 + n_steps]
+
+    def sample_run(self, tokens, n_steps, cond, special, is_timeshift, repeat_counts, temp_note, temp_rest,
+                   penalty_coeff, top_k, top_p, uniforms, use_graph=True):
+        """The sampling loop of generate() (generate.py:99-189) on the device: feed `tokens` (int64 [B]) at the next
+        position, sample the next token with me_sample_step (NaN / specials mask, log-softmax, the per-row temperature
+        with its repeat penalty, top-k, nucleus cut, inverse-CDF draw at uniforms[step], repeat-counter update), append
+        it and feed it back, n_steps times.  One HIP graph per token (33 launches) instead of ~40 eager launches and a
+        dozen small torch ops from Python.  `uniforms` float32 [n_steps, B] are drawn by the caller (so the random
+        stream is the caller's generator's); `repeat_counts` float32 [B] is updated in place.
+        Returns the sampled ids int64 [B, n_steps] (on the device)."""
+        m = self.m
+        dev = m.flat_params.device
+        n_steps = int(n_steps)
+        if m.vocab_size > 1024:
+            raise RuntimeError("sample_run: the sampling kernel sorts at most 1024 logits (vocab %d)" % m.vocab_size)
+        if self.t + n_steps > m.max_seq:
+            raise RuntimeError("decode positions %d..%d exceed max_seq %d" % (self.t, self.t + n_steps, m.max_seq))
+        if uniforms.shape[0] < n_steps or uniforms.shape[1] != self.B or uniforms.dtype != torch.float32:
+            raise ValueError("uniforms must be float32 [>= n_steps, B]")
+        if not hasattr(self, "_tok"):
+            self._tok = torch.zeros(self.B, 1, dtype=torch.int64, device=dev)
+            self._hist = torch.zeros(self.B, m.max_seq, dtype=torch.int64, device=dev)
+            self._pos = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._cond = torch.zeros(self.B, 2, dtype=torch.float32, device=dev)
+            self._special = None
+        if not hasattr(self, "_s_u"):
+            self._s_u = torch.zeros(m.max_seq, self.B, dtype=torch.float32, device=dev)
+            self._s_rc = torch.zeros(self.B, dtype=torch.float32, device=dev)
+            self._s_ts = torch.zeros(m.vocab_size, dtype=torch.uint8, device=dev)
+            self._s_graph, self._s_key = None, None
+        self._tok.copy_(tokens.to(device=dev, dtype=torch.int64).reshape(self.B, 1))
+        self._pos.fill_(self.t)
+        if m.d_condition > 0:
+            self._cond.copy_(cond.to(device=dev, dtype=torch.float32))
+        self._s_u[:n_steps].copy_(uniforms[:n_steps])
+        self._s_rc.copy_(repeat_counts.to(device=dev, dtype=torch.float32))
+        self._s_ts.copy_(is_timeshift.to(device=dev, dtype=torch.uint8))
+        sp = None if special is None else special.to(device=dev, dtype=torch.int32).contiguous()
+        # everything that is baked into the captured step: scalars, the special-id list and the position origin
+        key = (float(temp_note), float(temp_rest), float(penalty_coeff), int(top_k), float(top_p), self.t,
+               None if sp is None else tuple(sp.tolist()))
+        if key != self._s_key:
+            self._s_key, self._s_graph, self._s_special = key, None, sp
+        t0 = self.t
+
+        def one_step():
+            self._pos_dev = self._pos
+            try:
+                self._embed_and_run(self._tok, self._cond if m.d_condition > 0 else None)
+                # block b reads the fed token of row b first and writes the sampled one last: the input buffer is reused
+                ops.sample_step(self.logits, m.vocab_size, self._s_special, self._tok, self._s_ts, self._s_rc, temp_note,
+                                temp_rest, penalty_coeff, top_k, top_p, self._s_u, self._pos, t0, self._tok)
+                ops.decode_commit(self._tok, self._hist, self._pos, self.B)         # history[pos] = next; ++pos
+            finally:
+                self._pos_dev = None
+
+        done = 0
+        if use_graph and self._s_graph is None and n_steps > 2:
+            one_step()                                      # warm-up outside the capture
+            done = 1
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                one_step()
+            self._s_graph = g
+        for _ in range(n_steps - done):
+            if use_graph and self._s_graph is not None:
+                self._s_graph.replay()
+            else:
+                one_step()
+        self.t = t0 + n_steps
+        repeat_counts.copy_(self._s_rc.to(repeat_counts.device))
+        return self._hist[:, t0:t0 + n_steps]

@@ -233,6 +233,16 @@ def sample_topk_topp(logits, V, special, temp, top_k, top_p, u, out_ids, n_choic
           "me_sample_topk_topp")
 
 
+def sample_step(logits, V, special, prev_tok, is_timeshift, repeat_counts, temp_note, temp_rest, penalty_coeff, top_k, top_p,
+                u_table, pos, pos0, out_ids, n_choices=None):
+    B = out_ids.numel()
+    check(lib().me_sample_step(_ptr(logits), logits.stride(0), V, _ptr(special),
+                               special.numel() if special is not None else 0, _ptr(prev_tok), _ptr(is_timeshift),
+                               _ptr(repeat_counts), float(temp_note), float(temp_rest), float(penalty_coeff), int(top_k),
+                               float(top_p), _ptr(u_table), u_table.stride(0), _ptr(pos), int(pos0), _ptr(out_ids),
+                               _ptr(n_choices), B, _stream()), "me_sample_step")
+
+
 def decode_commit(tok, history, pos, B):
     check(lib().me_decode_commit(_ptr(tok), _ptr(history), history.stride(0), _ptr(pos), B, _stream()), "me_decode_commit")
 

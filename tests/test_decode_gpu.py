@@ -79,6 +79,35 @@ def test_sampling_path_runs_and_respects_exclusions(golden_dir):
     assert ((ids[1:] >= 2) & (ids[1:] < 1007)).all()
 
 
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("cd", ["fp32", "bf16"])
+def test_device_resident_sampling_loop_equals_eager_loop(golden_dir, mode, cd):
+    """generate() with sampling: while the KV cache is valid the loop runs on the device (DecodeSession.sample_run: one
+    HIP graph per token with me_sample_step computing the temperature / repeat penalty, drawing from the uniforms
+    generate() prepared, and updating the repeat counters).  Same seed -> the same token stream as one Python
+    iteration per token, bit for bit, including the hand-over to the sliding-window (full recompute) part and the
+    repeat penalty (a peaked model: long runs of one- and two-choice steps)."""
+    G, model, maps, conds, disc, z = setup(mode, cd, golden_dir)
+    with torch.no_grad():                                # peaked logits: repeat counters grow, the penalty matters
+        model.fc.weight.mul_(6.0)
+        model.mark_params_changed()
+
+    def go(device_loop, gen_len, mil, top_k, top_p):
+        torch.manual_seed(11)
+        return G.generate(model, maps, torch.device("cuda"), "/tmp/none", mode, discrete_conditions=disc,
+                          continuous_conditions=None if mode == "none" else conds, max_input_len=mil, amp=False,
+                          gen_len=gen_len, top_k=top_k, top_p=top_p, temperatures=[1.3, 0.9], penalty_coeff=0.5, debug=True,
+                          min_n_instruments=0, primers=[["<START>"]] * 4 if mode == "none" else [["<START>"]],
+                          use_cache=True, return_ids=True, device_loop=device_loop).numpy()
+
+    for gen_len, mil, top_k, top_p in [(60, 1024, -1, 0.7), (50, 30, 8, 1.0), (33, 1024, 3, 0.9)]:
+        a = go(True, gen_len, mil, top_k, top_p)
+        b = go(False, gen_len, mil, top_k, top_p)
+        assert a.shape == b.shape == (gen_len, 4)
+        assert np.array_equal(a, b), (mode, cd, gen_len, mil, np.argwhere(a != b)[:4])
+        assert ((a[1:] >= 2) & (a[1:] < 1007)).all()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("conditioning", ["none", "continuous_concat"])
 def test_device_resident_greedy_loop_matches_eager_steps(conditioning):
