@@ -326,8 +326,14 @@ def main():
     backend = os.environ.get("MIDIEMO_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # MIDIEMO_BENCH_FORCE_DIST=1 (test hook): take the distributed code path (process group, bucket all-reduce hooks,
+    # barrier, MAX over ranks) even with one rank, so RCCL itself is exercised on a single-GPU box
+    dist_on = world > 1 or bool(os.environ.get("MIDIEMO_BENCH_FORCE_DIST"))
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -351,13 +357,13 @@ def main():
 
     def step(i):
         tok, cond, tgt = batches[i % len(batches)]
-        loss = model.loss_and_backward(tok, cond, tgt, bucket_hook=reducer.hook if world > 1 else None)
+        loss = model.loss_and_backward(tok, cond, tgt, bucket_hook=reducer.hook if dist_on else None)
         reducer.finish()
         opt.step(grad_scale=reducer.grad_scale)
         return loss
 
     def fence():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -378,7 +384,7 @@ def main():
     per_step = sorted(a.elapsed_time(b) for a, b in zip([e0] + step_ev[:-1], step_ev))
     median_ms = per_step[len(per_step) // 2]
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     final_loss = float(loss.item())

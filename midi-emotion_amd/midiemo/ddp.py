@@ -31,6 +31,9 @@ class GradAllReducer:
         self.ranges = list(bucket_ranges)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # one rank has nothing to exchange; MIDIEMO_DDP_FORCE=1 (test hook) issues the collectives anyway, so the RCCL
+        # path (asynchronous all-reduce on RCCL's stream, work handles, comm windows) can be exercised on a 1-GPU box
+        self._active = self.world > 1 or (dist.is_initialized() and bool(os.environ.get("MIDIEMO_DDP_FORCE")))
         self.policy = policy or os.environ.get("MIDIEMO_DDP_POLICY", "window")
         if self.policy not in ("window", "eager", "end"):
             raise ValueError("MIDIEMO_DDP_POLICY must be window, eager or end")
@@ -62,7 +65,7 @@ class GradAllReducer:
     def hook(self, bucket_index):
         """Called by the engine's backward: bucket_index >= 0 -- that bucket is final on the compute stream;
         -1 -- a comm window opens (see the class docstring)."""
-        if self.world == 1:
+        if not self._active:
             return
         if bucket_index < 0:
             if self.policy == "window":
@@ -79,7 +82,7 @@ class GradAllReducer:
     def finish(self):
         """Launch what is still parked, then make the compute stream wait for every outstanding bucket (no host
         block on GPU backends)."""
-        if self.world == 1:
+        if not self._active:
             return
         if len(self._done) != len(self.ranges):
             missing = sorted(set(range(len(self.ranges))) - self._done)

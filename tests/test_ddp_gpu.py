@@ -45,10 +45,10 @@ def rel(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm())
 
 
-def run_workers(tmp_path, policy, accumulate, backend, compute_dtype, port):
-    out = str(tmp_path / f"ddp_{policy}_{accumulate}_{backend}.pt")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+def run_workers(tmp_path, policy, accumulate, backend, compute_dtype, port, nproc=2):
+    out = str(tmp_path / f"ddp_{policy}_{accumulate}_{backend}_{nproc}.pt")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", MIDIEMO_DDP_FORCE="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
                         "--master-addr", "127.0.0.1", "--master-port", str(port),
                         os.path.join(ROOT, "tests", "ddp_worker.py"), "--policy", policy, "--accumulate", str(accumulate),
                         "--backend", backend, "--compute_dtype", compute_dtype, "--out", out],
@@ -83,6 +83,35 @@ def test_two_ranks_one_gpu_rccl_backend(tmp_path):
     got = torch.load(out)
     g1, params, p0, keep = single_rank_reference(2, 1, "fp32")
     assert rel(got["g1"][keep], g1[keep]) <= 1e-5 and rel(got["params"][keep], params[keep]) <= 1e-4
+
+
+@pytest.mark.parametrize("policy", ["window", "eager", "end"])
+def test_one_rank_through_rccl(tmp_path, policy):
+    """The RCCL code path itself (backend "nccl": communicator on the device, asynchronous all-reduce of every bucket on
+    RCCL's stream, the comm-window / eager / end policies waiting on the work handles, 1 / world folded into the optimiser)
+    with the one rank a single-GPU box allows: the trajectory must equal the plain single-process run."""
+    r, out = run_workers(tmp_path, policy, 1, "nccl", "fp32", 29571 + len(policy), nproc=1)
+    assert r.returncode == 0 and r.stdout.count("done") == 1, r.stdout[-3000:] + r.stderr[-3000:]
+    got = torch.load(out)
+    g1, params, p0, keep = single_rank_reference(1, 1, "fp32")
+    assert rel(got["g1"][keep], g1[keep]) <= 1e-6 and rel(got["params"][keep], params[keep]) <= 1e-6
+
+
+def test_bench_one_rank_under_the_launcher_rccl():
+    """bench.py under the driver's launch line with one rank and the real backend: init_process_group("nccl") on the
+    device, RCCL barrier and MAX all-reduce around the timed region."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MIDIEMO_BENCH_FORCE_DIST="1", MIDIEMO_DDP_FORCE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29537", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--no_decode", "--no_extra", "--no_cpu_baseline", "--no_probe"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-3000:]
+    lines = [l for l in out.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, out[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["global_batch"] == 32 and d["value"] > 0
 
 
 def test_bench_two_ranks_on_one_device():
