@@ -161,9 +161,10 @@ int me_rga_fwd(const void* qkv, const void* Epk, const uint8_t* key_pad, void* o
                int B, int L, int H, int dh, int M, int causal, int dtype, void* stream);
 /* PT / MT (both NULL for inference, both given for training): the forward additionally leaves what the backward needs
  * instead of recomputing the softmax --
- *   PT : T, per (batch, head) the 32 x 32 tiles [query][key] of the UNNORMALISED probabilities p = exp((s - m_t)) taken
- *        against the running row maximum m_t at that key tile: the packed lower triangle (key tile, query tile >= key
- *        tile) for causal = 1, the full square for causal = 0        (bytes: me_workspace_bytes(ME_WS_RGA_PT, B*H, Lp, causal));
+ *   PT : T, per (batch, head) the 32 x 32 tiles (32 queries x 32 keys, stored in the forward's register-image order:
+ *        opaque to the caller) of the UNNORMALISED probabilities p = exp((s - m_t)) taken against the running row
+ *        maximum m_t at that key tile: the packed lower triangle (key tile, query tile >= key tile) for causal = 1,
+ *        the full square for causal = 0        (bytes: me_workspace_bytes(ME_WS_RGA_PT, B*H, Lp, causal));
  *   MT : f32 [B*H][Lp/32 key tiles][Lp] the running maxima m_t (raw logit units)   (ME_WS_RGA_MT).
  * P = p * exp(m_t / sqrt(dh) - lse).  Lp = L rounded up to 32.  No initialisation needed; kept until me_rga_bwd of the
  * same layer has run. */
@@ -178,8 +179,9 @@ int me_rga_pack_rel(const void* E, void* Epk, int M, int dh, int dtype, void* st
 /* Backward of me_rga_fwd.  dout: T [B,L,H,dh].  Writes dqkv (T, same layout as qkv), accumulates (+=) dE f32 [M, dh]
  * (natural layout).  PT / MT: what me_rga_fwd left for this layer (read only).  Workspaces (caller-owned, 16-byte
  * aligned, contents need NOT be initialised): delta f32 [B,H,L];
- *   dGT : T, per (batch, head) the tiles (query tile qt, step t <= qt) of the skewed dS (rows = rows of the relative
- *         table, columns = queries): what dE is contracted from       (ME_WS_RGA_DGT).
+ *   dGT : T, per (batch, head) the tiles (query tile qt, step t <= qt) of the skewed dS (32 rows of the relative table
+ *         x 32 queries, stored as the dE kernel's operand fragment images: opaque): what dE is contracted from
+ *         (ME_WS_RGA_DGT).
  * Neither S nor dS is stored or recomputed from Q.K^T: dS = P o (V dO^T - delta) / sqrt(dh) with P from PT / MT.
  * causal: as in me_rga_fwd (autograd of music_multi.py:211-235 for 1, of music_regression.py's mask = None attention for 0). */
 int me_rga_bwd(const void* qkv, const void* Epk, const void* out, const float* lse, const void* dout,
