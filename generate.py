@@ -272,6 +272,7 @@ def main():
     parser.add_argument("--batch_gen_dir", type=str, default="")
     parser.add_argument("--output_root", type=str, default="../output", help="reference hard-codes ../output")
     parser.add_argument("--no_cache", action='store_true', help="reference-style full recompute every step")
+    parser.add_argument("--no_device_loop", action='store_true', help="one Python iteration per token instead of the HIP-graph sampling loop")
     args = parser.parse_args()
 
     assert len(args.valence) == len(args.arousal), "Lengths of valence and arousal must be equal"
@@ -328,7 +329,7 @@ def main():
                 penalty_coeff=args.penalty_coeff, short_filename=args.short_filename, top_p=args.topp,
                 gen_len=args.gen_len, max_input_len=args.max_input_len, amp=not args.no_amp, primers=p_run,
                 temperatures=args.temp, top_k=args.topk, debug=args.debug, verbose=not args.quiet, seed=args.seed,
-                use_cache=not args.no_cache)
+                use_cache=not args.no_cache, device_loop=not args.no_device_loop)
 
 
 if __name__ == '__main__':
