@@ -108,6 +108,22 @@ def test_device_resident_sampling_loop_equals_eager_loop(golden_dir, mode, cd):
         assert ((a[1:] >= 2) & (a[1:] < 1007)).all()
 
 
+def test_device_resident_sampling_loop_more_than_eight_sequences(golden_dir):
+    """B = 10 > the 8 rows a decode kernel call takes: the step runs in two row chunks, the sampling kernel and the
+    commit over all rows; the device loop must still equal the per-token loop."""
+    G, model, maps, conds, disc, z = setup("continuous_concat", "fp32", golden_dir)
+    conds10 = [[((3 * i) % 7 - 3) / 4.0, ((5 * i) % 9 - 4) / 5.0] for i in range(10)]
+
+    def go(device_loop):
+        torch.manual_seed(21)
+        return G.generate(model, maps, torch.device("cuda"), "/tmp/none", "continuous_concat", continuous_conditions=conds10,
+                          max_input_len=1024, amp=False, gen_len=24, top_k=-1, top_p=0.8, debug=True, min_n_instruments=0,
+                          use_cache=True, return_ids=True, device_loop=device_loop).numpy()
+
+    a, b = go(True), go(False)
+    assert a.shape == (24, 10) and np.array_equal(a, b)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("conditioning", ["none", "continuous_concat"])
 def test_device_resident_greedy_loop_matches_eager_steps(conditioning):
