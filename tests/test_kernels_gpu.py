@@ -554,6 +554,25 @@ def test_rga_fwd_bwd_shapes(ops, dtype, B, H, L, dh, M):
         assert (got["dE"][: M - L] == 0).all()
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("L,M", [(512, 2048), (448, 512), (200, 256)])
+def test_rga_long_unpadded_and_mixed_rows(ops, dtype, L, M):
+    """Sequences long enough for the mask-free MAIN steps of the 64-key-step kernels (bf16, dh 64): batch row 0 has no
+    padded key (MAIN steps + the diagonal / ragged tail), batch row 1 has padded keys (general path only)."""
+    q, k, v, E, dO, _ = attn_case(2, 2, L, 64, M, seed=300 + L, pad_rows=False)
+    pad = torch.zeros(2, L, dtype=torch.bool)
+    pad[1, 5] = True
+    pad[1, -(L // 7):] = True
+    got = run_attn(ops, dtype, q, k, v, E, dO, pad)
+    ref = ref_attn(q, k, v, E, dO, pad, dtype)
+    errs = {n: relerr(got[n], ref[n]) for n in ("O", "lse", "dq", "dk", "dv", "dE")}
+    assert all(e < tol(dtype, 3e-5, 1.5e-2) for e in errs.values()), errs
+    got0 = run_attn(ops, dtype, q, k, v, E, dO, None)                  # no pad mask at all
+    ref0 = ref_attn(q, k, v, E, dO, torch.zeros(2, L, dtype=torch.bool), dtype)
+    errs = {n: relerr(got0[n], ref0[n]) for n in ("O", "lse", "dq", "dk", "dv", "dE")}
+    assert all(e < tol(dtype, 3e-5, 1.5e-2) for e in errs.values()), errs
+
+
 def test_rga_fully_masked_row_is_nan(ops):
     """PAD at key 0: query 0 has no valid key -> NaN (reference behaviour, SURVEY hard part 6);
     later queries with leading masked keys must stay finite."""
