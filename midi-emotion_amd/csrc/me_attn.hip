@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
         const int ktc = min(kt, kt_hi);
         const T* tp = ptb + pt_tile(ktc, qt, nq32, CAUSAL) * 1024;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) pp[g] = *reinterpret_cast<const PH*>(tp + 4 * g);      // the lane's own 16 elements, contiguous
+        for (int g = 0; g < 4; ++g) pp[g] = nt_load(reinterpret_cast<const PH*>(tp + 4 * g));      // the lane's own 16 elements, contiguous
         mtn = mtb[(size_t)ktc * Lp];
     };
     gload(0);
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
                         reinterpret_cast<v4s*>(&c)[0] = x[0];
                         reinterpret_cast<v4s*>(&c)[1] = x[1];
                         // row m = 16 kh + l16, queries 8 gidx .. + 7 -> fragment-image position (dg_pos)
-                        st_chunk(dg_dst + (gidx >> 1) * 512 + (kh * 16 + l16 + 32 * (gidx & 1)) * 8, c);
+                        nt_store(c.v, reinterpret_cast<u32x4_t*>(dg_dst + (gidx >> 1) * 512 + (kh * 16 + l16 + 32 * (gidx & 1)) * 8));
                     }
                 } else {
 #pragma unroll
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(256) void rga_bwd_kv_kernel(const T* __restrict__ P
             const int c = tid + i * 256, row = c / CPRP, cc = (c % CPRP) * CH;
             const int kt = min(kb * 4 + (row >> 5), nq32 - 1);
             // tiles above the diagonal do not exist in the packed triangle: clamped to the diagonal tile (never used)
-            rp[i] = ld_chunk(ptb + pt_tile(kt, CAUSAL ? max(qs, kt) : qs, nq32, CAUSAL) * 1024 + (row & 31) * 32 + cc);
+            rp[i].v = nt_load(reinterpret_cast<const u32x4_t*>(ptb + pt_tile(kt, CAUSAL ? max(qs, kt) : qs, nq32, CAUSAL) * 1024 + (row & 31) * 32 + cc));
         }
         const int qv = L - qs * 32;
 #pragma unroll
@@ -754,8 +754,8 @@ __global__ __launch_bounds__(256) void rga_bwd_e_kernel(const T* __restrict__ dG
     int g_bh = bh_lo, g_qs = qs0, g_left = nsteps;      // cursor of the dG^T loads
     auto gload = [&](Frag<T>* g) __attribute__((always_inline)) {
         const T* src = dGT + (size_t)g_bh * dg_bh + dg_tile(g_qs, min(max(g_qs + tshift, 0), g_qs)) * 1024 + lane * 8;
-        frag_load(g[0], src);
-        frag_load(g[1], src + 512);
+        frag_load_nt(g[0], src);
+        frag_load_nt(g[1], src + 512);
         if (g_left > 1) {                               // past the last step the cursor stays on it (harmless re-loads)
             --g_left;
             if (++g_qs == nqt) { g_qs = qs0; ++g_bh; }

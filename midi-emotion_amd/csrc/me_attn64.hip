@@ -36,7 +36,11 @@ constexpr int LDR = 68;                        // G ring row (floats): 64-column
 constexpr int K_BYTES = 64 * LDK * 2;          // 9216
 constexpr int V_BYTES = 64 * LDV * 2;          // 12288
 constexpr int G_BYTES = 32 * LDR * 4;          // 8704 per wave
+#ifdef ABL_LDS
+constexpr int FWD_LDS = ABL_LDS;                                                   // occupancy experiments
+#else
 constexpr int FWD_LDS = 2 * K_BYTES + 2 * V_BYTES + 4 * G_BYTES;                   // 77824
+#endif
 
 // =====================================================================================
 // forward

@@ -102,6 +102,28 @@ ME_DEV int dg_pos(int m, int q) { return (q >> 4) * 512 + (m + 32 * ((q >> 3) & 
 // full cache lines) instead of four 8-byte pieces scattered over 32 rows (measured: +80 us per forward launch).
 ME_DEV int p_col(int key) { return ((key >> 2) & 1) * 16 + (key >> 3) * 4 + (key & 3); }
 
+// Streaming accesses (workspace tiles written once and read once or twice much later): non-temporal loads / stores
+// keep them from displacing the K / V / Q rows the other blocks re-read through L2.  -DME_NO_NT: plain accesses (A/B).
+template <typename V> ME_DEV V nt_load(const V* p) {
+#ifdef ME_NO_NT
+    return *p;
+#else
+    return __builtin_nontemporal_load(p);
+#endif
+}
+template <typename V> ME_DEV void nt_store(V v, V* p) {
+#ifdef ME_NO_NT
+    *p = v;
+#else
+    __builtin_nontemporal_store(v, p);
+#endif
+}
+ME_DEV void frag_load_nt(Frag<bf16_t>& f, const bf16_t* p) { f.v = nt_load(reinterpret_cast<const bf16x8_t*>(p)); }
+ME_DEV void frag_load_nt(Frag<float>& f, const float* p) {
+    f.lo = nt_load(reinterpret_cast<const f32x4_t*>(p));
+    f.hi = nt_load(reinterpret_cast<const f32x4_t*>(p + 4));
+}
+
 // v_exp_f32 without the denormal-range fix-up of exp2f (arguments here are <= 0: tiny results may flush to 0)
 ME_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
