@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 15
+#define ME_ABI_VERSION 16
 
 enum { ME_F32 = 0, ME_BF16 = 1 };
 
@@ -130,7 +130,8 @@ enum {
     ME_WS_GEMM_TN = 1,   /* me_gemm_tn_acc partial tiles: (M, N, K) = (T, N, K) */
     ME_WS_RGA_PT = 2,    /* me_rga_fwd / me_rga_bwd PT: (M, N, K) = (B*H, Lp, causal) */
     ME_WS_RGA_DGT = 3,   /* me_rga_bwd dGT workspace:   (M, N, K) = (B*H, Lp, unused) */
-    ME_WS_RGA_MT = 4     /* me_rga_fwd / me_rga_bwd MT: (M, N, K) = (B*H, Lp, unused) */
+    ME_WS_RGA_MT = 4,    /* me_rga_fwd / me_rga_bwd MT: (M, N, K) = (B*H, Lp, unused) */
+    ME_WS_GEMM_TN_GROUP = 5  /* me_gemm_tn_acc_group: (M, N, K) = (T, sum over the items of ceil(N/256) * (K/256), unused) */
 };
 size_t me_workspace_bytes(int op, int M, int N, int K, int dtype);
 
@@ -144,6 +145,24 @@ size_t me_workspace_bytes(int op, int M, int N, int K, int dtype);
  * error (ME_ERR_WORKSPACE), never a silent fallback. */
 int me_gemm_tn_acc(const void* A, int lda, const void* B, int ldb, float* dW, int lddw,
                    float* dbias, int T, int N, int K, void* ws, size_t ws_bytes, int dtype, void* stream);
+
+/* Several weight gradients over the SAME token dimension in one launch (the four nn.Linear weight gradients of an
+ * EncoderLayer, music_multi.py:126-135,196-237: autograd of FFN_suf, FFN_pre, rga.fc and the fused Wq|Wk|Wv).  Same
+ * results as n_items calls of me_gemm_tn_acc up to the summation order (still fixed, bit-reproducible); the token
+ * dimension is split #CUs / (tiles of ALL items) ways instead of once per product, which at the headline shapes cuts the
+ * partial-tile traffic to a quarter and replaces eight launches by two.  `items` is a HOST array (read during the call
+ * only).  bf16, every N readable up to a multiple of 256 columns (lda), K % 256 == 0, T >= 2048 run the grouped kernel
+ * (workspace: me_workspace_bytes(ME_WS_GEMM_TN_GROUP, T, total tiles, 0, dtype)); anything else is executed as
+ * separate me_gemm_tn_acc calls with the same workspace. */
+#define ME_TN_MAX_GROUP 4
+typedef struct me_tn_item {
+    const void* A; int lda;      /* dY [T, N] */
+    const void* B; int ldb;      /* X  [T, K] */
+    float* dW; int lddw;         /* [N, K] f32, accumulated into */
+    float* dbias;                /* [N] f32 or NULL */
+    int N, K;
+} me_tn_item;
+int me_gemm_tn_acc_group(const me_tn_item* items, int n_items, int T, void* ws, size_t ws_bytes, int dtype, void* stream);
 
 /* ---- relative global attention ---------------------------------------------
  * qkv  : T [B, L, 3, H, dh]  (token-major output of the fused QKV projection; the kernels read

@@ -721,24 +721,41 @@ constexpr int TN256_BT = 64;                                    // tokens per sl
 constexpr int TN256_OP = TN256_BT * TN256_LD * 2;               // bytes per operand slab (36864)
 constexpr int TN256_LDS = 4 * TN256_OP;                         // two buffers x two operands (147456)
 
-__global__ __launch_bounds__(512) void gemm_tn256_kernel(
-    const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, float* __restrict__ dW, int lddw,
-    float* __restrict__ dbias, int Tn, int N, int K, int t_per_block, int tn, int tk, int nsplit, float* __restrict__ ws) {
+// One launch serves up to ME_TN_MAX_GROUP products that share the token dimension (the four weight gradients of a
+// layer): the work items (token range, tile) of ALL products are numbered together, so the token split is
+// #CUs / (total tiles) instead of #CUs / (tiles of one product) -- at the headline shapes 5 ranges instead of 16-64, i.e.
+// a quarter of the partial-tile bytes written here and read by the reduce pass, one flush and one launch instead of four.
+struct tn_prod {
+    const bf16_t* A; const bf16_t* B; float* dW; float* dbias;
+    int lda, ldb, lddw, N, tn, tk, tile0, pad_;
+};
+struct tn_group { tn_prod p[ME_TN_MAX_GROUP]; int np, ntile, nsplit, t_per_block, Tn, pad_; };
+
+__global__ __launch_bounds__(512) void gemm_tn256_kernel(const tn_group G, float* __restrict__ ws) {
     typedef bf16_t T;
     extern __shared__ __attribute__((aligned(16))) char smem[];          // [2 buffers][A slab | B slab]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
+    const int Tn = G.Tn, nsplit = G.nsplit, t_per_block = G.t_per_block;
     // XCD-aware order (block b runs on XCD b % 8, each XCD has its own L2): the work items g = (token range z, tile)
     // are numbered range-major and XCD x takes the contiguous run [x * per, (x + 1) * per), so the tn x tk tiles of
     // a token range -- which all stream the same dY / X slabs -- sit on one XCD (two at a run boundary) and share
     // the slabs through L2.  (Spreading them over the XCDs read 295 MB from HBM per launch instead of ~135; the launch time did not
     // change -- the re-reads hit the Infinity Cache -- but the fabric traffic halves.)
-    const int ntile = tn * tk, total = ntile * nsplit, per = (total + 7) / 8;
+    const int ntile = G.ntile, total = ntile * nsplit, per = (total + 7) / 8;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int g = xcd * per + slot;
     if (slot >= per || g >= total) return;
-    const int z = g / ntile, tile = g % ntile;
+    const int z = g / ntile, gtile = g % ntile;
+    int pi = 0;
+    while (pi + 1 < G.np && gtile >= G.p[pi + 1].tile0) ++pi;
+    const bf16_t* __restrict__ A = G.p[pi].A;
+    const bf16_t* __restrict__ B = G.p[pi].B;
+    float* __restrict__ dW = G.p[pi].dW;
+    float* __restrict__ dbias = G.p[pi].dbias;
+    const int lda = G.p[pi].lda, ldb = G.p[pi].ldb, lddw = G.p[pi].lddw, N = G.p[pi].N, tn = G.p[pi].tn;
+    const int tile = gtile - G.p[pi].tile0;
     const int nx = tile % tn, ky = tile / tn;
     const int n0 = nx * 256, k0 = ky * 256;
     const int t_begin = z * t_per_block;
@@ -858,16 +875,21 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(
 // dW tile (nx, ky) += sum over the token ranges z of the partial tiles gemm_tn256_kernel left in the
 // workspace (67 MB of f32 atomics cost 40-48 us per launch, the same bytes as plain stores + this pass
 // ~15 us, and the sum no longer depends on the arrival order).  grid (tn * tk, 32 slots), 512 threads.
-__global__ __launch_bounds__(512) void tn256_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, int lddw,
-                                                           int tn, int tk, int nsplit, int N) {
+__global__ __launch_bounds__(512) void tn256_reduce_kernel(const float* __restrict__ ws, const tn_group G) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 2, wc = wid & 3;
-    const int nx = blockIdx.x % tn, ky = blockIdx.x / tn;
+    const int gtile = blockIdx.x, nsplit = G.nsplit;
+    int pi = 0;
+    while (pi + 1 < G.np && gtile >= G.p[pi + 1].tile0) ++pi;
+    float* __restrict__ dW = G.p[pi].dW;
+    const int lddw = G.p[pi].lddw, N = G.p[pi].N, tn = G.p[pi].tn;
+    const int tile = gtile - G.p[pi].tile0;
+    const int nx = tile % tn, ky = tile / tn;
     const int slot = blockIdx.y, q = slot & 3, j = (slot >> 2) & 1, i = slot >> 3;
     f32x4_t sum = {0.f, 0.f, 0.f, 0.f};
-    const int ntile = tn * tk, per = (ntile * nsplit + 7) / 8;
+    const int ntile = G.ntile, per = (ntile * nsplit + 7) / 8;
     auto part = [&](int z) -> f32x4_t {
-        const int g = z * ntile + ky * tn + nx;
+        const int g = z * ntile + gtile;
         const int blk = (g % per) * 8 + g / per;                              // inverse of the kernel's block order
         return reinterpret_cast<const f32x4_t*>(ws)[((size_t)blk * 32 + slot) * 512 + tid];
     };
@@ -990,11 +1012,13 @@ int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int 
         // the 256-tile kernel addresses its operands with 32-bit byte offsets
         const bool off32 = (unsigned long long)M * lda * 2ull < (1ull << 32) && (unsigned long long)N * ldb * 2ull < (1ull << 32);
         if (K % 64 == 0 && M >= 256 && N >= 192 && off32 && !g_disable_nt256) {
-            static bool attr_set = false;
-            if (!attr_set) {
+            static bool attr_set[16] = {false};
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+            if (dev < 0 || dev >= 16 || !attr_set[dev]) {                   // the attribute is per device
                 (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
                 (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<true, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
-                attr_set = true;
+                if (dev >= 0 && dev < 16) attr_set[dev] = true;
             }
             unsigned g256 = (unsigned)(((N + 255) / 256) * ((M + 255) / 256));
             const unsigned ncu = (unsigned)persistent_cus();
@@ -1020,6 +1044,56 @@ int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int 
     return me_launch_status();
 }
 
+// plan of a (grouped) 256-tile launch: token ranges so that tiles x ranges just fills the chip (one block per CU)
+struct tn_item_256 { const bf16_t* A; int lda; const bf16_t* B; int ldb; float* dW; int lddw; float* dbias; int N, K; };
+static void tn256_plan(int Tn, int ntile, int* ns_out, int* tp_out, int* grid_out) {
+    int ns = persistent_cus() / ntile;
+    if (ns < 1) ns = 1;
+    int tp = (Tn + ns - 1) / ns;
+    tp = ((tp + TN256_BT - 1) / TN256_BT) * TN256_BT;
+    ns = (Tn + tp - 1) / tp;
+    *ns_out = ns; *tp_out = tp; *grid_out = ((ntile * ns + 7) / 8) * 8;
+}
+static bool tn256_eligible(int Tn, int N, int K, int lda, int ldb) {
+    static const bool no256 = getenv("MIDIEMO_NO_TN256") != nullptr;
+    const bool off32 = (unsigned long long)Tn * lda * 2ull < (1ull << 32) && (unsigned long long)Tn * ldb * 2ull < (1ull << 32);
+    const int n256 = ((N + 255) / 256) * 256;
+    return !no256 && (N % 256 == 0 || lda >= n256) && K % 256 == 0 && Tn >= 2048 && off32;
+}
+static int tn256_group_launch(const tn_item_256* it, int n, int Tn, void* ws_caller, size_t ws_bytes, hipStream_t st) {
+    static bool attr_set[16] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    if (dev < 0 || dev >= 16 || !attr_set[dev]) {                       // the attribute is per device
+        (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN256_LDS);
+        if (dev >= 0 && dev < 16) attr_set[dev] = true;
+    }
+    tn_group G;
+    int ntile = 0;
+    for (int i = 0; i < n; ++i) {
+        tn_prod& p = G.p[i];
+        p.A = it[i].A; p.B = it[i].B; p.dW = it[i].dW; p.dbias = it[i].dbias;
+        p.lda = it[i].lda; p.ldb = it[i].ldb; p.lddw = it[i].lddw; p.N = it[i].N;
+        p.tn = (it[i].N + 255) / 256; p.tk = it[i].K / 256; p.tile0 = ntile; p.pad_ = 0;
+        ntile += p.tn * p.tk;
+    }
+    for (int i = n; i < ME_TN_MAX_GROUP; ++i) G.p[i] = G.p[n - 1];
+    int ns, tp, grid256;
+    tn256_plan(Tn, ntile, &ns, &tp, &grid256);
+    G.np = n; G.ntile = ntile; G.nsplit = ns; G.t_per_block = tp; G.Tn = Tn; G.pad_ = 0;
+    // partial tiles (256 KB per block) go to the caller's workspace and are summed in a fixed order by
+    // tn256_reduce_kernel; without a workspace the blocks accumulate with f32 atomics (order-dependent sum)
+    const size_t need = (size_t)grid256 * 32 * 512 * 16;
+    float* ws = nullptr;
+    if (ws_caller && ns > 1) {
+        if (ws_bytes < need || !aligned16(ws_caller)) return ME_ERR_WORKSPACE;
+        ws = reinterpret_cast<float*>(ws_caller);
+    }
+    gemm_tn256_kernel<<<grid256, 512, TN256_LDS, st>>>(G, ws);
+    if (ws) tn256_reduce_kernel<<<dim3(ntile, 32), 512, 0, st>>>(ws, G);
+    return me_launch_status();
+}
+
 template <typename T>
 int gemm_tn_launch(const void* A, int lda, const void* B, int ldb, float* dW, int lddw, float* dbias, int Tn, int N,
                    int K, void* ws_caller, size_t ws_bytes, hipStream_t st) {
@@ -1038,35 +1112,9 @@ int gemm_tn_launch(const void* A, int lda, const void* B, int ldb, float* dW, in
     nsplit = (Tn + t_per - 1) / t_per;
     dim3 grid(tn, tk, nsplit);
     if constexpr (sizeof(T) == 2) {
-        static const bool no256 = getenv("MIDIEMO_NO_TN256") != nullptr;
-        const bool off32 = (unsigned long long)Tn * lda * 2ull < (1ull << 32) && (unsigned long long)Tn * ldb * 2ull < (1ull << 32);
-        const int n256 = ((N + 255) / 256) * 256;
-        if (!no256 && (N % 256 == 0 || lda >= n256) && K % 256 == 0 && Tn >= 2048 && off32) {
-            // one block per CU: split the tokens so that tiles x ranges just fills the chip
-            static bool attr_set = false;
-            if (!attr_set) {
-                (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN256_LDS);
-                attr_set = true;
-            }
-            const int tn2 = n256 / 256, tk2 = K / 256;
-            int ns = persistent_cus() / (tn2 * tk2);
-            if (ns < 1) ns = 1;
-            int tp = (Tn + ns - 1) / ns;
-            tp = ((tp + TN256_BT - 1) / TN256_BT) * TN256_BT;
-            ns = (Tn + tp - 1) / tp;
-            const int grid256 = ((tn2 * tk2 * ns + 7) / 8) * 8;
-            // partial tiles (256 KB per block) go to the caller's workspace and are summed in a fixed order by
-            // tn256_reduce_kernel; without a workspace the blocks accumulate with f32 atomics (order-dependent sum)
-            const size_t need = (size_t)grid256 * 32 * 512 * 16;
-            float* ws = nullptr;
-            if (ws_caller && ns > 1) {
-                if (ws_bytes < need || !aligned16(ws_caller)) return ME_ERR_WORKSPACE;
-                ws = reinterpret_cast<float*>(ws_caller);
-            }
-            gemm_tn256_kernel<<<grid256, 512, TN256_LDS, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, dW, lddw, dbias, Tn, N,
-                                                             K, tp, tn2, tk2, ns, ws);
-            if (ws) tn256_reduce_kernel<<<dim3(tn2 * tk2, 32), 512, 0, st>>>(ws, dW, lddw, tn2, tk2, ns, N);
-            return me_launch_status();
+        if (tn256_eligible(Tn, N, K, lda, ldb)) {
+            tn_item_256 it = {(const bf16_t*)A, lda, (const bf16_t*)B, ldb, dW, lddw, dbias, N, K};
+            return tn256_group_launch(&it, 1, Tn, ws_caller, ws_bytes, st);
         }
         const int npairs8 = ((tn * nsplit + 7) / 8) * 8;
         gemm_tn_bf16_kernel<<<npairs8 * tk, NTHREADS, 0, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, dW, lddw, dbias, Tn, N, K,
@@ -1092,24 +1140,23 @@ int me_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
     return ME_ERR_BAD_DTYPE;
 }
 
-// bytes of partial-tile workspace gemm_tn_launch<bf16> needs for (T, N, K); 0 = the shape runs a kernel without one
-static size_t tn_ws_bytes(int Tn, int N, int K, int lda_min) {
-    const int n256 = ((N + 255) / 256) * 256;
-    (void)lda_min;
-    if (K % 256 != 0 || Tn < 2048) return 0;
-    const int tn2 = n256 / 256, tk2 = K / 256;
-    int ns = persistent_cus() / (tn2 * tk2);
-    if (ns < 1) ns = 1;
-    int tp = (Tn + ns - 1) / ns;
-    tp = ((tp + TN256_BT - 1) / TN256_BT) * TN256_BT;
-    ns = (Tn + tp - 1) / tp;
+// bytes of partial-tile workspace a 256-tile launch over `ntile` tiles needs; 0 = no token split
+static size_t tn_ws_bytes_tiles(int Tn, int ntile) {
+    if (Tn < 2048 || ntile <= 0) return 0;
+    int ns, tp, grid256;
+    tn256_plan(Tn, ntile, &ns, &tp, &grid256);
     if (ns <= 1) return 0;
-    const int grid256 = ((tn2 * tk2 * ns + 7) / 8) * 8;
     return (size_t)grid256 * 32 * 512 * 16;
+}
+// ... gemm_tn_launch<bf16> needs for (T, N, K); 0 = the shape runs a kernel without one
+static size_t tn_ws_bytes(int Tn, int N, int K) {
+    if (K % 256 != 0) return 0;
+    return tn_ws_bytes_tiles(Tn, ((N + 255) / 256) * (K / 256));
 }
 
 size_t me_workspace_bytes(int op, int M, int N, int K, int dtype) {
-    if (op == ME_WS_GEMM_TN) return dtype == ME_BF16 ? tn_ws_bytes(M, N, K, 0) : 0;
+    if (op == ME_WS_GEMM_TN) return dtype == ME_BF16 ? tn_ws_bytes(M, N, K) : 0;
+    if (op == ME_WS_GEMM_TN_GROUP) return dtype == ME_BF16 ? tn_ws_bytes_tiles(M, N) : 0;      // N = total 256 x 256 tiles of the group
     if (op == ME_WS_RGA_PT || op == ME_WS_RGA_DGT) {
         // 32 x 32 tiles of the compute type per (batch, head): M = B*H, N = Lp (multiple of 32), K = causal flag
         if (M <= 0 || N <= 0 || (N & 31)) return 0;
@@ -1129,6 +1176,35 @@ int me_gemm_tn_acc(const void* A, int lda, const void* B, int ldb, float* dW, in
     if (dtype == ME_F32) return gemm_tn_launch<float>(A, lda, B, ldb, dW, lddw, dbias, T, N, K, ws, ws_bytes, st);
     if (dtype == ME_BF16) return gemm_tn_launch<bf16_t>(A, lda, B, ldb, dW, lddw, dbias, T, N, K, ws, ws_bytes, st);
     return ME_ERR_BAD_DTYPE;
+}
+
+int me_gemm_tn_acc_group(const me_tn_item* items, int n_items, int T, void* ws, size_t ws_bytes, int dtype, void* stream) {
+    me_clear_error();
+    if (!items) return ME_ERR_NULL;
+    if (n_items <= 0 || n_items > ME_TN_MAX_GROUP) return ME_ERR_BAD_SHAPE;
+    for (int i = 0; i < n_items; ++i)
+        if (!items[i].A || !items[i].B || !items[i].dW) return ME_ERR_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    bool grouped = dtype == ME_BF16 && n_items > 1;
+    for (int i = 0; grouped && i < n_items; ++i) {
+        const me_tn_item& m = items[i];
+        grouped = m.N > 0 && m.K > 0 && m.lda % 8 == 0 && m.ldb % 8 == 0 && aligned16(m.A) && aligned16(m.B) &&
+                  tn256_eligible(T, m.N, m.K, m.lda, m.ldb);
+    }
+    if (grouped) {
+        tn_item_256 it[ME_TN_MAX_GROUP];
+        for (int i = 0; i < n_items; ++i)
+            it[i] = {(const bf16_t*)items[i].A, items[i].lda, (const bf16_t*)items[i].B, items[i].ldb, items[i].dW, items[i].lddw,
+                     items[i].dbias, items[i].N, items[i].K};
+        return tn256_group_launch(it, n_items, T, ws, ws_bytes, st);
+    }
+    // shapes / types the grouped kernel does not take: one launch per product (same results as me_gemm_tn_acc)
+    for (int i = 0; i < n_items; ++i) {
+        const me_tn_item& m = items[i];
+        const int rc = me_gemm_tn_acc(m.A, m.lda, m.B, m.ldb, m.dW, m.lddw, m.dbias, T, m.N, m.K, ws, ws_bytes, dtype, stream);
+        if (rc) return rc;
+    }
+    return ME_OK;
 }
 
 int me_cast_transpose(const float* src, int rows, int cols, void* dst, int ld_dst, void* dstT, int ld_dstT,

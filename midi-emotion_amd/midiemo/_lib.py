@@ -12,8 +12,9 @@ LIB_PATH = os.environ.get("MIDIEMO_LIB") or os.path.join(HERE, "libmidiemo_hip.s
 ME_F32, ME_BF16 = 0, 1
 ME_COND_NONE, ME_COND_CONCAT, ME_COND_TOKEN = 0, 1, 2
 ME_EPI_RELU, ME_EPI_OUT_F32, ME_EPI_RELU_BWD = 1, 2, 4
-ME_WS_GEMM_TN, ME_WS_RGA_PT, ME_WS_RGA_DGT, ME_WS_RGA_MT = 1, 2, 3, 4
-ABI_VERSION = 15
+ME_WS_GEMM_TN, ME_WS_RGA_PT, ME_WS_RGA_DGT, ME_WS_RGA_MT, ME_WS_GEMM_TN_GROUP = 1, 2, 3, 4, 5
+ME_TN_MAX_GROUP = 4
+ABI_VERSION = 16
 
 ERRORS = {0: "ME_OK", -1: "ME_ERR_BAD_DTYPE", -2: "ME_ERR_BAD_SHAPE", -3: "ME_ERR_ALIGNMENT",
           -4: "ME_ERR_LAUNCH", -5: "ME_ERR_NULL", -6: "ME_ERR_WORKSPACE"}
@@ -32,6 +33,7 @@ SIGNATURES = {
     "me_gemm_nt": [_p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "me_workspace_bytes": [_i, _i, _i, _i, _i],
     "me_gemm_tn_acc": [_p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _p, ctypes.c_size_t, _i, _p],
+    "me_gemm_tn_acc_group": [_p, _i, _i, _p, ctypes.c_size_t, _i, _p],
     "me_rga_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "me_rga_pack_rel": [_p, _p, _i, _i, _i, _p],
     "me_rga_bwd": [_p] * 11 + [_i, _i, _i, _i, _i, _i, _i, _i, _p],
@@ -52,6 +54,13 @@ SIGNATURES = {
     "me_decode_commit": [_p, _p, _i, _p, _i, _p],
     "me_greedy_pick_commit": [_p, _i, _i, _p, _i, _p, _p, _i, _p, _i, _p],
 }
+
+
+
+class TnItem(ctypes.Structure):
+    """struct me_tn_item of include/midiemo.h (one weight gradient of a grouped launch)."""
+    _fields_ = [("A", _p), ("lda", _i), ("B", _p), ("ldb", _i), ("dW", _p), ("lddw", _i), ("dbias", _p), ("N", _i), ("K", _i)]
+
 
 _lib = None
 

@@ -468,19 +468,30 @@ class MusicTransformerHIP(nn.Module):
         # measured 1.5 % slower -- both experiments were removed with the library-owned workspace (round 2).
         tnws = self._tn_workspace(T)
 
-        def wgrad(role, dY, X, gW, gb, **kw):
-            ops.gemm_tn_acc(dY, X, gW, gb, ws=tnws, **kw)
+        # The four weight gradients of a layer are deferred to the end of the layer's backward and run as ONE grouped
+        # launch (me_gemm_tn_acc_group): the token split is #CUs / 48 tiles = 5 ranges instead of 16-64 per product, a
+        # quarter of the partial-tile traffic, two launches instead of eight.  (dY buffers dC / dhid / dC2 / dqkv and the
+        # saved activations they pair with stay valid until the next layer's backward starts.)
+        pending = []
+
+        def wgrad(role, dY, X, gW, gb, T, N, K, dtype):
+            pending.append((dY, X, gW, gb, N, K))
+
+        def flush_wgrads():
+            if pending:
+                ops.gemm_tn_acc_group(pending, T, dt, ws=tnws)
+                del pending[:]
 
         def reuse(role):
             pass
 
         def join():
-            pass
+            flush_wgrads()
 
         wgrad("dlogits", ws.dlogits, hN, gv(self._HEAD_W), gv(self._HEAD_B), T=T, N=V, K=d, dtype=dt)
+        flush_wgrads()
         ops.gemm_nt(ws.dlogits, head["WfT"], ws.dA, M=T, N=d, K=ldv, dtype=dt)
         if bucket_hook:
-            join()
             bucket_hook(N + 1)
         dy = ws.dA
         for i in reversed(range(N)):
@@ -514,8 +525,8 @@ class MusicTransformerHIP(nn.Module):
                   dtype=dt)
             ops.gemm_nt(ws.dqkv, W["WqkvT"], ws.dA, add=ws.dB, M=T, N=d, K=3 * d, dtype=dt)     # d(x) total
             dy = ws.dA
+            flush_wgrads()
             if bucket_hook:
-                join()
                 bucket_hook(i + 1)
         g = self._cond_params(gflat)
         ops.embed_bwd(dy, tokens, cond, gv("embedding.weight"), g[0], g[1], g[2], g[3], self._mode(), B, Ltok, d,
@@ -530,6 +541,8 @@ class MusicTransformerHIP(nn.Module):
         d, di, V = self.embedding_dim, self.d_inner, self.head_size
         shapes = [(3 * d, d), (d, d), (di, d), (d, di), (V, d)]
         need = max(ops.workspace_bytes(ops.ME_WS_GEMM_TN, T, n, k, self.compute_dtype) for n, k in shapes)
+        if all(k % 256 == 0 for _, k in shapes[:4]):      # the grouped launch of a layer's four products
+            need = max(need, ops.workspace_bytes(ops.ME_WS_GEMM_TN_GROUP, T, ops.tn_group_tiles(shapes[:4]), 0, self.compute_dtype))
         if need == 0:
             return None
         buf = getattr(self, "_tnws", None)

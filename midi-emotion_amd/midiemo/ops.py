@@ -7,7 +7,8 @@ import torch
 
 from . import _lib
 from ._lib import (ME_BF16, ME_COND_CONCAT, ME_COND_NONE, ME_COND_TOKEN, ME_EPI_OUT_F32, ME_EPI_RELU,
-                   ME_EPI_RELU_BWD, ME_F32, ME_WS_GEMM_TN, ME_WS_RGA_DGT, ME_WS_RGA_MT, ME_WS_RGA_PT, check)
+                   ME_EPI_RELU_BWD, ME_F32, ME_TN_MAX_GROUP, ME_WS_GEMM_TN, ME_WS_GEMM_TN_GROUP, ME_WS_RGA_DGT, ME_WS_RGA_MT,
+                   ME_WS_RGA_PT, check)
 
 DTYPE_CODE = {torch.float32: ME_F32, torch.bfloat16: ME_BF16}
 
@@ -111,6 +112,24 @@ def gemm_tn_acc(A, B, dW, dbias=None, T=None, N=None, K=None, dtype=None, ws=Non
     check(lib().me_gemm_tn_acc(_ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(dW), dW.stride(0), _ptr(dbias),
                                T, N, K, _ptr(ws), ws.numel() * ws.element_size() if ws is not None else 0,
                                _code(dtype), _stream()), "me_gemm_tn_acc")
+
+
+def gemm_tn_acc_group(items, T, dtype, ws=None):
+    """items: list of (dY [T, N], X [T, K], dW [N, K] f32, dbias [N] f32 or None, N, K) sharing the token dimension T --
+    one grouped launch (me_gemm_tn_acc_group); ws: uint8 workspace of workspace_bytes(ME_WS_GEMM_TN_GROUP, T, tiles, 0)."""
+    if not 0 < len(items) <= ME_TN_MAX_GROUP:
+        raise RuntimeError("gemm_tn_acc_group takes 1..%d products" % ME_TN_MAX_GROUP)
+    arr = (_lib.TnItem * len(items))()
+    for it, (A, B, dW, db, N, K) in zip(arr, items):
+        it.A, it.lda, it.B, it.ldb = _ptr(A), A.stride(0), _ptr(B), B.stride(0)
+        it.dW, it.lddw, it.dbias, it.N, it.K = _ptr(dW), dW.stride(0), _ptr(db), N, K
+    check(lib().me_gemm_tn_acc_group(arr, len(items), T, _ptr(ws), ws.numel() * ws.element_size() if ws is not None else 0,
+                                     _code(dtype), _stream()), "me_gemm_tn_acc_group")
+
+
+def tn_group_tiles(shapes):
+    """total 256 x 256 tiles of a list of (N, K) weight-gradient shapes (argument N of ME_WS_GEMM_TN_GROUP)."""
+    return sum(((n + 255) // 256) * (k // 256) for n, k in shapes)
 
 
 def rel_pack_numel(M, dh):

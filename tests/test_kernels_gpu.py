@@ -159,6 +159,42 @@ def test_gemm_tn_acc_caller_workspace(ops):
         ops.gemm_tn_acc(A, B, atom, None, T=T, N=N, K=K, ws=ws[:need // 2])
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T,shapes", [(8192, [(512, 2048), (2048, 512), (512, 512), (1536, 512)]),    # a layer's four weight gradients
+                                      (4100, [(256, 256), (1007, 512)]),                             # ragged token ranges, N % 256 != 0
+                                      (4096, [(96, 256), (512, 512)]),                               # one item not readable to 256 columns: separate launches
+                                      (300, [(128, 128), (64, 72)])])                                # small shapes: separate launches
+def test_gemm_tn_acc_group(ops, dtype, T, shapes):
+    """me_gemm_tn_acc_group: several dW += dY^T X products over one token dimension in one launch == the separate calls
+    (same values up to the summation order, which stays fixed: two runs are bit-identical)."""
+    ch = 4 if dtype == torch.float32 else 8
+    items, refs = [], []
+    for i, (N, K) in enumerate(shapes):
+        ldA = 1024 if N == 1007 else ((N + ch - 1) // ch) * ch
+        A = torch.zeros(T, ldA, dtype=dtype)
+        A[:, :N] = rnd(T, N, seed=40 + i).to(dtype)
+        X = rnd(T, K, seed=50 + i).to(dtype)
+        dW0, db0 = rnd(N, K, seed=60 + i).float(), rnd(N, seed=70 + i).float()
+        refs.append((dW0.double() + A[:, :N].double().t() @ X.double(), db0.double() + A[:, :N].double().sum(0)))
+        items.append([A.to(DEV), X.to(DEV), dW0, db0 if i != 1 else None, N, K])
+    need = max([ops.workspace_bytes(ops.ME_WS_GEMM_TN_GROUP, T, ops.tn_group_tiles([(n, k) for n, k in shapes if k % 256 == 0]), 0, dtype)] +
+               [ops.workspace_bytes(ops.ME_WS_GEMM_TN, T, n, k, dtype) for n, k in shapes])
+    ws = torch.empty(need, dtype=torch.uint8, device=DEV) if need else None
+    runs = []
+    for _ in range(2):
+        cur = [(A, X, dW0.clone().to(DEV), db0.clone().to(DEV) if db0 is not None else None, N, K) for A, X, dW0, db0, N, K in items]
+        ops.gemm_tn_acc_group(cur, T, dtype, ws=ws)
+        runs.append(cur)
+    for (A, X, dW, db, N, K), (rW, rb) in zip(runs[0], refs):
+        assert relerr(dW, rW) < 2e-5, (N, K, relerr(dW, rW))
+        if db is not None:
+            assert relerr(db, rb) < 2e-5, (N, K, relerr(db, rb))
+    grouped = dtype == torch.bfloat16 and T >= 2048 and all(k % 256 == 0 and (n % 256 == 0 or n == 1007) for n, k in shapes)
+    if ws is not None and grouped:                       # the grouped kernel: fixed summation order
+        for a, b in zip(runs[0], runs[1]):
+            assert torch.equal(a[2], b[2])
+
+
 def test_resid_ln_fwd_hi_lo_residual_stream(ops):
     """bf16 tier: the residual stream travels as hi + lo (me_resid_ln_fwd x_lo / y_lo).  y must be exactly
     bf16(LN(x_hi + x_lo + a)) computed in f32, and y + y_lo must carry ~16 mantissa bits of it."""
