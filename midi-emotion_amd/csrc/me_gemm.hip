@@ -731,6 +731,9 @@ struct tn_prod {
 };
 struct tn_group { tn_prod p[ME_TN_MAX_GROUP]; int np, ntile, nsplit, t_per_block, Tn, pad_; };
 
+// RAGGED = false: every slab of every range is whole (Tn % t_per_block == 0, t_per_block % 64 == 0): the operand feed has
+// no clamp, no zero-fill select and no per-piece address multiply (73 -> ~35 VALU instructions per slab and wave).
+template <bool RAGGED>
 __global__ __launch_bounds__(512) void gemm_tn256_kernel(const tn_group G, float* __restrict__ ws) {
     typedef bf16_t T;
     extern __shared__ __attribute__((aligned(16))) char smem[];          // [2 buffers][A slab | B slab]
@@ -770,18 +773,29 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const tn_group G, float
     const char* Bb = reinterpret_cast<const char*>(B) + (size_t)(k0 + pcol) * 2;
     chunk16 R[8];
     int d_slab = 0;                                                       // slab being fetched
+    // whole slabs: piece i of slab s sits at wave-uniform base (s, i) + one fixed lane offset
+    const uint32_t vA = (uint32_t)prow * lda2, vB = (uint32_t)prow * ldb2;
+    const char* sA = Ab + (size_t)(t_begin + wid * 8) * lda2;
+    const char* sB = Bb + (size_t)(t_begin + wid * 8) * ldb2;
     auto ld_piece = [&](int i) __attribute__((always_inline)) {
-        const int row = (wid * 4 + (i & 3)) * 2 + prow;
-        const uint32_t t = (uint32_t)min(t_begin + d_slab * TN256_BT + row, Tn - 1);
-        if (i < 4) R[i] = ld_chunk(Ab + t * lda2);
-        else R[i] = ld_chunk(Bb + t * ldb2);
+        if constexpr (RAGGED) {
+            const int row = (wid * 4 + (i & 3)) * 2 + prow;
+            const uint32_t t = (uint32_t)min(t_begin + d_slab * TN256_BT + row, Tn - 1);
+            if (i < 4) R[i] = ld_chunk(Ab + t * lda2);
+            else R[i] = ld_chunk(Bb + t * ldb2);
+        } else {
+            if (i < 4) R[i] = ld_chunk(sA + (size_t)(d_slab * TN256_BT + (i & 3) * 2) * lda2 + vA);
+            else R[i] = ld_chunk(sB + (size_t)(d_slab * TN256_BT + (i & 3) * 2) * ldb2 + vB);
+        }
     };
     char* const st_base = smem + ((wid * 8 + prow) * TN256_LD + pcol) * 2;
     auto st_piece = [&](int i, int slab) __attribute__((always_inline)) {
-        const int row = (wid * 4 + (i & 3)) * 2 + prow;
-        const bool valid = t_begin + slab * TN256_BT + row < t_end;       // false as well for the slab past the end
-        st_chunk(st_base + (slab & 1) * (2 * TN256_OP) + ((i >> 2) * TN256_OP + (i & 3) * 2 * TN256_LD * 2),
-                 valid ? R[i] : zero_chunk());
+        char* dst = st_base + (slab & 1) * (2 * TN256_OP) + ((i >> 2) * TN256_OP + (i & 3) * 2 * TN256_LD * 2);
+        if constexpr (RAGGED) {
+            const int row = (wid * 4 + (i & 3)) * 2 + prow;
+            const bool valid = t_begin + slab * TN256_BT + row < t_end;   // false as well for the slab past the end
+            st_chunk(dst, valid ? R[i] : zero_chunk());
+        } else st_chunk(dst, R[i]);                                       // the slab past the end goes to the free buffer, never read
     };
     auto ld_advance = [&]() __attribute__((always_inline)) { if (d_slab + 1 < nsteps) ++d_slab; };
 
@@ -790,8 +804,23 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const tn_group G, float
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc_zero(acc[i][j]);
-    float bsum = 0.f;
+    // bias gradient (column sums of dY) of the ky == 0 blocks: accumulated from the dY pieces while they pass through the
+    // registers (8 columns x the thread's token rows; VALU only -- the previous version re-read every column of the slab
+    // from LDS, 64 two-byte reads per thread and slab, in the pipe this kernel is bound by), combined through LDS at the end
+    float bs8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const bool do_bias = dbias != nullptr && ky == 0;
+    auto bias_acc = [&](int i, int slab) __attribute__((always_inline)) {
+        if constexpr (RAGGED) {
+            const int row = (wid * 4 + (i & 3)) * 2 + prow;
+            if (!(t_begin + slab * TN256_BT + row < t_end)) return;
+        }
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t u = R[i].v[w];
+            bs8[2 * w] += __builtin_bit_cast(float, u << 16);
+            bs8[2 * w + 1] += __builtin_bit_cast(float, u & 0xffff0000u);
+        }
+    };
 
     // transpose-read lane geometry (see frag_load_tr): lane l of a 16-lane group points at token row l / 4,
     // columns 4 (l % 4)..; the group receives 4 consecutive token rows of 16 columns
@@ -806,6 +835,10 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const tn_group G, float
     ld_advance();
 #pragma unroll
     for (int i = 0; i < 8; ++i) st_piece(i, 0);
+    if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias_acc(i, 0);
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) ld_piece(i);
     ld_advance();
@@ -814,11 +847,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const tn_group G, float
 
     for (int step = 0; step < nsteps; ++step) {
         const char* buf = smem + (step & 1) * (2 * TN256_OP);
-        if (do_bias && tid < 256) {
-            const T* col = reinterpret_cast<const T*>(buf) + tid;
-#pragma unroll 8
-            for (int t = 0; t < TN256_BT; ++t) bsum += (float)col[t * TN256_LD];
-        }
+        const bool bias_step = do_bias && step + 1 < nsteps;             // the slab past the end is a re-load of the last one
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             Frag<T> fa[4], fb[2];
@@ -834,6 +863,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const tn_group G, float
             }
             st_piece(2 * kk, step + 1);
             st_piece(2 * kk + 1, step + 1);
+            if (kk < 2 && bias_step) { bias_acc(2 * kk, step + 1); bias_acc(2 * kk + 1, step + 1); }
             ld_piece(2 * kk);
             ld_piece(2 * kk + 1);
 #pragma unroll
@@ -845,7 +875,19 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const tn_group G, float
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // my stores of slab step+1 are in LDS
         slot_barrier();                                                    // everybody's; slab `step` fully consumed
     }
-    if (do_bias && tid < 256 && n0 + tid < N) atomicAdd(&dbias[n0 + tid], bsum);
+    if (do_bias) {                                                         // block uniform; the slab buffers are free now
+        float* red = reinterpret_cast<float*>(smem);                       // [16 (wave, token-row parity)][256 columns]
+        float* mine = red + (wid * 2 + prow) * 256 + pcol;
+        *reinterpret_cast<f32x4_t*>(mine) = (f32x4_t){bs8[0], bs8[1], bs8[2], bs8[3]};
+        *reinterpret_cast<f32x4_t*>(mine + 4) = (f32x4_t){bs8[4], bs8[5], bs8[6], bs8[7]};
+        __syncthreads();
+        if (tid < 256 && n0 + tid < N) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += red[r * 256 + tid];
+            atomicAdd(&dbias[n0 + tid], t);
+        }
+    }
     if (ws) {
         // partial tile -> workspace in register order: slot (i, j, q) of thread tid is one 16-byte store, 1 KiB
         // contiguous per wave instruction; tn256_reduce_kernel adds the token ranges in a fixed order
@@ -1065,7 +1107,8 @@ static int tn256_group_launch(const tn_item_256* it, int n, int Tn, void* ws_cal
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
     if (dev < 0 || dev >= 16 || !attr_set[dev]) {                       // the attribute is per device
-        (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN256_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, TN256_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, TN256_LDS);
         if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
     tn_group G;
@@ -1089,7 +1132,8 @@ static int tn256_group_launch(const tn_item_256* it, int n, int Tn, void* ws_cal
         if (ws_bytes < need || !aligned16(ws_caller)) return ME_ERR_WORKSPACE;
         ws = reinterpret_cast<float*>(ws_caller);
     }
-    gemm_tn256_kernel<<<grid256, 512, TN256_LDS, st>>>(G, ws);
+    if (Tn % tp == 0) gemm_tn256_kernel<false><<<grid256, 512, TN256_LDS, st>>>(G, ws);
+    else gemm_tn256_kernel<true><<<grid256, 512, TN256_LDS, st>>>(G, ws);
     if (ws) tn256_reduce_kernel<<<dim3(ntile, 32), 512, 0, st>>>(ws, G);
     return me_launch_status();
 }
