@@ -147,14 +147,14 @@ int me_gemm_tn_acc(const void* A, int lda, const void* B, int ldb, float* dW, in
                    float* dbias, int T, int N, int K, void* ws, size_t ws_bytes, int dtype, void* stream);
 
 /* Several weight gradients over the SAME token dimension in one launch (the four nn.Linear weight gradients of an
- * EncoderLayer, music_multi.py:126-135,196-237: autograd of FFN_suf, FFN_pre, rga.fc and the fused Wq|Wk|Wv).  Same
+ * EncoderLayer -- for the last layer also the vocabulary head's --, music_multi.py:126-135,196-237: autograd of FFN_suf, FFN_pre, rga.fc and the fused Wq|Wk|Wv).  Same
  * results as n_items calls of me_gemm_tn_acc up to the summation order (still fixed, bit-reproducible); the token
  * dimension is split #CUs / (tiles of ALL items) ways instead of once per product, which at the headline shapes cuts the
  * partial-tile traffic to a quarter and replaces eight launches by two.  `items` is a HOST array (read during the call
  * only).  bf16, every N readable up to a multiple of 256 columns (lda), K % 256 == 0, T >= 2048 run the grouped kernel
  * (workspace: me_workspace_bytes(ME_WS_GEMM_TN_GROUP, T, total tiles, 0, dtype)); anything else is executed as
  * separate me_gemm_tn_acc calls with the same workspace. */
-#define ME_TN_MAX_GROUP 4
+#define ME_TN_MAX_GROUP 5
 typedef struct me_tn_item {
     const void* A; int lda;      /* dY [T, N] */
     const void* B; int ldb;      /* X  [T, K] */

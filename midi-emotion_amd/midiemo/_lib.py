@@ -13,7 +13,7 @@ ME_F32, ME_BF16 = 0, 1
 ME_COND_NONE, ME_COND_CONCAT, ME_COND_TOKEN = 0, 1, 2
 ME_EPI_RELU, ME_EPI_OUT_F32, ME_EPI_RELU_BWD = 1, 2, 4
 ME_WS_GEMM_TN, ME_WS_RGA_PT, ME_WS_RGA_DGT, ME_WS_RGA_MT, ME_WS_GEMM_TN_GROUP = 1, 2, 3, 4, 5
-ME_TN_MAX_GROUP = 4
+ME_TN_MAX_GROUP = 5
 ABI_VERSION = 16
 
 ERRORS = {0: "ME_OK", -1: "ME_ERR_BAD_DTYPE", -2: "ME_ERR_BAD_SHAPE", -3: "ME_ERR_ALIGNMENT",

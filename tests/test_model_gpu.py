@@ -28,6 +28,55 @@ def relerr(got, ref):
     return float((got - ref).norm() / n)
 
 
+# ---- bf16 tier: bounds DERIVED from the reference arithmetic itself (no hand-picked numbers).  The oracle is run under
+# torch.autocast(bfloat16) on the host next to its fp32 run on the SAME batch; what it loses there is what the reference
+# would lose under its own --amp path (train.py:281).  The HIP path must stay within K x that loss, K recorded here:
+#   logits  K = 1.25  (the HIP path keeps an ~f32 residual stream, rounds P to bf16 like autocast's matmul inputs)
+#   loss    K = 2     (+ 1e-4 absolute: both errors are tiny differences of O(7) numbers)
+#   grads   K = 1.5   (dS / dP are rounded to bf16 where autocast's backward keeps fp32 intermediates); measured ratios go
+#                      to gpurun_out/parity_report.txt
+K_LOGITS, K_LOSS, K_GRADS = 1.25, 2.0, 1.5
+
+
+def autocast_forward_err(cfg, P, tok, cond):
+    """rel-L2 of the oracle's bf16-autocast logits against its own fp32 logits on this batch."""
+    P32 = {k: v.float() for k, v in P.items()}
+    ref = O.forward(cfg, P32, tok, cond)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        ac = O.forward(cfg, P32, tok, cond)
+    ok = ~torch.isnan(ref)
+    return relerr(ac.float()[ok], ref[ok])
+
+
+def autocast_train_err(cfg, P, tok, cond, tgt, fn=None):
+    """(logits rel-L2, |loss difference|, {parameter: gradient rel-L2}) of the oracle under bf16 autocast vs its fp32 run."""
+    fn = fn or O.loss_and_grads
+    P32 = {k: v.float() for k, v in P.items()}
+    cond32 = cond.float() if torch.is_tensor(cond) and cond.is_floating_point() else cond
+    loss_ref, lg_ref, G = fn(cfg, P32, tok, cond32, tgt)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        loss_ac, lg_ac, G_ac = fn(cfg, P32, tok, cond32, tgt)
+    ge = {k: relerr(G_ac[k].float(), G[k]) for k in G}
+    le = relerr(lg_ac.float(), lg_ref) if lg_ref is not None else 0.0
+    return le, abs(float(loss_ac) - float(loss_ref)), ge
+
+
+def check_bf16_grads(model, G, ge_ac, what):
+    """every parameter gradient within K_GRADS x the oracle's own autocast error for that tensor (+ 1e-6 for tensors whose
+    gradient is rounding noise); returns the worst ratio for the report."""
+    bad, worst = {}, (0.0, None)
+    for k, p in model.named_parameters():
+        if k.endswith("Wk.bias") or float(torch.as_tensor(G[k]).double().norm()) < 1e-9:
+            continue
+        eg, ea = relerr(p.grad, G[k]), ge_ac[k]
+        if eg / max(ea, 1e-12) > worst[0]:
+            worst = (eg / max(ea, 1e-12), k)
+        if eg > K_GRADS * ea + 1e-6:
+            bad[k] = (eg, ea)
+    report("%s: worst gradient error / oracle autocast error = %.2f (%s)" % (what, worst[0], worst[1]))
+    assert not bad, bad
+
+
 def make_model(cfg, params, compute_dtype, dropout=0.0):
     from midiemo.models.build_model import build_model
     from midiemo.models.music_transformer import MusicTransformerContinuousToken, MusicTransformerMulti
@@ -82,15 +131,18 @@ def test_f1_logits_vs_golden(golden_dir, mode, cd):
     z = np.load(os.path.join(golden_dir, f"f1_{mode}.npz"))
     cfg = f1_cfg(mode, z)
     model = make_model(cfg, O.seeded_params(cfg, int(z["weight_seed"])), cd).eval()
-    errs = {}
+    errs, lims = {}, {}
+    P = O.seeded_params(cfg, int(z["weight_seed"]))
     for L in (1, 7, 33, 64):
         tok = torch.from_numpy(z[f"L{L}_tokens"]).to(DEV)
         cond = torch.from_numpy(z[f"L{L}_cond"]).to(DEV)
         with torch.no_grad():
             lg = model(tok, cond)
         errs[L] = relerr(lg, z[f"L{L}_logits"])
-    report("f1 %s logits rel-L2 vs reference, compute=%s: %s" % (mode, cd, {k: "%.2e" % v for k, v in errs.items()}))
-    assert all(e < (1e-4 if cd == "fp32" else 1.2e-2) for e in errs.values()), errs
+        lims[L] = 1e-4 if cd == "fp32" else K_LOGITS * autocast_forward_err(cfg, P, tok.cpu(), cond.cpu())
+    report("f1 %s logits rel-L2 vs reference, compute=%s: %s (bound %s)" %
+           (mode, cd, {k: "%.2e" % v for k, v in errs.items()}, {k: "%.2e" % v for k, v in lims.items()}))
+    assert all(errs[L] <= lims[L] for L in errs), (errs, lims)
     # PAD at position 0 -> the reference's NaN pattern
     with torch.no_grad():
         lg = model(torch.from_numpy(z["pad0_tokens"]).to(DEV), torch.from_numpy(z["pad0_cond"]).to(DEV))
@@ -161,21 +213,24 @@ def test_grads_vs_oracle_random_batch(mode, cd):
     tgt[-1, -10:] = 0
     loss_ref, lg_ref, G = O.loss_and_grads(cfg, {k: v.double() for k, v in P.items()}, tok, cond.double(), tgt)
     loss = model.loss_and_backward(tok.to(DEV), cond.to(DEV), tgt.to(DEV))
-    tl = 1e-5 if cd == "fp32" else 5e-3
-    assert abs(loss.item() - loss_ref.item()) < tl * 10, (loss.item(), loss_ref.item())
     model.link_grads()
-    bad = {}
-    for k, p in model.named_parameters():
-        if k.endswith("Wk.bias"):
-            assert float(p.grad.abs().max()) < (1e-6 if cd == "fp32" else 1e-3)
-            continue
-        e = relerr(p.grad, G[k])
-        # bf16: ReLU gates computed from bf16-rounded pre-activations flip for |x| ~ 1e-3, which
-        # dominates the FFN_pre gradient error (measured 4-6 %); everything else is < 4 %.
-        lim = 2e-4 if cd == "fp32" else (8e-2 if "FFN_pre" in k else 4e-2)
-        if e > lim:
-            bad[k] = e
-    assert not bad, bad
+    if cd == "fp32":
+        assert abs(loss.item() - loss_ref.item()) < 1e-4, (loss.item(), loss_ref.item())
+        bad = {}
+        for k, p in model.named_parameters():
+            if k.endswith("Wk.bias"):
+                assert float(p.grad.abs().max()) < 1e-6
+                continue
+            e = relerr(p.grad, G[k])
+            if e > 2e-4:
+                bad[k] = e
+        assert not bad, bad
+    else:
+        # bf16: e.g. ReLU gates computed from bf16-rounded pre-activations flip for |x| ~ 1e-3 -- in the oracle's autocast run
+        # just as here, which is why the bound is the oracle's own autocast error per tensor and not one number
+        _, dl_ac, ge_ac = autocast_train_err(cfg, P, tok, cond, tgt)
+        assert abs(loss.item() - loss_ref.item()) <= K_LOSS * dl_ac + 1e-4, (loss.item(), loss_ref.item(), dl_ac)
+        check_bf16_grads(model, G, ge_ac, "random batch %s bf16" % mode)
 
 
 def test_max_seq_discrete_token_config4_shape():
@@ -251,7 +306,7 @@ def test_forward_follows_torch_optimizer_updates():
     (cast / transposed / packed) weights must be refreshed anyway: logits after the step must match the oracle run
     with the stepped parameters, in both tiers."""
     cfg = O.Cfg(1007, 2, 2, 128, 256, d_condition=32, conditioning="continuous_concat")
-    for cd, tol in (("fp32", 1e-4), ("bf16", 1.2e-2)):
+    for cd, tol in (("fp32", 1e-4), ("bf16", None)):
         P = O.seeded_params(cfg, 11)
         model = make_model(cfg, P, cd).train()
         tok, cond, tgt = O.synthetic_batch(cfg, 2, 64, seed=4)
