@@ -26,8 +26,25 @@ DEV = "cuda"
 DTYPES = [torch.float32, torch.bfloat16]
 
 
-def tol(dtype, f32=2e-5, bf16=2e-2):
-    return f32 if dtype == torch.float32 else bf16
+def store_err(ref, dtype=torch.bfloat16):
+    """rel-L2 error of rounding the exact (f64) result to the storage type ONCE -- what a torch bf16 op with f32
+    accumulation commits on the same inputs, and the floor of any kernel that stores T."""
+    r = torch.as_tensor(ref).detach().double().cpu()
+    n = float(r.norm())
+    return float((r.to(dtype).double() - r).norm() / n) if n > 1e-12 else 0.0
+
+
+K_STORE = 2.0     # a bf16 result may sit one rounding away from the rounded exact value (f32 accumulation order, fused adds)
+
+
+def tol(dtype, f32, *stored):
+    """f32 tier: the given absolute bound.  bf16 tier: DERIVED, not picked -- K_STORE x the sum of the single-rounding errors
+    of every tensor the kernel keeps in bf16 between the f64-exact inputs and the checked output (`stored`: their exact
+    values; the inputs themselves are rounded before the reference is formed)."""
+    if dtype == torch.float32:
+        return f32
+    assert stored, "bf16 bound needs the exact value(s) of the stored tensor(s)"
+    return K_STORE * sum(store_err(t) for t in stored) + 1e-6
 
 
 def relerr(got, ref):
@@ -56,7 +73,7 @@ def test_gemm_nt_plain_and_bias(ops, dtype, M, N, K):
     Ad, Bd, bd = A.to(DEV), B.to(DEV), bias.to(DEV)
     C = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
     ops.gemm_nt(Ad, Bd, C, bias=bd)
-    assert relerr(C, ref) < tol(dtype, 1e-5, 6e-3), (relerr(C, ref))
+    assert relerr(C, ref) < tol(dtype, 1e-5, ref), (relerr(C, ref))
     C32 = torch.full((M, N + 3), float("nan"), dtype=torch.float32, device=DEV)
     ops.gemm_nt(Ad, Bd, C32, bias=bd, flags=ops.ME_EPI_OUT_F32)
     assert relerr(C32[:, :N], ref) < 1e-5 * (1 if dtype == torch.float32 else 1), relerr(C32[:, :N], ref)
@@ -104,11 +121,11 @@ def test_gemm_nt_epilogues(ops, dtype):
     Ad, Bd = A.to(DEV), B.to(DEV)
     C = torch.empty(M, N, dtype=dtype, device=DEV)
     ops.gemm_nt(Ad, Bd, C, bias=bias.to(DEV), flags=ops.ME_EPI_RELU)
-    assert relerr(C, torch.relu(base + bias.double())) < tol(dtype, 1e-5, 6e-3)
+    assert relerr(C, torch.relu(base + bias.double())) < tol(dtype, 1e-5, torch.relu(base + bias.double()))
     ops.gemm_nt(Ad, Bd, C, add=add.to(DEV))
-    assert relerr(C, base + add.double()) < tol(dtype, 1e-5, 6e-3)
+    assert relerr(C, base + add.double()) < tol(dtype, 1e-5, base + add.double())
     ops.gemm_nt(Ad, Bd, C, gate=gate.to(DEV), flags=ops.ME_EPI_RELU_BWD)
-    assert relerr(C, base * (gate.double() > 0)) < tol(dtype, 1e-5, 6e-3)
+    assert relerr(C, base * (gate.double() > 0)) < tol(dtype, 1e-5, base * (gate.double() > 0))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -132,7 +149,7 @@ def test_gemm_tn_acc(ops, dtype, T, N, K):
     need = ops.workspace_bytes(ops.ME_WS_GEMM_TN, T, N, K, dtype)
     ws = torch.empty(need, dtype=torch.uint8, device=DEV) if need else None
     ops.gemm_tn_acc(A.to(DEV), B.to(DEV), dW, db, T=T, N=N, K=K, ws=ws)
-    assert relerr(dW, ref) < tol(dtype, 2e-5, 2e-5), relerr(dW, ref)   # inputs already rounded -> f32 accumulate
+    assert relerr(dW, ref) < 2e-5, relerr(dW, ref)   # inputs already rounded, f32 accumulate and f32 output in both tiers
     assert relerr(db, refb) < 2e-5, relerr(db, refb)
 
 
@@ -250,12 +267,12 @@ def test_dec_ln_proj(ops, dtype, Mr):
     xo = torch.zeros(Mr, K, dtype=torch.float32, device=DEV)
     ops.dec_ln_proj(s_in.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-6, W.to(DEV), bias.to(DEV), xo, y, Mr, N, K,
                     ops.ME_EPI_OUT_F32, dtype)
-    assert relerr(y, ref) < tol(dtype, 1e-5, 2e-3), relerr(y, ref)     # bf16: an LN output on a rounding boundary may round the other way
+    assert relerr(y, ref) < tol(dtype, 1e-5, xr), relerr(y, ref)     # bf16: the LN rows are rounded to bf16 before the projection (f32 output)
     assert relerr(xo, x) < 1e-5
     yt = torch.zeros(Mr, N + 8, dtype=dtype, device=DEV)
     ops.dec_ln_proj(s_in.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-6, W.to(DEV), bias.to(DEV), None, yt, Mr, N, K,
                     ops.ME_EPI_RELU, dtype)
-    assert relerr(yt[:, :N], torch.relu(ref)) < tol(dtype, 1e-5, 6e-3)
+    assert relerr(yt[:, :N], torch.relu(ref)) < tol(dtype, 1e-5, torch.relu(ref), xr)
     assert (yt[:, N:] == 0).all()
 
 
@@ -292,9 +309,9 @@ def test_dec_qkv_ln_prologue_and_cache_append(ops, dtype):
         t_dev = torch.tensor([t], dtype=torch.int32, device=DEV) if use_dev else None
         ops.dec_qkv(s_in.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-6, None, None, W.to(DEV), bias.to(DEV), xo, q, kc, vc, Mr, d, H,
                     dh, Mc, 0 if use_dev else t, t_dev, dtype)
-        assert relerr(q, ref[:, :d]) < tol(dtype, 1e-5, 6e-3)
-        assert relerr(kc[:, :, t].reshape(Mr, d), ref[:, d:2 * d]) < tol(dtype, 1e-5, 6e-3)
-        assert relerr(vc[:, :, t].reshape(Mr, d), ref[:, 2 * d:]) < tol(dtype, 1e-5, 6e-3)
+        assert relerr(q, ref[:, :d]) < tol(dtype, 1e-5, ref[:, :d], xr)
+        assert relerr(kc[:, :, t].reshape(Mr, d), ref[:, d:2 * d]) < tol(dtype, 1e-5, ref[:, d:2 * d], xr)
+        assert relerr(vc[:, :, t].reshape(Mr, d), ref[:, 2 * d:]) < tol(dtype, 1e-5, ref[:, 2 * d:], xr)
         keep = torch.ones(Mc, dtype=torch.bool)
         keep[t] = False
         assert (kc[:, :, keep] == 7.0).all() and (vc[:, :, keep] == -7.0).all()
@@ -306,7 +323,7 @@ def test_dec_qkv_ln_prologue_and_cache_append(ops, dtype):
     ref2 = ((hi.double() + lo.double()).float().to(dtype).double() @ W.double().t() + bias.double())
     ops.dec_qkv(None, None, None, 1e-6, hi.to(DEV), lo.to(DEV) if dtype != torch.float32 else None, W.to(DEV), bias.to(DEV), xo, q,
                 kc, vc, Mr, d, H, dh, Mc, 3, None, dtype)
-    assert relerr(q, ref2[:, :d]) < tol(dtype, 1e-5, 6e-3)
+    assert relerr(q, ref2[:, :d]) < tol(dtype, 1e-5, ref2[:, :d])
     assert relerr(xo, hi.double() + (lo.double() if dtype != torch.float32 else 0)) < 1e-6
 
 
@@ -331,17 +348,17 @@ def test_resid_ln_fwd_bwd(ops, dtype, rows, d):
     s = torch.empty_like(y)
     stats = torch.empty(rows, 2, dtype=torch.float32, device=DEV)
     ops.resid_ln_fwd(x.to(DEV), a.to(DEV), gamma.to(DEV), beta.to(DEV), y, s, stats, rows, d, 1e-6, 0.0, 0, 1)
-    assert relerr(y, yref.detach()) < tol(dtype, 2e-6, 4e-3)
-    assert relerr(s, (x.double() + a.double())) < tol(dtype, 1e-7, 4e-3)
+    assert relerr(y, yref.detach()) < tol(dtype, 2e-6, yref)
+    assert relerr(s, (x.double() + a.double())) < tol(dtype, 1e-7, x.double() + a.double())
     dx = torch.empty_like(y)
     da = torch.empty_like(y)
     dg = torch.zeros(d, dtype=torch.float32, device=DEV)
     db = torch.zeros(d, dtype=torch.float32, device=DEV)
     ops.resid_ln_bwd(dy.to(DEV), s, stats, gamma.to(DEV), dx, da, dg, db, rows, d, 0.0, 0, 1)
-    assert relerr(dx, xs.grad) < tol(dtype, 1e-5, 1e-2)
+    assert relerr(dx, xs.grad) < tol(dtype, 1e-5, xs.grad, x.double() + a.double())      # bf16: dx stored, the saved sum s stored
     assert torch.equal(dx, da)
-    assert relerr(dg, g64.grad) < tol(dtype, 1e-5, 1e-2)
-    assert relerr(db, b64.grad) < tol(dtype, 1e-5, 1e-2)
+    assert relerr(dg, g64.grad) < tol(dtype, 1e-5, x.double() + a.double())
+    assert relerr(db, b64.grad) < tol(dtype, 1e-5, x.double() + a.double())
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -397,7 +414,7 @@ def test_ce_fwd_bwd(ops, dtype):
     assert relerr(row_lse, torch.logsumexp(lg.double(), -1)) < 1e-6
     dl = torch.full((rows, ld), float("nan"), dtype=dtype, device=DEV)
     ops.ce_bwd(lgd, tgt.to(DEV), row_lse, dl, acc[1:2], 1.0, rows, V, 0)
-    assert relerr(dl[:, :V], l64.grad) < tol(dtype, 1e-5, 4e-3)
+    assert relerr(dl[:, :V], l64.grad) < tol(dtype, 1e-5, l64.grad)
     assert (dl[:, V:] == 0).all()
 
 
@@ -475,22 +492,22 @@ def test_embed_fwd_bwd(ops, dtype, mode):
     out = torch.empty(B, Lm, d, dtype=dtype, device=DEV)
     ops.embed_fwd(out, tok.to(DEV), cond.to(DEV), f("embedding.weight"), cw0, cb0, cw1, cb1, pe, code, B, Ltok, d,
                   cfg.d_condition, 0.0, 0)
-    assert relerr(out, ref.detach()) < tol(dtype, 1e-6, 4e-3)
+    assert relerr(out, ref.detach()) < tol(dtype, 1e-6, ref)
     zl = lambda t: torch.zeros_like(t) if t is not None else None
     g_emb, g_cw0, g_cb0, g_cw1, g_cb1 = zl(f("embedding.weight")), zl(cw0), zl(cb0), zl(cw1), zl(cb1)
     ops.embed_bwd(dy.to(dtype).to(DEV), tok.to(DEV), cond.to(DEV), g_emb, g_cw0, g_cb0, g_cw1, g_cb1, code, B, Ltok, d,
                   cfg.d_condition, 0, 0.0, 0)
     gref = Pg["embedding.weight"].grad.clone()
     gref[0] = 0
-    assert relerr(g_emb, gref) < tol(dtype, 1e-5, 6e-3)
+    assert relerr(g_emb, gref) < tol(dtype, 1e-5, dy)          # f32 sums of the bf16-rounded dy rows
     assert (g_emb[0] == 0).all()
     if mode == "continuous_concat":
-        assert relerr(g_cw0, Pg["fc_condition.weight"].grad) < tol(dtype, 1e-5, 6e-3)
-        assert relerr(g_cb0, Pg["fc_condition.bias"].grad) < tol(dtype, 1e-5, 6e-3)
+        assert relerr(g_cw0, Pg["fc_condition.weight"].grad) < tol(dtype, 1e-5, dy)
+        assert relerr(g_cb0, Pg["fc_condition.bias"].grad) < tol(dtype, 1e-5, dy)
     if mode == "continuous_token":
         for i, (gw, gb) in enumerate(((g_cw0, g_cb0), (g_cw1, g_cb1))):
-            assert relerr(gw, Pg[f"fc_condition.{i}.weight"].grad) < tol(dtype, 1e-5, 6e-3)
-            assert relerr(gb, Pg[f"fc_condition.{i}.bias"].grad) < tol(dtype, 1e-5, 6e-3)
+            assert relerr(gw, Pg[f"fc_condition.{i}.weight"].grad) < tol(dtype, 1e-5, dy)
+            assert relerr(gb, Pg[f"fc_condition.{i}.bias"].grad) < tol(dtype, 1e-5, dy)
 
 
 def test_key_pad_mask(ops):
@@ -560,6 +577,41 @@ def ref_attn(q, k, v, E, dO, pad, dtype, causal=True):
     return {"O": o.detach(), "lse": lse.detach(), "dq": q.grad, "dk": k.grad, "dv": v.grad, "dE": E.grad}
 
 
+K_ATTN = 1.5      # the kernels round P and dS to bf16 once more than autocast's matmuls do on some paths (measured ratios < 1 mostly)
+
+
+def attn_bounds(dtype, f32, q, k, v, E, dO, pad, causal=True, backward=True):
+    """Per-output bound.  f32 tier: the given number.  bf16 tier: K_ATTN x what the ORACLE's own arithmetic loses on these
+    inputs under torch.autocast(bfloat16) (bf16 matmuls, f32 softmax -- the reference's --amp path, train.py:281) against
+    its f64 run, + 1e-4 -- derived per case instead of one hand-picked 1.5e-2."""
+    names = ("O", "lse", "dq", "dk", "dv", "dE") if backward else ("O", "lse")
+    if dtype == torch.float32:
+        return {n: f32 for n in names}
+    ref = ref_attn(q, k, v, E, dO, pad, dtype, causal) if backward else None
+    r = lambda t: t.to(dtype).float().requires_grad_(backward)
+    q32, k32, v32, E32 = r(q), r(k), r(v), r(E)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        o, lse = O.rga_attention_core(q32, k32, v32, E32, pad, causal)
+    if backward:
+        (o.float() * dO.to(dtype).float()).sum().backward()
+        ac = {"O": o.detach().float(), "lse": lse.detach().float(), "dq": q32.grad, "dk": k32.grad, "dv": v32.grad, "dE": E32.grad}
+    else:
+        rr = lambda t: t.to(dtype).double()
+        o64, lse64 = O.rga_attention_core(rr(q), rr(k), rr(v), rr(E), pad, causal)
+        ref = {"O": o64, "lse": lse64}
+        ac = {"O": o.detach().float(), "lse": lse.detach().float()}
+    out = {}
+    for n in names:
+        a_, r_ = ac[n].double(), ref[n].double()
+        ok = ~(torch.isnan(a_) | torch.isnan(r_))
+        out[n] = K_ATTN * relerr(a_[ok], r_[ok]) + 1e-4
+    return out
+
+
+def attn_ok(errs, lims):
+    return all(errs[n] <= lims[n] for n in errs)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_rga_golden_f5(ops, dtype, golden_dir):
     z = np.load(os.path.join(golden_dir, "f5_attn_core.npz"))
@@ -572,7 +624,8 @@ def test_rga_golden_f5(ops, dtype, golden_dir):
     else:
         ref = ref_attn(q, k, v, E, dO, pad, dtype)
         errs = {n: relerr(got[n], ref[n]) for n in ("O", "lse", "dq", "dk", "dv", "dE")}
-        assert all(e < 1.5e-2 for e in errs.values()), errs
+        lims = attn_bounds(dtype, 0, q, k, v, E, dO, pad)
+        assert attn_ok(errs, lims), (errs, lims)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -584,7 +637,8 @@ def test_rga_fwd_bwd_shapes(ops, dtype, B, H, L, dh, M):
     got = run_attn(ops, dtype, q, k, v, E, dO, pad)
     ref = ref_attn(q, k, v, E, dO, pad, dtype)
     errs = {n: relerr(got[n], ref[n]) for n in ("O", "lse", "dq", "dk", "dv", "dE")}
-    assert all(e < tol(dtype, 3e-5, 1.5e-2) for e in errs.values()), errs
+    lims = attn_bounds(dtype, 3e-5, q, k, v, E, dO, pad)
+    assert attn_ok(errs, lims), (errs, lims)
     # rows of E that can never be reached (relative distance >= L) get exactly zero gradient
     if M > L:
         assert (got["dE"][: M - L] == 0).all()
@@ -602,11 +656,14 @@ def test_rga_long_unpadded_and_mixed_rows(ops, dtype, L, M):
     got = run_attn(ops, dtype, q, k, v, E, dO, pad)
     ref = ref_attn(q, k, v, E, dO, pad, dtype)
     errs = {n: relerr(got[n], ref[n]) for n in ("O", "lse", "dq", "dk", "dv", "dE")}
-    assert all(e < tol(dtype, 3e-5, 1.5e-2) for e in errs.values()), errs
+    lims = attn_bounds(dtype, 3e-5, q, k, v, E, dO, pad)
+    assert attn_ok(errs, lims), (errs, lims)
     got0 = run_attn(ops, dtype, q, k, v, E, dO, None)                  # no pad mask at all
-    ref0 = ref_attn(q, k, v, E, dO, torch.zeros(2, L, dtype=torch.bool), dtype)
+    nopad = torch.zeros(2, L, dtype=torch.bool)
+    ref0 = ref_attn(q, k, v, E, dO, nopad, dtype)
     errs = {n: relerr(got0[n], ref0[n]) for n in ("O", "lse", "dq", "dk", "dv", "dE")}
-    assert all(e < tol(dtype, 3e-5, 1.5e-2) for e in errs.values()), errs
+    lims = attn_bounds(dtype, 3e-5, q, k, v, E, dO, nopad)
+    assert attn_ok(errs, lims), (errs, lims)
 
 
 def test_rga_fully_masked_row_is_nan(ops):
@@ -645,6 +702,7 @@ def test_dec_attn_matches_full(ops, dtype, dh, nsplit):
     B, H, L, M = 3, 2, 45, 2048
     q, k, v, E, dO, pad = attn_case(B, H, L, dh, M, seed=77, pad_rows=False)
     ref = ref_attn(q, k, v, E, dO, None, dtype)["O"]            # [B,H,L,dh]
+    lim_o = attn_bounds(dtype, 2e-5, q, k, v, E, dO, None, backward=False)["O"]
     Ed = E.to(dtype).to(DEV).contiguous()
     Mc = 64
     d = H * dh
@@ -666,7 +724,7 @@ def test_dec_attn_matches_full(ops, dtype, dh, nsplit):
             ops.dec_attn(qt, kc, vc, Ed, None, 0, part, nsplit, B, H, dh, M, Mc, 0, t_dev, dtype)
         ops.dec_proj_resid(part, nsplit, H, dh, None, eye, None, zero, out, B, d, d, dtype)
         e = relerr(out.view(B, H, dh), ref[:, :, t])
-        assert e < tol(dtype, 2e-5, 1.5e-2), (t, e)
+        assert e <= (lim_o if t >= 8 else 4 * lim_o), (t, e, lim_o)      # one row of very few keys: 4 x the whole-tensor figure
 
 
 def test_dec_attn_pad_keys_and_fully_masked_row(ops):
@@ -739,7 +797,8 @@ def test_rga_fwd_bidirectional(ops, dtype, B, H, L, dh, M):
         r = lambda t: t.to(dtype).double()
         o, lse = O.rga_attention_core(r(q), r(k), r(v), r(E), use_pad, causal=False)
         errs = {"O": relerr(got["O"], o), "lse": relerr(got["lse"], lse)}
-        assert all(e < tol(dtype, 3e-5, 1.5e-2) for e in errs.values()), (errs, use_pad is not None)
+        lims = attn_bounds(dtype, 3e-5, q, k, v, E, dO, use_pad, causal=False, backward=False)
+        assert attn_ok(errs, lims), (errs, lims, use_pad is not None)
     # and it really differs from the causal result once there is more than one key
     if L > 1:
         c = run_attn(ops, dtype, q, k, v, E, dO, None, backward=False, causal=True)
@@ -758,4 +817,5 @@ def test_rga_bwd_bidirectional(ops, dtype, B, H, L, dh, M):
         got = run_attn(ops, dtype, q, k, v, E, dO, use_pad, causal=False)
         ref = ref_attn(q, k, v, E, dO, use_pad, dtype, causal=False)
         errs = {n: relerr(got[n], ref[n]) for n in ("O", "lse", "dq", "dk", "dv", "dE")}
-        assert all(e < tol(dtype, 3e-5, 1.5e-2) for e in errs.values()), (errs, use_pad is not None)
+        lims = attn_bounds(dtype, 3e-5, q, k, v, E, dO, use_pad, causal=False)
+        assert attn_ok(errs, lims), (errs, lims, use_pad is not None)

@@ -33,9 +33,11 @@ def relerr(got, ref):
 # would lose under its own --amp path (train.py:281).  The HIP path must stay within K x that loss, K recorded here:
 #   logits  K = 1.25  (the HIP path keeps an ~f32 residual stream, rounds P to bf16 like autocast's matmul inputs)
 #   loss    K = 2     (+ 1e-4 absolute: both errors are tiny differences of O(7) numbers)
-#   grads   K = 1.5   (dS / dP are rounded to bf16 where autocast's backward keeps fp32 intermediates); measured ratios go
-#                      to gpurun_out/parity_report.txt
-K_LOGITS, K_LOSS, K_GRADS = 1.25, 2.0, 1.5
+#   grads   K = 1.5   (dS / dP are rounded to bf16 where autocast's backward keeps fp32 intermediates), floored at ONE bf16
+#                      rounding unit 2^-9: a tensor whose autocast error is below the resolution of the storage type (fc.bias: the
+#                      column sums of dlogits, which this path stores in bf16 and autocast keeps in fp32 -- 6.7e-4 vs 3.7e-4)
+#                      is not held to less than that resolution.  Measured ratios go to gpurun_out/parity_report.txt
+K_LOGITS, K_LOSS, K_GRADS, BF16_ULP = 1.25, 2.0, 1.5, 2.0 ** -9
 
 
 def autocast_forward_err(cfg, P, tok, cond):
@@ -71,7 +73,7 @@ def check_bf16_grads(model, G, ge_ac, what):
         eg, ea = relerr(p.grad, G[k]), ge_ac[k]
         if eg / max(ea, 1e-12) > worst[0]:
             worst = (eg / max(ea, 1e-12), k)
-        if eg > K_GRADS * ea + 1e-6:
+        if eg > max(K_GRADS * ea, BF16_ULP):
             bad[k] = (eg, ea)
     report("%s: worst gradient error / oracle autocast error = %.2f (%s)" % (what, worst[0], worst[1]))
     assert not bad, bad
@@ -321,13 +323,16 @@ def test_forward_follows_torch_optimizer_updates():
         lg_ref = O.forward(cfg, P1, tok, cond)
         moved = relerr(lg1, lg0.detach())
         assert moved > 1e-2, moved                                  # lr 1e-2: the logits must move visibly
-        assert relerr(lg1, lg_ref) < tol, (cd, relerr(lg1, lg_ref))
+        if tol is None:
+            tol = K_LOGITS * autocast_forward_err(cfg, P1, tok, cond)
+        assert relerr(lg1, lg_ref) <= tol, (cd, relerr(lg1, lg_ref), tol)
         with torch.no_grad():                                      # p.copy_() / manual re-init through a parameter
             model.fc.weight.mul_(0.5)
             lg2 = model(tok.to(DEV), cond.to(DEV))
         P2 = dict(P1)
         P2["fc.weight"] = P1["fc.weight"] * 0.5
-        assert relerr(lg2, O.forward(cfg, P2, tok, cond)) < tol
+        tol2 = tol if cd == "fp32" else K_LOGITS * autocast_forward_err(cfg, P2, tok, cond)
+        assert relerr(lg2, O.forward(cfg, P2, tok, cond)) <= tol2
 
 
 def test_backward_survives_eval_forward_and_other_shapes():
@@ -368,18 +373,26 @@ def test_head_dim_48_like_published_checkpoints(cd):
     loss_ref, lg_ref, G = O.loss_and_grads(cfg, {k: v.double() for k, v in P.items()}, tok, cond.double(), tgt)
     loss = model.loss_and_backward(tok.to(DEV), cond.to(DEV), tgt.to(DEV))
     model.link_grads()
-    assert abs(loss.item() - loss_ref.item()) < (1e-4 if cd == "fp32" else 5e-2)
     worst = max(relerr(p.grad, G[k]) for k, p in model.named_parameters() if not k.endswith("Wk.bias"))
-    assert worst < (2e-4 if cd == "fp32" else 8e-2), worst
+    if cd == "fp32":
+        lim_lg, lim_step = 1e-4, 1e-4
+        assert abs(loss.item() - loss_ref.item()) < 1e-4
+        assert worst < 2e-4, worst
+    else:
+        le_ac, dl_ac, ge_ac = autocast_train_err(cfg, P, tok, cond, tgt)
+        assert abs(loss.item() - loss_ref.item()) <= K_LOSS * dl_ac + 1e-4, (loss.item(), loss_ref.item(), dl_ac)
+        check_bf16_grads(model, G, ge_ac, "head dim 48 bf16")
+        lim_lg = K_LOGITS * le_ac
+        lim_step = K_LOGITS * autocast_forward_err(cfg, P, tok[:, :12], cond)     # the decode step sees the 12-token prefix
     model.eval()
     with torch.no_grad():
         lg = model(tok.to(DEV), cond.to(DEV))
-        assert relerr(lg, lg_ref) < (1e-4 if cd == "fp32" else 1e-2)
+        assert relerr(lg, lg_ref) <= lim_lg, (relerr(lg, lg_ref), lim_lg)
         from midiemo.decode import DecodeSession
         sess = DecodeSession(model, 2)
         for t in range(12):
             step_lg = sess.step(tok[:, t].to(DEV), cond.to(DEV))
-        assert relerr(step_lg, lg_ref[:, 11]) < (1e-4 if cd == "fp32" else 1e-2)
+        assert relerr(step_lg, lg_ref[:, 11]) <= lim_step * (1.0 if cd == "fp32" else 2.0), (relerr(step_lg, lg_ref[:, 11]), lim_step)
     report("head dim 48 (%s): logits rel %.2e, worst grad rel %.2e" % (cd, relerr(lg, lg_ref), worst))
 
 
@@ -480,16 +493,25 @@ def test_f3_headline_model_logits(golden_dir, cd):
         report("cfg2 bf16 logits vs the reference's bf16-autocast logits: %.3e" % e_ac)
         assert e_ac < 1.5 * ref_bf16, e_ac
     loss = model.loss_and_backward(inp.to(DEV), cond.to(DEV), tgt.to(DEV))
-    assert abs(loss.item() - float(z["loss"])) < (5e-5 if cd == "fp32" else 5e-3)
+    # bf16 loss bound: a logit perturbation of relative size e moves the cross entropy by at most ~e * |logits| (rows of
+    # O(1) logits): K_LOSS x the stored autocast logit error, against the hand-picked 5e-3 of round 2
+    assert abs(loss.item() - float(z["loss"])) < (5e-5 if cd == "fp32" else K_LOSS * ref_bf16), (loss.item(), float(z["loss"]))
     model.link_grads()
+    ge_ac = None
+    if cd == "bf16":
+        # per-tensor bound for the gradient NORMS the fixture stores: | ||g|| - ||g_ref|| | <= ||g - g_ref|| <= K_GRADS x the
+        # oracle's own bf16-autocast error for that tensor on this batch (host run of the oracle, fp32 and autocast)
+        torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+        _, _, ge_ac = autocast_train_err(cfg, O.seeded_params(cfg, int(z["weight_seed"])), inp, cond, tgt)
     bad = {}
     for k, p in model.named_parameters():
         if k.endswith("Wk.bias"):
             continue
         gn = float(p.grad.double().norm())
         ref = float(z[f"gradnorm/{k}"])
-        if abs(gn - ref) > (1e-3 if cd == "fp32" else 5e-2) * ref + 1e-9:
-            bad[k] = (gn, ref)
+        lim = 1e-3 if cd == "fp32" else max(K_GRADS * ge_ac[k], BF16_ULP)
+        if abs(gn - ref) > lim * ref + 1e-9:
+            bad[k] = (gn, ref, lim)
     assert not bad, bad
 
 
@@ -613,12 +635,22 @@ def test_regression_l1_loss_and_grads_vs_oracle(golden_dir, cd):
     model.flat_grads.zero_()
     loss = model.loss_and_backward(tok.to(DEV), tgt.to(DEV))
     model.link_grads()
-    assert abs(float(loss) - float(loss_ref)) < (1e-5 if cd == "fp32" else 2e-2)
     errs = {k: relerr(p.grad, G[k]) for k, p in model.named_parameters() if float(G[k].norm()) > 1e-9}
     worst = max(errs.values())
     report("regression grads[%s]: loss %.6f (oracle %.6f), worst grad rel %.2e (%s)" %
            (cd, float(loss), float(loss_ref), worst, max(errs, key=errs.get)))
-    assert worst < (3e-4 if cd == "fp32" else 8e-2), errs
+    if cd == "fp32":
+        assert abs(float(loss) - float(loss_ref)) < 1e-5
+        assert worst < 3e-4, errs
+    else:                                                  # bounds: the oracle's own bf16-autocast error on this batch
+        P32 = {k: v.float() for k, v in P.items()}
+        l32, _, G32 = O.regression_loss_and_grads(cfg, P32, tok, tgt)
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            lac, _, Gac = O.regression_loss_and_grads(cfg, P32, tok, tgt)
+        assert abs(float(loss) - float(loss_ref)) <= K_LOSS * abs(float(lac) - float(l32)) + 1e-4
+        bad = {k: (e, relerr(Gac[k].float(), G32[k])) for k, e in errs.items()
+               if not k.endswith("Wk.bias") and e > max(K_GRADS * relerr(Gac[k].float(), G32[k]), BF16_ULP)}
+        assert not bad, bad
     # the key / value biases get exactly-cancelling or tiny gradients like in the language model; everything else learns
     opt = FusedAdamW(model, lr=2e-5)                       # the first Adam step moves every weight by lr
     opt.step()
