@@ -234,11 +234,14 @@ int me_resid_ln_bwd(const void* dy, const void* s, const float* stats, const flo
  *             *n_valid  += count(target != ignore)          (both f32 device scalars)
  * me_ce_bwd:  dlogits (T [rows, ld_d]) = (exp(logit - row_lse) - onehot) * (target != ignore)
  *             * extra_scale / *n_valid ; columns V..ld_d-1 are written as 0.
+ *             dbias (f32 [V] or NULL): dbias[j] += sum over rows of the f32 dlogits[:, j] BEFORE the rounding to T -- the
+ *             vocabulary head's bias gradient (music_multi.py:71,106), which would otherwise be summed from the bf16
+ *             dlogits by me_gemm_tn_acc (bf16 logits and dlogits, ld_d <= 2048 only; anything else: ME_ERR_BAD_SHAPE).
  * Replaces CrossEntropyLoss(ignore_index=pad) + its autograd (train.py:124,288-290). */
 int me_ce_fwd(const void* logits, int ld, const int64_t* target, float* row_lse,
               float* loss_sum, float* n_valid, int rows, int V, int ignore_index, int logits_dtype, void* stream);
 int me_ce_bwd(const void* logits, int ld, const int64_t* target, const float* row_lse,
-              void* dlogits, int ld_d, const float* n_valid, float extra_scale,
+              void* dlogits, int ld_d, const float* n_valid, float extra_scale, float* dbias,
               int rows, int V, int ignore_index, int logits_dtype, int dtype, void* stream);
 
 /* ---- optimiser: global-norm clip + Adam(W) -----------------------------------

@@ -296,8 +296,8 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(const DecArgs a) {
     } else {    // PRO_ATTN: softmax-combine the key-split partials of every (row, head)
         const int dh = a.dh, ns = a.nsplit, rec = dh + 2, nmh = Mr * a.H;
         float* wn = xs + MR * K;                                        // [nmh][DEC_NSMAX] normalised split weights
-        if (tid < nmh) {
-            const float* p = a.part + (size_t)tid * ns * rec;
+        for (int mh = tid; mh < nmh; mh += 256) {                       // Mr * H may exceed the block (8 rows x > 32 heads)
+            const float* p = a.part + (size_t)mh * ns * rec;
             float ms[DEC_NSMAX], ls[DEC_NSMAX];
 #pragma unroll
             for (int s_ = 0; s_ < DEC_NSMAX; ++s_) {
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(const DecArgs a) {
             }
             const float inv = 1.f / l;                                  // every key masked: 0 * inf = NaN like the reference's softmax
 #pragma unroll
-            for (int s_ = 0; s_ < DEC_NSMAX; ++s_) wn[tid * DEC_NSMAX + s_] = w[s_] * inv;
+            for (int s_ = 0; s_ < DEC_NSMAX; ++s_) wn[mh * DEC_NSMAX + s_] = w[s_] * inv;
         }
         __syncthreads();
         // 4 consecutive head-dim elements per thread and pass, two passes in flight: 2 x DEC_NSMAX independent 16-byte loads
@@ -561,8 +561,13 @@ template <typename T, int PRO, int EPI, int MR, int CW, bool KS>
 int gemv_launch3(const DecArgs& a, size_t lds, hipStream_t st) {
     const unsigned grid = (unsigned)(KS ? (a.N + CW - 1) / CW : (a.N + 4 * CW - 1) / (4 * CW));
     if (lds > 48 * 1024) {                                  // FFN_suf rows of the published 145 M model (8 x 3072 f32)
-        static bool done = false;                           // idempotent attribute: a benign race at worst
-        if (!done) { (void)hipFuncSetAttribute((const void*)dec_gemv_kernel<T, PRO, EPI, MR, CW, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); done = true; }
+        static bool done[16] = {false};                     // the attribute is per device; idempotent: a benign race at worst
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+        if (dev < 0 || dev >= 16 || !done[dev]) {
+            (void)hipFuncSetAttribute((const void*)dec_gemv_kernel<T, PRO, EPI, MR, CW, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            if (dev >= 0 && dev < 16) done[dev] = true;
+        }
     }
     dec_gemv_kernel<T, PRO, EPI, MR, CW, KS><<<grid, 256, lds, st>>>(a);
     return me_launch_status();

@@ -597,13 +597,23 @@ __global__ __launch_bounds__(CE_NW * 64) void ce_fwd_kernel(const LT* __restrict
     }
 }
 
+// dbias (optional): the head's bias gradient = column sums of the f32 dlogits BEFORE they are rounded to T -- summing
+// the bf16-rounded dlogits in the weight-gradient GEMM gave that tensor a 2e-3 relative error against 4e-4 for the
+// reference's own autocast; here every lane keeps f32 partial sums of its columns over the rows of its wave (16-byte
+// path: <= 4 chunks of 8 columns per lane), waves are combined through LDS and a block issues one atomic per column.
 template <typename T, typename LT>
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const LT* __restrict__ logits, int ld,
                                                      const int64_t* __restrict__ target, const float* __restrict__ row_lse,
                                                      T* __restrict__ dlogits, int ld_d, const float* __restrict__ n_valid,
-                                                     float extra_scale, int rows, int V, int ignore_index) {
+                                                     float extra_scale, int rows, int V, int ignore_index, float* __restrict__ dbias) {
+    __shared__ float red[4][64 * 33];                      // dbias: [wave][lane][32 partial sums], +1 padding
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const float scale = extra_scale / fmaxf(*n_valid, 0.f);   // n_valid == 0 -> inf/nan like torch's 0/0 mean
+    float bs[4][8];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bs[c][e] = 0.f;
     for (int64_t row = (int64_t)blockIdx.x * 4 + wid; row < rows; row += (int64_t)gridDim.x * 4) {
         const LT* lg = logits + row * ld;
         const int64_t t = target[row];
@@ -613,14 +623,31 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const LT* __restrict__ logi
             // both 16-bit: 8 columns per lane and 16-byte access (2-byte accesses made this kernel issue bound: 37 us
             // for 133 MB); columns in [V, ld) of the logits are never used, columns in [V, ld_d) are written as 0
             if ((ld & 7) == 0 && (ld_d & 7) == 0 && ld >= ld_d && ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits)) & 15) == 0) {
-                for (int j = lane * 8; j < ld_d; j += 512) {
-                    const chunk16 c = ld_chunk(lg + j);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int j = lane * 8 + 512 * c;
+                    if (j >= ld_d) break;
+                    const chunk16 ch = ld_chunk(lg + j);
                     chunk16 o;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         float g = 0.f;
                         if (valid && j + e < V)
-                            g = (__builtin_amdgcn_exp2f(((float)reinterpret_cast<const bf16_t*>(&c)[e] - lse) * 1.4426950408889634f) -
+                            g = (__builtin_amdgcn_exp2f(((float)reinterpret_cast<const bf16_t*>(&ch)[e] - lse) * 1.4426950408889634f) -
+                                 (j + e == t ? 1.f : 0.f)) * scale;
+                        bs[c][e] += g;
+                        reinterpret_cast<bf16_t*>(&o)[e] = ET<T>::from_f(g);
+                    }
+                    st_chunk(dlogits + row * ld_d + j, o);
+                }
+                for (int j = lane * 8 + 2048; j < ld_d; j += 512) {              // wider rows: no dbias support (launcher checks)
+                    const chunk16 ch = ld_chunk(lg + j);
+                    chunk16 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float g = 0.f;
+                        if (valid && j + e < V)
+                            g = (__builtin_amdgcn_exp2f(((float)reinterpret_cast<const bf16_t*>(&ch)[e] - lse) * 1.4426950408889634f) -
                                  (j + e == t ? 1.f : 0.f)) * scale;
                         reinterpret_cast<bf16_t*>(&o)[e] = ET<T>::from_f(g);
                     }
@@ -634,6 +661,17 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const LT* __restrict__ logi
             if (valid && j < V) g = (expf((float)lg[j] - lse) - (j == t ? 1.f : 0.f)) * scale;
             dlogits[row * ld_d + j] = ET<T>::from_f(g);
         }
+    }
+    if (dbias == nullptr) return;                          // block uniform
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[wid][lane * 33 + c * 8 + e] = bs[c][e];
+    __syncthreads();
+    for (int col = threadIdx.x; col < V; col += 256) {     // column = 512 c + 8 lane' + e
+        const int c = col >> 9, l2 = (col & 511) >> 3, e = col & 7;
+        const int idx = l2 * 33 + c * 8 + e;
+        atomicAdd(&dbias[col], red[0][idx] + red[1][idx] + red[2][idx] + red[3][idx]);
     }
 }
 
@@ -1114,20 +1152,27 @@ int me_ce_fwd(const void* logits, int ld, const int64_t* target, float* row_lse,
 }
 
 int me_ce_bwd(const void* logits, int ld, const int64_t* target, const float* row_lse, void* dlogits, int ld_d,
-              const float* n_valid, float extra_scale, int rows, int V, int ignore_index, int logits_dtype, int dtype,
-              void* stream) {
+              const float* n_valid, float extra_scale, float* dbias, int rows, int V, int ignore_index, int logits_dtype,
+              int dtype, void* stream) {
     me_clear_error();
     if (!logits || !target || !row_lse || !dlogits || !n_valid) return ME_ERR_NULL;
     if (logits_dtype != ME_F32 && logits_dtype != ME_BF16) return ME_ERR_BAD_DTYPE;
     if (rows <= 0) return ME_OK;
     if (V <= 0 || ld < V || ld_d < V) return ME_ERR_BAD_SHAPE;
+    if (dbias) {
+        // fused bias gradient: 16-bit logits and dlogits, 16-byte rows, at most 2048 columns (four chunks per lane)
+        const bool ok = logits_dtype == ME_BF16 && dtype == ME_BF16 && (ld & 7) == 0 && (ld_d & 7) == 0 && ld >= ld_d && ld_d <= 2048 &&
+                        ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits)) & 15) == 0;
+        if (!ok) return ME_ERR_BAD_SHAPE;
+    }
     hipStream_t st = (hipStream_t)stream;
+    const int cap = dbias ? 256 : 8192;                     // one atomic per column and block
     if (logits_dtype == ME_F32) {
-        ME_DISPATCH(dtype, (ce_bwd_kernel<T, float><<<row_grid(rows, 8192), 256, 0, st>>>((const float*)logits, ld, target, row_lse,
-                                                                                        (T*)dlogits, ld_d, n_valid, extra_scale, rows, V, ignore_index)));
+        ME_DISPATCH(dtype, (ce_bwd_kernel<T, float><<<row_grid(rows, cap), 256, 0, st>>>((const float*)logits, ld, target, row_lse,
+                                                                                       (T*)dlogits, ld_d, n_valid, extra_scale, rows, V, ignore_index, dbias)));
     } else {
-        ME_DISPATCH(dtype, (ce_bwd_kernel<T, bf16_t><<<row_grid(rows, 8192), 256, 0, st>>>((const bf16_t*)logits, ld, target, row_lse,
-                                                                                         (T*)dlogits, ld_d, n_valid, extra_scale, rows, V, ignore_index)));
+        ME_DISPATCH(dtype, (ce_bwd_kernel<T, bf16_t><<<row_grid(rows, cap), 256, 0, st>>>((const bf16_t*)logits, ld, target, row_lse,
+                                                                                        (T*)dlogits, ld_d, n_valid, extra_scale, rows, V, ignore_index, dbias)));
     }
     return me_launch_status();
 }

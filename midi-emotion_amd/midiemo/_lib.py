@@ -40,7 +40,7 @@ SIGNATURES = {
     "me_resid_ln_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _f, _u64, _u32, _i, _p],
     "me_resid_ln_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _u64, _u32, _i, _p],
     "me_ce_fwd": [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p],
-    "me_ce_bwd": [_p, _i, _p, _p, _p, _i, _p, _f, _i, _i, _i, _i, _i, _p],
+    "me_ce_bwd": [_p, _i, _p, _p, _p, _i, _p, _f, _p, _i, _i, _i, _i, _i, _p],
     "me_sumsq": [_p, _i64, _p, _p],
     "me_adamw_step": [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _p],
     "me_dec_qkv": [_p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p],

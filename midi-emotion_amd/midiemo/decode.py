@@ -52,6 +52,10 @@ class DecodeSession:
         self.s1, self.s2 = e(B, d, dtype=f32), e(B, d, dtype=f32)           # f32 pre-norm sums
         # key splits of the attention: B*H*nsplit blocks should cover the chip (256 CUs)
         self.nsplit = int(os.environ.get("MIDIEMO_DEC_NSPLIT", "0")) or max(1, min(8, 256 // max(1, min(B, ROWS) * H)))
+        # me_dec_attn keeps one split's scores in LDS: at most 2048 keys per split
+        self.nsplit = min(8, max(self.nsplit, -(-m.max_seq // 2048)))
+        if -(-m.max_seq // self.nsplit) > 2048:
+            raise RuntimeError("max_seq %d exceeds the cached decode's %d keys (8 splits of 2048)" % (m.max_seq, 8 * 2048))
         self.part = e(B * H, self.nsplit, dh + 2, dtype=f32)
         self.logits = e(B, V, dtype=f32)
         self.t = 0                      # next model position to be written

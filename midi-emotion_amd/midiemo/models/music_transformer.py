@@ -452,7 +452,7 @@ class MusicTransformerHIP(nn.Module):
         return ws
 
     # ------------------------------------------------------------------ engine: backward
-    def _backward_impl(self, ws, tokens, cond, B, Ltok, Lm, p_drop, seed, gflat, bucket_hook=None):
+    def _backward_impl(self, ws, tokens, cond, B, Ltok, Lm, p_drop, seed, gflat, bucket_hook=None, head_bias_done=False):
         """dlogits in ws.dlogits (T, padded ld) -> accumulates every parameter gradient into gflat."""
         dt = self.compute_dtype
         d, di, H, dh, V, N, M = (self.embedding_dim, self.d_inner, self.num_head, self.dh, self.head_size,
@@ -490,7 +490,7 @@ class MusicTransformerHIP(nn.Module):
 
         # (the head's product stays a launch of its own: grouped with the last layer it makes 56 tiles = 4 token ranges on
         # 224 of the 256 CUs -- measured no faster than 48 tiles x 5 ranges on 240 CUs plus the small head launch)
-        wgrad("dlogits", ws.dlogits, hN, gv(self._HEAD_W), gv(self._HEAD_B), T=T, N=V, K=d, dtype=dt)
+        wgrad("dlogits", ws.dlogits, hN, gv(self._HEAD_W), None if head_bias_done else gv(self._HEAD_B), T=T, N=V, K=d, dtype=dt)
         flush_wgrads()
         ops.gemm_nt(ws.dlogits, head["WfT"], ws.dA, M=T, N=d, K=ldv, dtype=dt)
         if bucket_hook:
@@ -592,8 +592,10 @@ class MusicTransformerHIP(nn.Module):
         ops.ce_fwd(ws.logits, target, ws.row_lse, ws.acc[0:1], ws.acc[1:2], T, V, self.pad_token)
         loss = ws.acc[0] / ws.acc[1]
         if backward:
-            ops.ce_bwd(ws.logits, target, ws.row_lse, ws.dlogits, ws.acc[1:2], grad_scale, T, V, self.pad_token)
-            self._backward_impl(ws, tokens, cond, B, Ltok, Lm, p_drop, seed, self._gflat, bucket_hook)
+            fuse_db = ops.ce_bwd_fuses_dbias(ws.logits, ws.dlogits)     # bf16 tier: head bias gradient from the f32 dlogits
+            ops.ce_bwd(ws.logits, target, ws.row_lse, ws.dlogits, ws.acc[1:2], grad_scale, T, V, self.pad_token,
+                       dbias=self._pview(self._gflat, self._HEAD_B) if fuse_db else None)
+            self._backward_impl(ws, tokens, cond, B, Ltok, Lm, p_drop, seed, self._gflat, bucket_hook, head_bias_done=fuse_db)
         if return_logits:                                   # f32 [B, Lm, V] copy of the workspace logits
             return loss, ws.logits[:, :V].float().view(B, Lm, V)
         return loss

@@ -197,9 +197,15 @@ def ce_fwd(logits, target, row_lse, loss_sum, n_valid, rows, V, ignore_index):
                           rows, V, ignore_index, _code(logits.dtype), _stream()), "me_ce_fwd")
 
 
-def ce_bwd(logits, target, row_lse, dlogits, n_valid, extra_scale, rows, V, ignore_index):
+def ce_bwd_fuses_dbias(logits, dlogits):
+    """can me_ce_bwd produce the head's bias gradient itself (f32 column sums before the bf16 rounding)?"""
+    return (logits.dtype == torch.bfloat16 and dlogits.dtype == torch.bfloat16 and logits.stride(0) % 8 == 0 and
+            dlogits.stride(0) % 8 == 0 and logits.stride(0) >= dlogits.stride(0) and dlogits.stride(0) <= 2048)
+
+
+def ce_bwd(logits, target, row_lse, dlogits, n_valid, extra_scale, rows, V, ignore_index, dbias=None):
     check(lib().me_ce_bwd(_ptr(logits), logits.stride(0), _ptr(target), _ptr(row_lse), _ptr(dlogits),
-                          dlogits.stride(0), _ptr(n_valid), float(extra_scale), rows, V, ignore_index,
+                          dlogits.stride(0), _ptr(n_valid), float(extra_scale), _ptr(dbias), rows, V, ignore_index,
                           _code(logits.dtype), _code(dlogits.dtype), _stream()), "me_ce_bwd")
 
 

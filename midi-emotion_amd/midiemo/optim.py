@@ -53,8 +53,13 @@ class FusedAdamW:
     def load_state_dict(self, sd):
         """Own format ({"m", "v", "step", "lr"}) or a torch.optim.Adam state_dict as the reference writes it
         (train.py:403: {"state": {i: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [...]}): the per-parameter
-        moments are copied into the flat buffers in the optimiser's parameter order (= model.parameters())."""
+        moments are copied into the flat buffers by NAME, position i of the torch state being the i-th key of the
+        checkpoint ABI (= the reference model's parameters() order = this model's state_dict order)."""
         if "state" in sd and "param_groups" in sd:
+            order = [n for n, _ in self.model.named_parameters()]
+            if order != [k for k in self.model.state_dict().keys() if k in set(order)]:
+                raise ValueError("model parameters() order differs from its state_dict order: a positional torch.optim "
+                                 "state cannot be mapped to names")
             params = list(self.model.parameters())
             idx = [i for g in sd["param_groups"] for i in g["params"]]
             if len(idx) != len(params):

@@ -16,6 +16,17 @@ import torch.distributed as dist  # noqa: E402
 CFG = dict(vocab_size=1007, n_layer=2, n_head=2, d_model=128, d_inner=256, dropout=0.0, d_condition=32,
            conditioning="continuous_concat")
 B, L, STEPS = 2, 96, 3
+# --big: the headline model (BASELINE configs 2 / 3: 6 layers, d 512, 8 heads) at B = 2 x L = 256 per rank
+BIG = dict(vocab_size=1007, n_layer=6, n_head=8, d_model=512, d_inner=2048, dropout=0.0, d_condition=128,
+           conditioning="continuous_concat")
+
+
+SMALL = CFG
+
+
+def use_big(big=True):
+    global CFG, L
+    CFG, L = (BIG, 256) if big else (SMALL, 96)
 
 
 def micro_batch(step, micro, rank, device):
@@ -39,7 +50,10 @@ def main():
     ap.add_argument("--backend", default="gloo")
     ap.add_argument("--compute_dtype", default="fp32")
     ap.add_argument("--out", required=True)
+    ap.add_argument("--big", action="store_true")
     a = ap.parse_args()
+    if a.big:
+        use_big()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)

@@ -15,9 +15,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
-def single_rank_reference(world, accumulate, compute_dtype):
+def single_rank_reference(world, accumulate, compute_dtype, big=False, rank_order=None):
     import ddp_worker as W
     from midiemo.optim import FusedAdamW
+    W.use_big(big)
     dev = torch.device("cuda", 0)
     model = W.build(compute_dtype, dev)
     opt = FusedAdamW(model, lr=2e-5, clip=1.0)
@@ -31,7 +32,7 @@ def single_rank_reference(world, accumulate, compute_dtype):
     g1 = None
     for step in range(W.STEPS):
         for micro in range(accumulate):
-            parts = [W.micro_batch(step, micro, r, dev) for r in range(world)]
+            parts = [W.micro_batch(step, micro, r, dev) for r in (rank_order or range(world))]
             x, c, y = (torch.cat([p[i] for p in parts]) for i in range(3))
             model.loss_and_backward(x, c, y, grad_scale=1.0 / accumulate)
         if step == 0:
@@ -45,13 +46,13 @@ def rel(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm())
 
 
-def run_workers(tmp_path, policy, accumulate, backend, compute_dtype, port, nproc=2):
-    out = str(tmp_path / f"ddp_{policy}_{accumulate}_{backend}_{nproc}.pt")
+def run_workers(tmp_path, policy, accumulate, backend, compute_dtype, port, nproc=2, big=False):
+    out = str(tmp_path / f"ddp_{policy}_{accumulate}_{backend}_{nproc}_{int(big)}.pt")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", MIDIEMO_DDP_FORCE="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
                         "--master-addr", "127.0.0.1", "--master-port", str(port),
                         os.path.join(ROOT, "tests", "ddp_worker.py"), "--policy", policy, "--accumulate", str(accumulate),
-                        "--backend", backend, "--compute_dtype", compute_dtype, "--out", out],
+                        "--backend", backend, "--compute_dtype", compute_dtype, "--out", out] + (["--big"] if big else []),
                        capture_output=True, text=True, env=env, timeout=600)
     return r, out
 
@@ -68,6 +69,26 @@ def test_two_ranks_one_gpu_match_single_rank(tmp_path, policy, accumulate):
     assert eg <= 1e-5, eg                  # f32 tier: same sums in a different order
     assert ep <= 1e-4, ep                  # lr 2e-5: dominated by the few noise-sign entries (each 2 lr per step)
     assert eu <= 2e-2, eu                  # Adam turns rounding noise of near-zero gradients into +-lr: a few entries differ
+
+
+def test_two_ranks_bf16_headline_model_accumulate(tmp_path):
+    """the tier and the model the benchmark times -- bf16 storage, hi + lo residual stream, bf16 weight refresh
+    after every reduced step, 6 layers d512 8 heads -- with world = 2 and --accumulate 2 through the model's backward
+    (grouped weight-gradient launches hand their buckets over at the end of each layer).  Bound DERIVED, not picked: the
+    2-rank run differs from the 1-rank run on the concatenated batch only by f32 summation order (each rank sums its own
+    rows, the all-reduce adds the two), the same kind of difference two 1-rank bf16 runs show when the rows of the batch
+    are fed in the other order; the 2-rank deviation must stay within 4 x that."""
+    r, out = run_workers(tmp_path, "window", 2, "gloo", "bf16", 29583, big=True)
+    assert r.returncode == 0 and r.stdout.count("done") == 2, r.stdout[-3000:] + r.stderr[-3000:]
+    got = torch.load(out)
+    g1, params, p0, keep = single_rank_reference(2, 2, "bf16", big=True)
+    g1p, paramsp, _, _ = single_rank_reference(2, 2, "bf16", big=True, rank_order=(1, 0))
+    eg, eu = rel(got["g1"][keep], g1[keep]), rel((got["params"] - p0)[keep], (params - p0)[keep])
+    bg, bu = rel(g1p[keep], g1[keep]), rel((paramsp - p0)[keep], (params - p0)[keep])
+    print("ddp bf16 6L d512 acc=2: grad rel %.2e (row-order noise of two 1-rank runs %.2e), 3-step update rel %.2e (%.2e)" %
+          (eg, bg, eu, bu))
+    assert eg <= 4 * bg + 1e-7, (eg, bg)
+    assert eu <= 4 * bu + 1e-7, (eu, bu)
 
 
 def test_two_ranks_one_gpu_rccl_backend(tmp_path):

@@ -61,14 +61,51 @@ def test_greedy_ids_bit_exact_vs_reference(golden_dir, mode):
 
 @pytest.mark.parametrize("mode", ["continuous_concat", "discrete_token"])
 def test_bf16_decode_agrees_with_reference_mostly(golden_dir, mode):
-    """bf16 tier: greedy ids are not expected to be bit-exact (logit gaps of a random-init model are
-    ~1e-2); report agreement of the first tokens."""
+    """bf16 tier against the reference's greedy ids over ALL 48 tokens.  Greedy ids cannot be bit-exact in
+    bf16 (a random-init model has top-2 logit gaps of ~1e-2, and one flipped token changes everything after it), so the
+    free-running agreement is REPORTED, and what is ASSERTED is the derived statement: under teacher forcing with the
+    reference's own tokens, every step whose fp32 top-2 gap exceeds twice the tier's logit error bound -- the oracle's own
+    bf16-autocast error at that step x K_LOGITS -- must pick the reference's token."""
     G, model, maps, conds, disc, z = setup(mode, "bf16", golden_dir)
     gen_len, mil = [int(x) for x in z[f"{mode}_noslide_cfg"]]
+    ref_ids = z[f"{mode}_noslide_ids"]                       # [steps, 4]
     ids = run(G, model, maps, mode, conds, disc, gen_len, mil, use_cache=True)
-    assert ids.shape == z[f"{mode}_noslide_ids"].shape
-    assert (ids[:2] == z[f"{mode}_noslide_ids"][:2]).all()
+    assert ids.shape == ref_ids.shape
     assert ((ids >= 2) & (ids < 1007))[1:].all()            # specials are never generated
+    same = ids == ref_ids
+    first_div = [int(np.argmin(same[:, b])) if not same[:, b].all() else same.shape[0] for b in range(same.shape[1])]
+    print("bf16 greedy vs reference ids (%s): %d / %d tokens equal free-running, first divergence per sample %s" %
+          (mode, int(same.sum()), same.size, first_div))
+    assert (ids[:2] == ref_ids[:2]).all()
+    if mode != "continuous_concat":
+        return
+    # teacher forcing through the cached decode: logits of both tiers and of the oracle (fp32 / bf16 autocast) per step
+    from midiemo.decode import DecodeSession
+    K_LOGITS = 1.25                                          # same constant as tests/test_model_gpu.py
+    cfg = O.Cfg(1007, 2, 2, 64, 128, d_condition=16, conditioning=mode)
+    P = O.seeded_params(cfg, int(z["weight_seed"]))
+    cond = torch.tensor(conds, dtype=torch.float32)
+    toks = torch.from_numpy(ref_ids.T.copy())                # [4, steps]
+    lg32 = O.forward(cfg, P, toks, cond)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        lgac = O.forward(cfg, P, toks, cond).float()
+    sess = DecodeSession(model, toks.shape[0])
+    agree = stable = 0
+    for t in range(toks.shape[1] - 1):
+        lg = sess.step(toks[:, t].cuda(), cond.cuda()).float().cpu()[:, 2:1007]     # generate() never emits the specials
+        r32 = lg32[:, t, 2:1007]
+        err_bound = K_LOGITS * (lgac[:, t, 2:1007] - r32).abs().max(-1).values      # per sample, this step
+        top2 = r32.topk(2, dim=-1)
+        gap = top2.values[:, 0] - top2.values[:, 1]
+        pick, want = lg.argmax(-1), top2.indices[:, 0]
+        assert (want + 2 == toks[:, t + 1]).all()                                     # the oracle's arg-max IS the reference's next token
+        must = gap > 2 * err_bound
+        assert (pick[must] == want[must]).all(), (t, pick, want, gap, err_bound)
+        agree += int((pick == want).sum())
+        stable += int(must.sum())
+    n = (toks.shape[1] - 1) * toks.shape[0]
+    print("bf16 teacher-forced decode: %d / %d steps pick the reference token; %d steps have a top-2 gap above twice the "
+          "derived logit error bound and all of them agree" % (agree, n, stable))
 
 
 def test_sampling_path_runs_and_respects_exclusions(golden_dir):

@@ -298,3 +298,65 @@ def test_sampling_temperature_and_repeat_penalty_match_reference(golden_dir):
             prev = torch.from_numpy(z[f"samp_{tag}_tokens"][s]).long()
         if tag == "k0p07":
             assert seen_penalty                              # the peaked rows drive the repeat counter past 3
+
+
+def test_eval_aggregation_matches_reference_accuracy(golden_dir):
+    """Runner.evaluate weights every batch's loss and utils.accuracy (top-1 / top-5 over the batch's non-PAD
+    targets) by input_.numel() (train.py:256-272).  Fixture f8: the reference's own utils.accuracy on seeded batches with
+    ragged trailing PAD + the aggregate those statements give; midiemo.metrics.EvalAccumulator (what train.py's evaluate()
+    runs) must reproduce the per-batch numbers and the aggregate."""
+    from midiemo.metrics import EvalAccumulator
+    z = np.load(os.path.join(golden_dir, "f8_eval.npz"))
+    pad, V = int(z["pad_idx"]), int(z["V"])
+    ev = EvalAccumulator("cpu")
+    ce = torch.nn.CrossEntropyLoss(ignore_index=pad)
+    for i in range(int(z["n_batches"])):
+        lg, tg, inp = (torch.from_numpy(z[f"b{i}_{n}"]) for n in ("logits", "target", "input"))
+        loss = ce(lg.view(-1, V), tg.view(-1))
+        assert float(loss) == pytest.approx(float(z[f"b{i}_loss"]), rel=1e-6)
+        one = EvalAccumulator("cpu")
+        one.add(loss, lg, tg, inp.numel(), pad)
+        _, accs = one.result()
+        assert accs[1] == pytest.approx(float(z[f"b{i}_acc1"]), rel=1e-6) and accs[5] == pytest.approx(float(z[f"b{i}_acc5"]), rel=1e-6)   # the reference divides in float32
+        ev.add(loss, lg, tg, inp.numel(), pad)
+    loss, accs = ev.result()
+    assert loss == pytest.approx(float(z["avg_loss"]), rel=1e-6)
+    assert accs[1] == pytest.approx(float(z["avg_acc1"]), rel=1e-6) and accs[5] == pytest.approx(float(z["avg_acc5"]), rel=1e-6)
+    # and it is NOT the pooled accuracy over all valid targets (what round 2 computed): the batches are ragged
+    hits = tot = 0
+    for i in range(int(z["n_batches"])):
+        lg, tg = torch.from_numpy(z[f"b{i}_logits"]), torch.from_numpy(z[f"b{i}_target"])
+        v = tg.view(-1) != pad
+        hits += int(((lg.view(-1, V).argmax(-1) == tg.view(-1)) & v).sum())
+        tot += int(v.sum())
+    assert abs(hits / tot - accs[1]) > 1e-4
+
+
+def test_fused_adam_loads_reference_optimizer_state_by_name():
+    """FusedAdamW.load_state_dict takes the reference's optimizer.pt (a torch.optim.Adam state_dict, train.py:403),
+    which carries no names -- only positions in the order of the REFERENCE model's parameters().  That order is the
+    checkpoint-ABI key order (O.param_shapes = the reference's state_dict order, pinned in test_build_model_contract);
+    many tensors share a shape (Wq / Wk / Wv / fc, the LayerNorm vectors), so a permutation would load silently: every
+    moment must land under its own NAME."""
+    from midiemo.models.build_model import build_model
+    from midiemo.optim import FusedAdamW
+    args = dict(vocab_size=97, n_layer=2, n_head=2, d_model=64, d_inner=128, dropout=0.0, d_condition=16,
+                conditioning="continuous_concat")
+    model, _ = build_model(args)
+    cfg = O.Cfg(97, 2, 2, 64, 128, d_condition=16, conditioning="continuous_concat")
+    names = list(O.param_shapes(cfg).keys())                      # reference registration order
+    ref_params = [torch.nn.Parameter(torch.zeros(O.param_shapes(cfg)[n])) for n in names]
+    ref_opt = torch.optim.Adam(ref_params, lr=3e-4)
+    g = torch.Generator().manual_seed(4)
+    for p in ref_params:                                          # one step with distinct per-tensor gradients
+        p.grad = torch.randn(p.shape, generator=g)
+    ref_opt.step()
+    sd = ref_opt.state_dict()
+    opt = FusedAdamW(model, lr=1e-3)
+    opt.load_state_dict(sd)
+    assert opt.step_count == 1 and opt.param_groups[0]["lr"] == 3e-4
+    for i, n in enumerate(names):
+        assert torch.equal(model._pview(opt.m, n), sd["state"][i]["exp_avg"]), n
+        assert torch.equal(model._pview(opt.v, n), sd["state"][i]["exp_avg_sq"]), n
+    # a model whose parameters() order differs from the reference's must be refused, not loaded by position
+    assert [n for n, _ in model.named_parameters()] == names

@@ -441,8 +441,23 @@ def test_ce_bf16_logits(ops, V, ld):
     assert relerr(row_lse, torch.logsumexp(lg.double(), -1)) < 1e-6
     dl = torch.full((rows, ld), float("nan"), dtype=torch.bfloat16, device=DEV)
     ops.ce_bwd(lgd, tgt.to(DEV), row_lse, dl, acc[1:2], 1.0, rows, V, 0)
-    assert relerr(dl[:, :V], l64.grad) < 4e-3
+    assert relerr(dl[:, :V], l64.grad) < tol(torch.bfloat16, 0, l64.grad)
     assert (dl[:, V:] == 0).all()
+    # fused head-bias gradient: f32 column sums of dlogits BEFORE the rounding to bf16 (accumulated into dbias)
+    if ld <= 2048:
+        assert ops.ce_bwd_fuses_dbias(lgd, dl)
+        db = torch.zeros(V, device=DEV)
+        dl2 = torch.full_like(dl, float("nan"))
+        ops.ce_bwd(lgd, tgt.to(DEV), row_lse, dl2, acc[1:2], 1.0, rows, V, 0, dbias=db)
+        assert torch.equal(dl2, dl)
+        assert relerr(db, l64.grad.sum(0)) < 2e-5                                    # f32 exact, not the bf16 column sums
+        ops.ce_bwd(lgd, tgt.to(DEV), row_lse, dl2, acc[1:2], 1.0, rows, V, 0, dbias=db)   # accumulates (+=)
+        assert relerr(db, 2 * l64.grad.sum(0)) < 2e-5
+        assert relerr(dl[:, :V].double().sum(0).cpu(), l64.grad.sum(0)) > 1e-4       # ... which is what it replaces
+    else:
+        assert not ops.ce_bwd_fuses_dbias(lgd, dl)
+        with pytest.raises(RuntimeError, match="ME_ERR_BAD_SHAPE"):
+            ops.ce_bwd(lgd, tgt.to(DEV), row_lse, dl, acc[1:2], 1.0, rows, V, 0, dbias=torch.zeros(V, device=DEV))
 
 
 # ------------------------------------------------------------------ optimiser

@@ -148,7 +148,7 @@ class LRSchedule:
     cosine / inv_sqrt: closed form (lr_at); cyclic / dev_perf: torch's CyclicLR / ReduceLROnPlateau run on a shadow
     SGD optimiser with one parameter, so the sequence of learning rates is torch's own."""
 
-    def __init__(self, args, opt):
+    def __init__(self, args, opt, start_step=0):
         self.args, self.opt, self.shadow, self.sched = args, opt, None, None
         if args.scheduler in ("cyclic", "dev_perf"):
             self.shadow = torch.optim.SGD([torch.zeros(1, requires_grad=True)], lr=opt.param_groups[0]["lr"])
@@ -157,6 +157,12 @@ class LRSchedule:
             else:
                 self.sched = torch.optim.lr_scheduler.ReduceLROnPlateau(self.shadow, factor=args.decay_rate,
                                                                         patience=args.patience, min_lr=args.lr_min)
+
+        if args.scheduler == "cyclic" and start_step > args.warmup_step:
+            # restart: put the triangle where the interrupted run left it (one scheduler.step() per step past the warm-up)
+            for _ in range(start_step - args.warmup_step):
+                self.shadow.step()
+                self.sched.step()
 
     def _copy(self):
         self.opt.param_groups[0]["lr"] = self.shadow.param_groups[0]["lr"]
@@ -287,7 +293,7 @@ def main(argv=None):
             os.makedirs(work_dir, exist_ok=True)                # train.py:173,118: the resumed run continues the table
             import shutil
             shutil.copy(os.path.join(restart, "performance.csv"), os.path.join(work_dir, "performance.csv"))
-    sched = LRSchedule(args, opt)
+    sched = LRSchedule(args, opt, start_step=int(stats.get("step", 0)))
     reducer = GradAllReducer(lambda: model.flat_grads, model.bucket_ranges())
     if rank == 0 and not args.debug:
         os.makedirs(work_dir, exist_ok=True)
@@ -332,9 +338,13 @@ def main(argv=None):
     train_iter = real_batches(train_loader, True) if train_loader is not None else None
 
     def evaluate():
-        """Mean loss and top-1 / top-5 token accuracy over non-PAD targets (train.py:222-275, utils.accuracy)."""
+        """The reference's Runner.evaluate (train.py:222-275): per-batch CE loss and utils.accuracy (top-1 / top-5 over the
+        batch's non-PAD targets), each weighted by input_.numel() -- midiemo.metrics.EvalAccumulator, pinned to the
+        reference's own utils.accuracy by tests/golden/f8_eval.npz."""
+        from midiemo.metrics import EvalAccumulator
         model.eval()
-        acc = torch.zeros(4, device=device, dtype=torch.float64)          # loss-sum, top1, top5, #targets
+        ev = EvalAccumulator(device)
+        acc = torch.zeros(4, device=device, dtype=torch.float64)          # regression: L1 sums, #sequences
         n = min(args.max_eval_step, 8) if test_loader is None else (args.max_eval_step if args.max_eval_step > 0 else 1 << 60)
         test_iter = iter(test_loader) if test_loader is not None else None
         with torch.no_grad():
@@ -355,15 +365,12 @@ def main(argv=None):
                     acc[3] += nb
                     continue
                 loss, logits = model.loss_and_backward(x, c, y, backward=False, return_logits=True)
-                valid = y.reshape(-1) != pad_idx
-                top5 = logits.reshape(-1, logits.size(-1)).topk(5, dim=-1).indices
-                hit = top5 == y.reshape(-1, 1)
-                nv = valid.sum()
-                acc[0] += loss.double() * nv
-                acc[1] += (hit[:, 0] & valid).sum()
-                acc[2] += (hit.any(-1) & valid).sum()
-                acc[3] += nv
+                ev.add(loss, logits, y, x.numel(), pad_idx)
         model.train()
+        if not args.regression:
+            if world > 1:
+                dist.all_reduce(ev.acc)
+            return ev.result()
         if world > 1:
             dist.all_reduce(acc)
         a = acc.tolist()
@@ -436,8 +443,11 @@ def main(argv=None):
             micro = 0
             reducer.finish()
             step += 1
-            sched.on_step(step)
+            # the reference steps the optimiser FIRST and only then writes the warm-up / scheduler learning rate, with its
+            # 0-based step counter (train.py:319-333,438): update n (1-based) runs with the rate written after update n - 1,
+            # i.e. the initial rate, then lr * 0 / warmup, lr * 1 / warmup, ...  Same sequence here.
             opt.step(grad_scale=reducer.grad_scale)
+            sched.on_step(step - 1)
             if step % args.gen_step == 0 and not args.regression and rank == 0:
                 generate_samples(step)
             if step % args.log_step == 0 or step == args.max_step:
