@@ -307,7 +307,14 @@ def main():
     ap.add_argument("--no_probe", action="store_true")
     ap.add_argument("--no_decode", action="store_true")
     ap.add_argument("--no_extra", action="store_true")
+    ap.add_argument("--only_config4", action="store_true", help="run only the config-4 sub-measurement (profiling passes)")
     args = ap.parse_args()
+    if args.only_config4:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+        torch.cuda.set_device(0)
+        print(json.dumps({"extra": {"config4": config4_bench()}}), flush=True)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -449,6 +456,13 @@ def main():
                                "avg_launch_us": round(1000.0 * ms / n, 2),
                                "gemm_nt_ms_per_step": round(ms / 3, 3),
                                "step_frac_of_peak": round(tps * fpt / 1e12 / world / PEAK_BF16_TFLOPS, 4)}
+        # multi-GPU knobs of this run (SCALE runs are only interpretable with them): the overlap policy of the bucket
+        # all-reduces (midiemo/ddp.py) and the CUs the persistent GEMM grids leave to RCCL (default 0: a reserve makes
+        # EVERY 256-tile launch take a second tile round -- measured on one GPU: qkv 59.6 -> 70.8 us, proj 27.1 -> 43.9 us
+        # with 64 CUs reserved -- so none is applied automatically)
+        out["ddp"] = {"policy": os.environ.get("MIDIEMO_DDP_POLICY", "window"),
+                      "cu_reserve": int(os.environ.get("MIDIEMO_CU_RESERVE", "0") or 0), "world": world,
+                      "backend": backend if dist_on else None}
         if hbm_table is not None:
             out["hbm_kernels"] = hbm_table
         if world == 1 and not args.no_cpu_baseline:

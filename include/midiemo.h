@@ -11,7 +11,8 @@
  * Conventions
  *   - all pointers are DEVICE addresses owned by the caller (PyTorch tensors);
  *     the library is stateless: it never allocates, frees or synchronises, keeps no
- *     global mutable state and never retains a pointer past the call.  Scratch memory
+ *     mutable state between calls (see "Process-wide switches" below for the read-once
+ *     settings) and never retains a pointer past the call.  Scratch memory
  *     is caller-owned: me_workspace_bytes() says how much an entry point needs;
  *   - `stream` is a hipStream_t passed as void*; calls only enqueue work;
  *   - `dtype` selects the activation/weight storage type T of the call:
@@ -19,6 +20,16 @@
  *       ME_BF16 : bf16 storage, f32 accumulate (v_mfma_f32_32x32x16_bf16)
  *     master parameters, gradients, optimiser state, statistics are always f32;
  *   - return value: ME_OK or a negative ME_ERR_* code; nothing throws/aborts.
+ *
+ * Process-wide switches.  The only state the library keeps is read-only after first use: a per-device cache of the CU
+ * count / "LDS limit raised" flags, and these environment variables, each read ONCE (getenv at first use) -- development
+ * and measurement aids, never needed for correct results:
+ *   MIDIEMO_CU_RESERVE=n   persistent GEMM grids use (#CUs - n) blocks (CUs left to a concurrent RCCL kernel; default 0)
+ *   MIDIEMO_NO_NT256=1     bf16 NT GEMMs run the generic 128 x 128 kernel instead of the persistent 256 x 256 one
+ *   MIDIEMO_NO_TN256=1     likewise for the weight-gradient (TN) GEMMs
+ *   MIDIEMO_ATTN_V1=1      bf16 / head-dim-64 / causal attention runs the generic 32-key-step forward kernel
+ *   MIDIEMO_DEC_CW=1|2|4, MIDIEMO_DEC_KS=0|1   column / K-split geometry of the decode GEMV kernels
+ *   MIDIEMO_DEBUG=1        print the HIP error string when a launch fails
  */
 #ifndef MIDIEMO_H
 #define MIDIEMO_H

@@ -1,6 +1,9 @@
 #!/bin/bash
 # End-of-milestone evidence, run on the GPU box from the repo root:  bash tools/round_profiles.sh r02_b
-#   1. rocprofv3 --kernel-trace --stats over the DEFAULT bench.py command  -> <tag>_bench_kernel_stats.txt, <tag>_bench.json
+#   0. the DEFAULT bench.py command, un-profiled                            -> <tag>_bench.json
+#   1. rocprofv3 --kernel-trace --stats over a C2-ONLY bench (--no_extra --no_decode) -> <tag>_bench_kernel_stats.txt,
+#      and over the config-4 sub-measurement alone                           -> <tag>_config4_kernel_stats.txt
+#      (round 2 traced the default command: attention rows mixed L = 1024 and L = 2048 launches, 40 % decode kernels)
 #   2. two PMC passes (FETCH_SIZE / WRITE_SIZE, counters only) over a short train-only bench -> <tag>_hbm_traffic.txt, hbm_traffic.json
 #   3. kernel trace of 64 eager decode steps at t = 1024                   -> <tag>_decode_kernel_stats.txt
 # Everything lands in gpurun_out/prof/ (copy what is to be judged into profiles/).
@@ -9,9 +12,13 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/rp_*
-timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/rp_bench -o p -- python $R/bench.py > /tmp/rp_bench.log 2>&1
-grep "^{\"metric\"" /tmp/rp_bench.log | tail -1 > $OUT/${TAG}_bench.json
+timeout 900 python $R/bench.py > /tmp/rp_plain.log 2>&1
+grep "^{\"metric\"" /tmp/rp_plain.log | tail -1 > $OUT/${TAG}_bench.json
+timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/rp_bench -o p -- python $R/bench.py --no_extra --no_decode --no_cpu_baseline --steps 20 --warmup 5 > /tmp/rp_bench.log 2>&1
 python $R/tools/rocpd_stats.py $(find /tmp/rp_bench -name "*.db" | head -1) > $OUT/${TAG}_bench_kernel_stats.txt 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/rp_c4 -o p -- python $R/bench.py --only_config4 > /tmp/rp_c4.log 2>&1
+python $R/tools/rocpd_stats.py $(find /tmp/rp_c4 -name "*.db" | head -1) > $OUT/${TAG}_config4_kernel_stats.txt 2>&1
+python $R/tools/make_roofline.py > /tmp/rp_roof.log 2>&1
 SHORT="--steps 4 --warmup 1 --no_cpu_baseline --no_probe --no_decode --no_extra"
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/rp_f -o p -- python $R/bench.py $SHORT > /tmp/rp_f.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/rp_w -o p -- python $R/bench.py $SHORT > /tmp/rp_w.log 2>&1
