@@ -304,6 +304,19 @@ int me_dec_attn(const void* q, const void* kcache, const void* vcache, const voi
                 float* part, int nsplit, int Mr, int H, int dh, int M, int Mc, int t, const int32_t* t_dev, int dtype,
                 void* stream);
 
+/* Fused decode stage: LayerNorm(s_in row) -> q | k | v projection of one head -> cache append at position t -> key-split
+ * attention partials, one block per (row, head, split): me_dec_qkv(s_in, ...) + me_dec_attn in ONE launch (a head's
+ * attention needs only that head's q and the keys 0..t-1 already cached, so the two launches had no real seam; splits
+ * 0..nsplit-2 share the cached keys, partial nsplit-1 is the new key t, computed -- with k_t / v_t and their cache
+ * append -- by two extra blocks per (row, head)).  part / nsplit as me_dec_attn (read by me_dec_proj_resid); x_out (f32
+ * [Mr, d] or NULL) receives the LayerNorm rows.  d <= 1024, 2 <= nsplit <= 8.
+ * Replaces, per layer >= 1 of a cached decode step, music_multi.py:133-134 (layernorm2 of the previous layer) and
+ * :196-232 for the one new position (generate.py:116-119). */
+int me_dec_ln_qkv_attn(const float* s_in, const float* gamma, const float* beta, float eps, const void* Wqkv, const float* bqkv,
+                       float* x_out, void* kcache, void* vcache, const void* E, const uint8_t* key_pad, int ld_pad, float* part,
+                       int nsplit, int Mr, int d, int H, int dh, int M, int Mc, int t, const int32_t* t_dev, int dtype,
+                       void* stream);
+
 /* me_dec_proj_resid: out f32 [Mr][N] = resid f32 [Mr][N] + bias + T(x).W^T with
  *   x = softmax-combine of the attention partials (part != NULL; K = H*dh; replaces the head merge + self.fc of
  *       music_multi.py:233-237 and the residual add of :128), or

@@ -150,6 +150,18 @@ ME_DEV void dec_fma_chunks(float (&acc)[CW][MR], const chunk16 (&w)[CW], bool ok
 // KS = true : the block owns CW columns, wave w contracts over the w-th quarter of K and the four partial results meet in
 //             LDS -- long rows (FFN_suf: K = 2048) then spread over as many blocks as the short ones: a cold weight
 //             stream is fetched fastest when every CU pulls a few KB (measured: 64 blocks x 32 KB 9.7 us, L2-hot 4.4 us).
+// weight rows: every element is read by exactly one wave per token -- streamed with the non-temporal policy (guide, price
+// list "nt-weights": issued -> landed -18 %); -DME_DEC_PLAIN_W: default policy (A/B)
+ME_DEV chunk16 ld_w(const void* p) {
+#ifdef ME_DEC_PLAIN_W
+    return ld_chunk(p);
+#else
+    chunk16 c;
+    c.v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    return c;
+#endif
+}
+
 template <typename T, int PRO, int EPI, int MR, int CW, bool KS>
 __global__ __launch_bounds__(256) void dec_gemv_kernel(const DecArgs a) {
     constexpr int CH = ET<T>::CH;
@@ -174,7 +186,7 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(const DecArgs a) {
 #pragma unroll
             for (int c = 0; c < CW; ++c) {
                 const int n = min(n0 + c, a.N - 1);                     // clamped: results of columns >= N are never stored
-                wp[u][c] = ld_chunk(W + (size_t)n * a.ldw + (size_t)chc * CH);
+                wp[u][c] = ld_w(W + (size_t)n * a.ldw + (size_t)chc * CH);
             }
         }
     }
@@ -379,7 +391,7 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(const DecArgs a) {
         for (int u = 0; u < U; ++u) {
             const int ch = ch0 + 64 * u, chc = ch < nch ? ch : ch0;
 #pragma unroll
-            for (int c = 0; c < CW; ++c) w[u][c] = ld_chunk(W + (size_t)min(n0 + c, a.N - 1) * a.ldw + (size_t)chc * CH);
+            for (int c = 0; c < CW; ++c) w[u][c] = ld_w(W + (size_t)min(n0 + c, a.N - 1) * a.ldw + (size_t)chc * CH);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -555,6 +567,247 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const T* __restrict__ q, 
     if (tid == 0) { pout[0] = mx; pout[1] = red[4] + red[5] + red[6] + red[7]; }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Fused {LayerNorm -> q | k | v projection of ONE head -> cache append -> key-split attention}: grid (row x head, nsplit + 1).
+// The separate kernels (dec_gemv<PRO_LN, EPI_QKV> + dec_attn) are two launches with an all-to-all seam that does not
+// exist per head: a head's attention needs only that head's q, and the keys 0..t-1 are already in the cache.  Roles:
+//   y <  nsplit - 1 : cached keys [j0, j1) of [0, t): LayerNorm row + the head's 64 q columns (64 KB of weights, L2
+//                     resident), then the usual (max, sum, P.V) partial;
+//   y == nsplit - 1 : the new key, part A: q AND k_t columns (both weight sets requested together: one round trip),
+//                     k_t appended to the cache, s_t = q.(k_t + E[M-1]) -> (max, sum) = (s_t, 1) of partial nsplit - 1;
+//   y == nsplit     : the new key, part B: v_t columns, appended to the cache and written as the o part of that partial.
+// Every block has exactly ONE dependent weight round trip; q never goes through memory; one launch and one boundary less per
+// layer.  (A first version let one "owner" block compute q, k and v one after the other: three round trips, slower than the
+// two launches it replaced -- 0.160 vs 0.150 ms per token.)  Needs nsplit >= 2.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void dec_ln_qkv_attn_kernel(const DecArgs a, const T* __restrict__ E,
+                                                              const uint8_t* __restrict__ key_pad, int ld_pad,
+                                                              float* __restrict__ part, int nsplit, int M, float scale) {
+    constexpr int CH = ET<T>::CH, CPR = DH / CH;            // 16-byte chunks per cache row
+    constexpr int G = CPR <= 4 ? 4 : (CPR <= 8 ? 8 : 16);   // lanes per key
+    constexpr int KPW = 64 / G, KPI = 4 * KPW;              // keys per wave / per block and iteration
+    constexpr int U = 4;                                    // iterations in flight
+    constexpr int CWQ = DH / 4;                             // projection columns per wave (one head = 4 waves x CWQ)
+    extern __shared__ __attribute__((aligned(16))) float xs[];          // [K]: the LayerNorm row, T-rounded values
+    __shared__ float qs[DH], kn[DH];                                    // scaled q; the new key row (T-rounded values)
+    __shared__ float ps[2048];
+    __shared__ float red[12];
+    __shared__ float osum[4][KPW][DH];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int H = a.H, K = a.K, Mc = a.Mc;
+    const int mh = blockIdx.x, role = blockIdx.y, m = mh / H, head = mh % H;
+    const int t = a.t_dev ? min(*a.t_dev, min(Mc, M) - 1) : a.t;
+    const bool part_a = role == nsplit - 1, part_b = role == nsplit;
+    int per = (t + nsplit - 2) / (nsplit - 1);
+    per = (per + KPI - 1) / KPI * KPI;
+    const int j0 = role * per, j1 = min(t, j0 + per);                   // cached keys of a split block
+    float* pout = part + ((size_t)mh * nsplit + min(role, nsplit - 1)) * (DH + 2);
+    if (!part_a && !part_b && j0 >= j1) {                               // empty split (short contexts)
+        if (tid < DH + 2) pout[tid] = tid == 0 ? -INFINITY : 0.f;
+        return;
+    }
+    // ---- weights: requested first, in flight during the LayerNorm (q | q + k | v columns of the head)
+    const int nch = K / CH, d = H * DH;
+    const int chc0 = lane < nch ? lane : 0;
+    const T* W0 = reinterpret_cast<const T*>(a.W) + (size_t)((part_b ? 2 * d : 0) + head * DH + wid * CWQ) * a.ldw;
+    const T* W1 = W0 + (size_t)d * a.ldw;                               // part A: the k columns
+    chunk16 w0[CWQ], w1[CWQ];
+#pragma unroll
+    for (int c = 0; c < CWQ; ++c) w0[c] = ld_w(W0 + (size_t)c * a.ldw + (size_t)chc0 * CH);
+    if (part_a) {
+#pragma unroll
+        for (int c = 0; c < CWQ; ++c) w1[c] = ld_w(W1 + (size_t)c * a.ldw + (size_t)chc0 * CH);
+    }
+    // ---- LayerNorm of row m (every wave computes the statistics: no cross-wave reduction, one barrier)
+    {
+        constexpr int NV = 4;
+        f32x4_t v[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int k = lane * 4 + 256 * i;
+            v[i] = k < K ? *reinterpret_cast<const f32x4_t*>(a.s_in + (size_t)m * K + k) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        const float mean = wave_sum(sum) / K;
+        float vs = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (lane * 4 + 256 * i < K) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d_ = v[i][e] - mean; vs += d_ * d_; }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(vs) / K + a.eps);
+        if (wid == 0) {                                                 // wave 0 writes the row (the others hold the same values)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int k = lane * 4 + 256 * i;
+                if (k < K) {
+                    const f32x4_t g = *reinterpret_cast<const f32x4_t*>(a.gamma + k);
+                    const f32x4_t be = *reinterpret_cast<const f32x4_t*>(a.beta + k);
+                    f32x4_t o, r;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { o[e] = (v[i][e] - mean) * rstd * g[e] + be[e]; r[e] = round_to<T>(o[e]); }
+                    if (a.x_out && head == 0 && part_a) *reinterpret_cast<f32x4_t*>(a.x_out + (size_t)m * K + k) = o;
+                    *reinterpret_cast<f32x4_t*>(&xs[k]) = r;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- projection of this wave's CWQ columns; result (T-rounded) times `mul` to LDS / memory
+    auto project = [&](const T* Wrow, chunk16 (&first)[CWQ], const float* bias, float* dst_lds, T* dst_cache, float* dst_f32, float mul)
+                       __attribute__((always_inline)) {
+        float acc[CWQ][1];
+#pragma unroll
+        for (int c = 0; c < CWQ; ++c) acc[c][0] = 0.f;
+        dec_fma_chunks<T, 1, CWQ>(acc, first, lane < nch, xs, K, chc0);
+        const int npass = (nch + 63) / 64;
+        for (int ps_ = 1; ps_ < npass; ++ps_) {                          // further chunk positions (K > 64 CH)
+            const int ch = lane + 64 * ps_, chc = ch < nch ? ch : 0;
+            chunk16 w[CWQ];
+#pragma unroll
+            for (int c = 0; c < CWQ; ++c) w[c] = ld_w(Wrow + (size_t)c * a.ldw + (size_t)chc * CH);
+            dec_fma_chunks<T, 1, CWQ>(acc, w, ch < nch, xs, K, chc);
+        }
+        float r[CWQ];
+#pragma unroll
+        for (int c = 0; c < CWQ; ++c) r[c] = acc[c][0];
+        reduce_scatter64<CWQ>(r);
+        float mine = 0.f;
+#pragma unroll
+        for (int i = 0; i < CWQ / 4; ++i) if ((lane & 15) == i) mine = r[i];
+        if ((lane & 15) < CWQ / 4) {
+            const int c = (lane & 15) + (CWQ / 4) * (lane >> 4), j = wid * CWQ + c;
+            const float v = round_to<T>(mine + bias[j]);
+            if (dst_lds) dst_lds[j] = v * mul;
+            if (dst_cache) dst_cache[j] = ET<T>::from_f(v);
+            if (dst_f32) dst_f32[j] = v;
+        }
+    };
+    if (part_b) {                                                       // v_t: cache row + the o part of the new key's partial
+        T* vcr = reinterpret_cast<T*>(a.vcache) + ((size_t)mh * Mc + t) * DH;
+        project(W0, w0, a.bias + 2 * d + head * DH, nullptr, vcr, pout + 2, 1.f);
+        return;
+    }
+    project(W0, w0, a.bias + head * DH, qs, nullptr, nullptr, scale);
+    const uint8_t* kp = key_pad ? key_pad + (size_t)m * ld_pad : nullptr;
+    if (part_a) {                                                       // k_t: cache row; (max, sum) = (s_t, 1)
+        T* kcr = reinterpret_cast<T*>(a.kcache) + ((size_t)mh * Mc + t) * DH;
+        project(W1, w1, a.bias + d + head * DH, kn, kcr, nullptr, 1.f);
+        __syncthreads();
+        if (wid == 0) {
+            float sp = 0.f;
+            for (int i = lane; i < DH; i += 64) sp = fmaf(qs[i], kn[i] + ET<T>::to_f(E[(size_t)(M - 1) * DH + i]), sp);
+            sp = wave_sum(sp);
+            if (kp && kp[t]) sp = -INFINITY;
+            if (lane == 0) { pout[0] = sp; pout[1] = 1.f; }
+        }
+        return;
+    }
+    __syncthreads();
+
+    // ---- attention over the cached keys [j0, j1) (same arithmetic as dec_attn_kernel)
+    const int kslot = lane / G, c = lane % G;
+    const bool active = c < CPR;
+    const int cc = active ? c : CPR - 1;
+    float qv[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) qv[i] = active ? qs[cc * CH + i] : 0.f;
+    const T* kc = reinterpret_cast<const T*>(a.kcache) + (size_t)mh * Mc * DH;
+    const T* vc = reinterpret_cast<const T*>(a.vcache) + (size_t)mh * Mc * DH;
+    const T* er = E + (size_t)(M - 1 - t) * DH;              // relative row of key j: E[M-1-(t-j)] = er + j * DH
+    float mx = -INFINITY;
+    chunk16 v0[U];
+    for (int jb = j0 + wid * KPW; jb < j1; jb += KPI * U) {
+        chunk16 kk[U], ee[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int jc = min(jb + u * KPI + kslot, j1 - 1);
+            kk[u] = ld_chunk(kc + (size_t)jc * DH + cc * CH);
+            ee[u] = ld_chunk(er + (size_t)jc * DH + cc * CH);
+        }
+        if (jb == j0 + wid * KPW) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) v0[u] = ld_chunk(vc + (size_t)min(jb + u * KPI + kslot, j1 - 1) * DH + cc * CH);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = jb + u * KPI + kslot;
+            const T* ke = reinterpret_cast<const T*>(&kk[u]);
+            const T* ev = reinterpret_cast<const T*>(&ee[u]);
+            float s_ = 0.f;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) s_ = fmaf(qv[i], ET<T>::to_f(ke[i]) + ET<T>::to_f(ev[i]), s_);
+            s_ = group_sum<G>(s_);
+            if (j < j1) {
+                if (kp && kp[j]) s_ = -INFINITY;
+                if (c == 0) ps[j - j0] = s_;
+                mx = fmaxf(mx, s_);
+            }
+        }
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wid] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float m_safe = mx == -INFINITY ? 0.f : mx;
+    float o[CH], lsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) o[i] = 0.f;
+    for (int jb = j0 + wid * KPW; jb < j1; jb += KPI * U) {
+        chunk16 vv[U];
+        if (jb == j0 + wid * KPW) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) vv[u] = v0[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int jc = min(jb + u * KPI + kslot, j1 - 1);
+                vv[u] = ld_chunk(vc + (size_t)jc * DH + cc * CH);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = jb + u * KPI + kslot;
+            const float p = j < j1 ? ET<T>::fexp(ps[j - j0] - m_safe) : 0.f;
+            const T* ve = reinterpret_cast<const T*>(&vv[u]);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) o[i] = fmaf(p, ET<T>::to_f(ve[i]), o[i]);
+            if (c == 0) lsum += p;
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) osum[wid][kslot][c * CH + i] = o[i];
+    }
+    lsum = wave_sum(lsum);
+    if (lane == 0) red[4 + wid] = lsum;
+    __syncthreads();
+    if (tid < DH) {
+        float s_ = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int k = 0; k < KPW; ++k) s_ += osum[w][k][tid];
+        pout[2 + tid] = s_;
+    }
+    if (tid == 0) { pout[0] = mx; pout[1] = red[4] + red[5] + red[6] + red[7]; }
+}
+
+template <typename T, int DH>
+int ln_qkv_attn_launch(const DecArgs& a, const void* E, const uint8_t* key_pad, int ld_pad, float* part, int nsplit, int M,
+                       hipStream_t st) {
+    const float scale = 1.f / sqrtf((float)DH);
+    dec_ln_qkv_attn_kernel<T, DH><<<dim3(a.Mr * a.H, nsplit + 1), 256, (size_t)a.K * sizeof(float), st>>>(a, (const T*)E, key_pad, ld_pad,
+                                                                                                part, nsplit, M, scale);
+    return me_launch_status();
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <typename T, int PRO, int EPI, int MR, int CW, bool KS>
@@ -686,6 +939,33 @@ int me_dec_attn(const void* q, const void* kcache, const void* vcache, const voi
     ME_DEC_ATTN_CASE(48)
     ME_DEC_ATTN_CASE(32)
 #undef ME_DEC_ATTN_CASE
+    return ME_ERR_BAD_SHAPE;
+}
+
+int me_dec_ln_qkv_attn(const float* s_in, const float* gamma, const float* beta, float eps, const void* Wqkv, const float* bqkv,
+                       float* x_out, void* kcache, void* vcache, const void* E, const uint8_t* key_pad, int ld_pad, float* part,
+                       int nsplit, int Mr, int d, int H, int dh, int M, int Mc, int t, const int32_t* t_dev, int dtype,
+                       void* stream) {
+    me_clear_error();
+    if (!s_in || !gamma || !beta || !Wqkv || !bqkv || !kcache || !vcache || !E || !part) return ME_ERR_NULL;
+    if (Mr <= 0 || H <= 0 || dh <= 0 || H * dh != d || d > 1024 || d % 8 || nsplit < 2 || nsplit > DEC_NSMAX || Mc <= 0 || M <= 0)
+        return ME_ERR_BAD_SHAPE;
+    if (!t_dev && (t < 0 || t >= Mc || t >= M)) return ME_ERR_BAD_SHAPE;
+    if ((Mc + nsplit - 2) / (nsplit - 1) + 64 > 2048 + 64) return ME_ERR_BAD_SHAPE;   // score buffer: 2048 keys per split
+    if (!aligned16(Wqkv) || !aligned16(kcache) || !aligned16(vcache) || !aligned16(E) || !aligned16(s_in)) return ME_ERR_ALIGNMENT;
+    DecArgs a = {};
+    a.s_in = s_in; a.gamma = gamma; a.beta = beta; a.eps = eps; a.x_out = x_out; a.W = Wqkv; a.ldw = d; a.bias = bqkv; a.Mr = Mr;
+    a.N = 3 * d; a.K = d; a.kcache = kcache; a.vcache = vcache; a.Mc = Mc; a.t = t; a.t_dev = t_dev; a.H = H; a.dh = dh;
+    hipStream_t st = (hipStream_t)stream;
+#define ME_DEC_FUSED_CASE(DHV)                                                                                    \
+    if (dh == DHV) {                                                                                            \
+        constexpr int DH = DHV;                                                                                 \
+        ME_DEC_T((ln_qkv_attn_launch<T, DH>(a, E, key_pad, ld_pad, part, nsplit, M, st)))                         \
+    }
+    ME_DEC_FUSED_CASE(64)
+    ME_DEC_FUSED_CASE(48)
+    ME_DEC_FUSED_CASE(32)
+#undef ME_DEC_FUSED_CASE
     return ME_ERR_BAD_SHAPE;
 }
 

@@ -57,6 +57,9 @@ class DecodeSession:
         if -(-m.max_seq // self.nsplit) > 2048:
             raise RuntimeError("max_seq %d exceeds the cached decode's %d keys (8 splits of 2048)" % (m.max_seq, 8 * 2048))
         self.part = e(B * H, self.nsplit, dh + 2, dtype=f32)
+        # fused qkv + attention stage (me_dec_ln_qkv_attn): the last split is the new key, so it needs >= 2 splits
+        self.fused = os.environ.get("MIDIEMO_DEC_UNFUSED", "0") in ("", "0") and d <= 1024 and self.nsplit >= 2 and \
+            -(-m.max_seq // (self.nsplit - 1)) <= 2048
         self.logits = e(B, V, dtype=f32)
         self.t = 0                      # next model position to be written
         self._pos_dev = None            # device-side position: set while a step is issued for graph capture / replay
@@ -92,13 +95,21 @@ class DecodeSession:
                     ops.dec_qkv(None, None, None, eps, x_hi[r0:r1], x_lo[r0:r1] if x_lo is not None else None, W["Wqkv"],
                                 W["bqkv"], self.xres[r0:r1], self.q[r0:r1], self.kc[i][r0:r1], self.vc[i][r0:r1], Mr, d, H, dh,
                                 M, t, self._pos_dev, dt)
+                elif self.fused:
+                    # layers >= 1: LayerNorm2 of the previous layer -> q|k|v of a head -> cache append -> attention partials
+                    # in ONE launch (me_dec_ln_qkv_attn): 27 instead of 32 launches per token at 6 layers
+                    pp = f"enc_layers.{i - 1}."
+                    ops.dec_ln_qkv_attn(self.s2[r0:r1], pv(pp + "layernorm2.weight"), pv(pp + "layernorm2.bias"), eps,
+                                        W["Wqkv"], W["bqkv"], self.xres[r0:r1], self.kc[i][r0:r1], self.vc[i][r0:r1], W["E"],
+                                        None, 0, part, ns, Mr, d, H, dh, M, M, t, self._pos_dev, dt)
                 else:
                     pp = f"enc_layers.{i - 1}."
                     ops.dec_qkv(self.s2[r0:r1], pv(pp + "layernorm2.weight"), pv(pp + "layernorm2.bias"), eps, None, None,
                                 W["Wqkv"], W["bqkv"], self.xres[r0:r1], self.q[r0:r1], self.kc[i][r0:r1], self.vc[i][r0:r1],
                                 Mr, d, H, dh, M, t, self._pos_dev, dt)
-                ops.dec_attn(self.q[r0:r1], self.kc[i][r0:r1], self.vc[i][r0:r1], W["E"], None, 0, part, ns, Mr, H, dh, M, M,
-                             t, self._pos_dev, dt)
+                if i == 0 or not self.fused:
+                    ops.dec_attn(self.q[r0:r1], self.kc[i][r0:r1], self.vc[i][r0:r1], W["E"], None, 0, part, ns, Mr, H, dh, M,
+                                 M, t, self._pos_dev, dt)
                 ops.dec_proj_resid(part, ns, H, dh, None, W["Wo"], pv(p + "rga.fc.bias"), self.xres[r0:r1], self.s1[r0:r1],
                                    Mr, d, d, dt)
                 ops.dec_ln_proj(self.s1[r0:r1], pv(p + "layernorm1.weight"), pv(p + "layernorm1.bias"), eps, W["W1"],

@@ -222,6 +222,14 @@ def adamw_step(p, g, m, v, sumsq_t, clip, grad_scale, lr, beta1, beta2, eps, wei
           "me_adamw_step")
 
 
+def dec_ln_qkv_attn(s_in, gamma, beta, eps, Wqkv, bqkv, x_out, kcache, vcache, E, key_pad, ld_pad, part, nsplit, Mr, d, H, dh, M,
+                    Mc, t, t_dev, dtype):
+    """fused LayerNorm -> q|k|v of one head -> cache append -> key-split attention partials (me_dec_ln_qkv_attn)."""
+    check(lib().me_dec_ln_qkv_attn(_ptr(s_in), _ptr(gamma), _ptr(beta), float(eps), _ptr(Wqkv), _ptr(bqkv), _ptr(x_out),
+                                   _ptr(kcache), _ptr(vcache), _ptr(E), _ptr(key_pad), ld_pad, _ptr(part), nsplit, Mr, d, H, dh, M,
+                                   Mc, int(t), _ptr(t_dev), _code(dtype), _stream()), "me_dec_ln_qkv_attn")
+
+
 def dec_qkv(s_in, gamma, beta, eps, x_hi, x_lo, Wqkv, bqkv, x_out, q_out, kcache, vcache, Mr, d, H, dh, Mc, t, t_dev, dtype):
     check(lib().me_dec_qkv(_ptr(s_in), _ptr(gamma), _ptr(beta), float(eps), _ptr(x_hi), _ptr(x_lo), _ptr(Wqkv), _ptr(bqkv),
                            _ptr(x_out), _ptr(q_out), _ptr(kcache), _ptr(vcache), Mr, d, H, dh, Mc, int(t), _ptr(t_dev),
