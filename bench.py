@@ -153,6 +153,46 @@ def decode_bench(cd, gen_len=2048):
             "ids_checksum": int(ids.sum().item())}
 
 
+def decode_slide_bench(cd="bf16", n_tok=48, window=1024):
+    """The sliding-window regime of the reference's DEFAULT generate flags (generate.py:259-285: --max_input_len 1024,
+    --gen_len 2048): past 1024 tokens the window moves, every remaining token shifts its absolute position
+    (generate.py:101-103, music_multi.py:163), the K/V cache is invalid and each new token costs a full forward over the
+    window -- what generate() of this build does there too (exact, SURVEY hard part 5).  Timed: n_tok tokens of that
+    regime, B = 4, greedy pick, exactly the statements of generate()'s reference path."""
+    from midiemo import ops
+    from midiemo.models.build_model import build_model
+    from midiemo.vocab import get_maps, special_token_ids
+    torch.manual_seed(0)
+    model, _ = build_model(dict(CFG, compute_dtype=cd))
+    model = model.cuda().eval()
+    B, V = 4, CFG["vocab_size"]
+    cond = torch.tensor([[-0.8, -0.8], [-0.8, 0.8], [0.8, -0.8], [0.8, 0.8]], device="cuda")
+    specials = torch.tensor(special_token_ids(get_maps()), dtype=torch.int32, device="cuda")
+    g = torch.Generator().manual_seed(5)
+    song = torch.randint(2, V, (window + 8, B), generator=g).cuda()            # a window that is already full
+    picked = torch.empty(B, dtype=torch.long, device="cuda")
+    def one():
+        nonlocal song
+        inp = song[-window:]
+        out = model(inp.t().contiguous(), cond)[:, -1, :]
+        ops.greedy_pick(out.contiguous(), V, specials, picked, B)
+        song = torch.cat((song, picked.clone()[None, :]), 0)
+    with torch.no_grad():
+        for _ in range(4):
+            one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_tok):
+            one()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+    del model
+    torch.cuda.empty_cache()
+    return {"dtype": cd, "batch": B, "window": window, "tokens_timed": n_tok, "tokens_per_s": round(B * n_tok / wall, 1),
+            "ms_per_token_step": round(1e3 * wall / n_tok, 3),
+            "note": "full forward over the 1024-token window per new token (the reference's sliding window invalidates every cached position)"}
+
+
 def decode_cpu_baseline(budget_s=12.0):
     """The oracle's restatement of the reference's decode loop (full-window recompute per token, no cache) on the host
     cores, on a bounded prefix: B = 4, as many tokens as fit the budget (the cost per token grows with the prefix)."""
@@ -476,6 +516,7 @@ def main():
             dec["fp32"] = {k: v for k, v in decode_bench("fp32").items() if k in ("tokens_per_s", "step_ms_p50", "step_ms_p90", "roofline")}
             if not args.no_cpu_baseline:
                 dec["cpu_baseline"] = decode_cpu_baseline()
+            dec["slide"] = decode_slide_bench("bf16")
             out["decode"] = dec
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -108,8 +108,8 @@ int me_embed_fwd(void* out, void* out_lo, int dtype, const int64_t* tokens, cons
 
 /* Gradient of the prologue: accumulates (+=) into the f32 gradient tensors.
  * Rows of g_emb for token == pad_token receive nothing (padding_idx,
- * music_multi.py:57-59).  vocab = number of rows of the table (sizes the LDS-privatised
- * accumulation; 0 selects plain global atomics). */
+ * music_multi.py:57-59).  vocab = number of rows of the table: one block per row collects the positions holding
+ * that token and sums their rows (no atomics on the table); 0 selects plain global atomics. */
 int me_embed_bwd(const void* dout, int dtype, const int64_t* tokens, const float* cond,
                  float* g_emb, float* g_cw0, float* g_cb0, float* g_cw1, float* g_cb1,
                  int mode, int B, int Ltok, int d_model, int d_cond, int vocab, int pad_token,

@@ -301,6 +301,107 @@ __global__ __launch_bounds__(256) void embed_bwd_table_kernel(const T* __restric
     }
 }
 
+// Embedding-table gradient, one block per table row (round 3; the LDS-atomic version above read 199 MB for 33.6 MB of input
+// -- every block one 16-byte column slice of every row -- and issued 12.6 M LDS atomic lane-operations: 95 us).
+// Block v scans the token ids (256 KB at the headline shape, L2 resident; 16 loads per thread in flight, no barrier until the
+// whole list has been seen), collects the positions holding token v in an LDS list, then reads exactly those rows WHOLE (coalesced, four rows per wave in
+// flight) and sums them in registers; one plain += of the table row at the end: no sort pass, no workspace, no atomics on
+// the table.  The order inside a round follows the arrival order of the LDS counter: sums are reproducible up to f32
+// rounding order, like the accumulation order of the old kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_gather_kernel(const T* __restrict__ dout, const int64_t* __restrict__ tokens,
+                                                               float* __restrict__ g_emb, int rows, int Ltok, int shift, int d, int de,
+                                                               int pad_token, uint32_t thr16, float inv_keep, uint64_t seed) {
+    constexpr int CH = ET<T>::CH, CAP = 2048, MAXC = 2;                   // de <= 128 CH (bf16: 1024 columns)
+    __shared__ int list[CAP];
+    __shared__ int cnt;
+    __shared__ float red[4][64 * CH];
+    const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63, slot = tid >> 6;
+    if (v == pad_token) return;
+    const int Lm = Ltok + shift, nch = de / CH;
+    const float sq = sqrtf((float)de);
+    float acc[MAXC][CH];
+#pragma unroll
+    for (int cb = 0; cb < MAXC; ++cb)
+#pragma unroll
+        for (int e = 0; e < CH; ++e) acc[cb][e] = 0.f;
+    // positions [r_lo, r_hi) -> list (entries past CAP are counted but not stored)
+    auto scan = [&](int r_lo, int r_hi) __attribute__((always_inline)) {
+        for (int r0 = r_lo; r0 < r_hi; r0 += 256 * 16) {                  // 16 token loads per thread in flight, no barrier in between
+            int64_t tk[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int r = r0 + tid + 256 * u; tk[u] = r < r_hi ? tokens[r] : -1; }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                if (tk[u] == v) { const int pos = atomicAdd(&cnt, 1); if (pos < CAP) list[pos] = r0 + tid + 256 * u; }
+            }
+        }
+    };
+    auto gather = [&](int n) __attribute__((always_inline)) {
+#pragma unroll
+        for (int cb = 0; cb < MAXC; ++cb) {
+            const int c = cb * 64 + lane;
+            const bool on = c < nch;
+            if (cb * 64 >= nch) break;
+            for (int i0 = slot; i0 < n; i0 += 16) {                       // four rows per wave in flight, four waves
+                chunk16 x[4];
+                int64_t rowi[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = list[min(i0 + 4 * u, n - 1)];
+                    rowi[u] = (int64_t)(r / Ltok) * Lm + r % Ltok + shift;
+                    x[u] = on ? ld_chunk(dout + rowi[u] * d + c * CH) : zero_chunk();
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (i0 + 4 * u < n && on) {
+                        float g[CH];
+                        chunk_to_f<T>(x[u], g);
+                        if (thr16) {
+                            float mult[CH];
+                            drop_mult<CH>(mult, seed, 0u, (uint64_t)rowi[u] * d + c * CH, thr16, inv_keep);
+#pragma unroll
+                            for (int e = 0; e < CH; ++e) g[e] *= mult[e];
+                        }
+#pragma unroll
+                        for (int e = 0; e < CH; ++e) acc[cb][e] += g[e];
+                    }
+                }
+            }
+        }
+    };
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    scan(0, rows);                                                        // the common case: the whole token list in one go
+    __syncthreads();
+    const int total = cnt;
+    if (total == 0) return;                                               // block uniform
+    if (total <= CAP) gather(total);
+    else {                                                                // a very frequent token: rounds of CAP positions
+        for (int r0 = 0; r0 < rows; r0 += CAP) {
+            __syncthreads();
+            if (tid == 0) cnt = 0;
+            __syncthreads();
+            scan(r0, min(rows, r0 + CAP));
+            __syncthreads();
+            const int n = cnt;
+            if (n) gather(n);
+        }
+    }
+#pragma unroll
+    for (int cb = 0; cb < MAXC; ++cb) {
+        if (cb * 64 >= nch) break;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < CH; ++e) red[slot][lane * CH + e] = acc[cb][e];
+        __syncthreads();
+        for (int j = tid; j < 64 * CH; j += 256) {
+            const int col = cb * 64 * CH + j;
+            if (col < de) g_emb[(size_t)v * de + col] += (red[0][j] + red[1][j] + red[2][j] + red[3][j]) * sq;
+        }
+    }
+}
+
 __global__ void key_pad_kernel(uint8_t* __restrict__ kp, const int64_t* __restrict__ tokens, int B, int Ltok, int shift,
                                int pad_token) {
     const int Lm = Ltok + shift;
@@ -614,52 +715,67 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const LT* __restrict__ logi
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int e = 0; e < 8; ++e) bs[c][e] = 0.f;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wid; row < rows; row += (int64_t)gridDim.x * 4) {
-        const LT* lg = logits + row * ld;
-        const int64_t t = target[row];
-        const float lse = row_lse[row];
-        const bool valid = t != ignore_index;
-        if constexpr (sizeof(LT) == 2 && sizeof(T) == 2) {
-            // both 16-bit: 8 columns per lane and 16-byte access (2-byte accesses made this kernel issue bound: 37 us
-            // for 133 MB); columns in [V, ld) of the logits are never used, columns in [V, ld_d) are written as 0
-            if ((ld & 7) == 0 && (ld_d & 7) == 0 && ld >= ld_d && ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits)) & 15) == 0) {
+    bool fast = false;
+    if constexpr (sizeof(LT) == 2 && sizeof(T) == 2) {
+        // both 16-bit: 8 columns per lane and 16-byte access (2-byte accesses made this kernel issue bound: 37 us
+        // for 133 MB); columns in [V, ld) of the logits are never used, columns in [V, ld_d) are written as 0
+        fast = (ld & 7) == 0 && (ld_d & 7) == 0 && ld >= ld_d && ld_d <= 2048 &&
+               ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits)) & 15) == 0;
+    }
+    if (fast) {
+        // RU rows of a wave in flight at once (2 x RU 16-byte loads per lane at ld_d = 1024): the bias-gradient variant runs on
+        // 256 blocks (one atomic per column and block) and would otherwise leave the memory pipe three quarters empty (65 us)
+        constexpr int RU = 4;
+        const int64_t stride = (int64_t)gridDim.x * 4;
+        for (int64_t row0 = (int64_t)blockIdx.x * 4 + wid; row0 < rows; row0 += stride * RU) {
+            chunk16 ch[RU][4];
+            int64_t tg[RU];
+            float ls[RU];
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                const int64_t rc = min(row0 + u * stride, (int64_t)rows - 1);
+                tg[u] = target[rc];
+                ls[u] = row_lse[rc];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int j = lane * 8 + 512 * c;
+                    if (j < ld_d) ch[u][c] = ld_chunk(reinterpret_cast<const bf16_t*>(logits) + rc * ld + j);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                const int64_t row = row0 + u * stride;
+                if (row >= rows) break;
+                const bool valid = tg[u] != ignore_index;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int j = lane * 8 + 512 * c;
                     if (j >= ld_d) break;
-                    const chunk16 ch = ld_chunk(lg + j);
                     chunk16 o;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         float g = 0.f;
                         if (valid && j + e < V)
-                            g = (__builtin_amdgcn_exp2f(((float)reinterpret_cast<const bf16_t*>(&ch)[e] - lse) * 1.4426950408889634f) -
-                                 (j + e == t ? 1.f : 0.f)) * scale;
+                            g = (__builtin_amdgcn_exp2f(((float)reinterpret_cast<const bf16_t*>(&ch[u][c])[e] - ls[u]) * 1.4426950408889634f) -
+                                 (j + e == tg[u] ? 1.f : 0.f)) * scale;
                         bs[c][e] += g;
-                        reinterpret_cast<bf16_t*>(&o)[e] = ET<T>::from_f(g);
+                        reinterpret_cast<bf16_t*>(&o)[e] = (bf16_t)g;
                     }
-                    st_chunk(dlogits + row * ld_d + j, o);
+                    st_chunk(reinterpret_cast<bf16_t*>(dlogits) + row * ld_d + j, o);
                 }
-                for (int j = lane * 8 + 2048; j < ld_d; j += 512) {              // wider rows: no dbias support (launcher checks)
-                    const chunk16 ch = ld_chunk(lg + j);
-                    chunk16 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float g = 0.f;
-                        if (valid && j + e < V)
-                            g = (__builtin_amdgcn_exp2f(((float)reinterpret_cast<const bf16_t*>(&ch)[e] - lse) * 1.4426950408889634f) -
-                                 (j + e == t ? 1.f : 0.f)) * scale;
-                        reinterpret_cast<bf16_t*>(&o)[e] = ET<T>::from_f(g);
-                    }
-                    st_chunk(dlogits + row * ld_d + j, o);
-                }
-                continue;
             }
         }
-        for (int j = lane; j < ld_d; j += 64) {
-            float g = 0.f;
-            if (valid && j < V) g = (expf((float)lg[j] - lse) - (j == t ? 1.f : 0.f)) * scale;
-            dlogits[row * ld_d + j] = ET<T>::from_f(g);
+    } else {
+        for (int64_t row = (int64_t)blockIdx.x * 4 + wid; row < rows; row += (int64_t)gridDim.x * 4) {
+            const LT* lg = logits + row * ld;
+            const int64_t t = target[row];
+            const float lse = row_lse[row];
+            const bool valid = t != ignore_index;
+            for (int j = lane; j < ld_d; j += 64) {
+                float g = 0.f;
+                if (valid && j < V) g = (expf((float)lg[j] - lse) - (j == t ? 1.f : 0.f)) * scale;
+                dlogits[row * ld_d + j] = ET<T>::from_f(g);
+            }
         }
     }
     if (dbias == nullptr) return;                          // block uniform
@@ -1039,7 +1155,16 @@ int me_embed_bwd(const void* dout, int dtype, const int64_t* tokens, const float
     hipStream_t st = (hipStream_t)stream;
     const int de = d - dc;
     const bool table = vocab > 0 && (size_t)vocab * 32 <= 65536 && Ltok > 0 && (de & 7) == 0;
-    if (table) {
+    const int64_t rows64 = (int64_t)B * Ltok;
+    // one gather block per table row (16-bit: de <= 1024 columns, f32: 512)
+    const bool grouped = vocab > 0 && Ltok > 0 && (de & 7) == 0 && de / (dtype == ME_F32 ? 4 : 8) <= 128 && rows64 < (1ll << 30);
+    if (grouped) {
+        const int shift = mode == ME_COND_TOKEN ? 2 : 0;
+        ME_DISPATCH(dtype, (embed_bwd_gather_kernel<T><<<vocab, 256, 0, st>>>((const T*)dout, tokens, g_emb, (int)rows64, Ltok, shift, d, de,
+                                                                             pad_token, thr, inv_keep, seed)));
+    }
+    if (table || grouped) {
+        if (!grouped) {
         int ysplit = (int)(((int64_t)B * Ltok + 256 * 16 - 1) / (256 * 16));
         if (ysplit < 1) ysplit = 1;
         if (ysplit > 16) ysplit = 16;
@@ -1048,6 +1173,7 @@ int me_embed_bwd(const void* dout, int dtype, const int64_t* tokens, const float
         ME_DISPATCH(dtype, (embed_bwd_table_kernel<T><<<g2, 256, (size_t)vocab * 32, st>>>((const T*)dout, tokens, g_emb, B, Ltok,
                                                                                            shift, d, de, vocab, pad_token, thr,
                                                                                            inv_keep, seed)));
+        }
         int rc = me_launch_status();
         if (rc) return rc;
         if (mode == ME_COND_NONE) return ME_OK;        // nothing but the table to differentiate
@@ -1064,7 +1190,7 @@ int me_embed_bwd(const void* dout, int dtype, const int64_t* tokens, const float
     }
     ME_DISPATCH(dtype, (embed_bwd_kernel<T><<<grid, 256, 0, st>>>((const T*)dout, tokens, cond, g_emb, g_cw0, g_cb0, g_cw1,
                                                                   g_cb1, mode, B, Ltok, d, dc, pad_token, thr, inv_keep, seed,
-                                                                  table ? 1 : 0)));
+                                                                  (table || grouped) ? 1 : 0)));
     return me_launch_status();
 }
 
@@ -1166,7 +1292,7 @@ int me_ce_bwd(const void* logits, int ld, const int64_t* target, const float* ro
         if (!ok) return ME_ERR_BAD_SHAPE;
     }
     hipStream_t st = (hipStream_t)stream;
-    const int cap = dbias ? 256 : 8192;                     // one atomic per column and block
+    const int cap = dbias ? 512 : 2048;                     // dbias: one atomic per column and block
     if (logits_dtype == ME_F32) {
         ME_DISPATCH(dtype, (ce_bwd_kernel<T, float><<<row_grid(rows, cap), 256, 0, st>>>((const float*)logits, ld, target, row_lse,
                                                                                        (T*)dlogits, ld_d, n_valid, extra_scale, rows, V, ignore_index, dbias)));
