@@ -289,16 +289,24 @@ __global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ q
 // CAUSAL = false: backward of the bidirectional forward (MusicRegression): every key tile is visited; tiles above the
 // diagonal have no relative term (no dG, no E^T product).
 template <typename T> struct PHalf;
-template <> struct PHalf<bf16_t> { typedef bf16x4_t type; };
-template <> struct PHalf<float> { typedef f32x4_t type; };
+#ifdef ABLQ_P8
+template <> struct PHalf<bf16_t> { typedef bf16x4_t type; static constexpr int N = 4; };
+#else
+template <> struct PHalf<bf16_t> { typedef bf16x8_t type; static constexpr int N = 8; };     // two 16-byte loads per lane and tile
+#endif
+template <> struct PHalf<float> { typedef f32x4_t type; static constexpr int N = 4; };
 
+#ifndef BQ_OCC
+#define BQ_OCC 2        // 186 registers; a cap of 168 (three waves per SIMD) spills 152 bytes per lane: 411 vs 388 us per backward
+#endif
 template <typename T, int DH, bool CAUSAL = true>
-__global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
+__global__ __launch_bounds__(256, BQ_OCC) void rga_bwd_q_kernel(
     const T* __restrict__ qkv, const T* __restrict__ Epk, const T* __restrict__ out, const float* __restrict__ lse,
     const T* __restrict__ dout, T* __restrict__ dqkv, float* __restrict__ delta_ws, const T* __restrict__ PT,
     const float* __restrict__ MT, T* __restrict__ dGT, int B, int L, int Lp, int H, int M, float scale) {
     using C = ACfg<T, DH>;
     using PH = typename PHalf<T>::type;
+    constexpr int PE = PHalf<T>::N, PN = 16 / PE;        // elements per piece, pieces per lane and tile
     constexpr int LDR = 72;                         // dG ring row (elements of T): 64-column ring + 8
     __shared__ __attribute__((aligned(16))) T Ks[2][32 * C::LDV];      // natural K tile, only read transposed (dQ): the transpose-read row stride
     __shared__ __attribute__((aligned(16))) T Vs[2][32 * C::LDN];      // natural V tile: 16-byte fragment reads (dP)
@@ -369,17 +377,22 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
     T* const dgb = dGT + (size_t)bh * pt_tiles(nq32, true) * 1024;
     const int kt_hi = CAUSAL ? min(my_last_kt, nq32 - 1) : nq32 - 1;     // last tile this wave owns (clamp for the prefetch)
     const int qt = min(q0 >> 5, nq32 - 1);
-    PH pp[4];
-    float mtn = 0.f;
-    auto load_p = [&](int kt) __attribute__((always_inline)) {
+    // two tiles in flight per wave: tile kt + 2 is requested as soon as the registers of tile kt are free (steps are
+    // unrolled in pairs, U = kt & 1 selects the register set at compile time)
+    constexpr int UNR = 2;               // (four tiles in flight, UNR = 4: 224 registers, +4 %)
+    PH pp[UNR][PN];
+    float mtn[UNR];
+    auto load_p = [&](int kt, auto u_tag) __attribute__((always_inline)) {
+        constexpr int U = decltype(u_tag)::value;
         const int ktc = min(kt, kt_hi);
         const T* tp = ptb + pt_tile(ktc, qt, nq32, CAUSAL) * 1024;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) pp[g] = nt_load(reinterpret_cast<const PH*>(tp + 4 * g));      // the lane's own 16 elements, contiguous
-        mtn = mtb[(size_t)ktc * Lp];
+        for (int g = 0; g < PN; ++g) pp[U][g] = nt_load(reinterpret_cast<const PH*>(tp + PE * g));      // the lane's own 16 elements, contiguous
+        mtn[U] = mtb[(size_t)ktc * Lp];
     };
     gload(0);
-    load_p(0);
+    load_p(0, std::integral_constant<int, 0>{});
+    load_p(1, std::integral_constant<int, 1>{});
     const int eb0 = (M - 32 - q0) >> 5;
     sstore(0);
     if (nkt > 1) gload(1);
@@ -387,24 +400,19 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
     // One key tile.  MAIN = every wave of the block is strictly above its diagonal tile and tiles kt + 1, kt + 2 lie
     // entirely below L: no wave-, tile- or bounds-dependent branch encloses a global load or store (exact s_waitcnt
     // bookkeeping: vmcnt is in order).
-    auto step = [&](int kt, auto main_tag) __attribute__((always_inline)) {
+    auto step = [&](int kt, auto u_tag, auto main_tag) __attribute__((always_inline)) {
         constexpr bool MAIN = decltype(main_tag)::value;
-        const int buf = kt & 1;
+        constexpr int U = decltype(u_tag)::value, buf = U;
         if (MAIN || (wave_on && (!CAUSAL || kt <= my_last_kt))) {
             const int k0 = kt * 32;
             const bool upper = !CAUSAL && !MAIN && kt > my_last_kt;      // bidirectional only: above the diagonal, no relative term
             const int eb_lo = eb0 + kt;
-            // The next step's probability tile is requested first and pinned there (sched_barrier): left alone, the
-            // scheduler sinks those loads to the end of the step and the register copy below waits out their whole
-            // latency.  (Fetching the E^T images a step ahead as well cost 44 registers and was not faster.)
-            PH pc[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) pc[g] = pp[g];
+            // (Fetching the E^T images a step ahead as well costs 32 registers and was not faster, rounds 2 and 3.)
             Frag<T> etf[C::DB][2];
+#ifndef ABLQ_NOET
             if (!upper) et_frags(etf, eb_lo);                            // in flight during dP / dS
-            const float fac = row_on ? fast_exp2(fmaf(mtn, c2, -lse2)) : 0.f;
-            load_p(kt + 1);
-            __builtin_amdgcn_sched_barrier(0);
+#endif
+            const float fac = row_on ? fast_exp2(fmaf(mtn[U], c2, -lse2)) : 0.f;
             f32x16_t s, dp; acc_zero(dp);
 #pragma unroll
             for (int kk = 0; kk < C::KA; ++kk) {
@@ -414,9 +422,19 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
             }
             const float nds = -delta * scale;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = (ET<T>::to_f(pc[r >> 2][r & 3]) * fac) * fmaf(dp[r], scale, nds);
+            for (int r = 0; r < 16; ++r) s[r] = (ET<T>::to_f(pp[U][r / PE][r % PE]) * fac) * fmaf(dp[r], scale, nds);
+            // the tile after next into the registers just consumed.  The asm pins the order: without it the compiler
+            // hoists the loads above the last use of the old tile and keeps the old tile alive in copies whose v_movs
+            // then wait for the newest loads (the prefetch distance collapses to one step).
+            asm volatile("" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]),
+                              "+v"(s[8]), "+v"(s[9]), "+v"(s[10]), "+v"(s[11]), "+v"(s[12]), "+v"(s[13]), "+v"(s[14]), "+v"(s[15]) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#ifndef ABLQ_NOP
+            load_p(kt + UNR, u_tag);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
             T* drow = &Ds[wid][a * LDR];
-            const int t0 = (eb_lo & 1) * 32 + 31 - a + 4 * h;            // band element m sits at ring column ((eb_lo & 1) * 32 + m) & 63
+            const int t0 = U * 32 + 31 - a + 4 * h;            // band element m sits at ring column (U * 32 + m) & 63 (the lo block of a step is the hi block of the one before)
             if (!upper) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -443,13 +461,13 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     Frag<T> dgf;
-                    const T* dlo = drow + (eb_lo & 1) * 32;
+                    const T* dlo = drow + U * 32;
                     frag_load(dgf, dlo + 16 * t + 8 * h);
 #pragma unroll
                     for (int i = 0; i < C::DB; ++i) mma32(dq[i], etf[i][t], dgf);
                 }
                 T* const dg_dst = dgb + dg_tile(q0 >> 5, kt) * 1024;
-                const T* ring = &Ds[wid][(eb_lo & 1) * 32];                  // lo block: ring rows q, 32 columns m, row stride LDR
+                const T* ring = &Ds[wid][U * 32];                  // lo block: ring rows q, 32 columns m, row stride LDR
                 if constexpr (sizeof(T) == 2) {
                     typedef short v4s __attribute__((ext_vector_type(4)));
                     const int gidx = lane >> 4, l16 = lane & 15;
@@ -465,7 +483,11 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
                         reinterpret_cast<v4s*>(&c)[0] = x[0];
                         reinterpret_cast<v4s*>(&c)[1] = x[1];
                         // row m = 16 kh + l16, queries 8 gidx .. + 7 -> fragment-image position (dg_pos)
+#ifndef ABLQ_NODG
                         nt_store(c.v, reinterpret_cast<u32x4_t*>(dg_dst + (gidx >> 1) * 512 + (kh * 16 + l16 + 32 * (gidx & 1)) * 8));
+#else
+                        if (c.v[0] == 0x12345678u && c.v[3] == 0x9abcdef0u) nt_store(c.v, reinterpret_cast<u32x4_t*>(dg_dst + (gidx >> 1) * 512 + (kh * 16 + l16 + 32 * (gidx & 1)) * 8));
+#endif
                     }
                 } else {
 #pragma unroll
@@ -478,7 +500,9 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
         }
         if constexpr (MAIN) {
             sstore(buf ^ 1);                      // buf^1 was last read in step kt-1 (barrier since)
+#ifndef ABLQ_NOKV
             gload_full(kt + 2);
+#endif
         } else if (kt + 1 < nkt) {
             sstore(buf ^ 1);
             if (kt + 2 < nkt) gload(kt + 2);
@@ -489,8 +513,15 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
     const int nmain = (qb * 128 + 96 < L) ? max(0, min(qb * 4, (L >> 5) - 2)) : 0;
     int kt = 0;
     vm_drain();                         // loop entry state = nothing in flight: the header's waits are the back edge's exact counts
-    for (; kt < nmain; ++kt) step(kt, std::true_type{});
-    for (; kt < nkt; ++kt) step(kt, std::false_type{});
+#ifndef ABLQ_EMPTY
+    using U0 = std::integral_constant<int, 0>;
+    using U1 = std::integral_constant<int, 1>;
+    for (; kt + 1 < nmain; kt += 2) { step(kt, U0{}, std::true_type{}); step(kt + 1, U1{}, std::true_type{}); }
+    for (; kt < nkt; kt += 2) {
+        step(kt, U0{}, std::false_type{});
+        if (kt + 1 < nkt) step(kt + 1, U1{}, std::false_type{});
+    }
+#endif
     if (!row_on) return;
     T* dqp = dqkv + ((size_t)b * L + q) * ldq + head * DH;
 #pragma unroll
