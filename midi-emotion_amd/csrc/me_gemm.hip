@@ -976,49 +976,105 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
 
 // Multi-tensor variant: one launch refreshes every prepared weight of the model (31 tensors at the headline
 // config: 31 launches of ~5 us for 164 MB of traffic that takes ~35 us at bandwidth).  desc = device array of
-// me_ct_desc; block b finds its tensor by a linear scan over the cumulative tile counts.
+// me_ct_desc.  Persistent blocks walk 64 x 64 supertiles (all tensors, in descriptor order): 16-byte loads of the f32
+// master rows (256 B per row segment), 8-byte stores of the T copy straight from the registers and, through the LDS
+// tile, 16-byte stores of the transposed copy (128 B per segment) -- the round-2 version moved one 32 x 32 tile per
+// block with 4-byte loads and 2-byte stores (80 k blocks, 2.6 TB/s).  Tensors whose shape or leading dimensions do not
+// allow the vector accesses take guarded element accesses on the same walk.
 template <typename T>
 __global__ __launch_bounds__(256) void cast_transpose_multi_kernel(const me_ct_desc* __restrict__ desc, int n) {
-    __shared__ float tile[32][33];
-    int ti = 0;
-    while (ti + 1 < n && (int)blockIdx.x >= desc[ti + 1].tile_begin) ++ti;
-    const me_ct_desc dsc = desc[ti];
-    const int local = blockIdx.x - dsc.tile_begin;
-    const int tiles_x = (dsc.cols + 31) / 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-    const int r0 = (local / tiles_x) * 32, c0 = (local % tiles_x) * 32;
-    const int rows = dsc.rows, cols = dsc.cols;
-    T* dst = reinterpret_cast<T*>(dsc.dst);
-    T* dstT = reinterpret_cast<T*>(dsc.dstT);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = r0 + ty + i * 8, c = c0 + tx;
-        float v = (r < rows && c < cols) ? dsc.src[(size_t)r * cols + c] : 0.f;
-        tile[ty + i * 8][tx] = v;
-        if (dst && r < rows && c < cols) dst[(size_t)r * dsc.ld_dst + c] = ET<T>::from_f(v);
-    }
-    if (!dstT) return;
-    __syncthreads();
-    if (dsc.mode == ME_CT_PACK_REL) {
-        // relative table: this 32 x 32 tile (row block eb, column block ib) holds two row images (kk = 2 ib, 2 ib + 1)
-        // and the two transposed images (ib, t = 0 / 1) of the packed block -- layout of rel_pack_kernel (me_attn.hip)
-        const int KA = cols / 16, DB = (cols + 31) / 32, eb = r0 >> 5, ib = c0 >> 5;
-        T* blk = dstT + (size_t)eb * (KA + 2 * DB) * 512;
-        const int img = (threadIdx.x >> 6) & 1, lane = threadIdx.x & 63, a = lane & 31, h = lane >> 5, j0 = (threadIdx.x >> 7) * 4;
-        if (2 * ib + img < KA) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                blk[((2 * ib + img) * 64 + lane) * 8 + j0 + j] = ET<T>::from_f(tile[a][img * 16 + h * 8 + j0 + j]);
+    __shared__ float tile[64][65];
+    const int tid = threadIdx.x;
+    int ti = 0, base = 0;
+    me_ct_desc dsc = desc[0];
+    auto nsup = [](const me_ct_desc& d) { return ((d.rows + 63) / 64) * ((d.cols + 63) / 64); };
+    int cnt = nsup(dsc);
+    for (int st = blockIdx.x;; st += gridDim.x) {
+        while (st >= base + cnt) {
+            base += cnt;
+            if (++ti >= n) return;
+            dsc = desc[ti];
+            cnt = nsup(dsc);
         }
+        const int local = st - base;
+        const int rows = dsc.rows, cols = dsc.cols;
+        const int tiles_x = (cols + 63) / 64;
+        const int r0 = (local / tiles_x) * 64, c0 = (local % tiles_x) * 64;
+        T* dst = reinterpret_cast<T*>(dsc.dst);
+        T* dstT = reinterpret_cast<T*>(dsc.dstT);
+        const bool vsrc = (cols & 3) == 0 && (reinterpret_cast<uintptr_t>(dsc.src) & 15) == 0;
+        const bool vdst = dst && (dsc.ld_dst & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+        {
+            const int cl = (tid & 15) * 4, c = c0 + cl;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            blk[(KA + 2 * ib + img) * 512 + lane * 8 + j0 + j] = ET<T>::from_f(tile[16 * img + 8 * h + j0 + j][a]);
-        return;
-    }
+            for (int i = 0; i < 4; ++i) {
+                const int rl = (tid >> 4) + 16 * i, r = r0 + rl;
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (r < rows) {
+                    if (vsrc && c + 3 < cols) {
+                        const f32x4_t x = *reinterpret_cast<const f32x4_t*>(dsc.src + (size_t)r * cols + c);
+                        v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+                    } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = c0 + ty + i * 8, r = r0 + tx;    // dstT[c][r]
-        if (c < cols && r < rows) dstT[(size_t)c * dsc.ld_dstT + r] = ET<T>::from_f(tile[tx][ty + i * 8]);
+                        for (int e = 0; e < 4; ++e) if (c + e < cols) v[e] = dsc.src[(size_t)r * cols + c + e];
+                    }
+                    if (dst) {
+                        if (vdst && c + 3 < cols) st4_t<T>(dst + (size_t)r * dsc.ld_dst + c, v[0], v[1], v[2], v[3]);
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) if (c + e < cols) dst[(size_t)r * dsc.ld_dst + c + e] = ET<T>::from_f(v[e]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tile[rl][cl + e] = v[e];
+            }
+        }
+        if (dstT) {
+            __syncthreads();
+            if (dsc.mode == ME_CT_PACK_REL) {
+                // relative table: a 32 x 32 tile (row block eb, column block ib) holds two row images (kk = 2 ib, 2 ib + 1)
+                // and the two transposed images (ib, t = 0 / 1) of the packed block -- layout of rel_pack_kernel (me_attn.hip)
+                const int KA = cols / 16, DB = (cols + 31) / 32;
+                const int img = (tid >> 6) & 1, lane = tid & 63, a = lane & 31, h = lane >> 5, j0 = (tid >> 7) * 4;
+#pragma unroll
+                for (int sub = 0; sub < 4; ++sub) {
+                    const int sr = (sub >> 1) * 32, sc = (sub & 1) * 32;
+                    if (r0 + sr >= rows || c0 + sc >= cols) continue;
+                    const int eb = (r0 + sr) >> 5, ib = (c0 + sc) >> 5;
+                    T* blk = dstT + (size_t)eb * (KA + 2 * DB) * 512;
+                    if (2 * ib + img < KA) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            blk[((2 * ib + img) * 64 + lane) * 8 + j0 + j] = ET<T>::from_f(tile[sr + a][sc + img * 16 + h * 8 + j0 + j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        blk[(KA + 2 * ib + img) * 512 + lane * 8 + j0 + j] = ET<T>::from_f(tile[sr + 16 * img + 8 * h + j0 + j][sc + a]);
+                }
+            } else {
+                const bool vT = (dsc.ld_dstT & 7) == 0 && (reinterpret_cast<uintptr_t>(dstT) & 15) == 0;
+                const int rg = (tid & 7) * 8, r = r0 + rg;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int cl = (tid >> 3) + 32 * i, c = c0 + cl;      // dstT[c][r .. r + 7]
+                    if (c < cols && r < rows) {
+                        float v[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = tile[rg + j][cl];
+                        T* o = dstT + (size_t)c * dsc.ld_dstT + r;
+                        if (vT && r + 7 < rows) {
+                            st4_t<T>(o, v[0], v[1], v[2], v[3]);
+                            st4_t<T>(o + 4, v[4], v[5], v[6], v[7]);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) if (r + j < rows) o[j] = ET<T>::from_f(v[j]);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();               // the tile is rewritten by the next supertile
     }
 }
 
@@ -1272,8 +1328,10 @@ int me_cast_transpose_multi(const me_ct_desc* desc_dev, int n_tensors, int total
     if (!desc_dev) return ME_ERR_NULL;
     if (n_tensors <= 0 || total_tiles <= 0) return ME_ERR_BAD_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == ME_F32) cast_transpose_multi_kernel<float><<<total_tiles, 256, 0, st>>>(desc_dev, n_tensors);
-    else if (dtype == ME_BF16) cast_transpose_multi_kernel<bf16_t><<<total_tiles, 256, 0, st>>>(desc_dev, n_tensors);
+    // persistent: every block walks the 64 x 64 supertiles st = blockIdx.x, + gridDim.x, ... (at most total_tiles of them)
+    const unsigned grid = (unsigned)(total_tiles < 2048 ? total_tiles : 2048);
+    if (dtype == ME_F32) cast_transpose_multi_kernel<float><<<grid, 256, 0, st>>>(desc_dev, n_tensors);
+    else if (dtype == ME_BF16) cast_transpose_multi_kernel<bf16_t><<<grid, 256, 0, st>>>(desc_dev, n_tensors);
     else return ME_ERR_BAD_DTYPE;
     return me_launch_status();
 }

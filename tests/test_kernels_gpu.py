@@ -801,6 +801,37 @@ def test_rel_pack_layout_and_refresh_path(ops, dtype, dh):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_cast_transpose_multi_shapes(ops, dtype):
+    """One launch over tensors of every kind the walk has to handle: vector path (multiples of 64), ragged edges
+    (1007 rows, 77 columns), odd column counts (element path), padded leading dimensions, copy-only and transpose-only
+    descriptors, a tensor smaller than one supertile.  Bit-exact against torch's cast / transpose."""
+    g = torch.Generator().manual_seed(17)
+    shapes = [(512, 512), (1007, 512), (512, 2048), (130, 77), (3, 5), (64, 200), (96, 64), (1, 512)]
+    items, want = [], []
+    for i, (r, c) in enumerate(shapes):
+        src = torch.randn(r, c, generator=g).to(DEV)
+        ld = c + (8 if i % 2 else 0)
+        ldT = (r + 7) // 8 * 8 + (8 if i % 3 == 0 else 0)
+        dst = torch.full((r, ld), 7.0, dtype=dtype, device=DEV)[:, :c] if i != 5 else None
+        dstT = torch.full((c, ldT), 7.0, dtype=dtype, device=DEV)[:, :r] if i != 6 else None
+        if i == 3:                                   # odd leading dimension as well: every access takes the element path
+            dstT = torch.full((c, r + 1), 7.0, dtype=dtype, device=DEV)[:, :r]
+        items.append((src, dst, dstT))
+        want.append((src.to(dtype), src.t().to(dtype)))
+    desc, n, tiles = ops.make_ct_desc(items, DEV)
+    ops.cast_transpose_multi(desc, n, tiles, dtype)
+    torch.cuda.synchronize()
+    for (src, dst, dstT), (w, wT), shp in zip(items, want, shapes):
+        if dst is not None:
+            assert torch.equal(dst, w), shp
+            assert (dst.as_strided((dst.shape[0], dst.stride(0)), (dst.stride(0), 1))[:, dst.shape[1]:] == 7).all(), shp   # padding untouched
+        if dstT is not None:
+            assert torch.equal(dstT, wT), shp
+            assert (dstT.as_strided((dstT.shape[0], dstT.stride(0)), (dstT.stride(0), 1))[:, dstT.shape[1]:] == 7).all(), shp
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,H,L,dh,M", [(2, 2, 1, 32, 64), (1, 3, 7, 64, 64), (2, 2, 33, 32, 64), (1, 2, 130, 64, 256),
                                          (2, 2, 256, 64, 2048), (1, 1, 300, 48, 512), (2, 4, 520, 64, 2048)])
 def test_rga_fwd_bidirectional(ops, dtype, B, H, L, dh, M):
