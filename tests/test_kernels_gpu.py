@@ -330,7 +330,7 @@ def test_dec_qkv_ln_prologue_and_cache_append(ops, dtype):
 
 # ------------------------------------------------------------------ residual + LayerNorm
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("rows,d", [(37, 64), (256, 512), (5, 256)])
+@pytest.mark.parametrize("rows,d", [(37, 64), (256, 512), (5, 256), (301, 512), (1, 512), (8195, 256)])   # odd row counts: the two-rows-per-wave tails
 def test_resid_ln_fwd_bwd(ops, dtype, rows, d):
     x = rnd(rows, d, seed=17).to(dtype)
     a = rnd(rows, d, seed=18).to(dtype)
