@@ -150,8 +150,8 @@ size_t me_workspace_bytes(int op, int M, int N, int K, int dtype);
  * A = dY (T, lda), B = X (T, ldb), dW f32 (lddw).  If dbias != NULL also
  * dbias[N] += column sums of A.  Replaces the weight/bias gradients of nn.Linear.
  * The token dimension is split over the CUs.  ws (16-byte aligned, ws_bytes >=
- * me_workspace_bytes(ME_WS_GEMM_TN, T, N, K, dtype)) receives the partial tiles, which are then summed in a FIXED
- * order (bit-reproducible dW); it may be reused by the next call on the same stream.  ws = NULL: the partial tiles
+ * me_workspace_bytes(ME_WS_GEMM_TN, T, N, K, dtype)) receives the partial tiles and the partial bias column sums, which
+ * are then summed in a FIXED order (bit-reproducible dW and dbias); it may be reused by the next call on the same stream.  ws = NULL: the partial tiles
  * are accumulated with f32 atomics instead (order-dependent rounding, slower); a workspace that is too small is an
  * error (ME_ERR_WORKSPACE), never a silent fallback. */
 int me_gemm_tn_acc(const void* A, int lda, const void* B, int ldb, float* dW, int lddw,

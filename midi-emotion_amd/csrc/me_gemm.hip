@@ -881,11 +881,14 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const tn_group G, float
         *reinterpret_cast<f32x4_t*>(mine) = (f32x4_t){bs8[0], bs8[1], bs8[2], bs8[3]};
         *reinterpret_cast<f32x4_t*>(mine + 4) = (f32x4_t){bs8[4], bs8[5], bs8[6], bs8[7]};
         __syncthreads();
-        if (tid < 256 && n0 + tid < N) {
+        if (tid < 256) {
             float t = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) t += red[r * 256 + tid];
-            atomicAdd(&dbias[n0 + tid], t);
+            // with a workspace the column sums of this token range go to its bias region (after all partial tiles) and the
+            // reduce kernel adds the ranges in a fixed order -- like dW, db is then reproducible bit for bit
+            if (ws) ws[(size_t)gridDim.x * (32 * 512 * 4) + (size_t)blockIdx.x * 256 + tid] = t;
+            else if (n0 + tid < N) atomicAdd(&dbias[n0 + tid], t);
         }
     }
     if (ws) {
@@ -948,6 +951,17 @@ __global__ __launch_bounds__(512) void tn256_reduce_kernel(const float* __restri
     const int row = nx * 256 + wr * 128 + i * 32 + 8 * q + 4 * (lane >> 5);
 #pragma unroll
     for (int e = 0; e < 4; ++e) if (row + e < N) dW[(size_t)(row + e) * lddw + col] += sum[e];
+    // bias column sums of the tile column's first tile (ky = 0): the token ranges in the same fixed order
+    float* __restrict__ dbias = G.p[pi].dbias;
+    if (dbias && ky == 0 && slot == 0 && tid < 256 && nx * 256 + tid < N) {
+        const float* wsb = ws + (size_t)per * 8 * (32 * 512 * 4);               // after the partial tiles of all gridDim.x = 8 per blocks
+        float t = 0.f;
+        for (int z2 = 0; z2 < nsplit; ++z2) {
+            const int g = z2 * ntile + gtile;
+            t += wsb[(size_t)((g % per) * 8 + g / per) * 256 + tid];
+        }
+        dbias[nx * 256 + tid] += t;
+    }
 }
 
 // f32 master -> T copy and/or T transposed copy, 32x32 tiles through LDS
@@ -1182,7 +1196,7 @@ static int tn256_group_launch(const tn_item_256* it, int n, int Tn, void* ws_cal
     G.np = n; G.ntile = ntile; G.nsplit = ns; G.t_per_block = tp; G.Tn = Tn; G.pad_ = 0;
     // partial tiles (256 KB per block) go to the caller's workspace and are summed in a fixed order by
     // tn256_reduce_kernel; without a workspace the blocks accumulate with f32 atomics (order-dependent sum)
-    const size_t need = (size_t)grid256 * 32 * 512 * 16;
+    const size_t need = (size_t)grid256 * (32 * 512 * 16 + 1024);             // partial tiles + 256 bias column sums per block
     float* ws = nullptr;
     if (ws_caller && ns > 1) {
         if (ws_bytes < need || !aligned16(ws_caller)) return ME_ERR_WORKSPACE;
@@ -1246,7 +1260,7 @@ static size_t tn_ws_bytes_tiles(int Tn, int ntile) {
     int ns, tp, grid256;
     tn256_plan(Tn, ntile, &ns, &tp, &grid256);
     if (ns <= 1) return 0;
-    return (size_t)grid256 * 32 * 512 * 16;
+    return (size_t)grid256 * (32 * 512 * 16 + 1024);
 }
 // ... gemm_tn_launch<bf16> needs for (T, N, K); 0 = the shape runs a kernel without one
 static size_t tn_ws_bytes(int Tn, int N, int K) {

@@ -210,6 +210,47 @@ def test_gemm_tn_acc_group(ops, dtype, T, shapes):
     if ws is not None and grouped:                       # the grouped kernel: fixed summation order
         for a, b in zip(runs[0], runs[1]):
             assert torch.equal(a[2], b[2])
+            if a[3] is not None:
+                assert torch.equal(a[3], b[3])               # the bias column sums go through the workspace as well
+
+
+def test_gemm_full_size_replication_property(ops):
+    """The train step's GEMM shapes at FULL size (T = 32768 tokens, bf16) through a size-independent property: the token
+    dimension is a 256-row block replicated 128 times.  NT: every 256-row block of C must be bit-identical to the 256-row
+    product (tile walk, XCD renumbering, persistent-tile bookkeeping).  TN (grouped launch of a layer's four products):
+    dW of the full problem = 128 x dW of one block up to f32 summation order, and two runs are bit-identical."""
+    dt = torch.bfloat16
+    T0, R = 256, 128
+    T = T0 * R
+    shapes = [(1536, 512), (512, 512), (2048, 512), (512, 2048)]
+    for N, K in shapes:
+        A0 = rnd(T0, K, seed=N + K).to(dt).to(DEV)
+        W = rnd(N, K, seed=N + 2 * K).to(dt).to(DEV)
+        bias = rnd(N, seed=5).float().to(DEV)
+        C0 = torch.empty(T0, N, dtype=dt, device=DEV)
+        ops.gemm_nt(A0, W, C0, bias=bias)
+        C = torch.empty(T, N, dtype=dt, device=DEV)
+        ops.gemm_nt(A0.repeat(R, 1), W, C, bias=bias)
+        assert torch.equal(C.view(R, T0, N), C0.expand(R, T0, N)), (N, K)
+        ref = (A0.double() @ W.double().t() + bias.double())
+        assert relerr(C0, ref) < tol(dt, 1e-6, ref)
+    items_small, items_full = [], []
+    for N, K in shapes:
+        dY0 = rnd(T0, N, seed=3 * N + K).to(dt).to(DEV)
+        X0 = rnd(T0, K, seed=N + 7 * K).to(dt).to(DEV)
+        items_small.append((dY0, X0))
+        items_full.append((dY0.repeat(R, 1), X0.repeat(R, 1)))
+    def run(items, Tn):
+        outs = [(torch.zeros(a.shape[1], b.shape[1], device=DEV), torch.zeros(a.shape[1], device=DEV)) for a, b in items]
+        need = max([ops.workspace_bytes(ops.ME_WS_GEMM_TN_GROUP, Tn, ops.tn_group_tiles(shapes), 0, dt)] +
+                   [ops.workspace_bytes(ops.ME_WS_GEMM_TN, Tn, n, k, dt) for n, k in shapes])
+        ws = torch.empty(max(need, 16), dtype=torch.uint8, device=DEV)
+        ops.gemm_tn_acc_group([(a, b, dW, db, a.shape[1], b.shape[1]) for (a, b), (dW, db) in zip(items, outs)], Tn, dt, ws=ws)
+        return outs
+    full1, full2, small = run(items_full, T), run(items_full, T), run(items_small, T0)
+    for (dW1, db1), (dW2, db2), (dWs, dbs), (N, K) in zip(full1, full2, small, shapes):
+        assert torch.equal(dW1, dW2) and torch.equal(db1, db2), (N, K)          # fixed summation order
+        assert relerr(dW1, R * dWs) < 1e-5 and relerr(db1, R * dbs) < 1e-5, (N, K)
 
 
 def test_resid_ln_fwd_hi_lo_residual_stream(ops):
@@ -416,6 +457,56 @@ def test_ce_fwd_bwd(ops, dtype):
     ops.ce_bwd(lgd, tgt.to(DEV), row_lse, dl, acc[1:2], 1.0, rows, V, 0)
     assert relerr(dl[:, :V], l64.grad) < tol(dtype, 1e-5, l64.grad)
     assert (dl[:, V:] == 0).all()
+
+
+def test_rowwise_kernels_full_size_replication_property(ops):
+    """LayerNorm forward / backward and the loss head at FULL size (T = 32768 rows, bf16, d = 512, V = 1007) through row
+    independence: the rows are a 256-row block replicated 128 times.  Per-row outputs of every replica must be bit-identical
+    to the 256-row launch (which the tests above check against f64); sums over rows (d gamma, d beta, loss, bias gradient)
+    must be 128 x the small launch's up to f32 summation order; dlogits scale with 1 / n_valid = an exact power of two."""
+    dt = torch.bfloat16
+    T0, R, d, V, ld = 256, 128, 512, 1007, 1024
+    T = T0 * R
+    x0, xl0, a0 = (rnd(T0, d, seed=90 + i).to(dt).to(DEV) for i in range(3))
+    gamma, beta = (1 + 0.1 * rnd(d, seed=93)).float().to(DEV), (0.1 * rnd(d, seed=94)).float().to(DEV)
+    def ln(x, xl, a, rows):
+        y, yl, s_ = (torch.empty(rows, d, dtype=dt, device=DEV) for _ in range(3))
+        st = torch.empty(rows, 2, device=DEV)
+        ops.resid_ln_fwd(x, a, gamma, beta, y, s_, st, rows, d, 1e-6, 0.0, 0, 1, x_lo=xl, y_lo=yl)
+        return y, yl, s_, st
+    small = ln(x0, xl0, a0, T0)
+    full = ln(x0.repeat(R, 1), xl0.repeat(R, 1), a0.repeat(R, 1), T)
+    for f, s_ in zip(full, small):
+        assert torch.equal(f.view(R, T0, -1), s_.expand(R, *s_.shape))
+    dy0 = rnd(T0, d, seed=95).to(dt).to(DEV)
+    def lnb(dy, s_, st, rows):
+        dx, da = torch.empty(rows, d, dtype=dt, device=DEV), torch.empty(rows, d, dtype=dt, device=DEV)
+        dg, db = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+        ops.resid_ln_bwd(dy, s_, st, gamma, dx, da, dg, db, rows, d, 0.0, 0, 1)
+        return dx, dg, db
+    bs = lnb(dy0, small[2], small[3], T0)
+    bf = lnb(dy0.repeat(R, 1), full[2], full[3], T)
+    assert torch.equal(bf[0].view(R, T0, d), bs[0].expand(R, T0, d))
+    assert relerr(bf[1], R * bs[1]) < 1e-5 and relerr(bf[2], R * bs[2]) < 1e-5
+    # loss head: bf16 logits [rows, ld], ignore_index 0
+    lg0 = torch.zeros(T0, ld, dtype=dt, device=DEV)
+    lg0[:, :V] = rnd(T0, V, seed=96, scale=4.0).to(dt).to(DEV)
+    tgt0 = torch.randint(0, V, (T0,), generator=torch.Generator().manual_seed(97))
+    tgt0[::6] = 0
+    def ce(lg, tgt, rows):
+        row_lse = torch.empty(rows, device=DEV)
+        acc = torch.zeros(2, device=DEV)
+        ops.ce_fwd(lg, tgt, row_lse, acc[0:1], acc[1:2], rows, V, 0)
+        dl = torch.empty(rows, ld, dtype=dt, device=DEV)
+        dbias = torch.zeros(ld, device=DEV)
+        ops.ce_bwd(lg, tgt, row_lse, dl, acc[1:2], 1.0, rows, V, 0, dbias=dbias if ops.ce_bwd_fuses_dbias(lg, dl) else None)
+        return row_lse, acc, dl, dbias
+    cs = ce(lg0, tgt0.to(DEV), T0)
+    cf = ce(lg0.repeat(R, 1), tgt0.repeat(R).to(DEV), T)
+    assert torch.equal(cf[0].view(R, T0), cs[0].expand(R, T0))
+    assert abs(cf[1][1].item() - R * cs[1][1].item()) < 0.5 and abs(cf[1][0].item() / (R * cs[1][0].item()) - 1) < 1e-5
+    assert torch.equal((cf[2].float() * R).view(R, T0, ld), cs[2].float().expand(R, T0, ld))      # 1 / n_valid: exact factor 2^-7
+    assert relerr(cf[3][:V], cs[3][:V]) < 1e-5                                                  # sum of 128 x (1 / 128) rows
 
 
 @pytest.mark.parametrize("V,ld", [(1007, 1024), (1017, 1024), (97, 128), (2500, 2560)])
@@ -679,6 +770,30 @@ def test_rga_long_unpadded_and_mixed_rows(ops, dtype, L, M):
     errs = {n: relerr(got0[n], ref0[n]) for n in ("O", "lse", "dq", "dk", "dv", "dE")}
     lims = attn_bounds(dtype, 3e-5, q, k, v, E, dO, nopad)
     assert attn_ok(errs, lims), (errs, lims)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_rga_full_size_replication_property(ops, dtype):
+    """BASELINE config 2 at FULL size (B = 32, H = 8, L = 1024, dh = 64, M = 1024) without a full-size oracle run: the batch is a
+    2-sequence case (oracle-checked by the tests above at this L) replicated 16 times, one sequence with trailing PAD.
+    Every (sequence, head) is computed independently, so O, lse, dq, dk, dv of every replica must be BIT-identical to the
+    2-sequence launch of the same kernels (grid mapping, workspace indexing and tile bookkeeping at the full grid), and dE --
+    a sum over the batch -- must be 16 x the small launch's dE up to f32 summation order."""
+    B0, R, H, L, dh, M = 2, 16, 8, 1024, 64, 1024
+    q, k, v, E, dO, _ = attn_case(B0, H, L, dh, M, seed=77, pad_rows=False)
+    pad = torch.zeros(B0, L, dtype=torch.bool)
+    pad[1, -100:] = True
+    small = run_attn(ops, dtype, q, k, v, E, dO, pad)
+    rep = lambda t: t.repeat(R, *([1] * (t.dim() - 1)))
+    full = run_attn(ops, dtype, rep(q), rep(k), rep(v), E, rep(dO), rep(pad))
+    for n in ("O", "lse", "dq", "dk", "dv"):
+        a, b = full[n].nan_to_num(7.0), rep(small[n]).nan_to_num(7.0)
+        assert torch.equal(a, b), (n, (a - b).abs().max().item())
+    assert relerr(full["dE"], R * small["dE"]) < 1e-5, relerr(full["dE"], R * small["dE"])
+    ok = ~pad[:, None, :, None].expand(B0, H, L, dh)                        # spot check of the small launch against the oracle's f64 run
+    ref = ref_attn(q[:, :1], k[:, :1], v[:, :1], E, dO[:, :1], pad, dtype)
+    lim = 3e-5 if dtype == torch.float32 else 2e-2
+    assert relerr(small["O"][:, :1][ok[:, :1]], ref["O"][ok[:, :1]]) < lim
 
 
 def test_rga_fully_masked_row_is_nan(ops):
