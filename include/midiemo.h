@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 16
+#define ME_ABI_VERSION 17
 
 enum { ME_F32 = 0, ME_BF16 = 1 };
 
@@ -109,11 +109,16 @@ int me_embed_fwd(void* out, void* out_lo, int dtype, const int64_t* tokens, cons
 /* Gradient of the prologue: accumulates (+=) into the f32 gradient tensors.
  * Rows of g_emb for token == pad_token receive nothing (padding_idx,
  * music_multi.py:57-59).  vocab = number of rows of the table: one block per row collects the positions holding
- * that token and sums their rows (no atomics on the table); 0 selects plain global atomics. */
+ * that token and sums their rows (no atomics on the table); 0 selects plain global atomics.
+ * ws (may be NULL): me_workspace_bytes(ME_WS_EMBED_BWD, 0, 0, 0, dtype) = 1024 bytes, 16-byte aligned, ZERO before the
+ * first call; the library leaves it zeroed, so one buffer serves every later call on the same stream.  With it, tokens
+ * that occur more than 192 times in the batch (real MIDI streams: time shifts, frequent notes) are cut into work items of
+ * ~128 occurrences and spread over the chip by a second launch instead of being summed by a single block; results are the
+ * same up to f32 summation order. */
 int me_embed_bwd(const void* dout, int dtype, const int64_t* tokens, const float* cond,
                  float* g_emb, float* g_cw0, float* g_cb0, float* g_cw1, float* g_cb1,
                  int mode, int B, int Ltok, int d_model, int d_cond, int vocab, int pad_token,
-                 float p_drop, uint64_t seed, void* stream);
+                 float p_drop, uint64_t seed, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- key padding mask -----------------------------------------------------
  * key_pad[B, Lm] (uint8, 1 = masked key) from tokens == pad_token; the `shift`
@@ -142,7 +147,8 @@ enum {
     ME_WS_RGA_PT = 2,    /* me_rga_fwd / me_rga_bwd PT: (M, N, K) = (B*H, Lp, causal) */
     ME_WS_RGA_DGT = 3,   /* me_rga_bwd dGT workspace:   (M, N, K) = (B*H, Lp, unused) */
     ME_WS_RGA_MT = 4,    /* me_rga_fwd / me_rga_bwd MT: (M, N, K) = (B*H, Lp, unused) */
-    ME_WS_GEMM_TN_GROUP = 5  /* me_gemm_tn_acc_group: (M, N, K) = (T, sum over the items of ceil(N/256) * (K/256), unused) */
+    ME_WS_GEMM_TN_GROUP = 5, /* me_gemm_tn_acc_group: (M, N, K) = (T, sum over the items of ceil(N/256) * (K/256), unused) */
+    ME_WS_EMBED_BWD = 6      /* me_embed_bwd frequent-token list: 1024 bytes, zero before the first use */
 };
 size_t me_workspace_bytes(int op, int M, int N, int K, int dtype);
 

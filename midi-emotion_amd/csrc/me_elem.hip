@@ -308,36 +308,41 @@ __global__ __launch_bounds__(256) void embed_bwd_table_kernel(const T* __restric
 // flight) and sums them in registers; one plain += of the table row at the end: no sort pass, no workspace, no atomics on
 // the table.  The order inside a round follows the arrival order of the LDS counter: sums are reproducible up to f32
 // rounding order, like the accumulation order of the old kernel.
-template <typename T>
+constexpr int EMB_HEAVY = 192, EMB_MAXH = 127, EMB_SLICE = 128;   // tokens with more occurrences go to the helper launch; capacity of its
+                                                                   // (token, count) list (1 KB workspace); rows per helper work item
+template <typename T, int TPB>
 __global__ __launch_bounds__(256) void embed_bwd_gather_kernel(const T* __restrict__ dout, const int64_t* __restrict__ tokens,
-                                                               float* __restrict__ g_emb, int rows, int Ltok, int shift, int d, int de,
-                                                               int pad_token, uint32_t thr16, float inv_keep, uint64_t seed) {
+                                                               float* __restrict__ g_emb, int* __restrict__ hv, int rows, int Ltok, int shift, int d, int de,
+                                                               int vocab, int pad_token, uint32_t thr16, float inv_keep, uint64_t seed) {
+    // TPB consecutive table rows per block: ONE scan of the token ids serves all of them (the scan -- every block reads the
+    // whole 256 KB id list through L2 -- is what bounds this kernel: 1007 blocks x 1 row 34 us, 504 x 2 rows see the launcher)
     constexpr int CH = ET<T>::CH, CAP = 2048, MAXC = 2;                   // de <= 128 CH (bf16: 1024 columns)
-    __shared__ int list[CAP];
-    __shared__ int cnt;
+    __shared__ int list[TPB][CAP];
+    __shared__ int cnt[TPB];
+    __shared__ int pub_idx;
     __shared__ float red[4][64 * CH];
-    const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63, slot = tid >> 6;
-    if (v == pad_token) return;
+    const int v0 = blockIdx.x * TPB, tid = threadIdx.x, lane = tid & 63, slot = tid >> 6;
     const int Lm = Ltok + shift, nch = de / CH;
     const float sq = sqrtf((float)de);
     float acc[MAXC][CH];
-#pragma unroll
-    for (int cb = 0; cb < MAXC; ++cb)
-#pragma unroll
-        for (int e = 0; e < CH; ++e) acc[cb][e] = 0.f;
-    // positions [r_lo, r_hi) -> list (entries past CAP are counted but not stored)
-    auto scan = [&](int r_lo, int r_hi) __attribute__((always_inline)) {
+    // positions [r_lo, r_hi) holding one of the tokens [vlo, vlo + nv) -> their lists (entries past CAP are counted, not stored)
+    auto scan = [&](int r_lo, int r_hi, int vlo, int nv) __attribute__((always_inline)) {
         for (int r0 = r_lo; r0 < r_hi; r0 += 256 * 16) {                  // 16 token loads per thread in flight, no barrier in between
             int64_t tk[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) { const int r = r0 + tid + 256 * u; tk[u] = r < r_hi ? tokens[r] : -1; }
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                if (tk[u] == v) { const int pos = atomicAdd(&cnt, 1); if (pos < CAP) list[pos] = r0 + tid + 256 * u; }
+                const int64_t dv = tk[u] - vlo;
+                if (dv >= 0 && dv < nv) {
+                    const int li = (int)(tk[u] - v0);
+                    const int pos = atomicAdd(&cnt[li], 1);
+                    if (pos < CAP) list[li][pos] = r0 + tid + 256 * u;
+                }
             }
         }
     };
-    auto gather = [&](int n) __attribute__((always_inline)) {
+    auto gather = [&](const int* lst, int n) __attribute__((always_inline)) {
 #pragma unroll
         for (int cb = 0; cb < MAXC; ++cb) {
             const int c = cb * 64 + lane;
@@ -348,7 +353,7 @@ __global__ __launch_bounds__(256) void embed_bwd_gather_kernel(const T* __restri
                 int64_t rowi[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int r = list[min(i0 + 4 * u, n - 1)];
+                    const int r = lst[min(i0 + 4 * u, n - 1)];
                     rowi[u] = (int64_t)(r / Ltok) * Lm + r % Ltok + shift;
                     x[u] = on ? ld_chunk(dout + rowi[u] * d + c * CH) : zero_chunk();
                 }
@@ -370,35 +375,174 @@ __global__ __launch_bounds__(256) void embed_bwd_gather_kernel(const T* __restri
             }
         }
     };
-    if (tid == 0) cnt = 0;
+    if (tid < TPB) cnt[tid] = 0;
     __syncthreads();
-    scan(0, rows);                                                        // the common case: the whole token list in one go
+    scan(0, rows, v0, TPB);                                               // the common case: the whole token list in one go
     __syncthreads();
-    const int total = cnt;
-    if (total == 0) return;                                               // block uniform
-    if (total <= CAP) gather(total);
-    else {                                                                // a very frequent token: rounds of CAP positions
-        for (int r0 = 0; r0 < rows; r0 += CAP) {
+    int total[TPB];
+#pragma unroll
+    for (int j = 0; j < TPB; ++j) total[j] = cnt[j];
+#pragma unroll
+    for (int j = 0; j < TPB; ++j) {
+        const int v = v0 + j;
+        if (v >= vocab || v == pad_token || total[j] == 0) continue;      // block uniform
+        if (hv && total[j] > EMB_HEAVY) {
+            // a frequent token (real MIDI streams: time shifts, common notes -- thousands of occurrences): one CU cannot pull
+            // its rows fast enough (5.8 k rows: 680 us), so it is published and embed_bwd_heavy_kernel spreads it over 64 blocks
+            __syncthreads();
+            if (tid == 0) {
+                const int idx = atomicAdd(&hv[0], 1);
+                if (idx < EMB_MAXH) { hv[2 + 2 * idx] = v; hv[3 + 2 * idx] = total[j]; }
+                pub_idx = idx;
+            }
+            __syncthreads();
+            if (pub_idx < EMB_MAXH) continue;                              // list full: handled here after all
+        }
+#pragma unroll
+        for (int cb = 0; cb < MAXC; ++cb)
+#pragma unroll
+            for (int e = 0; e < CH; ++e) acc[cb][e] = 0.f;
+        if (total[j] <= CAP) gather(list[j], total[j]);
+        else {                                                            // a very frequent token: rounds of CAP positions
+            for (int r0 = 0; r0 < rows; r0 += CAP) {
+                __syncthreads();
+                if (tid == 0) cnt[j] = 0;
+                __syncthreads();
+                scan(r0, min(rows, r0 + CAP), v, 1);
+                __syncthreads();
+                const int n = cnt[j];
+                if (n) gather(list[j], n);
+            }
+        }
+#pragma unroll
+        for (int cb = 0; cb < MAXC; ++cb) {
+            if (cb * 64 >= nch) break;
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < CH; ++e) red[slot][lane * CH + e] = acc[cb][e];
+            __syncthreads();
+            for (int jj = tid; jj < 64 * CH; jj += 256) {
+                const int col = cb * 64 * CH + jj;
+                if (col < de) g_emb[(size_t)v * de + col] += (red[0][jj] + red[1][jj] + red[2][jj] + red[3][jj]) * sq;
+            }
+        }
+    }
+}
+
+// Frequent tokens published by embed_bwd_gather_kernel (token, count): a token with n occurrences becomes
+// g = min(64, ceil(n / 128)) work items, item s = the s-th of g equal slices of the token-id list; the blocks take the
+// items round robin, scan their slice, gather the matching rows and add the partial sum with atomics (g per table element,
+// for a handful of rows).  Always launched after the gather kernel when the caller gave a workspace (a few us when the
+// list is empty); the last block to finish leaves the workspace zeroed for the next call.
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_heavy_kernel(const T* __restrict__ dout, const int64_t* __restrict__ tokens,
+                                                              float* __restrict__ g_emb, int* __restrict__ hv, int rows, int Ltok, int shift,
+                                                              int d, int de, uint32_t thr16, float inv_keep, uint64_t seed) {
+    constexpr int CH = ET<T>::CH, CAP = 2048, MAXC = 2;
+    __shared__ int list[CAP];
+    __shared__ int cnt;
+    __shared__ int first[EMB_MAXH + 1];                                  // first work item of every listed token
+    __shared__ float red[4][64 * CH];
+    const int tid = threadIdx.x, lane = tid & 63, slot = tid >> 6;
+    const int nh = min(hv[0], EMB_MAXH);
+    if (nh <= 0) return;                                                  // every block sees the same value: nothing to reset either
+    const int Lm = Ltok + shift, nch = de / CH;
+    const float sq = sqrtf((float)de);
+    if (tid == 0) {
+        int o = 0;
+        for (int i = 0; i < nh; ++i) { first[i] = o; o += min(64, (hv[3 + 2 * i] + EMB_SLICE - 1) / EMB_SLICE); }
+        first[nh] = o;
+    }
+    __syncthreads();
+    const int nitems = first[nh];
+    int ti = 0;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        while (item >= first[ti + 1]) ++ti;                               // items ascend: the cursor only moves forward
+        const int v = hv[2 + 2 * ti], g = first[ti + 1] - first[ti], sl = item - first[ti];
+        const int r_lo = (int)((int64_t)rows * sl / g), r_hi = (int)((int64_t)rows * (sl + 1) / g);
+        float acc[MAXC][CH];
+#pragma unroll
+        for (int cb = 0; cb < MAXC; ++cb)
+#pragma unroll
+            for (int e = 0; e < CH; ++e) acc[cb][e] = 0.f;
+        for (int r0 = r_lo; r0 < r_hi; r0 += 256 * 16) {
             __syncthreads();
             if (tid == 0) cnt = 0;
             __syncthreads();
-            scan(r0, min(rows, r0 + CAP));
+            {                                                             // 16 token loads per thread in flight
+                int64_t tk[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { const int r = r0 + tid + 256 * u; tk[u] = r < r_hi ? tokens[r] : -1; }
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (tk[u] == v) { const int pos = atomicAdd(&cnt, 1); if (pos < CAP) list[pos] = r0 + tid + 256 * u; }
+            }
             __syncthreads();
-            const int n = cnt;
-            if (n) gather(n);
+            const int n = cnt;                                            // may exceed CAP (more than half of the positions): re-scanned in halves below
+            auto gather = [&](int n_) __attribute__((always_inline)) {
+#pragma unroll
+                for (int cb = 0; cb < MAXC; ++cb) {
+                    const int c = cb * 64 + lane;
+                    const bool on = c < nch;
+                    if (cb * 64 >= nch) break;
+                    for (int i0 = slot; i0 < n_; i0 += 16) {
+                        chunk16 x[4];
+                        int64_t rowi[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int r = list[min(i0 + 4 * u, n_ - 1)];
+                            rowi[u] = (int64_t)(r / Ltok) * Lm + r % Ltok + shift;
+                            x[u] = on ? ld_chunk(dout + rowi[u] * d + c * CH) : zero_chunk();
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (i0 + 4 * u < n_ && on) {
+                                float gq[CH];
+                                chunk_to_f<T>(x[u], gq);
+                                if (thr16) {
+                                    float mult[CH];
+                                    drop_mult<CH>(mult, seed, 0u, (uint64_t)rowi[u] * d + c * CH, thr16, inv_keep);
+#pragma unroll
+                                    for (int e = 0; e < CH; ++e) gq[e] *= mult[e];
+                                }
+#pragma unroll
+                                for (int e = 0; e < CH; ++e) acc[cb][e] += gq[e];
+                            }
+                        }
+                    }
+                }
+            };
+            if (n <= CAP) { if (n) gather(n); }
+            else {
+                for (int h0 = r0; h0 < min(r_hi, r0 + 256 * 16); h0 += CAP) {      // CAP positions at a time: the list cannot overflow
+                    __syncthreads();
+                    if (tid == 0) cnt = 0;
+                    __syncthreads();
+                    for (int r = h0 + tid; r < min(r_hi, h0 + CAP); r += 256)
+                        if (tokens[r] == v) list[atomicAdd(&cnt, 1)] = r;
+                    __syncthreads();
+                    const int n2 = cnt;
+                    if (n2) gather(n2);
+                }
+            }
+        }
+#pragma unroll
+        for (int cb = 0; cb < MAXC; ++cb) {
+            if (cb * 64 >= nch) break;
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < CH; ++e) red[slot][lane * CH + e] = acc[cb][e];
+            __syncthreads();
+            for (int jj = tid; jj < 64 * CH; jj += 256) {
+                const int col = cb * 64 * CH + jj;
+                const float t = (red[0][jj] + red[1][jj] + red[2][jj] + red[3][jj]) * sq;
+                if (col < de && t != 0.f) atomicAdd(&g_emb[(size_t)v * de + col], t);
+            }
         }
     }
-#pragma unroll
-    for (int cb = 0; cb < MAXC; ++cb) {
-        if (cb * 64 >= nch) break;
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < CH; ++e) red[slot][lane * CH + e] = acc[cb][e];
-        __syncthreads();
-        for (int j = tid; j < 64 * CH; j += 256) {
-            const int col = cb * 64 * CH + j;
-            if (col < de) g_emb[(size_t)v * de + col] += (red[0][j] + red[1][j] + red[2][j] + red[3][j]) * sq;
-        }
+    __syncthreads();
+    if (tid == 0 && atomicAdd(&hv[1], 1) == (int)gridDim.x - 1) {
+        for (int i = 0; i < 2 + 2 * EMB_MAXH; ++i) hv[i] = 0;
     }
 }
 
@@ -691,7 +835,8 @@ __global__ __launch_bounds__(NW * 64) void resid_ln_bwd_kernel(const T* __restri
             red[wid][1][(i * NC + c) * 64 + lane] = pb[c][i];
         }
     __syncthreads();
-    for (int j = threadIdx.x; j < 2 * d; j += NW * 64) {
+    for (int j0 = threadIdx.x; j0 < 2 * d; j0 += NW * 64) {
+        const int j = (j0 + (int)blockIdx.x * 64) % (2 * d);      // blocks start their flush at different columns (32.8 -> 32.0 us at C2)
         const int which = j >= d, col = which ? j - d : j;
         const int q = col / CH, idx = ((col % CH) * NC + q / 64) * 64 + (q & 63);      // column = ((c * 64 + lane) * CH + i)
         float acc = 0.f;
@@ -1244,9 +1389,10 @@ int me_embed_fwd(void* out, void* out_lo, int dtype, const int64_t* tokens, cons
 
 int me_embed_bwd(const void* dout, int dtype, const int64_t* tokens, const float* cond, float* g_emb, float* g_cw0,
                  float* g_cb0, float* g_cw1, float* g_cb1, int mode, int B, int Ltok, int d, int dc, int vocab, int pad_token,
-                 float p, uint64_t seed, void* stream) {
+                 float p, uint64_t seed, void* ws, size_t ws_bytes, void* stream) {
     me_clear_error();
     if (!dout || !tokens || !g_emb) return ME_ERR_NULL;
+    if (ws && (ws_bytes < 1024 || (reinterpret_cast<uintptr_t>(ws) & 15))) return ME_ERR_WORKSPACE;
     if (mode == ME_COND_CONCAT && (!cond || !g_cw0 || !g_cb0)) return ME_ERR_NULL;
     if (mode == ME_COND_TOKEN && (!cond || !g_cw0 || !g_cb0 || !g_cw1 || !g_cb1)) return ME_ERR_NULL;
     if (mode != ME_COND_CONCAT) dc = 0;
@@ -1266,8 +1412,16 @@ int me_embed_bwd(const void* dout, int dtype, const int64_t* tokens, const float
     const bool grouped = vocab > 0 && Ltok > 0 && (de & 7) == 0 && de / (dtype == ME_F32 ? 4 : 8) <= 128 && rows64 < (1ll << 30);
     if (grouped) {
         const int shift = mode == ME_COND_TOKEN ? 2 : 0;
-        ME_DISPATCH(dtype, (embed_bwd_gather_kernel<T><<<vocab, 256, 0, st>>>((const T*)dout, tokens, g_emb, (int)rows64, Ltok, shift, d, de,
-                                                                             pad_token, thr, inv_keep, seed)));
+#ifndef EMB_TPB
+#define EMB_TPB 2
+#endif
+        int* hv = reinterpret_cast<int*>(ws);
+        ME_DISPATCH(dtype, (embed_bwd_gather_kernel<T, EMB_TPB><<<(vocab + EMB_TPB - 1) / EMB_TPB, 256, 0, st>>>(
+                               (const T*)dout, tokens, g_emb, hv, (int)rows64, Ltok, shift, d, de, vocab, pad_token, thr, inv_keep, seed)));
+        if (hv) {
+            ME_DISPATCH(dtype, (embed_bwd_heavy_kernel<T><<<256, 256, 0, st>>>((const T*)dout, tokens, g_emb, hv, (int)rows64, Ltok, shift, d,
+                                                                               de, thr, inv_keep, seed)));
+        }
     }
     if (table || grouped) {
         if (!grouped) {
@@ -1365,6 +1519,7 @@ int me_resid_ln_bwd(const void* dy, const void* s, const float* stats, const flo
         };
         using I1 = std::integral_constant<int, 1>;
         // two rows per wave and iteration (independent reductions overlap): 34.3 -> 33.0 us at C2
+        // (four rows per iteration spill under the 128-register cap of a 16-wave block: 77 us)
         if (nc <= 1) launch(I1{}, std::integral_constant<int, 16>{}, std::integral_constant<int, 2>{});
         else if (nc == 2) launch(std::integral_constant<int, 2>{}, std::integral_constant<int, 8>{}, I1{});
         else launch(std::integral_constant<int, 4>{}, std::integral_constant<int, 8>{}, I1{});

@@ -7,7 +7,7 @@ import torch
 
 from . import _lib
 from ._lib import (ME_BF16, ME_COND_CONCAT, ME_COND_NONE, ME_COND_TOKEN, ME_EPI_OUT_F32, ME_EPI_RELU,
-                   ME_EPI_RELU_BWD, ME_F32, ME_TN_MAX_GROUP, ME_WS_GEMM_TN, ME_WS_GEMM_TN_GROUP, ME_WS_RGA_DGT, ME_WS_RGA_MT,
+                   ME_EPI_RELU_BWD, ME_F32, ME_TN_MAX_GROUP, ME_WS_EMBED_BWD, ME_WS_GEMM_TN, ME_WS_GEMM_TN_GROUP, ME_WS_RGA_DGT, ME_WS_RGA_MT,
                    ME_WS_RGA_PT, check)
 
 DTYPE_CODE = {torch.float32: ME_F32, torch.bfloat16: ME_BF16}
@@ -74,11 +74,18 @@ def embed_fwd(out, tokens, cond, emb, cw0, cb0, cw1, cb1, pe, mode, B, Ltok, d, 
           "me_embed_fwd")
 
 
-def embed_bwd(dout, tokens, cond, g_emb, g_cw0, g_cb0, g_cw1, g_cb1, mode, B, Ltok, d, dc, pad_token, p, seed):
+def embed_bwd(dout, tokens, cond, g_emb, g_cw0, g_cb0, g_cw1, g_cb1, mode, B, Ltok, d, dc, pad_token, p, seed, ws=None):
+    """ws: zero-initialised uint8/int32 device buffer of embed_bwd_ws_bytes() bytes (the library leaves it zeroed): tokens with
+    more than 512 occurrences in the batch are then spread over 64 blocks instead of being summed by one."""
     vocab = g_emb.shape[0]
     check(lib().me_embed_bwd(_ptr(dout), _code(dout.dtype), _ptr(tokens), _ptr(cond), _ptr(g_emb), _ptr(g_cw0),
                              _ptr(g_cb0), _ptr(g_cw1), _ptr(g_cb1), mode, B, Ltok, d, dc, vocab, pad_token, float(p),
-                             int(seed), _stream()), "me_embed_bwd")
+                             int(seed), _ptr(ws), ws.numel() * ws.element_size() if ws is not None else 0, _stream()), "me_embed_bwd")
+
+
+def embed_bwd_ws(device):
+    """the (zeroed) frequent-token workspace of embed_bwd"""
+    return torch.zeros(workspace_bytes(ME_WS_EMBED_BWD, 0, 0, 0, torch.bfloat16), dtype=torch.uint8, device=device)
 
 
 def key_pad_mask(key_pad, tokens, B, Ltok, shift, pad_token):

@@ -616,6 +616,36 @@ def test_embed_fwd_bwd(ops, dtype, mode):
             assert relerr(gb, Pg[f"fc_condition.{i}.bias"].grad) < tol(dtype, 1e-5, dy)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("use_ws", [False, True])
+@pytest.mark.parametrize("p_top", [0.45, 0.85])
+def test_embed_bwd_frequent_tokens(ops, dtype, use_ws, p_top):
+    """Token ids as skewed as real MIDI streams (one id on ~45 % of the positions, another on 12 %, PAD in between): the
+    table gradient must equal the index_add of the dy rows whether the frequent rows are summed by their own block (no
+    workspace: rounds of 2048 positions) or spread over 64 blocks by the helper launch (workspace); the workspace comes
+    back zeroed and serves the next call."""
+    V, d, B, L = 211, 256, 8, 1500
+    g = torch.Generator().manual_seed(12)
+    tok = torch.randint(1, V, (B, L), generator=g)
+    u = torch.rand(B, L, generator=g)
+    tok[u < p_top] = 17                                     # 0.85: more than half of every scanned slice (list overflow paths)
+    tok[(u >= p_top) & (u < p_top + 0.12)] = 101
+    tok[:, -7:] = 0
+    dy = rnd(B, L, d, seed=33).to(dtype)
+    ref = torch.zeros(V, d, dtype=torch.float64)
+    ref.index_add_(0, tok.flatten(), dy.double().view(-1, d) * (d ** 0.5))
+    ref[0] = 0
+    ws = ops.embed_bwd_ws(DEV) if use_ws else None
+    for rep_ in range(2):                                   # the second call reuses the workspace the first one left behind
+        g_emb = torch.zeros(V, d, device=DEV)
+        ops.embed_bwd(dy.to(DEV), tok.to(DEV), None, g_emb, None, None, None, None, ops.ME_COND_NONE, B, L, d, 0, 0, 0.0, 0, ws=ws)
+        assert relerr(g_emb, ref) < tol(dtype, 1e-5, dy), (use_ws, rep_)
+        assert (g_emb[0] == 0).all()
+        if ws is not None:
+            torch.cuda.synchronize()
+            assert int(ws.view(torch.int32)[:2].abs().sum()) == 0
+
+
 def test_key_pad_mask(ops):
     tok = torch.tensor([[5, 0, 7, 0], [0, 1, 2, 3]])
     kp = torch.empty(2, 6, dtype=torch.uint8, device=DEV)
