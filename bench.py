@@ -171,10 +171,12 @@ def decode_slide_bench(cd="bf16", n_tok=48, window=1024):
     g = torch.Generator().manual_seed(5)
     song = torch.randint(2, V, (window + 8, B), generator=g).cuda()            # a window that is already full
     picked = torch.empty(B, dtype=torch.long, device="cuda")
+    from midiemo.decode import WindowForward
+    win = WindowForward(model)
     def one():
         nonlocal song
         inp = song[-window:]
-        out = model(inp.t().contiguous(), cond)[:, -1, :]
+        out = win.last_logits(inp.t().contiguous(), cond)                       # generate()'s sliding path: the window forward as one HIP graph
         ops.greedy_pick(out.contiguous(), V, specials, picked, B)
         song = torch.cat((song, picked.clone()[None, :]), 0)
     with torch.no_grad():
@@ -190,7 +192,7 @@ def decode_slide_bench(cd="bf16", n_tok=48, window=1024):
     torch.cuda.empty_cache()
     return {"dtype": cd, "batch": B, "window": window, "tokens_timed": n_tok, "tokens_per_s": round(B * n_tok / wall, 1),
             "ms_per_token_step": round(1e3 * wall / n_tok, 3),
-            "note": "full forward over the 1024-token window per new token (the reference's sliding window invalidates every cached position)"}
+            "note": "full forward over the 1024-token window per new token (the reference's sliding window invalidates every cached position), replayed as one HIP graph"}
 
 
 def decode_cpu_baseline(budget_s=12.0):

@@ -32,7 +32,7 @@ import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
 from midiemo import ops  # noqa: E402
-from midiemo.decode import DecodeSession  # noqa: E402
+from midiemo.decode import DecodeSession, WindowForward  # noqa: E402
 from midiemo.models.build_model import build_model  # noqa: E402
 from midiemo.midi_writer import write_midi  # noqa: E402
 from midiemo.vocab import (emotion_symbols, get_maps, get_n_instruments, ind_list_to_str,  # noqa: E402
@@ -62,9 +62,10 @@ def generate(model, maps, device, out_dir, conditioning, short_filename=False,
              gen_len=2048, temperatures=[1.2, 1.2], top_k=-1,
              top_p=0.7, debug=False, varying_condition=None, seed=-1,
              verbose=False, primers=[["<START>"]], min_n_instruments=2,
-             use_cache=True, return_ids=False, device_loop=True):
+             use_cache=True, return_ids=False, device_loop=True, use_window_graph=True):
     """Reference signature (generate.py:20-26) + `use_cache`, `return_ids`, `device_loop` (sampling loop replayed on
-    the device as one HIP graph per token while the KV cache is valid; False = one Python iteration per token).
+    the device as one HIP graph per token while the KV cache is valid; False = one Python iteration per token) and
+    `use_window_graph` (once the window slides, its full forward is replayed as one HIP graph per token).
     `amp` is accepted for compatibility; the engine's precision is model.compute_dtype."""
     if not debug:
         os.makedirs(out_dir, exist_ok=True)
@@ -125,6 +126,7 @@ def generate(model, maps, device, out_dir, conditioning, short_filename=False,
 
     cache_ok = bool(use_cache) and varying_condition is None
     sess = None
+    win = None                                                    # WindowForward of the sliding regime (created on first use)
     fed = 0                                                      # tokens of gen_song already in the cache
     picked = torch.empty(batch_size, dtype=torch.long, device=device)
     n_choices_buf = torch.empty(batch_size, dtype=torch.int32, device=device)
@@ -169,7 +171,13 @@ def generate(model, maps, device, out_dir, conditioning, short_filename=False,
                 input_ = gen_song[-max_input_len:] if T > max_input_len else gen_song
                 if conditioning == "discrete_token":
                     input_ = torch.cat((discrete_conditions_tensor, input_), 0)
-                output = model(input_.t().contiguous(), conditions_tensor)[:, -1, :]
+                if T > max_input_len and use_window_graph:
+                    # the window has a fixed shape from here on: one captured HIP graph per token instead of ~55 eager launches
+                    if win is None:
+                        win = WindowForward(model)
+                    output = win.last_logits(input_.t().contiguous(), conditions_tensor)
+                else:
+                    output = model(input_.t().contiguous(), conditions_tensor)[:, -1, :]
 
             if top_k == 1:
                 # greedy: NaN->0, specials->-inf, argmax -- one kernel (generate.py:122-136,166-183)
@@ -273,6 +281,7 @@ def main():
     parser.add_argument("--output_root", type=str, default="../output", help="reference hard-codes ../output")
     parser.add_argument("--no_cache", action='store_true', help="reference-style full recompute every step")
     parser.add_argument("--no_device_loop", action='store_true', help="one Python iteration per token instead of the HIP-graph sampling loop")
+    parser.add_argument("--no_window_graph", action='store_true', help="eager full forward per token in the sliding-window regime instead of the captured HIP graph")
     args = parser.parse_args()
 
     assert len(args.valence) == len(args.arousal), "Lengths of valence and arousal must be equal"
@@ -329,7 +338,8 @@ def main():
                 penalty_coeff=args.penalty_coeff, short_filename=args.short_filename, top_p=args.topp,
                 gen_len=args.gen_len, max_input_len=args.max_input_len, amp=not args.no_amp, primers=p_run,
                 temperatures=args.temp, top_k=args.topk, debug=args.debug, verbose=not args.quiet, seed=args.seed,
-                use_cache=not args.no_cache, device_loop=not args.no_device_loop)
+                use_cache=not args.no_cache, device_loop=not args.no_device_loop,
+                use_window_graph=not args.no_window_graph)
 
 
 if __name__ == '__main__':

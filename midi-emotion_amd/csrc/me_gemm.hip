@@ -1123,7 +1123,12 @@ int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int 
     if constexpr (sizeof(T) == 2) {
         // the 256-tile kernel addresses its operands with 32-bit byte offsets
         const bool off32 = (unsigned long long)M * lda * 2ull < (1ull << 32) && (unsigned long long)N * ldb * 2ull < (1ull << 32);
-        if (K % 64 == 0 && M >= 256 && N >= 192 && off32 && !g_disable_nt256) {
+        // few tiles on many CUs (the sliding-window forward of generate(): M = 4 x 1024 rows): a launch costs one whole
+        // 256 x 256 x K tile regardless, and 128 x 128 tiles finish sooner -- measured at M = 2048 .. 8192, N = 512 / 1007:
+        // 15.0-16.2 vs 17.1-20.5 us (K = 512), 33.5 vs 45.6 us (K = 2048); below M = 2048 and above 64 tiles the big tile wins
+        const long t256 = (long)((N + 255) / 256) * ((M + 255) / 256);
+        const bool few_tiles = M >= 2048 && t256 * 4 <= persistent_cus();
+        if (K % 64 == 0 && M >= 256 && N >= 192 && off32 && !g_disable_nt256 && !few_tiles) {
             static bool attr_set[16] = {false};
             int dev = 0;
             if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }

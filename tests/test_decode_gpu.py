@@ -361,3 +361,32 @@ def test_sampling_kernel_matches_reference_distribution(golden_dir, tag):
         assert torch.allclose(dense_got, dense_ref, atol=3e-6, rtol=2e-4), (s, float((dense_got - dense_ref).abs().max()))
         assert torch.equal(nch.cpu().long(), (probs > 0).sum(-1)), s
         assert bool(((dense_ref.gather(1, out.cpu()[:, None]) > 0).all())), s     # the draw lands on a surviving id
+
+
+@pytest.mark.parametrize("cd", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode", ["continuous_concat", "continuous_token", "none"])
+def test_window_forward_graph_equals_eager_forward(golden_dir, cd, mode):
+    """WindowForward (the sliding-window regime of generate(): one captured HIP graph per token) returns exactly the last-
+    position logits of the eager model(x, cond) call, for successive different windows of the same shape, after a shape
+    change (re-capture), and after a parameter update (prepared weights refreshed outside the graph)."""
+    from midiemo.decode import WindowForward
+    G, model, maps, conds, disc, z = setup(mode, cd, golden_dir)
+    model.eval()
+    win = WindowForward(model)
+    g = torch.Generator().manual_seed(21)
+    cond = None if mode == "none" else torch.tensor(conds, dtype=torch.float32, device="cuda")
+    B = 4
+    for L in (40, 40, 40, 57, 40):
+        x = torch.randint(2, 1007, (B, L), generator=g).cuda()
+        with torch.no_grad():
+            ref = model(x, cond)[:, -1, :].clone()
+        got = win.last_logits(x, cond)
+        assert torch.equal(got, ref), (cd, mode, L)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(1.01)
+    model.mark_params_changed()
+    x = torch.randint(2, 1007, (B, 40), generator=g).cuda()
+    with torch.no_grad():
+        ref = model(x, cond)[:, -1, :].clone()
+    assert torch.equal(win.last_logits(x, cond), ref)
