@@ -644,6 +644,16 @@ def test_embed_bwd_frequent_tokens(ops, dtype, use_ws, p_top):
         if ws is not None:
             torch.cuda.synchronize()
             assert int(ws.view(torch.int32)[:2].abs().sum()) == 0
+    # continuous_token layout: two condition slots in front of every sequence (row index = b * (L + 2) + l + 2)
+    dy2 = rnd(B, L + 2, d, seed=34).to(dtype)
+    ref2 = torch.zeros(V, d, dtype=torch.float64)
+    ref2.index_add_(0, tok.flatten(), dy2[:, 2:].double().reshape(-1, d) * (d ** 0.5))
+    ref2[0] = 0
+    cond = torch.rand(B, 2, generator=g) * 2 - 1
+    g_emb = torch.zeros(V, d, device=DEV)
+    z = lambda *sh: torch.zeros(*sh, device=DEV)
+    ops.embed_bwd(dy2.to(DEV), tok.to(DEV), cond.to(DEV), g_emb, z(d, 1), z(d), z(d, 1), z(d), ops.ME_COND_TOKEN, B, L, d, 0, 0, 0.0, 0, ws=ws)
+    assert relerr(g_emb, ref2) < tol(dtype, 1e-5, dy2), ("continuous_token", use_ws)
 
 
 def test_key_pad_mask(ops):
