@@ -40,7 +40,11 @@ int main(void) {
     ME(me_cast_transpose(dW32, N, K, dW, K, NULL, 0, ME_BF16, NULL));
     /* C = relu(A . W^T + b), bf16 out */
     ME(me_gemm_nt(dA, K, dW, K, dC, N, db, NULL, 0, NULL, 0, M, N, K, ME_EPI_RELU, ME_BF16, NULL));
-    ME(me_sumsq(dA32, (int64_t)M * K, dss, NULL));
+    /* caller-owned, zeroed scratch: block sums are added in a fixed order (bit-reproducible result) */
+    void* dsw;
+    CK(hipMalloc(&dsw, me_workspace_bytes(ME_WS_SUMSQ, 0, 0, 0, ME_F32)));
+    CK(hipMemset(dsw, 0, me_workspace_bytes(ME_WS_SUMSQ, 0, 0, 0, ME_F32)));
+    ME(me_sumsq(dA32, (int64_t)M * K, dss, dsw, me_workspace_bytes(ME_WS_SUMSQ, 0, 0, 0, ME_F32), NULL));
     CK(hipDeviceSynchronize());
     uint16_t* hC = malloc(2 * M * N);
     float ss = 0.f;

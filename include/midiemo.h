@@ -41,7 +41,8 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 17
+#define ME_ABI_VERSION 18
+#define ME_SUMSQ_WS_BYTES 1040   /* me_sumsq workspace: ticket counter + 256 block sums + padding */
 
 enum { ME_F32 = 0, ME_BF16 = 1 };
 
@@ -148,7 +149,8 @@ enum {
     ME_WS_RGA_DGT = 3,   /* me_rga_bwd dGT workspace:   (M, N, K) = (B*H, Lp, unused) */
     ME_WS_RGA_MT = 4,    /* me_rga_fwd / me_rga_bwd MT: (M, N, K) = (B*H, Lp, unused) */
     ME_WS_GEMM_TN_GROUP = 5, /* me_gemm_tn_acc_group: (M, N, K) = (T, sum over the items of ceil(N/256) * (K/256), unused) */
-    ME_WS_EMBED_BWD = 6      /* me_embed_bwd frequent-token list: 1024 bytes, zero before the first use */
+    ME_WS_EMBED_BWD = 6,     /* me_embed_bwd frequent-token list: 1024 bytes, zero before the first use */
+    ME_WS_SUMSQ = 7          /* me_sumsq ordered block sums: ME_SUMSQ_WS_BYTES, zero before the first use */
 };
 size_t me_workspace_bytes(int op, int M, int N, int K, int dtype);
 
@@ -262,14 +264,19 @@ int me_ce_bwd(const void* logits, int ld, const int64_t* target, const float* ro
               int rows, int V, int ignore_index, int logits_dtype, int dtype, void* stream);
 
 /* ---- optimiser: global-norm clip + Adam(W) -----------------------------------
- * me_sumsq: *out += sum g[i]^2   (zero *out first; multiple calls accumulate)
+ * me_sumsq: *out += sum g[i]^2   (zero *out first; multiple calls accumulate).  ws (may be NULL): caller-owned scratch of
+ *   me_workspace_bytes(ME_WS_SUMSQ, 0, 0, 0, dtype) = ME_SUMSQ_WS_BYTES bytes, 4-byte aligned, ZERO before the first use
+ *   (a call that returns 0 leaves it ready for the next): the block sums are then added in a fixed order and the result
+ *   is bit-reproducible -- which is what keeps the parameters of data-parallel ranks bit-identical after the clip
+ *   (they hold identical reduced gradients; SURVEY 8e "identical optimizer state evolution on every rank").  NULL: the
+ *   block sums are added with atomics in arrival order (last-bit differences from call to call).
  * me_adamw_step: coef = min(1, clip/(sqrt(*sumsq)+1e-6)) (clip <= 0: coef = 1);
  *   g' = g*coef*grad_scale ; m = b1 m + (1-b1) g' ; v = b2 v + (1-b2) g'^2 ;
  *   p = p*(1 - lr*wd) - (lr/bias_corr1) * m / (sqrt(v)/sqrt(bias_corr2) + eps)
  * with bias_corr{1,2} = 1 - beta^step computed by the caller.  weight_decay = 0 is
  * exactly torch.optim.Adam.  If zero_grad != 0 the gradient is zeroed in the same pass.
  * Replaces clip_grad_norm_ + optim.Adam.step + zero_grad (train.py:320-325). */
-int me_sumsq(const float* g, int64_t n, float* out, void* stream);
+int me_sumsq(const float* g, int64_t n, float* out, void* ws, size_t ws_bytes, void* stream);
 int me_adamw_step(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq,
                   float clip, float grad_scale, float lr, float beta1, float beta2, float eps,
                   float weight_decay, float bias_corr1, float bias_corr2, int zero_grad,

@@ -953,27 +953,50 @@ __global__ __launch_bounds__(CE_NW * 64) void ce_fwd_kernel(const LT* __restrict
 // the bf16-rounded dlogits in the weight-gradient GEMM gave that tensor a 2e-3 relative error against 4e-4 for the
 // reference's own autocast; here every lane keeps f32 partial sums of its columns over the rows of its wave (16-byte
 // path: <= 4 chunks of 8 columns per lane), waves are combined through LDS and a block issues one atomic per column.
-template <typename T, typename LT>
+// HAS_DBIAS is a template flag: the 33.8 KB of LDS and the 32 partial-sum registers exist only in the instantiation that
+// emits the bias gradient (the f32 tier and the autograd path run without: ADVICE r3).
+template <typename T, typename LT, bool HAS_DBIAS>
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const LT* __restrict__ logits, int ld,
                                                      const int64_t* __restrict__ target, const float* __restrict__ row_lse,
                                                      T* __restrict__ dlogits, int ld_d, const float* __restrict__ n_valid,
                                                      float extra_scale, int rows, int V, int ignore_index, float* __restrict__ dbias) {
-    __shared__ float red[4][64 * 33];                      // dbias: [wave][lane][32 partial sums], +1 padding
+    __shared__ float red[HAS_DBIAS ? 4 : 1][HAS_DBIAS ? 64 * 33 : 1];     // dbias: [wave][lane][32 partial sums], +1 padding
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const float scale = extra_scale / fmaxf(*n_valid, 0.f);   // n_valid == 0 -> inf/nan like torch's 0/0 mean
-    float bs[4][8];
+    float bs[HAS_DBIAS ? 4 : 1][8];
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < (HAS_DBIAS ? 4 : 1); ++c)
 #pragma unroll
         for (int e = 0; e < 8; ++e) bs[c][e] = 0.f;
-    bool fast = false;
+    bool fast = false, wide = false;
     if constexpr (sizeof(LT) == 2 && sizeof(T) == 2) {
         // both 16-bit: 8 columns per lane and 16-byte access (2-byte accesses made this kernel issue bound: 37 us
         // for 133 MB); columns in [V, ld) of the logits are never used, columns in [V, ld_d) are written as 0
-        fast = (ld & 7) == 0 && (ld_d & 7) == 0 && ld >= ld_d && ld_d <= 2048 &&
-               ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits)) & 15) == 0;
+        const bool ok16 = (ld & 7) == 0 && (ld_d & 7) == 0 && ld >= ld_d &&
+                          ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits)) & 15) == 0;
+        fast = ok16 && ld_d <= 2048;
+        wide = ok16 && !fast && !HAS_DBIAS;                // vocabularies above 2048 columns: unbounded 16-byte column loop
     }
-    if (fast) {
+    if (wide) {
+        for (int64_t row = (int64_t)blockIdx.x * 4 + wid; row < rows; row += (int64_t)gridDim.x * 4) {
+            const int64_t t = target[row];
+            const float lse = row_lse[row];
+            const bool valid = t != ignore_index;
+            for (int j = lane * 8; j < ld_d; j += 512) {
+                const chunk16 in = ld_chunk(reinterpret_cast<const bf16_t*>(logits) + row * ld + j);
+                chunk16 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float g = 0.f;
+                    if (valid && j + e < V)
+                        g = (__builtin_amdgcn_exp2f(((float)reinterpret_cast<const bf16_t*>(&in)[e] - lse) * 1.4426950408889634f) -
+                             (j + e == t ? 1.f : 0.f)) * scale;
+                    reinterpret_cast<bf16_t*>(&o)[e] = (bf16_t)g;
+                }
+                st_chunk(reinterpret_cast<bf16_t*>(dlogits) + row * ld_d + j, o);
+            }
+        }
+    } else if (fast) {
         // RU rows of a wave in flight at once (2 x RU 16-byte loads per lane at ld_d = 1024): the bias-gradient variant runs on
         // 256 blocks (one atomic per column and block) and would otherwise leave the memory pipe three quarters empty (65 us)
         constexpr int RU = 4;
@@ -1009,7 +1032,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const LT* __restrict__ logi
                         if (valid && j + e < V)
                             g = (__builtin_amdgcn_exp2f(((float)reinterpret_cast<const bf16_t*>(&ch[u][c])[e] - ls[u]) * 1.4426950408889634f) -
                                  (j + e == tg[u] ? 1.f : 0.f)) * scale;
-                        bs[c][e] += g;
+                        if constexpr (HAS_DBIAS) bs[c][e] += g;
                         reinterpret_cast<bf16_t*>(&o)[e] = (bf16_t)g;
                     }
                     st_chunk(reinterpret_cast<bf16_t*>(dlogits) + row * ld_d + j, o);
@@ -1029,23 +1052,32 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const LT* __restrict__ logi
             }
         }
     }
-    if (dbias == nullptr) return;                          // block uniform
+    if constexpr (HAS_DBIAS) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) red[wid][lane * 33 + c * 8 + e] = bs[c][e];
-    __syncthreads();
-    for (int col = threadIdx.x; col < V; col += 256) {     // column = 512 c + 8 lane' + e
-        const int c = col >> 9, l2 = (col & 511) >> 3, e = col & 7;
-        const int idx = l2 * 33 + c * 8 + e;
-        atomicAdd(&dbias[col], red[0][idx] + red[1][idx] + red[2][idx] + red[3][idx]);
+            for (int e = 0; e < 8; ++e) red[wid][lane * 33 + c * 8 + e] = bs[c][e];
+        __syncthreads();
+        for (int col = threadIdx.x; col < V; col += 256) {     // column = 512 c + 8 lane' + e
+            const int c = col >> 9, l2 = (col & 511) >> 3, e = col & 7;
+            const int idx = l2 * 33 + c * 8 + e;
+            atomicAdd(&dbias[col], red[0][idx] + red[1][idx] + red[2][idx] + red[3][idx]);
+        }
     }
 }
 
 // ------------------------------------------------------------------ clip + AdamW
-// <= 256 blocks of 16 waves: one same-address atomic per block (at ~15 ns each, 1024 blocks cost 12 us of a 24 us kernel)
-__global__ __launch_bounds__(1024) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+// <= 256 blocks of 16 waves.  The block sums are combined in a FIXED order: every block leaves its sum in the caller's
+// workspace, takes a ticket, and the block that draws the last ticket adds the slots 0 .. grid-1 in index order (one wave,
+// the same instruction sequence whatever the arrival order) -- so that the clip coefficient, and with it every parameter
+// after the update, is bit-identical on all data-parallel ranks (they hold bit-identical reduced gradients).  Round 3 added
+// the block sums with one same-address atomic per block: ranks then differed in the last bit of the coefficient, a few
+// thousand parameters per step moved to the other f32 neighbour and every few steps one of them crossed a bf16 rounding
+// boundary on one rank only (round-4 DDP diagnosis, profiles/r04_ddp_diagnosis.txt).  part == nullptr: the atomic variant.
+__global__ __launch_bounds__(1024) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out,
+                                                     float* __restrict__ part, unsigned int* __restrict__ ticket) {
     __shared__ float red[16];
+    __shared__ bool last;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     float s = 0.f;
     const int64_t n4 = n >> 2;
@@ -1062,7 +1094,25 @@ __global__ __launch_bounds__(1024) void sumsq_kernel(const float* __restrict__ g
         float t = 0.f;
 #pragma unroll
         for (int w = 0; w < 16; ++w) t += red[w];
-        atomicAdd(out, t);
+        if (part == nullptr) {
+            atomicAdd(out, t);
+            last = false;
+        } else {
+            __hip_atomic_store(&part[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // release: the slot is visible device-wide before the ticket is; acquire on the same atomic for the last block
+            const unsigned int tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            last = tk == gridDim.x - 1;
+        }
+    }
+    __syncthreads();
+    if (!last || wid != 0) return;
+    float t = 0.f;
+    for (int i = lane; i < (int)gridDim.x; i += 64)          // grid <= 256: at most four slots per lane, index order
+        t += __hip_atomic_load(&part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = wave_sum(t);
+    if (lane == 0) {
+        *out += t;
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // left zeroed for the next call
     }
 }
 
@@ -1566,24 +1616,31 @@ int me_ce_bwd(const void* logits, int ld, const int64_t* target, const float* ro
     hipStream_t st = (hipStream_t)stream;
     const int cap = dbias ? 512 : 2048;                     // dbias: one atomic per column and block
     if (logits_dtype == ME_F32) {
-        ME_DISPATCH(dtype, (ce_bwd_kernel<T, float><<<row_grid(rows, cap), 256, 0, st>>>((const float*)logits, ld, target, row_lse,
-                                                                                       (T*)dlogits, ld_d, n_valid, extra_scale, rows, V, ignore_index, dbias)));
+        ME_DISPATCH(dtype, (ce_bwd_kernel<T, float, false><<<row_grid(rows, cap), 256, 0, st>>>((const float*)logits, ld, target, row_lse,
+                                                                                              (T*)dlogits, ld_d, n_valid, extra_scale, rows, V, ignore_index, nullptr)));
+    } else if (dbias) {
+        ME_DISPATCH(dtype, (ce_bwd_kernel<T, bf16_t, true><<<row_grid(rows, cap), 256, 0, st>>>((const bf16_t*)logits, ld, target, row_lse,
+                                                                                              (T*)dlogits, ld_d, n_valid, extra_scale, rows, V, ignore_index, dbias)));
     } else {
-        ME_DISPATCH(dtype, (ce_bwd_kernel<T, bf16_t><<<row_grid(rows, cap), 256, 0, st>>>((const bf16_t*)logits, ld, target, row_lse,
-                                                                                        (T*)dlogits, ld_d, n_valid, extra_scale, rows, V, ignore_index, dbias)));
+        ME_DISPATCH(dtype, (ce_bwd_kernel<T, bf16_t, false><<<row_grid(rows, cap), 256, 0, st>>>((const bf16_t*)logits, ld, target, row_lse,
+                                                                                               (T*)dlogits, ld_d, n_valid, extra_scale, rows, V, ignore_index, nullptr)));
     }
     return me_launch_status();
 }
 
-int me_sumsq(const float* g, int64_t n, float* out, void* stream) {
+int me_sumsq(const float* g, int64_t n, float* out, void* ws, size_t ws_bytes, void* stream) {
     me_clear_error();
     if (!g || !out) return ME_ERR_NULL;
     if (n <= 0) return ME_OK;
     if (!aligned16(g)) return ME_ERR_ALIGNMENT;
+    if (ws && (ws_bytes < ME_SUMSQ_WS_BYTES || (reinterpret_cast<uintptr_t>(ws) & 3))) return ME_ERR_BAD_SHAPE;
     int64_t blocks = (n / 4 + 255) / 256;
     if (blocks > 256) blocks = 256;
     if (blocks < 1) blocks = 1;
-    sumsq_kernel<<<(unsigned)blocks, 1024, 0, (hipStream_t)stream>>>(g, n, out);
+    // workspace layout: [0] ticket counter (zero between calls), [1 .. 256] block sums
+    unsigned int* ticket = reinterpret_cast<unsigned int*>(ws);
+    float* part = ws ? reinterpret_cast<float*>(ws) + 1 : nullptr;
+    sumsq_kernel<<<(unsigned)blocks, 1024, 0, (hipStream_t)stream>>>(g, n, out, part, ticket);
     return me_launch_status();
 }
 

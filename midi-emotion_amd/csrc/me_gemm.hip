@@ -1284,6 +1284,7 @@ size_t me_workspace_bytes(int op, int M, int N, int K, int dtype) {
         return (size_t)M * tiles * 1024 * es;
     }
     if (op == ME_WS_RGA_MT) return (M > 0 && N > 0 && !(N & 31)) ? (size_t)M * (N / 32) * N * sizeof(float) : 0;
+    if (op == ME_WS_SUMSQ) return ME_SUMSQ_WS_BYTES;                      // ordered block sums of me_sumsq (zero before the first use)
     if (op == ME_WS_EMBED_BWD) return 1024;                               // frequent-token list of me_embed_bwd (zero before the first use)
     return 0;
 }

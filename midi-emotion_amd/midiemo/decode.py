@@ -310,13 +310,21 @@ class WindowForward:
         tokens, cond_c, B, Ltok, Lm = m._check_inputs(tokens, cond)
         V = m.head_size
         m._refresh_weights()                                 # host-side version check; never part of the captured graph
-        key = (B, Ltok, Lm, m._flat.data_ptr())
-        if key != self._key:
-            self._key, self._graph = key, None
+        # The captured launches carry raw device addresses of the model's workspace of this shape and of its prepared
+        # weights: both objects are part of the key AND referenced from here, so that model._workspace() dropping its
+        # cache (more than 6 shapes) or a rebuilt _prep (dtype change) can neither free the memory under a replay nor go
+        # unnoticed.
+        ws_now = m._ws.get((B, Lm, False))
+        key = (B, Ltok, Lm, m._flat.data_ptr(), m.compute_dtype, id(m._prep), id(ws_now))
+        if key != self._key or ws_now is None:
+            self._graph = None
             self._tok = tokens.clone()
             self._cond = cond_c.clone()
             self._out = torch.empty(B * Lm, V, dtype=torch.float32, device=tokens.device)
-            m._forward_impl(self._tok, self._cond, B, Ltok, Lm, False, 0.0, 0, self._out)      # warm-up: workspaces exist afterwards
+            # warm-up: the workspace exists afterwards
+            self._ws_ref = m._forward_impl(self._tok, self._cond, B, Ltok, Lm, False, 0.0, 0, self._out)
+            self._prep_ref = m._prep
+            self._key = (B, Ltok, Lm, m._flat.data_ptr(), m.compute_dtype, id(m._prep), id(self._ws_ref))
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):

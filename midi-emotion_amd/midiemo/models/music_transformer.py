@@ -533,8 +533,14 @@ class MusicTransformerHIP(nn.Module):
         g = self._cond_params(gflat)
         if getattr(self, "_emb_ws", None) is None or self._emb_ws.device != dy.device:
             self._emb_ws = ops.embed_bwd_ws(dy.device)                 # zeroed once; the library leaves it zeroed
-        ops.embed_bwd(dy, tokens, cond, gv("embedding.weight"), g[0], g[1], g[2], g[3], self._mode(), B, Ltok, d,
-                      self.d_condition, self.pad_token, p_drop, seed, ws=self._emb_ws)
+        try:
+            ops.embed_bwd(dy, tokens, cond, gv("embedding.weight"), g[0], g[1], g[2], g[3], self._mode(), B, Ltok, d,
+                          self.d_condition, self.pad_token, p_drop, seed, ws=self._emb_ws)
+        except Exception:
+            # a launch that failed between the gather and the frequent-token kernel can leave (token, count) entries
+            # behind; the "library leaves it zeroed" contract only holds for calls that returned 0
+            self._emb_ws = None
+            raise
         join()                                             # optimizer / next forward see every gradient
         if bucket_hook:
             bucket_hook(0)

@@ -7,7 +7,7 @@ import torch
 
 from . import _lib
 from ._lib import (ME_BF16, ME_COND_CONCAT, ME_COND_NONE, ME_COND_TOKEN, ME_EPI_OUT_F32, ME_EPI_RELU,
-                   ME_EPI_RELU_BWD, ME_F32, ME_TN_MAX_GROUP, ME_WS_EMBED_BWD, ME_WS_GEMM_TN, ME_WS_GEMM_TN_GROUP, ME_WS_RGA_DGT, ME_WS_RGA_MT,
+                   ME_EPI_RELU_BWD, ME_F32, ME_TN_MAX_GROUP, ME_WS_EMBED_BWD, ME_WS_SUMSQ, ME_WS_GEMM_TN, ME_WS_GEMM_TN_GROUP, ME_WS_RGA_DGT, ME_WS_RGA_MT,
                    ME_WS_RGA_PT, check)
 
 DTYPE_CODE = {torch.float32: ME_F32, torch.bfloat16: ME_BF16}
@@ -75,8 +75,10 @@ def embed_fwd(out, tokens, cond, emb, cw0, cb0, cw1, cb1, pe, mode, B, Ltok, d, 
 
 
 def embed_bwd(dout, tokens, cond, g_emb, g_cw0, g_cb0, g_cw1, g_cb1, mode, B, Ltok, d, dc, pad_token, p, seed, ws=None):
-    """ws: zero-initialised uint8/int32 device buffer of embed_bwd_ws_bytes() bytes (the library leaves it zeroed): tokens with
-    more than 512 occurrences in the batch are then spread over 64 blocks instead of being summed by one."""
+    """ws: zero-initialised uint8/int32 device buffer of workspace_bytes(ME_WS_EMBED_BWD) bytes.  Tokens with more than 192
+    occurrences in the batch are published there by the gather kernel and summed by the second launch in slices of about
+    128 occurrences spread over the chip, instead of by one block.  A call that returns 0 leaves the buffer zeroed; after a
+    call that RAISED the caller must zero it again (or drop it) before the next use."""
     vocab = g_emb.shape[0]
     check(lib().me_embed_bwd(_ptr(dout), _code(dout.dtype), _ptr(tokens), _ptr(cond), _ptr(g_emb), _ptr(g_cw0),
                              _ptr(g_cb0), _ptr(g_cw1), _ptr(g_cb1), mode, B, Ltok, d, dc, vocab, pad_token, float(p),
@@ -216,8 +218,15 @@ def ce_bwd(logits, target, row_lse, dlogits, n_valid, extra_scale, rows, V, igno
                           _code(logits.dtype), _code(dlogits.dtype), _stream()), "me_ce_bwd")
 
 
-def sumsq(g, out):
-    check(lib().me_sumsq(_ptr(g), g.numel(), _ptr(out), _stream()), "me_sumsq")
+def sumsq(g, out, ws=None):
+    """out[0] += sum g^2.  ws: zeroed uint8 buffer of workspace_bytes(ME_WS_SUMSQ) bytes (sumsq_ws): block sums are added
+    in a fixed order -- bit-reproducible, identical on every data-parallel rank; None: atomics in arrival order."""
+    check(lib().me_sumsq(_ptr(g), g.numel(), _ptr(out), _ptr(ws), ws.numel() * ws.element_size() if ws is not None else 0,
+                         _stream()), "me_sumsq")
+
+
+def sumsq_ws(device):
+    return torch.zeros(workspace_bytes(ME_WS_SUMSQ, 0, 0, 0, torch.float32), dtype=torch.uint8, device=device)
 
 
 def adamw_step(p, g, m, v, sumsq_t, clip, grad_scale, lr, beta1, beta2, eps, weight_decay, step, zero_grad):

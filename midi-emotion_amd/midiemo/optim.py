@@ -24,11 +24,14 @@ class FusedAdamW:
         self.m = torch.zeros_like(f)
         self.v = torch.zeros_like(f)
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=f.device)
+        # ordered block sums: the clip coefficient is bit-reproducible, so data-parallel ranks (identical reduced
+        # gradients) stay bit-identical through the update
+        self._sumsq_ws = ops.sumsq_ws(f.device)
 
     def grad_norm(self):
         """Device scalar: global L2 norm of the (already all-reduced) flat gradient."""
         self.sumsq.zero_()
-        ops.sumsq(self.model.flat_grads, self.sumsq)
+        ops.sumsq(self.model.flat_grads, self.sumsq, ws=self._sumsq_ws)
         return self.sumsq.sqrt()
 
     def step(self, grad_scale=1.0, zero_grad=True):
@@ -39,7 +42,11 @@ class FusedAdamW:
         lr = self.param_groups[0]["lr"]
         self.sumsq.zero_()
         if self.clip and self.clip > 0:
-            ops.sumsq(m.flat_grads, self.sumsq)
+            try:
+                ops.sumsq(m.flat_grads, self.sumsq, ws=self._sumsq_ws)
+            except Exception:
+                self._sumsq_ws = ops.sumsq_ws(m.flat_params.device)      # a failed launch may leave the ticket counter set
+                raise
         ops.adamw_step(m.flat_params, m.flat_grads, self.m, self.v, self.sumsq, self.clip or 0.0, grad_scale, lr,
                        self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count, zero_grad)
         m.mark_params_changed()

@@ -1,6 +1,7 @@
 """Worker of tests/test_ddp_gpu.py: one data-parallel rank running REAL train steps of the HIP engine
 (loss_and_backward with bucket_hook=GradAllReducer.hook -> finish -> FusedAdamW.step(grad_scale=1/world)), every rank on
-cuda:0 (1-GPU boxes).  Rank 0 writes the averaged flat gradient of step 1 and the parameters after the last step."""
+cuda:0 (1-GPU boxes).  Rank 0 writes, for every step, the parameters the step started from, the averaged flat gradient
+the optimiser was given and the parameters after the update (+ Adam's m / v at the end)."""
 import argparse
 import os
 import sys
@@ -51,6 +52,7 @@ def main():
     ap.add_argument("--compute_dtype", default="fp32")
     ap.add_argument("--out", required=True)
     ap.add_argument("--big", action="store_true")
+    ap.add_argument("--dump_prep", action="store_true", help="diagnosis: also save the prepared (cast) weights every step ran with")
     a = ap.parse_args()
     if a.big:
         use_big()
@@ -73,18 +75,34 @@ def main():
     opt = FusedAdamW(model, lr=2e-5, clip=1.0)          # same as the reference run in test_ddp_gpu.py
     red = GradAllReducer(lambda: model.flat_grads, model.bucket_ranges(), policy=a.policy)
     g1 = None
+    gs, pb, pa, preps = [], [], [], []
     for step in range(STEPS):
+        pb.append(model.flat_params.detach().cpu().clone())          # the parameters this step's gradient is taken at
         for micro in range(a.accumulate):
             x, c, y = micro_batch(step, micro, rank, dev)
             last = micro + 1 == a.accumulate
             model.loss_and_backward(x, c, y, grad_scale=1.0 / a.accumulate, bucket_hook=red.hook if last else None)
+            if a.dump_prep and micro == 0 and rank == 0:
+                preps.append([{k: v.detach().cpu().clone() for k, v in L.items() if torch.is_tensor(v)} for L in model._prep["layers"]] +
+                             [{k: v.detach().cpu().clone() for k, v in model._prep["head"].items()}])
         red.finish()
         if step == 0:
             g1 = (model.flat_grads * red.grad_scale).clone()
+        gs.append((model.flat_grads * red.grad_scale).cpu())         # averaged gradient as the optimiser sees it
         opt.step(grad_scale=red.grad_scale)
+        pa.append(model.flat_params.detach().cpu().clone())
     torch.cuda.synchronize()
+    # the invariant data-parallel training rests on (SURVEY 8e "identical optimizer state evolution on every rank"): every
+    # rank holds BIT-identical parameters and Adam moments after every update -- same reduced gradients, and an optimiser
+    # whose clip coefficient does not depend on block arrival order (me_sumsq's ordered block sums)
+    for name, t in (("params", model.flat_params.detach()), ("m", opt.m), ("v", opt.v)):
+        ref = t.clone()
+        dist.broadcast(ref, src=0)
+        ndiff = int((ref != t).sum())
+        assert ndiff == 0, "rank %d: %d entries of %s differ from rank 0 after %d steps" % (rank, ndiff, name, STEPS)
     if rank == 0:
-        torch.save({"g1": g1.cpu(), "params": model.flat_params.detach().cpu().clone()}, a.out)
+        torch.save({"g1": g1.cpu(), "params": model.flat_params.detach().cpu().clone(), "grads": gs, "params_before": pb,
+                    "params_steps": pa, "m": opt.m.cpu(), "v": opt.v.cpu(), "preps": preps}, a.out)
     dist.barrier()
     dist.destroy_process_group()
     print("rank", rank, "done")

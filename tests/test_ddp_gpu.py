@@ -1,8 +1,10 @@
 """SURVEY 8e / VERDICT r1 item 1c: the data-parallel path through the REAL train step.  Two ranks on ONE GPU run
 3 steps of loss_and_backward(bucket_hook=GradAllReducer.hook) -> finish() -> FusedAdamW.step(grad_scale=1/world) under
-each overlap policy (and with gradient accumulation) and must reproduce the 1-rank trajectory on the concatenated
-batch: averaged flat gradient of step 1 and parameters after 3 steps.  (The gloo test in test_host_cpu.py only feeds
-the reducer synthetic vectors; this one checks that _backward_impl hands over FINAL gradients bucket by bucket.)"""
+each overlap policy (and with gradient accumulation); EVERY step's reduced gradient must equal the 1-rank gradient on the
+concatenated batch at the same parameters, and the optimiser must turn those gradients into the run's parameters
+(check_against_single_rank; all bounds derived).  (The gloo test in test_host_cpu.py only feeds the reducer synthetic
+vectors; this one checks that _backward_impl hands over FINAL gradients bucket by bucket, at every step.)
+This file is collected LAST (tests/conftest.py): a stop here under `pytest -x` leaves the whole parity record."""
 import os
 import subprocess
 import sys
@@ -15,31 +17,123 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
-def single_rank_reference(world, accumulate, compute_dtype, big=False, rank_order=None):
+LR = 2e-5
+
+
+def _row_orders(n):
+    """up to five distinct non-identity row orders of an n-row micro-batch"""
+    cand = [tuple(range(k, n)) + tuple(range(k)) for k in range(1, n)] + [tuple(reversed(range(n)))]
+    if n >= 4:
+        cand += [(1, 0) + tuple(range(3, n)) + (2,), (0, 2, 1) + tuple(range(3, n))]
+    out = []
+    for c in cand:
+        if c != tuple(range(n)) and c not in out:
+            out.append(c)
+    return out[:5]
+
+
+def _keep_mask(model):
+    # d loss / d Wk.bias is exactly zero (softmax shift invariance): every run steps on rounding noise there and Adam
+    # normalises noise to +-lr, so those entries are excluded from the comparisons (DESIGN section 5)
+    keep = torch.ones(model.flat_params.numel(), dtype=torch.bool)
+    for name, (o, n, _) in model._slices.items():
+        if name.endswith("Wk.bias"):
+            keep[o:o + n] = False
+    return keep
+
+
+def _grad_at(model, W, step, world, accumulate, order=None, split=False):
+    """Averaged gradient of train step `step` at the model's CURRENT parameters, one rank, the ranks' micro-batches
+    concatenated (rows optionally permuted), or -- split -- fed rank piece by rank piece as separate micro-batches (the
+    per-launch shapes of a rank of the data-parallel run)."""
+    dev = model.flat_params.device
+    model.flat_grads.zero_()
+    for micro in range(accumulate):
+        parts = [W.micro_batch(step, micro, r, dev) for r in range(world)]
+        if split:
+            for x, c, y in parts:
+                model.loss_and_backward(x, c, y, grad_scale=1.0 / (accumulate * world))
+            continue
+        x, c, y = (torch.cat([p[i] for p in parts]) for i in range(3))
+        if order is not None:
+            idx = torch.tensor(order, device=dev)
+            x, c, y = x[idx], c[idx], y[idx]
+        model.loss_and_backward(x, c, y, grad_scale=1.0 / accumulate)
+    return model.flat_grads.detach().cpu().clone()
+
+
+def check_against_single_rank(got, world, accumulate, compute_dtype, big=False, tag=""):
+    """What data-parallel training has to guarantee, checked step by step so that no comparison runs through Adam's
+    chaotic sign amplification (tools/diag_ddp_bf16.py, tools/diag_ddp_forced.py, profiles/r04_ddp_diagnosis.txt: in the
+    bf16 tier ONE weight that rounds to the other bf16 neighbour after step 1 moves every gradient of step 2 by 1e-3,
+    whichever way the batch is fed):
+      (1) the broadcast repaired rank 1's parameters (step 0 starts from the seed-7 weights);
+      (2) for EVERY step s, the averaged gradient the ranks reduced equals the 1-rank gradient on the concatenated batch
+          taken AT THE SAME PARAMETERS (the run's own, loaded into the 1-rank model) -- this is where a stale bucket, a
+          bucket handed over before its last kernel, a lost accumulation or a wrong 1 / world would show, at any step;
+          bound DERIVED: 4 x the largest deviation among the 1-rank evaluations of step 0 that differ from the reference
+          evaluation only in summation order (up to five row orders of the micro-batches, the rank-piece-wise feed, and
+          the same evaluation repeated);
+      (3) the optimiser, fed the run's reduced gradients, reproduces the run's parameters after every step (clip on the
+          averaged gradient, 1 / world folded into grad_scale) -- elementwise arithmetic, bound 1e-5 of the update;
+    the free-running 3-step trajectory against a free-running 1-rank run is printed for the record (not asserted beyond
+    a sanity bound: it measures the model's sensitivity, not the exchange)."""
     import ddp_worker as W
     from midiemo.optim import FusedAdamW
     W.use_big(big)
     dev = torch.device("cuda", 0)
     model = W.build(compute_dtype, dev)
-    opt = FusedAdamW(model, lr=2e-5, clip=1.0)
+    keep = _keep_mask(model)
     p0 = model.flat_params.detach().cpu().clone()
-    # d loss / d Wk.bias is exactly zero (softmax shift invariance): both runs step on rounding noise there and Adam
-    # normalises noise to +-lr, so those entries are excluded from the trajectory comparison
-    keep = torch.ones(p0.numel(), dtype=torch.bool)
-    for name, (o, n, _) in model._slices.items():
-        if name.endswith("Wk.bias"):
-            keep[o:o + n] = False
-    g1 = None
-    for step in range(W.STEPS):
-        for micro in range(accumulate):
-            parts = [W.micro_batch(step, micro, r, dev) for r in (rank_order or range(world))]
-            x, c, y = (torch.cat([p[i] for p in parts]) for i in range(3))
-            model.loss_and_backward(x, c, y, grad_scale=1.0 / accumulate)
-        if step == 0:
-            g1 = model.flat_grads.clone()
+    assert torch.equal(got["params_before"][0], p0), "step 0 did not start from the broadcast seed-7 parameters"
+    g_ref0 = _grad_at(model, W, 0, world, accumulate)
+    noise = [rel(_grad_at(model, W, 0, world, accumulate, order=o)[keep], g_ref0[keep]) for o in _row_orders(world * W.B)]
+    noise.append(rel(_grad_at(model, W, 0, world, accumulate, split=True)[keep], g_ref0[keep]))
+    noise.append(rel(_grad_at(model, W, 0, world, accumulate)[keep], g_ref0[keep]))         # the same evaluation again: atomics' arrival order
+    bound = 4 * max(noise) + 1e-9
+    eg = []
+    for s in range(W.STEPS):
+        with torch.no_grad():
+            model.flat_params.copy_(got["params_before"][s].to(dev))
+        model.mark_params_changed()
+        eg.append(rel(got["grads"][s][keep], _grad_at(model, W, s, world, accumulate)[keep]))
+    # (3) optimiser replay on the run's own gradients
+    with torch.no_grad():
+        model.flat_params.copy_(p0.to(dev))
+    model.mark_params_changed()
+    opt = FusedAdamW(model, lr=LR, clip=1.0)
+    eo = []
+    for s in range(W.STEPS):
+        model.flat_grads.copy_(got["grads"][s].to(dev))
         opt.step()
-    torch.cuda.synchronize()
-    return g1.cpu(), model.flat_params.detach().cpu().clone(), p0, keep
+        mine = model.flat_params.detach().cpu()
+        eo.append(rel(mine - got["params_before"][s], got["params_steps"][s] - got["params_before"][s]))
+    # free-running 1-rank trajectory, for the record
+    with torch.no_grad():
+        model.flat_params.copy_(p0.to(dev))
+    model.mark_params_changed()
+    opt = FusedAdamW(model, lr=LR, clip=1.0)
+    for s in range(W.STEPS):
+        model.flat_grads.copy_(_grad_at(model, W, s, world, accumulate).to(dev))
+        opt.step()
+    free = model.flat_params.detach().cpu()
+    eu = rel((got["params"] - p0)[keep], (free - p0)[keep])
+    line = ("ddp %s %s world %d acc %d: gradient at the run's own parameters, steps 1..%d: %s  (bound %.2e = 4 x max of %s); "
+            "optimiser replay %s; free-running %d-step update rel %.2e" %
+            (tag, compute_dtype, world, accumulate, W.STEPS, " ".join("%.2e" % e for e in eg), bound,
+             " ".join("%.1e" % n for n in noise), " ".join("%.1e" % e for e in eo), W.STEPS, eu))
+    print(line)
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "parity_report.txt"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+    for s, e in enumerate(eg):
+        assert e <= bound, ("step %d: reduced gradient differs from the 1-rank gradient at the same parameters" % (s + 1), e, bound)
+    for s, e in enumerate(eo):
+        assert e <= 1e-5, ("step %d: optimiser replay" % (s + 1), e)
+    assert eu <= 0.1, eu                  # sanity only (see the docstring)
 
 
 def rel(a, b):
@@ -61,34 +155,18 @@ def run_workers(tmp_path, policy, accumulate, backend, compute_dtype, port, npro
 def test_two_ranks_one_gpu_match_single_rank(tmp_path, policy, accumulate):
     r, out = run_workers(tmp_path, policy, accumulate, "gloo", "fp32", 29541 + accumulate + len(policy))
     assert r.returncode == 0 and r.stdout.count("done") == 2, r.stdout[-3000:] + r.stderr[-3000:]
-    got = torch.load(out)
-    g1, params, p0, keep = single_rank_reference(2, accumulate, "fp32")
-    eg, ep = rel(got["g1"][keep], g1[keep]), rel(got["params"][keep], params[keep])
-    eu = rel((got["params"] - p0)[keep], (params - p0)[keep])
-    print("ddp %s acc=%d: grad rel %.2e, params-after-3-steps rel %.2e, 3-step update rel %.2e" % (policy, accumulate, eg, ep, eu))
-    assert eg <= 1e-5, eg                  # f32 tier: same sums in a different order
-    assert ep <= 1e-4, ep                  # lr 2e-5: dominated by the few noise-sign entries (each 2 lr per step)
-    assert eu <= 2e-2, eu                  # Adam turns rounding noise of near-zero gradients into +-lr: a few entries differ
+    check_against_single_rank(torch.load(out), 2, accumulate, "fp32", tag=policy)
 
 
 def test_two_ranks_bf16_headline_model_accumulate(tmp_path):
-    """the tier and the model the benchmark times -- bf16 storage, hi + lo residual stream, bf16 weight refresh
-    after every reduced step, 6 layers d512 8 heads -- with world = 2 and --accumulate 2 through the model's backward
-    (grouped weight-gradient launches hand their buckets over at the end of each layer).  Bound DERIVED, not picked: the
-    2-rank run differs from the 1-rank run on the concatenated batch only by f32 summation order (each rank sums its own
-    rows, the all-reduce adds the two), the same kind of difference two 1-rank bf16 runs show when the rows of the batch
-    are fed in the other order; the 2-rank deviation must stay within 4 x that."""
+    """the tier and the model the benchmark times -- bf16 storage, hi + lo residual stream, bf16
+    weight refresh after every reduced step, 6 layers d512 8 heads -- with world = 2 and --accumulate 2 through the
+    model's backward (grouped weight-gradient launches hand their buckets over at the end of each layer).  Every bound is
+    derived (check_against_single_rank).  Round 3 compared free-running 3-step trajectories against 4 x ONE permuted run;
+    that quantity is chaotic in this tier and the test went red on the driver's box: see profiles/r04_ddp_diagnosis.txt."""
     r, out = run_workers(tmp_path, "window", 2, "gloo", "bf16", 29583, big=True)
     assert r.returncode == 0 and r.stdout.count("done") == 2, r.stdout[-3000:] + r.stderr[-3000:]
-    got = torch.load(out)
-    g1, params, p0, keep = single_rank_reference(2, 2, "bf16", big=True)
-    g1p, paramsp, _, _ = single_rank_reference(2, 2, "bf16", big=True, rank_order=(1, 0))
-    eg, eu = rel(got["g1"][keep], g1[keep]), rel((got["params"] - p0)[keep], (params - p0)[keep])
-    bg, bu = rel(g1p[keep], g1[keep]), rel((paramsp - p0)[keep], (params - p0)[keep])
-    print("ddp bf16 6L d512 acc=2: grad rel %.2e (row-order noise of two 1-rank runs %.2e), 3-step update rel %.2e (%.2e)" %
-          (eg, bg, eu, bu))
-    assert eg <= 4 * bg + 1e-7, (eg, bg)
-    assert eu <= 4 * bu + 1e-7, (eu, bu)
+    check_against_single_rank(torch.load(out), 2, 2, "bf16", big=True, tag="6L d512 window")
 
 
 def test_two_ranks_one_gpu_rccl_backend(tmp_path):
@@ -101,9 +179,7 @@ def test_two_ranks_one_gpu_rccl_backend(tmp_path):
             # measured on the MI355X boxes (RCCL 2.26.6): "Duplicate GPU detected : rank 1 and rank 0 both on CUDA device"
             pytest.skip("RCCL refuses two ranks on one device (ncclInvalidUsage: Duplicate GPU detected)")
         assert False, msg[-4000:]
-    got = torch.load(out)
-    g1, params, p0, keep = single_rank_reference(2, 1, "fp32")
-    assert rel(got["g1"][keep], g1[keep]) <= 1e-5 and rel(got["params"][keep], params[keep]) <= 1e-4
+    check_against_single_rank(torch.load(out), 2, 1, "fp32", tag="rccl")
 
 
 @pytest.mark.parametrize("policy", ["window", "eager", "end"])
@@ -113,9 +189,7 @@ def test_one_rank_through_rccl(tmp_path, policy):
     with the one rank a single-GPU box allows: the trajectory must equal the plain single-process run."""
     r, out = run_workers(tmp_path, policy, 1, "nccl", "fp32", 29571 + len(policy), nproc=1)
     assert r.returncode == 0 and r.stdout.count("done") == 1, r.stdout[-3000:] + r.stderr[-3000:]
-    got = torch.load(out)
-    g1, params, p0, keep = single_rank_reference(1, 1, "fp32")
-    assert rel(got["g1"][keep], g1[keep]) <= 1e-6 and rel(got["params"][keep], params[keep]) <= 1e-6
+    check_against_single_rank(torch.load(out), 1, 1, "fp32", tag="rccl 1 rank " + policy)
 
 
 def test_bench_one_rank_under_the_launcher_rccl():

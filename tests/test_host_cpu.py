@@ -215,6 +215,25 @@ def test_lr_schedules_follow_torch_schedulers():
     assert got == pytest.approx(want, rel=1e-12)
     assert got[-1] > got[5] > a.lr_min                       # the triangle is rising (step_size_up = 2000)
 
+    # restart: a run interrupted after n updates and resumed must continue the uninterrupted lr sequence.
+    # The train loop calls on_step(step - 1) after update `step`, so n completed updates = on_step(0) .. on_step(n - 1).
+    for warm in (3, 0):
+        a = train.parse_args(["--scheduler", "cyclic", "--lr_min", "1e-5", "--lr_max", "1e-3", "--warmup_step", str(warm)])
+        opt = Opt(a.lr)
+        s = train.LRSchedule(a, opt)
+        full = []
+        for upd in range(1, 31):
+            s.on_step(upd - 1)
+            full.append(opt.param_groups[0]["lr"])
+        for n in (2, 3, 4, 5, 17):
+            opt2 = Opt(full[n - 1])                          # the checkpointed optimiser carries the last written lr
+            s2 = train.LRSchedule(a, opt2, start_step=n)
+            rest = []
+            for upd in range(n + 1, 31):
+                s2.on_step(upd - 1)
+                rest.append(opt2.param_groups[0]["lr"])
+            assert rest == pytest.approx(full[n:], rel=1e-12), (warm, n)
+
     # dev_perf: stepped with the validation loss at evaluations only
     a = train.parse_args(["--scheduler", "dev_perf", "--lr", "1e-3", "--decay_rate", "0.5", "--patience", "1", "--lr_min", "2e-4"])
     opt = Opt(a.lr)

@@ -574,6 +574,38 @@ def test_sumsq_and_adamw(ops):
         assert float((p.double().cpu() - P["w"]).abs().max()) < 2e-6, step
 
 
+def test_sumsq_ordered_is_bit_reproducible(ops):
+    """me_sumsq with the caller's workspace adds the block sums in index order: the result must not depend on which block
+    finishes when (it sets the clip coefficient, and data-parallel ranks must come out of the update bit-identical --
+    round-4 DDP diagnosis).  20.6 M elements = the headline model's flat gradient; the same call repeated while other
+    work (a second stream hammering the memory system) perturbs the arrival order; the workspace is reused (the library
+    leaves its ticket zeroed); the accumulate contract (*out +=) holds."""
+    n = 20604399
+    g = torch.randn(n, device=DEV) * 1e-3
+    ws = ops.sumsq_ws(DEV)
+    ref = None
+    side = torch.cuda.Stream()
+    junk = torch.empty(64 << 20, device=DEV)
+    for it in range(24):
+        out = torch.zeros(1, device=DEV)
+        if it % 2:
+            with torch.cuda.stream(side):
+                junk.normal_()                                  # competes for CUs / HBM: different block arrival order
+        ops.sumsq(g, out, ws=ws)
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = out.clone()
+            exact = float((g.double() ** 2).sum())
+            assert abs(float(ref) - exact) <= 1e-5 * exact
+        assert torch.equal(out, ref), (it, float(out), float(ref))
+    assert int(ws.view(torch.int32)[0]) == 0                    # ticket counter left zeroed
+    out = torch.full((1,), 2.0, device=DEV)
+    ops.sumsq(g, out, ws=ws)
+    assert abs(float(out) - 2.0 - float(ref)) <= 1e-6 * float(ref) + 1e-6
+    with pytest.raises(RuntimeError, match="ME_ERR_BAD_SHAPE"):
+        ops.sumsq(g, out, ws=torch.zeros(16, dtype=torch.uint8, device=DEV))
+
+
 # ------------------------------------------------------------------ embedding prologue
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("mode", ["none", "continuous_concat", "continuous_token"])

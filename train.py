@@ -158,11 +158,17 @@ class LRSchedule:
                 self.sched = torch.optim.lr_scheduler.ReduceLROnPlateau(self.shadow, factor=args.decay_rate,
                                                                         patience=args.patience, min_lr=args.lr_min)
 
-        if args.scheduler == "cyclic" and start_step > args.warmup_step:
-            # restart: put the triangle where the interrupted run left it (one scheduler.step() per step past the warm-up)
-            for _ in range(start_step - args.warmup_step):
-                self.shadow.step()
-                self.sched.step()
+        if args.scheduler == "cyclic":
+            # restart: put the triangle where the interrupted run left it.  A run that completed start_step updates has
+            # called on_step(0) .. on_step(start_step - 1); the scheduler stepped for those arguments that were not warm-up
+            # steps -- counted with on_step's own predicate (one step ahead before).
+            for s in range(start_step):
+                if not self._in_warmup(s):
+                    self.shadow.step()
+                    self.sched.step()
+
+    def _in_warmup(self, step):
+        return self.args.warmup_step > 0 and step <= self.args.warmup_step
 
     def _copy(self):
         self.opt.param_groups[0]["lr"] = self.shadow.param_groups[0]["lr"]
@@ -173,7 +179,7 @@ class LRSchedule:
             return
         if a.scheduler in ("cosine", "inv_sqrt"):
             self.opt.param_groups[0]["lr"] = lr_at(a, step)
-        elif a.warmup_step > 0 and step <= a.warmup_step:
+        elif self._in_warmup(step):
             self.opt.param_groups[0]["lr"] = a.lr * step / a.warmup_step
         elif a.scheduler == "cyclic":
             self.shadow.step()                       # keeps torch's "optimizer.step() before scheduler.step()" order
