@@ -419,6 +419,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
+    reducer.timing = dist_on               # two event records per step around the bucket waits (exposed communication)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     t0 = time.perf_counter()
@@ -437,6 +438,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     final_loss = float(loss.item())
+    exposed = sorted(reducer.exposed_ms()) if dist_on else []
+    reducer.timing = False
+    if dist_on and exposed:
+        # slowest rank's view: MAX over ranks of the mean exposed wait
+        tw = torch.tensor([sum(exposed) / len(exposed), exposed[len(exposed) // 2]], dtype=torch.float64, device=dev)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        exposed_mean, exposed_p50 = float(tw[0]), float(tw[1])
 
     probe, hbm_table = None, None
     if not args.no_probe:
@@ -505,6 +513,13 @@ def main():
         out["ddp"] = {"policy": os.environ.get("MIDIEMO_DDP_POLICY", "window"),
                       "cu_reserve": int(os.environ.get("MIDIEMO_CU_RESERVE", "0") or 0), "world": world,
                       "backend": backend if dist_on else None}
+        if dist_on and exposed:
+            # time per step the compute stream sat in GradAllReducer.finish() waiting for bucket all-reduces (HIP events
+            # around the waits, max over ranks): communication NOT hidden behind the backward.  The first thing to read in
+            # a SCALE run: value(N) / (N value(1)) ~ 1 - exposed / step when nothing else changes.
+            out["ddp"].update(exposed_wait_ms_per_step=round(exposed_mean, 4), exposed_wait_ms_p50=round(exposed_p50, 4),
+                              exposed_frac_of_step=round(exposed_mean / (1000.0 * elapsed / args.steps), 4),
+                              grad_bytes_per_step=int(model.flat_grads.numel() * 4))
         if hbm_table is not None:
             out["hbm_kernels"] = hbm_table
         if world == 1 and not args.no_cpu_baseline:

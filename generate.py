@@ -29,7 +29,6 @@ for _p in (ROOT, os.path.join(ROOT, "midi-emotion_amd")):
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
-import torch.nn.functional as F  # noqa: E402
 
 from midiemo import ops  # noqa: E402
 from midiemo.decode import DecodeSession, WindowForward  # noqa: E402
@@ -123,6 +122,13 @@ def generate(model, maps, device, out_dir, conditioning, short_filename=False,
     repeat_counts = torch.zeros(batch_size, device=device)
     temp_note, temp_rest = float(temperatures[0]), float(temperatures[1])
     V = model.vocab_size
+    if V > 1024 and top_k != 1:
+        # the device sampling tail (me_sample_topk_topp / me_sample_step) sorts one row of at most 1024 (value, id) pairs in
+        # LDS; the reference's vocabularies have 1007 / 1017 symbols (data_processing.py get_maps, loader.py:58-75).  There is
+        # no second, non-HIP sampling path in this build: a larger vocabulary is refused, not silently served
+        # by torch ops.  Greedy decoding (--topk 1) has no such limit.
+        raise NotImplementedError("sampled generation supports vocabularies of at most 1024 symbols (got %d); "
+                                  "use top_k=1 (greedy) or extend sample_kernel's sort width" % V)
 
     cache_ok = bool(use_cache) and varying_condition is None
     sess = None
@@ -193,27 +199,10 @@ def generate(model, maps, device, out_dir, conditioning, short_filename=False,
             temp = sampling_temperature(gen_inds[0], repeat_counts, is_timeshift, temp_note, temp_rest, penalty_coeff)
             lg = output.float()
             lg = lg if lg.is_contiguous() else lg.contiguous()
-            if V <= 1024:
-                uni = torch.rand(batch_size, device=device)
-                ops.sample_topk_topp(lg, V, specials, temp.float().contiguous(), top_k, top_p, uni, picked, n_choices_buf)
-                gen_inds = picked.clone()[None, :]
-                n_choices = n_choices_buf
-            else:                                                 # vocabulary larger than the kernel's sort: torch path
-                out2 = lg.clone()
-                out2[out2 != out2] = 0
-                out2[:, specials.long()] = -float("inf")
-                out2 = F.log_softmax(out2, dim=-1) / temp[:, None]
-                k_eff = V if (top_k <= 0 or top_k > V) else top_k
-                out2, top_inds = torch.topk(out2, k_eff)
-                if 0 < top_p < 1:                                 # generate.py:173-177
-                    cum = torch.cumsum(F.softmax(out2, dim=-1), dim=-1)
-                    remove = cum > top_p
-                    remove[:, 0] = False
-                    out2[remove] = -float("inf")
-                probs = F.softmax(out2, dim=-1)
-                sampled = torch.multinomial(probs, 1, replacement=True)
-                gen_inds = top_inds.gather(1, sampled).t()
-                n_choices = (probs > 0).sum(-1)
+            uni = torch.rand(batch_size, device=device)
+            ops.sample_topk_topp(lg, V, specials, temp.float().contiguous(), top_k, top_p, uni, picked, n_choices_buf)
+            gen_inds = picked.clone()[None, :]
+            n_choices = n_choices_buf
             repeat_counts = update_repeat_counts(repeat_counts, n_choices)
 
     ids = gen_song.cpu()

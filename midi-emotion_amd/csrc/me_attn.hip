@@ -288,23 +288,8 @@ __global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ q
 // goes through the dG ring (LDS) and gives the relative part dQ^T += E^T dG^T (2 DB atoms) and the dG^T tile for dE.
 // CAUSAL = false: backward of the bidirectional forward (MusicRegression): every key tile is visited; tiles above the
 // diagonal have no relative term (no dG, no E^T product).
-#ifdef ME_PROFQ
-// development aid: per-phase s_memtime sums of rga_bwd_q_kernel (lane 0 of every wave, atomics at kernel end)
-__device__ unsigned long long g_profq[16];
-#define PROFQ_DECL unsigned long long pf_t0 = __builtin_amdgcn_s_memtime(), pf_acc[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
-#define PROFQ(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pf_acc[i] += t_ - pf_t0; pf_t0 = t_; } while (0)
-#define PROFQ_END do { if (lane == 0) { for (int i_ = 0; i_ < 15; ++i_) atomicAdd(&g_profq[i_], pf_acc[i_]); atomicAdd(&g_profq[15], 1ull); } } while (0)
-#else
-#define PROFQ_DECL
-#define PROFQ(i)
-#define PROFQ_END
-#endif
 template <typename T> struct PHalf;
-#ifdef ABLQ_P8
-template <> struct PHalf<bf16_t> { typedef bf16x4_t type; static constexpr int N = 4; };
-#else
 template <> struct PHalf<bf16_t> { typedef bf16x8_t type; static constexpr int N = 8; };     // two 16-byte loads per lane and tile
-#endif
 template <> struct PHalf<float> { typedef f32x4_t type; static constexpr int N = 4; };
 
 #ifndef BQ_OCC
@@ -325,7 +310,7 @@ __global__ __launch_bounds__(256, BQ_OCC) void rga_bwd_q_kernel(
     // E^T fragment images of the relative blocks in use (16-bit tier): at step kt wave w needs block ebB - w + kt, i.e. the
     // block's four waves use four consecutive blocks and only ONE is new per step.  It is fetched once per block and step
     // (one 16-byte chunk per thread, two steps ahead, like the key tiles) instead of once per wave: 16 KB -> 4 KB of L1
-    // requests per step.  (-DME_PROFQ phase sums showed the waves stalling at the ISSUE of their loads: the CU's L1 miss
+    // requests per step.  (round 3's per-phase s_memtime sums showed the waves stalling at the ISSUE of their loads: the CU's L1 miss
     // queue, not the latency of any single load, bounds this kernel.)  5 slots: 4 in use + the one being written.
     constexpr bool ERING = sizeof(T) == 2;
     constexpr int EIMG = 2 * C::DB * 512, ENCH = EIMG * (int)sizeof(T) / 16, ENPT = (ENCH + 255) / 256, ESLOTS = 5;
@@ -348,18 +333,16 @@ __global__ __launch_bounds__(256, BQ_OCC) void rga_bwd_q_kernel(
     const int my_last_kt = qb * 4 + wid;
     const float c2 = scale * 1.4426950408889634f;
 
-    PROFQ_DECL;
     Frag<T> dof[C::KA];
     const size_t orow = ((size_t)b * L + q) * dm + head * DH;
     // Prologue: EVERY load of the block's start-up (dO / O rows, lse, key tiles 0 and 1, probability tiles 0 and 1) is
     // requested before the first use -- one memory round trip under load instead of three dependent ones (per-phase
-    // s_memtime sums, -DME_PROFQ: the prologue was 18 % of the waves' time).
+    // s_memtime sums of round 3: the prologue was 18 % of the waves' time).
     Frag<T> oof[C::KA];
     row_frags<T, DH>(dof, dout + orow, row_on, h);
     row_frags<T, DH>(oof, out + orow, row_on, h);
     float lse2 = row_on ? lse[((size_t)b * H + head) * L + q] * 1.4426950408889634f : 0.f;
 
-    PROFQ(10);
     f32x16_t dq[C::DB];
 #pragma unroll
     for (int i = 0; i < C::DB; ++i) acc_zero(dq[i]);
@@ -406,7 +389,6 @@ __global__ __launch_bounds__(256, BQ_OCC) void rga_bwd_q_kernel(
         for (int g = 0; g < PN; ++g) pp[U][g] = nt_load(reinterpret_cast<const PH*>(tp + PE * g));      // the lane's own 16 elements, contiguous
         mtn[U] = mtb[(size_t)ktc * Lp];
     };
-    PROFQ(11);
     chunk16 rk0[TileT<T, 32, DH>::NPT], rv0[TileT<T, 32, DH>::NPT];          // key tile 0 (start-up only); rk / rv receive tile 1
     tile_gload<T, 32, DH>(rk0, kb_, ldq, L, tid);
     tile_gload<T, 32, DH>(rv0, vb_, ldq, L, tid);
@@ -431,7 +413,6 @@ __global__ __launch_bounds__(256, BQ_OCC) void rga_bwd_q_kernel(
         for (int j = 0; j < 4; ++j) eload(re0[j], ebB - 3 + j);           // blocks of step 0
         eload(re, ebB + 1);                                              // wave 0's block of step 1
     }
-    PROFQ(12);
     float delta = 0.f;
 #pragma unroll
     for (int kk = 0; kk < C::KA; ++kk)
@@ -439,7 +420,6 @@ __global__ __launch_bounds__(256, BQ_OCC) void rga_bwd_q_kernel(
         for (int e = 0; e < 8; ++e) delta += frag_get(dof[kk], e) * frag_get(oof[kk], e);
     delta = half_sum(delta);
     if (row_on && h == 0) delta_ws[((size_t)b * H + head) * L + q] = delta;
-    PROFQ(13);
     tile_sstore<T, 32, DH, C::LDV>(rk0, Ks[0], tid);
     tile_sstore<T, 32, DH, C::LDN>(rv0, Vs[0], tid);
     if constexpr (ERING) {
@@ -447,7 +427,6 @@ __global__ __launch_bounds__(256, BQ_OCC) void rga_bwd_q_kernel(
         for (int j = 0; j < 4; ++j) estore(re0[j], ebB - 3 + j);
     }
     __syncthreads();
-    PROFQ(14);
     // One key tile.  MAIN = every wave of the block is strictly above its diagonal tile and tiles kt + 1, kt + 2 lie
     // entirely below L: no wave-, tile- or bounds-dependent branch encloses a global load or store (exact s_waitcnt
     // bookkeeping: vmcnt is in order).
@@ -460,9 +439,7 @@ __global__ __launch_bounds__(256, BQ_OCC) void rga_bwd_q_kernel(
             const int eb_lo = eb0 + kt;
             // (Fetching the E^T images a step ahead as well costs 32 registers and was not faster, rounds 2 and 3.)
             Frag<T> etf[C::DB][2];
-#ifndef ABLQ_NOET
             if constexpr (!ERING) { if (!upper) et_frags(etf, eb_lo); }  // f32 tier: straight from global memory, in flight during dP / dS
-#endif
             const float fac = row_on ? fast_exp2(fmaf(mtn[U], c2, -lse2)) : 0.f;
             f32x16_t s, dp; acc_zero(dp);
 #pragma unroll
@@ -471,7 +448,6 @@ __global__ __launch_bounds__(256, BQ_OCC) void rga_bwd_q_kernel(
                 frag_load(vf, &Vs[buf][a * C::LDN + kk * 16 + h * 8]);
                 mma32(dp, vf, dof[kk]);        // dP^T[key][q] = V[key] . dO[q]
             }
-            PROFQ(1);
             const float nds = -delta * scale;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = (ET<T>::to_f(pp[U][r / PE][r % PE]) * fac) * fmaf(dp[r], scale, nds);
@@ -481,11 +457,8 @@ __global__ __launch_bounds__(256, BQ_OCC) void rga_bwd_q_kernel(
             asm volatile("" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]),
                               "+v"(s[8]), "+v"(s[9]), "+v"(s[10]), "+v"(s[11]), "+v"(s[12]), "+v"(s[13]), "+v"(s[14]), "+v"(s[15]) :: "memory");
             __builtin_amdgcn_sched_barrier(0);
-#ifndef ABLQ_NOP
             load_p(kt + UNR, u_tag);
-#endif
             __builtin_amdgcn_sched_barrier(0);
-            PROFQ(2);
             T* drow = &Ds[wid][a * LDR];
             const int t0 = U * 32 + 31 - a + 4 * h;            // band element m sits at ring column (U * 32 + m) & 63 (the lo block of a step is the hi block of the one before)
             if (!upper) {
@@ -507,7 +480,6 @@ __global__ __launch_bounds__(256, BQ_OCC) void rga_bwd_q_kernel(
                     mma32(dq[i], kf, dsf);
                 }
             }
-            PROFQ(3);
             // ---- the lo block of dG is complete now: relative part of dQ, and the block leaves as the dG^T tile
             //      (qt, t = kt) [E row m][query]: the ring rows [q][m] are read back transposed (16-bit tier:
             //      ds_read_b64_tr_b16, two 16-byte stores per lane) -- the E kernel streams these tiles as they are.
@@ -527,7 +499,6 @@ __global__ __launch_bounds__(256, BQ_OCC) void rga_bwd_q_kernel(
 #pragma unroll
                     for (int i = 0; i < C::DB; ++i) mma32(dq[i], etf[i][t], dgf);
                 }
-                PROFQ(4);
                 T* const dg_dst = dgb + dg_tile(q0 >> 5, kt) * 1024;
                 const T* ring = &Ds[wid][U * 32];                  // lo block: ring rows q, 32 columns m, row stride LDR
                 if constexpr (sizeof(T) == 2) {
@@ -545,11 +516,7 @@ __global__ __launch_bounds__(256, BQ_OCC) void rga_bwd_q_kernel(
                         reinterpret_cast<v4s*>(&c)[0] = x[0];
                         reinterpret_cast<v4s*>(&c)[1] = x[1];
                         // row m = 16 kh + l16, queries 8 gidx .. + 7 -> fragment-image position (dg_pos)
-#ifndef ABLQ_NODG
                         nt_store(c.v, reinterpret_cast<u32x4_t*>(dg_dst + (gidx >> 1) * 512 + (kh * 16 + l16 + 32 * (gidx & 1)) * 8));
-#else
-                        if (c.v[0] == 0x12345678u && c.v[3] == 0x9abcdef0u) nt_store(c.v, reinterpret_cast<u32x4_t*>(dg_dst + (gidx >> 1) * 512 + (kh * 16 + l16 + 32 * (gidx & 1)) * 8));
-#endif
                     }
                 } else {
 #pragma unroll
@@ -560,28 +527,21 @@ __global__ __launch_bounds__(256, BQ_OCC) void rga_bwd_q_kernel(
                 }
             }
         }
-        PROFQ(5);
         if constexpr (MAIN) {
             sstore(buf ^ 1);                      // buf^1 was last read in step kt-1 (barrier since)
             if constexpr (ERING) { estore(re, ebB + kt + 1); eload(re, ebB + kt + 2); }     // slot of block ebB + kt - 4: last read in step kt - 1
-#ifndef ABLQ_NOKV
             gload_full(kt + 2);
-#endif
         } else if (kt + 1 < nkt) {
             sstore(buf ^ 1);
             if constexpr (ERING) { estore(re, ebB + kt + 1); eload(re, ebB + kt + 2); }
             if (kt + 2 < nkt) gload(kt + 2);
         }
-        PROFQ(6);
         block_sync_lds();               // LDS hand-over only: prefetch loads / tile stores stay in flight
-        PROFQ(7);
     };
     // MAIN steps: all four waves on and off-diagonal (kt < 4 qb), tiles kt + 1, kt + 2 whole (kt + 3 <= L / 32)
     const int nmain = (qb * 128 + 96 < L) ? max(0, min(qb * 4, (L >> 5) - 2)) : 0;
     int kt = 0;
     vm_drain();                         // loop entry state = nothing in flight: the header's waits are the back edge's exact counts
-    PROFQ(0);
-#ifndef ABLQ_EMPTY
     using U0 = std::integral_constant<int, 0>;
     using U1 = std::integral_constant<int, 1>;
     for (; kt + 1 < nmain; kt += 2) { step(kt, U0{}, std::true_type{}); step(kt + 1, U1{}, std::true_type{}); }
@@ -589,8 +549,7 @@ __global__ __launch_bounds__(256, BQ_OCC) void rga_bwd_q_kernel(
         step(kt, U0{}, std::false_type{});
         if (kt + 1 < nkt) step(kt + 1, U1{}, std::false_type{});
     }
-#endif
-    if (!row_on) { PROFQ_END; return; }
+    if (!row_on) return;
     T* dqp = dqkv + ((size_t)b * L + q) * ldq + head * DH;
 #pragma unroll
     for (int i = 0; i < C::DB; ++i)
@@ -598,8 +557,7 @@ __global__ __launch_bounds__(256, BQ_OCC) void rga_bwd_q_kernel(
         for (int gq = 0; gq < 4; ++gq)
             if (i * 32 + 8 * gq + 4 * h < DH)
                 st4<T>(dqp + i * 32 + 8 * gq + 4 * h, dq[i][4 * gq], dq[i][4 * gq + 1], dq[i][4 * gq + 2], dq[i][4 * gq + 3]);
-    PROFQ(8);
-    PROFQ_END;
+
 }
 
 // =====================================================================================
@@ -1042,10 +1000,3 @@ int me_rga_bwd(const void* qkv, const void* Epk, const void* out, const float* l
 
 }  // extern "C"
 
-#ifdef ME_PROFQ
-extern "C" int me_profq_read(unsigned long long* out16, int reset) {
-    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_profq), sizeof(unsigned long long) * 16);
-    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_profq), z, sizeof(z)); }
-    return e == hipSuccess ? 0 : -1;
-}
-#endif

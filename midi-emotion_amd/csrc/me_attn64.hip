@@ -16,17 +16,6 @@
 namespace me_attn64 {
 using namespace me_attn;
 
-#ifdef ME_PROF
-// development aid: per-phase s_memtime sums (lane 0 of every wave, atomics at kernel end); read back with hipMemcpyFromSymbol
-__device__ unsigned long long g_prof[16];
-#define PROF_DECL unsigned long long pf_t0 = __builtin_amdgcn_s_memtime(), pf_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
-#define PROF(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pf_acc[i] += t_ - pf_t0; pf_t0 = t_; } while (0)
-#define PROF_END do { if (lane == 0) { for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&g_prof[i_], pf_acc[i_]); atomicAdd(&g_prof[15], 1ull); } } while (0)
-#else
-#define PROF_DECL
-#define PROF(i)
-#define PROF_END
-#endif
 
 typedef bf16_t T;
 constexpr int DH = 64, KA = 4, DB = 2;
@@ -36,11 +25,7 @@ constexpr int LDR = 68;                        // G ring row (floats): 64-column
 constexpr int K_BYTES = 64 * LDK * 2;          // 9216
 constexpr int V_BYTES = 64 * LDV * 2;          // 12288
 constexpr int G_BYTES = 32 * LDR * 4;          // 8704 per wave
-#ifdef ABL_LDS
-constexpr int FWD_LDS = ABL_LDS;                                                   // occupancy experiments
-#else
 constexpr int FWD_LDS = 2 * K_BYTES + 2 * V_BYTES + 4 * G_BYTES;                   // 77824
-#endif
 
 // =====================================================================================
 // forward
@@ -80,7 +65,6 @@ __global__ __launch_bounds__(256, 2) void rga_fwd64_kernel(const T* __restrict__
     const int my_last_kt = qb * 4 + wid;                  // diagonal tile of this wave
     const float c2 = scale * 1.4426950408889634f;         // logits are kept in log2 units
     const int nE = M >> 5;
-    PROF_DECL;
 
     // ---- K / V tile stream: 64 rows x 128 B per operand and step = two 16-byte chunks per thread.  The pad flags of the
     // step's 64 keys travel with it: EVERY wave loads all 64 of them (one byte per lane), so the step's pad mask is a
@@ -179,11 +163,7 @@ __global__ __launch_bounds__(256, 2) void rga_fwd64_kernel(const T* __restrict__
             frag_from_acc(pf, p, t);
             if constexpr (STORE_P) {
                 // written once, read by the backward much later: streaming (non-temporal) stores
-#ifndef ABL_PLAINST
                 if (store) __builtin_nontemporal_store(pf.v, reinterpret_cast<bf16x8_t*>(ptile + 8 * t));
-#else
-                if (store) frag_store(ptile + 8 * t, pf);
-#endif
             }
 #pragma unroll
             for (int i = 0; i < DB; ++i) {
@@ -215,7 +195,6 @@ __global__ __launch_bounds__(256, 2) void rga_fwd64_kernel(const T* __restrict__
     unsigned long long pb_cur = pad_mask();
     if (nst > 1) gload(1);
     __syncthreads();
-    PROF(1);
 
     // ---- two tiles with one running-maximum update and no per-element predicate.  TAIL: the wave may be at its diagonal.
     // The keys a diagonal tile must not see (key > q) are exactly its band elements m >= 32, i.e. its hi block -- which the
@@ -234,13 +213,9 @@ __global__ __launch_bounds__(256, 2) void rga_fwd64_kernel(const T* __restrict__
             for (int r = 0; r < 16; ++r) g2[r] = -INFINITY;
         } else g_mma(g2, efB);
         s_mma(s1, Kt + 32 * LDK);
-        PROF(2);
         const int X = eb0 + 2 * s;
-#ifndef ABL_NOE
         e_frags(efA, X + 3);
         e_frags(efB, X + 4);
-#endif
-#ifndef ABL_NORING
         ring_write(g1, wA, hA);
         float gv[16];
 #pragma unroll
@@ -256,11 +231,6 @@ __global__ __launch_bounds__(256, 2) void rga_fwd64_kernel(const T* __restrict__
             for (int i = 0; i < 4; ++i) gv[4 * j + i] = rB[j][i];
 #pragma unroll
         for (int r = 0; r < 16; ++r) s1[r] += gv[r];
-#else
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s0[r] += g1[r]; s1[r] += g2[r]; }
-#endif
-        PROF(3);
         float mt = fmaxf(s0[0], s1[0]);
 #pragma unroll
         for (int r = 1; r < 16; ++r) mt = fmaxf(mt, fmaxf(s0[r], s1[r]));
@@ -277,12 +247,8 @@ __global__ __launch_bounds__(256, 2) void rga_fwd64_kernel(const T* __restrict__
                 f32x2_t x0 = {s0[r], s0[r + 1]}, x1 = {s1[r], s1[r + 1]};
                 x0 = __builtin_elementwise_fma(x0, c2v, nmv);
                 x1 = __builtin_elementwise_fma(x1, c2v, nmv);
-#ifndef ABL_NOEXP
                 s0[r] = fast_exp2(x0[0]); s0[r + 1] = fast_exp2(x0[1]);
                 s1[r] = fast_exp2(x1[0]); s1[r + 1] = fast_exp2(x1[1]);
-#else
-                s0[r] = x0[0]; s0[r + 1] = x0[1]; s1[r] = x1[0]; s1[r + 1] = x1[1];
-#endif
             }
         }
         float u[16];
@@ -300,7 +266,6 @@ __global__ __launch_bounds__(256, 2) void rga_fwd64_kernel(const T* __restrict__
                 for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
         }
         m_run = m_new;
-        PROF(4);
         T* tileA = nullptr;
         T* tileB = nullptr;
         if constexpr (STORE_P) {
@@ -311,14 +276,8 @@ __global__ __launch_bounds__(256, 2) void rga_fwd64_kernel(const T* __restrict__
             mp[0] = m_safe;                                          // both tiles were taken against the same maximum
             if (!TAIL || storeB) mp[Lp] = m_safe;
         }
-#ifndef ABL_NOPV
         pv(s0, Vt, tileA, true);
         pv(s1, Vt + 32 * LDV, tileB, !TAIL || storeB);
-#else
-#pragma unroll
-        for (int r = 0; r < 16; ++r) asm volatile("" :: "v"(s0[r]), "v"(s1[r]));
-#endif
-        PROF(5);
     };
 
     // ---- MAIN step: every wave of the block runs body_pair; no branch around any memory instruction
@@ -326,16 +285,11 @@ __global__ __launch_bounds__(256, 2) void rga_fwd64_kernel(const T* __restrict__
     auto step_main = [&](int s) __attribute__((always_inline)) {
         const int buf = s & 1;
         // tiles of step s + 1 (registers) -> the other buffer (free since the barrier); tiles of step s + 2 -> registers
-#ifndef ABL_NOKV
         sstore(buf ^ 1);
         pb_nxt = pad_mask();
         gload_full(s + 2);
-#endif
         body_pair(s, Ksm + buf * (64 * LDK), Vsm + buf * (64 * LDV), std::false_type{}, false, false, true);
-#ifndef ABL_NOBAR
         block_sync_lds();
-#endif
-        PROF(6);
     };
 
     // ---- general tile: own running-maximum update; mask word mk (bit r = element r masked): diagonal, keys >= L, padded keys
@@ -403,7 +357,6 @@ __global__ __launch_bounds__(256, 2) void rga_fwd64_kernel(const T* __restrict__
             pb_nxt = pad_mask();
             if (s + 2 < nst) gload(s + 2);
         }
-#ifndef ABL_NOGEN
         const int dgn = my_last_kt - 2 * s;       // 0: tile A is the wave's diagonal tile, 1: tile B, < 0: nothing left for this wave
         if (wave_on && dgn >= 0 && pb_cur == 0ull && 64 * s + 32 <= L && (64 * s + 64 <= L || dgn == 0)) {
             // no padded key, both tiles inside the sequence (or tile B above the diagonal anyway): predicate-free path
@@ -417,32 +370,18 @@ __global__ __launch_bounds__(256, 2) void rga_fwd64_kernel(const T* __restrict__
                 e_frags(efB, X + 4);
             }
         }
-#endif
-        PROF(7);
         block_sync_lds();
-        PROF(8);
     };
 
     // MAIN: s < 2 qb (both tiles strictly below every wave's diagonal), all four waves on, tiles of step s + 2 whole,
     // no padded key among the step's 64 (the loop ends at the first step that has one)
-#ifdef ABL_ALLGEN
-    const int nmain = 0;
-#else
     const int nmain = (qb * 128 + 96 < L) ? max(0, min(2 * qb, (L >> 6) - 2)) : 0;
-#endif
     int s = 0;
-#ifdef ABL_EMPTY
-    return;
-#endif
     vm_drain();
-#ifndef ABL_NOMAIN
     for (; s < nmain && pb_cur == 0ull; ++s) { step_main(s); pb_cur = pb_nxt; }
-#else
-    s = nmain;
-#endif
     for (; s < nst; ++s) { step_gen(s); pb_cur = pb_nxt; }
 
-    if (!wave_on) { PROF_END; return; }
+    if (!wave_on) return;
     // ---- write-out: O^T (lane = query, registers = head-dim rows) is normalised, staged through the wave's ring area as
     // [32 q][64 d] and leaves as full 128-byte rows (per-lane 8-byte pieces at a 1 KB row stride touch 32 lines per store)
     const float l_tot = half_sum(l_run);
@@ -462,17 +401,9 @@ __global__ __launch_bounds__(256, 2) void rga_fwd64_kernel(const T* __restrict__
         const chunk16 v = ld_chunk(stg + row * 72 + ch * 8);
         if (q0 + row < L) st_chunk(ob + (size_t)row * dm + ch * 8, v);
     }
-    PROF(9);
-    PROF_END;
+
 }
 
-#ifdef ME_PROF
-extern "C" int me_prof_read(unsigned long long* out16, int reset) {
-    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 16);
-    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
-    return e == hipSuccess ? 0 : -1;
-}
-#endif
 
 static void set_lds_limit(const void* fn, int bytes, bool* done) {
     int dev = 0;

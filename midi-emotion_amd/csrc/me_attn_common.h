@@ -103,20 +103,12 @@ ME_DEV int dg_pos(int m, int q) { return (q >> 4) * 512 + (m + 32 * ((q >> 3) & 
 ME_DEV int p_col(int key) { return ((key >> 2) & 1) * 16 + (key >> 3) * 4 + (key & 3); }
 
 // Streaming accesses (workspace tiles written once and read once or twice much later): non-temporal loads / stores
-// keep them from displacing the K / V / Q rows the other blocks re-read through L2.  -DME_NO_NT: plain accesses (A/B).
+// keep them from displacing the K / V / Q rows the other blocks re-read through L2.
 template <typename V> ME_DEV V nt_load(const V* p) {
-#ifdef ME_NO_NT
-    return *p;
-#else
     return __builtin_nontemporal_load(p);
-#endif
 }
 template <typename V> ME_DEV void nt_store(V v, V* p) {
-#ifdef ME_NO_NT
-    *p = v;
-#else
     __builtin_nontemporal_store(v, p);
-#endif
 }
 ME_DEV void frag_load_nt(Frag<bf16_t>& f, const bf16_t* p) { f.v = nt_load(reinterpret_cast<const bf16x8_t*>(p)); }
 ME_DEV void frag_load_nt(Frag<float>& f, const float* p) {

@@ -151,15 +151,11 @@ ME_DEV void dec_fma_chunks(float (&acc)[CW][MR], const chunk16 (&w)[CW], bool ok
 //             LDS -- long rows (FFN_suf: K = 2048) then spread over as many blocks as the short ones: a cold weight
 //             stream is fetched fastest when every CU pulls a few KB (measured: 64 blocks x 32 KB 9.7 us, L2-hot 4.4 us).
 // weight rows: every element is read by exactly one wave per token -- streamed with the non-temporal policy (guide, price
-// list "nt-weights": issued -> landed -18 %); -DME_DEC_PLAIN_W: default policy (A/B)
+// list "nt-weights": issued -> landed -18 %)
 ME_DEV chunk16 ld_w(const void* p) {
-#ifdef ME_DEC_PLAIN_W
-    return ld_chunk(p);
-#else
     chunk16 c;
     c.v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
     return c;
-#endif
 }
 
 template <typename T, int PRO, int EPI, int MR, int CW, bool KS>

@@ -40,6 +40,10 @@ class GradAllReducer:
         self._works = []
         self._pending = []
         self._done = set()
+        # exposed communication: device time the compute stream spends in finish() waiting for bucket work handles
+        # (one event pair per step while `timing` is on; read with exposed_ms() after a synchronize)
+        self.timing = False
+        self._wait_events = []
 
     @property
     def grad_scale(self):
@@ -88,10 +92,25 @@ class GradAllReducer:
             missing = sorted(set(range(len(self.ranges))) - self._done)
             raise RuntimeError("backward did not report buckets %s" % missing)
         self._flush()
+        if self.timing:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
         for w in self._works:
             w.wait()
+        if self.timing:
+            b.record()
+            self._wait_events.append((a, b))
         self._works.clear()
         self._done.clear()
+
+    def exposed_ms(self, clear=True):
+        """Per finish() call since timing was switched on: milliseconds between the compute stream reaching the waits and
+        getting past them = communication that was NOT hidden behind the backward pass (what is left parked for finish()
+        is launched right before the first event, so its whole duration counts).  Call after torch.cuda.synchronize()."""
+        out = [a.elapsed_time(b) for a, b in self._wait_events]
+        if clear:
+            self._wait_events.clear()
+        return out
 
 
 def broadcast_params(flat_params, src=0, group=None):
