@@ -330,6 +330,15 @@ int me_dec_ln_qkv_attn(const float* s_in, const float* gamma, const float* beta,
                        int nsplit, int Mr, int d, int H, int dh, int M, int Mc, int t, const int32_t* t_dev, int dtype,
                        void* stream);
 
+/* The same stage for the FIRST layer: the block's input row is the embedding of the fed token (arguments and arithmetic
+ * of me_dec_embed_qkv: token row * sqrt(d - d_cond) | condition projection, + the sinusoid row of position t, f32) instead
+ * of a LayerNorm; me_dec_embed_qkv + me_dec_attn in ONE launch.  x_out receives the f32 embedding rows (the residual input
+ * of the layer).  Replaces music_multi.py:89-101 + :196-232 for the one new position (generate.py:116-119). */
+int me_dec_embed_qkv_attn(const int64_t* tokens, const float* cond, const float* emb, const float* cw, const float* cb,
+                          const float* pe, int d_cond, const void* Wqkv, const float* bqkv, float* x_out, void* kcache,
+                          void* vcache, const void* E, const uint8_t* key_pad, int ld_pad, float* part, int nsplit, int Mr, int d,
+                          int H, int dh, int M, int Mc, int t, const int32_t* t_dev, int dtype, void* stream);
+
 /* me_dec_proj_resid: out f32 [Mr][N] = resid f32 [Mr][N] + bias + T(x).W^T with
  *   x = softmax-combine of the attention partials (part != NULL; K = H*dh; replaces the head merge + self.fc of
  *       music_multi.py:233-237 and the residual add of :128), or

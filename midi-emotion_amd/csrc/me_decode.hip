@@ -577,7 +577,10 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const T* __restrict__ q, 
 // layer.  (A first version let one "owner" block compute q, k and v one after the other: three round trips, slower than the
 // two launches it replaced -- 0.160 vs 0.150 ms per token.)  Needs nsplit >= 2.
 // ---------------------------------------------------------------------------------------------------------
-template <typename T, int DH>
+// EMBED = true: the FIRST layer's variant -- the block's input row is not a LayerNorm of the previous layer's sum but the
+// embedding of the fed token (token row * sqrt(d - dc) | condition projection, + sinusoid row of position t, f32), so layer 0
+// needs one launch like every other layer (round 4: 26 launches per token instead of 27).
+template <typename T, int DH, bool EMBED = false>
 __global__ __launch_bounds__(256) void dec_ln_qkv_attn_kernel(const DecArgs a, const T* __restrict__ E,
                                                               const uint8_t* __restrict__ key_pad, int ld_pad,
                                                               float* __restrict__ part, int nsplit, int M, float scale) {
@@ -616,8 +619,29 @@ __global__ __launch_bounds__(256) void dec_ln_qkv_attn_kernel(const DecArgs a, c
 #pragma unroll
         for (int c = 0; c < CWQ; ++c) w1[c] = ld_w(W1 + (size_t)c * a.ldw + (size_t)chc0 * CH);
     }
-    // ---- LayerNorm of row m (every wave computes the statistics: no cross-wave reduction, one barrier)
-    {
+    if constexpr (EMBED) {
+        // ---- embedding row of sequence m (music_multi.py:89-101 for one position), same arithmetic as PRO_EMBED of dec_gemv_kernel
+        const int dc = a.dc, de = K - dc;
+        const float sq = sqrtf((float)de);
+        for (int k = tid * 4; k < K; k += 1024) {
+            f32x4_t v, r;
+            const f32x4_t p4 = *reinterpret_cast<const f32x4_t*>(a.pe + (size_t)t * K + k);
+            if (k < de) {
+                const f32x4_t e4 = *reinterpret_cast<const f32x4_t*>(a.emb + (size_t)a.tokens[m] * de + k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = e4[e] * sq + p4[e];
+            } else {
+                const float c0 = a.cond[m * 2], c1 = a.cond[m * 2 + 1];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = a.cw[(k - de + e) * 2] * c0 + a.cw[(k - de + e) * 2 + 1] * c1 + a.cb[k - de + e] + p4[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = round_to<T>(v[e]);
+            if (a.x_out && head == 0 && part_a) *reinterpret_cast<f32x4_t*>(a.x_out + (size_t)m * K + k) = v;
+            *reinterpret_cast<f32x4_t*>(&xs[k]) = r;
+        }
+    } else {
+        // ---- LayerNorm of row m (every wave computes the statistics: no cross-wave reduction, one barrier)
         constexpr int NV = 4;
         f32x4_t v[NV];
 #pragma unroll
@@ -795,12 +819,12 @@ __global__ __launch_bounds__(256) void dec_ln_qkv_attn_kernel(const DecArgs a, c
     if (tid == 0) { pout[0] = mx; pout[1] = red[4] + red[5] + red[6] + red[7]; }
 }
 
-template <typename T, int DH>
+template <typename T, int DH, bool EMBED = false>
 int ln_qkv_attn_launch(const DecArgs& a, const void* E, const uint8_t* key_pad, int ld_pad, float* part, int nsplit, int M,
                        hipStream_t st) {
     const float scale = 1.f / sqrtf((float)DH);
-    dec_ln_qkv_attn_kernel<T, DH><<<dim3(a.Mr * a.H, nsplit + 1), 256, (size_t)a.K * sizeof(float), st>>>(a, (const T*)E, key_pad, ld_pad,
-                                                                                                part, nsplit, M, scale);
+    dec_ln_qkv_attn_kernel<T, DH, EMBED><<<dim3(a.Mr * a.H, nsplit + 1), 256, (size_t)a.K * sizeof(float), st>>>(
+        a, (const T*)E, key_pad, ld_pad, part, nsplit, M, scale);
     return me_launch_status();
 }
 
@@ -957,6 +981,36 @@ int me_dec_ln_qkv_attn(const float* s_in, const float* gamma, const float* beta,
     if (dh == DHV) {                                                                                            \
         constexpr int DH = DHV;                                                                                 \
         ME_DEC_T((ln_qkv_attn_launch<T, DH>(a, E, key_pad, ld_pad, part, nsplit, M, st)))                         \
+    }
+    ME_DEC_FUSED_CASE(64)
+    ME_DEC_FUSED_CASE(48)
+    ME_DEC_FUSED_CASE(32)
+#undef ME_DEC_FUSED_CASE
+    return ME_ERR_BAD_SHAPE;
+}
+
+int me_dec_embed_qkv_attn(const int64_t* tokens, const float* cond, const float* emb, const float* cw, const float* cb,
+                          const float* pe, int d_cond, const void* Wqkv, const float* bqkv, float* x_out, void* kcache,
+                          void* vcache, const void* E, const uint8_t* key_pad, int ld_pad, float* part, int nsplit, int Mr, int d,
+                          int H, int dh, int M, int Mc, int t, const int32_t* t_dev, int dtype, void* stream) {
+    me_clear_error();
+    if (!tokens || !emb || !pe || !Wqkv || !bqkv || !kcache || !vcache || !E || !part) return ME_ERR_NULL;
+    if (d_cond > 0 && (!cond || !cw || !cb)) return ME_ERR_NULL;
+    if (Mr <= 0 || H <= 0 || dh <= 0 || H * dh != d || d > 1024 || d % 8 || nsplit < 2 || nsplit > DEC_NSMAX || Mc <= 0 || M <= 0 ||
+        d_cond >= d || (d_cond > 0 && d_cond % 4))
+        return ME_ERR_BAD_SHAPE;
+    if (!t_dev && (t < 0 || t >= Mc || t >= M)) return ME_ERR_BAD_SHAPE;
+    if ((Mc + nsplit - 2) / (nsplit - 1) + 64 > 2048 + 64) return ME_ERR_BAD_SHAPE;   // score buffer: 2048 keys per split
+    if (!aligned16(Wqkv) || !aligned16(kcache) || !aligned16(vcache) || !aligned16(E) || !aligned16(emb) || !aligned16(pe)) return ME_ERR_ALIGNMENT;
+    DecArgs a = {};
+    a.tokens = tokens; a.cond = cond; a.emb = emb; a.cw = cw; a.cb = cb; a.pe = pe; a.dc = d_cond > 0 ? d_cond : 0; a.x_out = x_out;
+    a.W = Wqkv; a.ldw = d; a.bias = bqkv; a.Mr = Mr; a.N = 3 * d; a.K = d; a.kcache = kcache; a.vcache = vcache; a.Mc = Mc; a.t = t;
+    a.t_dev = t_dev; a.H = H; a.dh = dh;
+    hipStream_t st = (hipStream_t)stream;
+#define ME_DEC_FUSED_CASE(DHV)                                                                                    \
+    if (dh == DHV) {                                                                                            \
+        constexpr int DH = DHV;                                                                                 \
+        ME_DEC_T((ln_qkv_attn_launch<T, DH, true>(a, E, key_pad, ld_pad, part, nsplit, M, st)))                   \
     }
     ME_DEC_FUSED_CASE(64)
     ME_DEC_FUSED_CASE(48)

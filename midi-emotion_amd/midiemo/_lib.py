@@ -45,6 +45,7 @@ SIGNATURES = {
     "me_adamw_step": [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _p],
     "me_dec_qkv": [_p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p],
     "me_dec_embed_qkv": [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p],
+    "me_dec_embed_qkv_attn": [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p],
     "me_dec_ln_qkv_attn": [_p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p],
     "me_dec_attn": [_p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p],
     "me_dec_proj_resid": [_p, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p],

@@ -84,10 +84,18 @@ class DecodeSession:
             r1 = min(B, r0 + ROWS)
             Mr = r1 - r0
             part = self.part[r0 * H:r1 * H]
+            fused0 = False
             for i in range(m.num_layer):
                 W = m._prep["layers"][i]
                 p = f"enc_layers.{i}."
-                if i == 0 and tokens is not None:
+                if i == 0 and tokens is not None and self.fused and d % 4 == 0 and (m.d_condition <= 0 or m.d_condition % 4 == 0):
+                    # first layer, fused like the others (round 4): embedding row -> q|k|v of a head -> cache append ->
+                    # attention partials in ONE launch (me_dec_embed_qkv_attn): 26 launches per token at 6 layers
+                    ops.dec_embed_qkv_attn(tokens[r0:r1], cond[r0:r1] if cw is not None else None, pv("embedding.weight"), cw, cb,
+                                           m._pe, m.d_condition, W["Wqkv"], W["bqkv"], self.xres[r0:r1], self.kc[i][r0:r1],
+                                           self.vc[i][r0:r1], W["E"], None, 0, part, ns, Mr, d, H, dh, M, M, t, self._pos_dev, dt)
+                    fused0 = True
+                elif i == 0 and tokens is not None:
                     ops.dec_embed_qkv(tokens[r0:r1], cond[r0:r1] if cw is not None else None, pv("embedding.weight"), cw, cb,
                                       m._pe, m.d_condition, W["Wqkv"], W["bqkv"], self.xres[r0:r1], self.q[r0:r1],
                                       self.kc[i][r0:r1], self.vc[i][r0:r1], Mr, d, H, dh, M, t, self._pos_dev, dt)
@@ -107,7 +115,7 @@ class DecodeSession:
                     ops.dec_qkv(self.s2[r0:r1], pv(pp + "layernorm2.weight"), pv(pp + "layernorm2.bias"), eps, None, None,
                                 W["Wqkv"], W["bqkv"], self.xres[r0:r1], self.q[r0:r1], self.kc[i][r0:r1], self.vc[i][r0:r1],
                                 Mr, d, H, dh, M, t, self._pos_dev, dt)
-                if i == 0 or not self.fused:
+                if (i == 0 and not fused0) or not self.fused:
                     ops.dec_attn(self.q[r0:r1], self.kc[i][r0:r1], self.vc[i][r0:r1], W["E"], None, 0, part, ns, Mr, H, dh, M,
                                  M, t, self._pos_dev, dt)
                 ops.dec_proj_resid(part, ns, H, dh, None, W["Wo"], pv(p + "rga.fc.bias"), self.xres[r0:r1], self.s1[r0:r1],

@@ -258,6 +258,14 @@ def dec_embed_qkv(tokens, cond, emb, cw, cb, pe, d_cond, Wqkv, bqkv, x_out, q_ou
                                  _ptr(t_dev), _code(dtype), _stream()), "me_dec_embed_qkv")
 
 
+def dec_embed_qkv_attn(tokens, cond, emb, cw, cb, pe, d_cond, Wqkv, bqkv, x_out, kcache, vcache, E, key_pad, ld_pad, part, nsplit,
+                       Mr, d, H, dh, M, Mc, t, t_dev, dtype):
+    """first layer: embedding row -> q|k|v of one head -> cache append -> key-split attention partials (me_dec_embed_qkv_attn)."""
+    check(lib().me_dec_embed_qkv_attn(_ptr(tokens), _ptr(cond), _ptr(emb), _ptr(cw), _ptr(cb), _ptr(pe), int(d_cond), _ptr(Wqkv),
+                                      _ptr(bqkv), _ptr(x_out), _ptr(kcache), _ptr(vcache), _ptr(E), _ptr(key_pad), ld_pad, _ptr(part),
+                                      nsplit, Mr, d, H, dh, M, Mc, int(t), _ptr(t_dev), _code(dtype), _stream()), "me_dec_embed_qkv_attn")
+
+
 def dec_attn(q, kcache, vcache, E, key_pad, ld_pad, part, nsplit, Mr, H, dh, M, Mc, t, t_dev, dtype):
     check(lib().me_dec_attn(_ptr(q), _ptr(kcache), _ptr(vcache), _ptr(E), _ptr(key_pad), ld_pad, _ptr(part), nsplit, Mr, H,
                             dh, M, Mc, int(t), _ptr(t_dev), _code(dtype), _stream()), "me_dec_attn")
