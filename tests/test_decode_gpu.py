@@ -200,6 +200,44 @@ def test_device_resident_greedy_loop_matches_eager_steps(conditioning):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cd", ["fp32", "bf16"])
+@pytest.mark.parametrize("conditioning", ["none", "discrete_token", "continuous_concat"])
+def test_fused_decode_stages_equal_the_separate_launches(conditioning, cd):
+    """The fused decode stages (me_dec_embed_qkv_attn for the first layer -- round 4 --, me_dec_ln_qkv_attn for the others)
+    against the separate launches they replace (me_dec_embed_qkv / me_dec_qkv + me_dec_attn) over 70 positions (more than one
+    key-split chunk), sequences at different tokens.  Same operands rounded at the same places; what differs is f32 summation
+    order (the fused stage keeps the newest key as a split of its own and sums the projection per head slice), so the bound
+    is f32 rounding in the f32 tier (1e-5 of the logit scale) and ONE rounding unit of the stored type in the bf16 tier
+    (2^-8 rel-L2: a k / v / hidden element may round to the other neighbour); the caches must agree likewise."""
+    import torch
+    from midiemo.decode import DecodeSession
+    from midiemo.models.build_model import build_model
+    torch.manual_seed(11)
+    V = 1017 if conditioning == "discrete_token" else 1007
+    dc = 32 if conditioning == "continuous_concat" else -1
+    model, _ = build_model(dict(vocab_size=V, n_layer=3, n_head=2, d_model=128, d_inner=256, dropout=0.0, d_condition=dc,
+                                conditioning=conditioning, compute_dtype=cd))
+    model = model.cuda().eval()
+    B, n = 4, 70
+    cond = torch.rand(B, 2, device="cuda") * 2 - 1
+    toks = torch.randint(2, 1007, (n, B), device="cuda")
+    tol = 1e-5 if cd == "fp32" else 2.0 ** -8
+    rel = lambda x, y: float((x.double() - y.double()).norm() / y.double().norm())
+    worst = 0.0
+    with torch.no_grad():
+        a, b = DecodeSession(model, B), DecodeSession(model, B)
+        assert a.fused
+        b.fused = False                                   # the round-2 form: one launch per piece
+        for i in range(n):
+            la, lb = a.step(toks[i], cond).clone(), b.step(toks[i], cond).clone()
+            worst = max(worst, rel(la, lb))
+            assert rel(la, lb) <= tol, (i, rel(la, lb))
+        for l in range(3):
+            assert rel(a.kc[l][:, :, :n], b.kc[l][:, :, :n]) <= tol and rel(a.vc[l][:, :, :n], b.vc[l][:, :, :n]) <= tol, l
+    print("fused vs separate decode stages, %s %s: worst logits rel-L2 over %d steps %.2e (bound %.1e)" % (conditioning, cd, n, worst, tol))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("top_k,top_p", [(-1, 0.7), (20, 1.0), (50, 0.9), (-1, 1.0), (3, 0.5)])
 def test_fused_sampling_tail_matches_torch_path(top_k, top_p):
     """me_sample_topk_topp == the torch restatement of generate.py:122-189 (same filtered distribution, same
