@@ -80,7 +80,7 @@ def test_gemm_nt_plain_and_bias(ops, dtype, M, N, K):
     assert torch.isnan(C32[:, N:]).all()
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 1536, 512), (700, 1007, 512), (1024, 512, 2048), (260, 200, 128)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 1536, 512), (700, 1007, 512), (1024, 512, 2048), (260, 200, 128), (2050, 2048, 512)])
 def test_gemm_nt_256_tile_path(ops, M, N, K):
     """bf16 shapes that take the 256x256 direct-to-LDS kernel (K % 64 == 0), incl. ragged M/N and all epilogues."""
     dtype = torch.bfloat16
@@ -104,6 +104,17 @@ def test_gemm_nt_256_tile_path(ops, M, N, K):
     gatep[:, :N] = gate.to(DEV)
     ops.gemm_nt(Ad, Bd, C, gate=gatep, flags=ops.ME_EPI_RELU_BWD, N=N)
     assert relerr(C[:, :N], base * (gate.double() > 0)) < 6e-3
+    assert torch.isnan(C[:, N:]).all()
+    # round 4: with 16-byte aligned gate rows and N % 8 == 0 the gate is applied to the staged (already rounded) rows, read
+    # row-contiguously; a select commutes with the rounding, so the result must be BIT-identical to the element-wise path,
+    # which an 8-byte-aligned view of the same values selects
+    wide = torch.zeros(M, ld + 16, dtype=dtype, device=DEV)
+    wide[:, 4:4 + N] = gate.to(DEV)
+    gate8 = wide[:, 4:4 + ld]
+    assert gate8.data_ptr() % 16 == 8
+    C2 = torch.full((M, ld), float("nan"), dtype=dtype, device=DEV)
+    ops.gemm_nt(Ad, Bd, C2, gate=gate8, flags=ops.ME_EPI_RELU_BWD, N=N)
+    assert torch.equal(C2[:, :N], C[:, :N]) and torch.isnan(C2[:, N:]).all()
     C32 = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
     ops.gemm_nt(Ad, Bd, C32, bias=bias.to(DEV), flags=ops.ME_EPI_OUT_F32)
     assert relerr(C32, base + bias.double()) < 1e-5
