@@ -128,7 +128,12 @@ ME_DEV void slot_barrier() {
 // WR x WC = wave grid over the 256 x 256 tile: 2 x 4 (8 waves, 128 x 64 per wave, two waves per SIMD) or
 // 2 x 2 (4 waves, 128 x 128 per wave, one wave per SIMD with the whole 512-entry register file: 8 instead of
 // 12 fragment reads per 16 MFMAs).
-template <bool OUT_F32, int WR, int WC>
+// EPI selects the ONE write-out path an instantiation contains (the host picks it from the operands and their alignment):
+//   0 = plain / bias / ReLU (a);  1 = ReLU gate applied to the staged rows (g);  2 = residual add through the staging buffer (r);
+//   3 = the general element-wise path (b: any combination, any alignment).
+// One path per instantiation because the kernel sits at the 256-register limit: with all four in one body hipcc spilled an
+// operand piece per slab inside the main loop (round 4).
+template <bool OUT_F32, int WR, int WC, int EPI>
 __global__ __launch_bounds__(WR * WC * 64) void gemm_nt256_kernel(
     const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc,
     const float* __restrict__ bias, const bf16_t* __restrict__ add, int ldadd, const bf16_t* __restrict__ gate,
@@ -201,8 +206,7 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_nt256_kernel(
     const int frow = lane & 31, h = lane >> 5;
     const bool relu = flags & ME_EPI_RELU;
     const bool vec_c = (ldc % (OUT_F32 ? 4 : 8)) == 0 && (reinterpret_cast<uintptr_t>(Cv) & 15) == 0;
-    constexpr bool GATE_ROWS = !OUT_F32;                                   // gate applied to the staged bf16 rows (write-out path g)
-    const bool gate_rows_ok = gate && (ldgate & 7) == 0 && (reinterpret_cast<uintptr_t>(gate) & 15) == 0 && vec_c && (N & 7) == 0;
+    static_assert(!(OUT_F32 && (EPI == 1 || EPI == 2)), "the row paths stage bf16 rows");
 
     // swz(r) = (r ^ (r >> 3)) & 7 makes every 16-lane group of a ds_read_b128 hit 16 distinct
     // 16-byte slots of the 256-byte bank row (conflict free).
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_nt256_kernel(
         };
         // vmcnt is in-order: a global load issued between two passes waits for the previous pass's STORES to retire
         // (measured: 20 us of an 80 us launch).  Hence two code paths (registers = max, not sum):
-        if (!add && !gate) {
+        if constexpr (EPI == 0) {
             // (a) bias (+ReLU): the wave's bias values are fetched once, before any store
             f32x4_t bv[BJ][4];
             const bool vec_bias = (reinterpret_cast<uintptr_t>(bias) & 15) == 0;
@@ -307,7 +311,7 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_nt256_kernel(
                     }
                 write_out(ps);
             }
-        } else if (GATE_ROWS && gate && !add && !relu && !bias && gate_rows_ok) {
+        } else if constexpr (EPI == 1) {
             // (g) ReLU gate alone (the FFN_suf dgrad, N = d_inner): a select commutes with the rounding, so the gate is
             // applied to the ROUNDED tile in its row-contiguous staged form -- the gate operand is then read exactly like the
             // output is written (16 bytes per lane, eight lanes per 128-byte row segment) instead of as 8-byte pieces of 32
@@ -351,6 +355,55 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_nt256_kernel(
                     const int col = n0 + wc * TN + j0 * 32 + ch * 8;
                     if (orow < M && col < N) st_chunk(reinterpret_cast<T*>(Cv) + (size_t)orow * ldc + col, v);
                 }
+            }
+        } else if constexpr (EPI == 2) {
+            // (r) residual add alone (the FFN_pre and qkv dgrads): the operand is read row-contiguously like the output is
+            // written (16 bytes per lane) and brought into the accumulators' layout through the wave's staging buffer --
+            // chunks in, 8-byte quads out, the mapping `stage` / `write_out` use in the other direction -- so the sum is still
+            // formed in f32 before the one rounding (bit-identical to the element-wise path b), but an instruction touches 8
+            // full 128-byte row segments instead of 16 bytes in each of 32 rows (same box, interleaved: +9.5 us -> see profiles).
+            chunk16 aq[2][4];
+            auto fetch_add = [&](int ps, chunk16 (&q)[4]) __attribute__((always_inline)) {
+                const int i = ps / JP, j0 = (ps % JP) * NJ;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int rr = it * 8 + (lane >> 3), ch = lane & 7;
+                    const int orow = min(m0 + wr * TM + i * 32 + rr, M - 1);
+                    const int col = min(n0 + wc * TN + j0 * 32 + ch * 8, N - 8);
+                    q[it] = ld_chunk(add + (size_t)orow * ldadd + col);
+                }
+            };
+            fetch_add(0, aq[0]);
+#pragma unroll
+            for (int ps = 0; ps < NP; ++ps) {
+                const int i = ps / JP, j0 = (ps % JP) * NJ;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int rr = it * 8 + (lane >> 3), ch = lane & 7;
+                    st_chunk(stg + rr * 128 + ((ch ^ (rr & 7)) << 4), aq[ps & 1][it]);
+                }
+                bf16x4_t av[NJ][4];
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        av[jj][g] = *reinterpret_cast<const bf16x4_t*>(stg + lr * 128 + (((jj * 4 + g) ^ (lr & 7)) << 4) + h * 8);
+                if (ps + 1 < NP) fetch_add(ps + 1, aq[(ps + 1) & 1]);
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int col = n0 + wc * TN + (j0 + jj) * 32 + 8 * g + 4 * h;
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = acc[i][j0 + jj][4 * g + e] + ((bias && col + e < N) ? bias[col + e] : 0.f);
+                            if (relu) v[e] = fmaxf(v[e], 0.f);
+                            v[e] += (float)av[jj][g][e];
+                        }
+                        stage(jj, g, v);
+                    }
+                write_out(ps);
             }
         } else {
             // (b) residual add / ReLU gate (the backward GEMMs): their operands for the NEXT pass are fetched (8 bytes
@@ -1180,8 +1233,12 @@ int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int 
             int dev = 0;
             if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
             if (dev < 0 || dev >= 16 || !attr_set[dev]) {                   // the attribute is per device
-                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
-                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<true, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, 2, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, 2, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, 2, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, 2, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<true, 2, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<true, 2, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
                 if (dev >= 0 && dev < 16) attr_set[dev] = true;
             }
             unsigned g256 = (unsigned)(((N + 255) / 256) * ((M + 255) / 256));
@@ -1189,12 +1246,20 @@ int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int 
             if (g256 > ncu) g256 = ncu;              // persistent: one block per CU
             // 2 x 4 waves.  The 2 x 2 instantiation (128 x 128 per wave, one wave per SIMD, accumulators in the 256
             // AGPRs) is correct but hipcc spills the 16 prefetch pieces to scratch inside the main loop: 45 TF/s.
-            if (flags & ME_EPI_OUT_F32)
-                gemm_nt256_kernel<true, 2, 4><<<g256, 512, NT256_LDS, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias,
-                                                                         (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags);
-            else
-                gemm_nt256_kernel<false, 2, 4><<<g256, 512, NT256_LDS, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias,
-                                                                          (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags);
+            // write-out path (EPI): the row paths need 16-byte aligned operand rows, a vector-storable C and N % 8 == 0
+            const bool vec_c = (ldc % 8) == 0 && aligned16(C) && (N & 7) == 0;
+            int epi = 3;
+            if (!add && !gate) epi = 0;
+            else if (!(flags & ME_EPI_OUT_F32) && gate && !add && !bias && !(flags & ME_EPI_RELU) && vec_c && (ldgate & 7) == 0 && aligned16(gate)) epi = 1;
+            else if (!(flags & ME_EPI_OUT_F32) && add && !gate && vec_c && (ldadd & 7) == 0 && aligned16(add)) epi = 2;
+#define ME_NT256(F32, E) gemm_nt256_kernel<F32, 2, 4, E><<<g256, 512, NT256_LDS, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias, \
+                                                                                   (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags)
+            if (flags & ME_EPI_OUT_F32) { if (epi == 0) ME_NT256(true, 0); else ME_NT256(true, 3); }
+            else if (epi == 0) ME_NT256(false, 0);
+            else if (epi == 1) ME_NT256(false, 1);
+            else if (epi == 2) ME_NT256(false, 2);
+            else ME_NT256(false, 3);
+#undef ME_NT256
             return me_launch_status();
         }
     }

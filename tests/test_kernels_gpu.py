@@ -100,6 +100,17 @@ def test_gemm_nt_256_tile_path(ops, M, N, K):
     addp[:, :N] = add.to(DEV)
     ops.gemm_nt(Ad, Bd, C, add=addp, N=N)
     assert relerr(C[:, :N], base + add.double()) < 6e-3
+    assert torch.isnan(C[:, N:]).all()
+    # round 4: a 16-byte aligned residual operand is read row-contiguously and transposed into the accumulators' layout through
+    # the staging buffer; the sum is still formed in f32 before the one rounding, so the result must be BIT-identical to the
+    # element-wise path, which an 8-byte-aligned view of the same values selects
+    widea = torch.zeros(M, ld + 16, dtype=dtype, device=DEV)
+    widea[:, 4:4 + N] = add.to(DEV)
+    add8 = widea[:, 4:4 + ld]
+    assert add8.data_ptr() % 16 == 8
+    Ca = torch.full((M, ld), float("nan"), dtype=dtype, device=DEV)
+    ops.gemm_nt(Ad, Bd, Ca, add=add8, N=N)
+    assert torch.equal(Ca[:, :N], C[:, :N]) and torch.isnan(Ca[:, N:]).all()
     gatep = torch.zeros(M, ld, dtype=dtype, device=DEV)
     gatep[:, :N] = gate.to(DEV)
     ops.gemm_nt(Ad, Bd, C, gate=gatep, flags=ops.ME_EPI_RELU_BWD, N=N)
