@@ -1319,7 +1319,9 @@ static int tn256_group_launch(const tn_item_256* it, int n, int Tn, void* ws_cal
         if (ws_bytes < need || !aligned16(ws_caller)) return ME_ERR_WORKSPACE;
         ws = reinterpret_cast<float*>(ws_caller);
     }
-    if (Tn % tp == 0) gemm_tn256_kernel<false><<<grid256, 512, TN256_LDS, st>>>(G, ws);
+    // whole slabs in every range is all the unpredicated feed needs (tp is a multiple of the slab; the last range may be shorter):
+    // at T = 32768 and 5 ranges (103 / 103 / 103 / 103 / 100 slabs) round 3 took the predicated kernel for no reason
+    if (Tn % TN256_BT == 0) gemm_tn256_kernel<false><<<grid256, 512, TN256_LDS, st>>>(G, ws);
     else gemm_tn256_kernel<true><<<grid256, 512, TN256_LDS, st>>>(G, ws);
     if (ws) tn256_reduce_kernel<<<dim3(ntile, 32), 512, 0, st>>>(ws, G);
     return me_launch_status();
