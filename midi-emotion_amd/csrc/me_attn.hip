@@ -601,6 +601,9 @@ __global__ __launch_bounds__(256) void rga_bwd_kv_kernel(const T* __restrict__ P
     __shared__ __attribute__((aligned(16))) T Pt[2][KB * LDP];         // four tiles [32 q][32 key], rows = w * 32 + q
     __shared__ __attribute__((aligned(16))) T Os[2][32 * LDV];         // natural dO / Q slabs [32 q][DH]
     __shared__ __attribute__((aligned(16))) T Qs[2][32 * LDV];
+    // second copy of the dO slab with the natural-read stride: the 192-byte rows of Os are conflict free for the transpose reads
+    // (dV) but put rows r and r + 4 on the same banks for the 16-byte fragment reads of dP (4-way conflicts)
+    __shared__ __attribute__((aligned(16))) T On[2][32 * C::LDN];
     __shared__ __attribute__((aligned(16))) float Dl[2][32];           // -delta[q] / sqrt(dh)
     __shared__ __attribute__((aligned(16))) float Fs[2][4 * 32];       // per key tile: exp2(m_t c2 - lse log2e)
 
@@ -663,7 +666,7 @@ __global__ __launch_bounds__(256) void rga_bwd_kv_kernel(const T* __restrict__ P
 #pragma unroll
         for (int i = 0; i < NPTQ; ++i) {
             const int c = tid + i * 256, row = c / CPRQ, cc = (c % CPRQ) * CH;
-            if (c < NCHQ) { st_chunk(&Os[buf][row * LDV + cc], ro[i]); st_chunk(&Qs[buf][row * LDV + cc], rq[i]); }
+            if (c < NCHQ) { st_chunk(&Os[buf][row * LDV + cc], ro[i]); st_chunk(&Qs[buf][row * LDV + cc], rq[i]); st_chunk(&On[buf][row * C::LDN + cc], ro[i]); }
         }
         if (tid < 32) Dl[buf][tid] = -rd * scale;
         if (tid < 128) Fs[buf][tid] = qs * 32 + (tid & 31) < L ? fast_exp2(fmaf(rm, c2, -rl * 1.4426950408889634f)) : 0.f;
@@ -679,7 +682,7 @@ __global__ __launch_bounds__(256) void rga_bwd_kv_kernel(const T* __restrict__ P
 #pragma unroll
             for (int kk = 0; kk < KA; ++kk) {
                 Frag<T> of;
-                frag_load(of, &Os[buf][a * LDV + kk * 16 + h * 8]);
+                frag_load(of, &On[buf][a * C::LDN + kk * 16 + h * 8]);
                 mma32(dp, of, vf[kk]);
             }
 #pragma unroll
