@@ -621,6 +621,18 @@ def test_sumsq_ordered_is_bit_reproducible(ops):
             assert abs(float(ref) - exact) <= 1e-5 * exact
         assert torch.equal(out, ref), (it, float(out), float(ref))
     assert int(ws.view(torch.int32)[0]) == 0                    # ticket counter left zeroed
+    # the slots of the REUSED workspace must never be served stale (another XCD's L2 may still hold the previous call's
+    # lines): different data on every call, each checked against its own f64 sum
+    for it in range(12):
+        gi = g * (1.0 + 0.37 * it)
+        out = torch.zeros(1, device=DEV)
+        if it % 3 == 1:
+            with torch.cuda.stream(side):
+                junk.normal_()
+        ops.sumsq(gi, out, ws=ws)
+        torch.cuda.synchronize()
+        exact = float((gi.double() ** 2).sum())
+        assert abs(float(out) - exact) <= 2e-6 * exact, (it, float(out), exact)
     out = torch.full((1,), 2.0, device=DEV)
     ops.sumsq(g, out, ws=ws)
     assert abs(float(out) - 2.0 - float(ref)) <= 1e-6 * float(ref) + 1e-6
