@@ -129,6 +129,9 @@ def test_gemm_nt_256_tile_path(ops, M, N, K):
     C32 = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
     ops.gemm_nt(Ad, Bd, C32, bias=bias.to(DEV), flags=ops.ME_EPI_OUT_F32)
     assert relerr(C32, base + bias.double()) < 1e-5
+    # f32 output with a residual operand and a gate: the element-wise write-out path of the f32-out instantiation
+    ops.gemm_nt(Ad, Bd, C32, bias=bias.to(DEV), add=addp, gate=gatep, flags=ops.ME_EPI_OUT_F32 | ops.ME_EPI_RELU_BWD, N=N)
+    assert relerr(C32, (base + bias.double() + add.double()) * (gate.double() > 0)) < 1e-5
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
