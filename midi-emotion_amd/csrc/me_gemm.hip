@@ -95,6 +95,250 @@ ME_DEV void epi_block_swapped(const f32x16_t& acc, int row_base, int col_base, i
     }
 }
 
+// ---- tile write-out of the 256 x 256 kernels (shared by the main-loop variants): stage 32 rows x 128 B at a time through
+// the wave's private 4 KB so that every store instruction writes 8 full 128-byte row segments (per-lane 8-byte pieces
+// across 32 rows are L2-transaction bound).  bf16: a pass = 32 rows x 64 columns; f32: 32 rows x 32 columns.
+// Ends with the accumulators zeroed for the next tile.
+template <bool OUT_F32, int WR, int WC, int EPI>
+ME_DEV void nt256_write_tile(f32x16_t (&acc)[256 / WR / 32][256 / WC / 32], char* smem, int m0, int n0, int wid, int lane,
+                             void* __restrict__ Cv, int ldc, const float* __restrict__ bias, const bf16_t* __restrict__ add,
+                             int ldadd, const bf16_t* __restrict__ gate, int ldgate, int M, int N, bool relu, bool vec_c) {
+    typedef bf16_t T;
+    constexpr int NW = WR * WC;
+    constexpr int TM = 256 / WR, TN = 256 / WC;
+    constexpr int AI = TM / 32, BJ = TN / 32;
+    const int wr = wid / WC, wc = wid % WC;
+    const int h = lane >> 5;
+    char* stg = smem + 2 * 65536 + wid * (32768 / NW);
+    constexpr int NJ = OUT_F32 ? 1 : 2;                                // accumulator blocks per pass
+    constexpr int JP = BJ / NJ;                                        // passes per 32-row group
+    constexpr int NP = AI * JP;                                        // passes
+    const int lr = lane & 31;
+    // one quad (4 consecutive columns of the lane's row) -> staging; 16-byte slot index XOR (row & 7) spreads
+    // the 32 rows of a store over the banks
+    auto stage = [&](int jj, int g, const float* v) __attribute__((always_inline)) {
+        if constexpr (OUT_F32) {
+            const int slot = (2 * g + h) ^ (lr & 7);
+            *reinterpret_cast<f32x4_t*>(stg + lr * 128 + (slot << 4)) = (f32x4_t){v[0], v[1], v[2], v[3]};
+        } else {
+            const int slot = (jj * 4 + g) ^ (lr & 7);
+            st4_t<T>(reinterpret_cast<T*>(stg + lr * 128 + (slot << 4) + h * 8), v[0], v[1], v[2], v[3]);
+        }
+    };
+    // read back: lane -> (row it*8 + lane/8, 16-byte chunk lane%8): full-row coalesced stores
+    auto write_out = [&](int ps) __attribute__((always_inline)) {
+        const int i = ps / JP, j0 = (ps % JP) * NJ;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int rr = it * 8 + (lane >> 3), ch = lane & 7;
+            const chunk16 v = ld_chunk(stg + rr * 128 + ((ch ^ (rr & 7)) << 4));
+            const int orow = m0 + wr * TM + i * 32 + rr;
+            constexpr int EPC = OUT_F32 ? 4 : 8;                       // elements per chunk
+            const int col = n0 + wc * TN + j0 * 32 + ch * EPC;
+            if (orow < M && col < N) {
+                if (col + EPC <= N && vec_c) {
+                    if constexpr (OUT_F32) st_chunk(reinterpret_cast<float*>(Cv) + (size_t)orow * ldc + col, v);
+                    else st_chunk(reinterpret_cast<T*>(Cv) + (size_t)orow * ldc + col, v);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e)
+                        if (col + e < N) {
+                            if constexpr (OUT_F32) (reinterpret_cast<float*>(Cv))[(size_t)orow * ldc + col + e] = reinterpret_cast<const float*>(&v)[e];
+                            else (reinterpret_cast<T*>(Cv))[(size_t)orow * ldc + col + e] = reinterpret_cast<const T*>(&v)[e];
+                        }
+                }
+            }
+        }
+    };
+    // vmcnt is in-order: a global load issued between two passes waits for the previous pass's STORES to retire
+    // (measured: 20 us of an 80 us launch).  Hence two code paths (registers = max, not sum):
+    if constexpr (EPI == 0) {
+        // (a) bias (+ReLU): the wave's bias values are fetched once, before any store
+        f32x4_t bv[BJ][4];
+        const bool vec_bias = (reinterpret_cast<uintptr_t>(bias) & 15) == 0;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = n0 + wc * TN + j * 32 + 8 * g + 4 * h;
+                bv[j][g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                if (bias) {
+                    if (vec_bias && col + 3 < N) bv[j][g] = *reinterpret_cast<const f32x4_t*>(bias + col);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (col + e < N) bv[j][g][e] = bias[col + e];
+                    }
+                }
+            }
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            const int i = ps / JP, j0 = (ps % JP) * NJ;
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[i][j0 + jj][4 * g + e] + bv[j0 + jj][g][e];
+                        if (relu) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    stage(jj, g, v);
+                }
+            write_out(ps);
+        }
+    } else if constexpr (EPI == 1) {
+        // (g) ReLU gate alone (the FFN_suf dgrad, N = d_inner): a select commutes with the rounding, so the gate is
+        // applied to the ROUNDED tile in its row-contiguous staged form -- the gate operand is then read exactly like the
+        // output is written (16 bytes per lane, eight lanes per 128-byte row segment) instead of as 8-byte pieces of 32
+        // different rows per instruction (same box, interleaved, N2048.K512: 130.0 -> 96.0 us; the product without a gate 76-78 us;
+        // the remaining 20 us are the 134 MB of gate rows at the HBM rate).
+        // Chunks of pass ps + 1 are requested before the stores of pass ps.
+        chunk16 gq[2][4];
+        auto fetch_gate = [&](int ps, chunk16 (&q)[4]) __attribute__((always_inline)) {
+            const int i = ps / JP, j0 = (ps % JP) * NJ;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int rr = it * 8 + (lane >> 3), ch = lane & 7;
+                const int orow = min(m0 + wr * TM + i * 32 + rr, M - 1);
+                const int col = min(n0 + wc * TN + j0 * 32 + ch * 8, N - 8);
+                q[it] = ld_chunk(gate + (size_t)orow * ldgate + col);
+            }
+        };
+        fetch_gate(0, gq[0]);
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            const int i = ps / JP, j0 = (ps % JP) * NJ;
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j0 + jj][4 * g + e];
+                    stage(jj, g, v);
+                }
+            if (ps + 1 < NP) fetch_gate(ps + 1, gq[(ps + 1) & 1]);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int rr = it * 8 + (lane >> 3), ch = lane & 7;
+                chunk16 v = ld_chunk(stg + rr * 128 + ((ch ^ (rr & 7)) << 4));
+                const T* gp = reinterpret_cast<const T*>(&gq[ps & 1][it]);
+                T* vp = reinterpret_cast<T*>(&v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) vp[e] = (float)gp[e] > 0.f ? vp[e] : (T)0.f;
+                const int orow = m0 + wr * TM + i * 32 + rr;
+                const int col = n0 + wc * TN + j0 * 32 + ch * 8;
+                if (orow < M && col < N) st_chunk(reinterpret_cast<T*>(Cv) + (size_t)orow * ldc + col, v);
+            }
+        }
+    } else if constexpr (EPI == 2) {
+        // (r) residual add alone (the FFN_pre and qkv dgrads): the operand is read row-contiguously like the output is
+        // written (16 bytes per lane) and brought into the accumulators' layout through the wave's staging buffer --
+        // chunks in, 8-byte quads out, the mapping `stage` / `write_out` use in the other direction -- so the sum is still
+        // formed in f32 before the one rounding (bit-identical to the element-wise path b), but an instruction touches 8
+        // full 128-byte row segments instead of 16 bytes in each of 32 rows (same box, interleaved: +9.5 us -> see profiles).
+        chunk16 aq[2][4];
+        auto fetch_add = [&](int ps, chunk16 (&q)[4]) __attribute__((always_inline)) {
+            const int i = ps / JP, j0 = (ps % JP) * NJ;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int rr = it * 8 + (lane >> 3), ch = lane & 7;
+                const int orow = min(m0 + wr * TM + i * 32 + rr, M - 1);
+                const int col = min(n0 + wc * TN + j0 * 32 + ch * 8, N - 8);
+                q[it] = ld_chunk(add + (size_t)orow * ldadd + col);
+            }
+        };
+        fetch_add(0, aq[0]);
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            const int i = ps / JP, j0 = (ps % JP) * NJ;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int rr = it * 8 + (lane >> 3), ch = lane & 7;
+                st_chunk(stg + rr * 128 + ((ch ^ (rr & 7)) << 4), aq[ps & 1][it]);
+            }
+            bf16x4_t av[NJ][4];
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    av[jj][g] = *reinterpret_cast<const bf16x4_t*>(stg + lr * 128 + (((jj * 4 + g) ^ (lr & 7)) << 4) + h * 8);
+            if (ps + 1 < NP) fetch_add(ps + 1, aq[(ps + 1) & 1]);
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = n0 + wc * TN + (j0 + jj) * 32 + 8 * g + 4 * h;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[i][j0 + jj][4 * g + e] + ((bias && col + e < N) ? bias[col + e] : 0.f);
+                        if (relu) v[e] = fmaxf(v[e], 0.f);
+                        v[e] += (float)av[jj][g][e];
+                    }
+                    stage(jj, g, v);
+                }
+            write_out(ps);
+        }
+    } else {
+        // (b) residual add / ReLU gate (the backward GEMMs): their operands for the NEXT pass are fetched (8 bytes
+        // per quad) before this pass's stores are issued
+        const bool vec_add = add && (ldadd & 3) == 0 && (reinterpret_cast<uintptr_t>(add) & 7) == 0;
+        const bool vec_gate = gate && (ldgate & 3) == 0 && (reinterpret_cast<uintptr_t>(gate) & 7) == 0;
+        auto load4 = [&](const bf16_t* base, int ld, bool vec, int row, int col) __attribute__((always_inline)) -> bf16x4_t {
+            bf16x4_t r = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+            if (base && row < M) {
+                if (vec && col + 3 < N) r = *reinterpret_cast<const bf16x4_t*>(base + (size_t)row * ld + col);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (col + e < N) r[e] = base[(size_t)row * ld + col + e];
+                }
+            }
+            return r;
+        };
+        bf16x4_t av[NJ][4], gv[NJ][4];
+        auto fetch_ag = [&](int ps) __attribute__((always_inline)) {
+            const int i = ps / JP, j0 = (ps % JP) * NJ;
+            const int row = m0 + wr * TM + i * 32 + lr;
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = n0 + wc * TN + (j0 + jj) * 32 + 8 * g + 4 * h;
+                    if (add) av[jj][g] = load4(add, ldadd, vec_add, row, col);
+                    if (gate) gv[jj][g] = load4(gate, ldgate, vec_gate, row, col);
+                }
+        };
+        fetch_ag(0);
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            const int i = ps / JP, j0 = (ps % JP) * NJ;
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = n0 + wc * TN + (j0 + jj) * 32 + 8 * g + 4 * h;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[i][j0 + jj][4 * g + e] + ((bias && col + e < N) ? bias[col + e] : 0.f);
+                        if (relu) v[e] = fmaxf(v[e], 0.f);
+                        if (add) v[e] += (float)av[jj][g][e];
+                        if (gate) v[e] = (float)gv[jj][g][e] > 0.f ? v[e] : 0.f;
+                    }
+                    stage(jj, g, v);
+                }
+            if (ps + 1 < NP) fetch_ag(ps + 1);
+            write_out(ps);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < AI; ++i)
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) acc_zero(acc[i][j]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // 256x256 tile, 8 waves (2 x 4, each 128 x 64 = 4 x 2 macro-atoms), bf16, K % 64 == 0.
 // Each slab [256 rows][64 k] of A and of B lives in LDS as a LINEAR image (128 B per row); a "piece" is
@@ -227,240 +471,10 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_nt256_kernel(
         for (int j = 0; j < BJ; ++j) frag_load(fb[j], reinterpret_cast<const T*>(((j & 1) ? bo : be) + j * 4096));
     };
 
-    // ---- tile write-out: stage 32 rows x 128 B at a time through the wave's private 4 KB so that every
-    // store instruction writes 8 full 128-byte row segments (per-lane 8-byte pieces across 32 rows are
-    // L2-transaction bound).  bf16: a pass = 32 rows x 64 columns; f32: 32 rows x 32 columns.
     auto epilogue = [&](int tile_it) __attribute__((always_inline)) {
         int m0, n0;
         tile_origin(tile_it, m0, n0);
-        char* stg = smem + 2 * 65536 + wid * (32768 / NW);
-        constexpr int NJ = OUT_F32 ? 1 : 2;                                // accumulator blocks per pass
-        constexpr int JP = BJ / NJ;                                        // passes per 32-row group
-        constexpr int NP = AI * JP;                                        // passes
-        const int lr = lane & 31;
-        // one quad (4 consecutive columns of the lane's row) -> staging; 16-byte slot index XOR (row & 7) spreads
-        // the 32 rows of a store over the banks
-        auto stage = [&](int jj, int g, const float* v) __attribute__((always_inline)) {
-            if constexpr (OUT_F32) {
-                const int slot = (2 * g + h) ^ (lr & 7);
-                *reinterpret_cast<f32x4_t*>(stg + lr * 128 + (slot << 4)) = (f32x4_t){v[0], v[1], v[2], v[3]};
-            } else {
-                const int slot = (jj * 4 + g) ^ (lr & 7);
-                st4_t<T>(reinterpret_cast<T*>(stg + lr * 128 + (slot << 4) + h * 8), v[0], v[1], v[2], v[3]);
-            }
-        };
-        // read back: lane -> (row it*8 + lane/8, 16-byte chunk lane%8): full-row coalesced stores
-        auto write_out = [&](int ps) __attribute__((always_inline)) {
-            const int i = ps / JP, j0 = (ps % JP) * NJ;
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int rr = it * 8 + (lane >> 3), ch = lane & 7;
-                const chunk16 v = ld_chunk(stg + rr * 128 + ((ch ^ (rr & 7)) << 4));
-                const int orow = m0 + wr * TM + i * 32 + rr;
-                constexpr int EPC = OUT_F32 ? 4 : 8;                       // elements per chunk
-                const int col = n0 + wc * TN + j0 * 32 + ch * EPC;
-                if (orow < M && col < N) {
-                    if (col + EPC <= N && vec_c) {
-                        if constexpr (OUT_F32) st_chunk(reinterpret_cast<float*>(Cv) + (size_t)orow * ldc + col, v);
-                        else st_chunk(reinterpret_cast<T*>(Cv) + (size_t)orow * ldc + col, v);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < EPC; ++e)
-                            if (col + e < N) {
-                                if constexpr (OUT_F32) (reinterpret_cast<float*>(Cv))[(size_t)orow * ldc + col + e] = reinterpret_cast<const float*>(&v)[e];
-                                else (reinterpret_cast<T*>(Cv))[(size_t)orow * ldc + col + e] = reinterpret_cast<const T*>(&v)[e];
-                            }
-                    }
-                }
-            }
-        };
-        // vmcnt is in-order: a global load issued between two passes waits for the previous pass's STORES to retire
-        // (measured: 20 us of an 80 us launch).  Hence two code paths (registers = max, not sum):
-        if constexpr (EPI == 0) {
-            // (a) bias (+ReLU): the wave's bias values are fetched once, before any store
-            f32x4_t bv[BJ][4];
-            const bool vec_bias = (reinterpret_cast<uintptr_t>(bias) & 15) == 0;
-#pragma unroll
-            for (int j = 0; j < BJ; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int col = n0 + wc * TN + j * 32 + 8 * g + 4 * h;
-                    bv[j][g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-                    if (bias) {
-                        if (vec_bias && col + 3 < N) bv[j][g] = *reinterpret_cast<const f32x4_t*>(bias + col);
-                        else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) if (col + e < N) bv[j][g][e] = bias[col + e];
-                        }
-                    }
-                }
-#pragma unroll
-            for (int ps = 0; ps < NP; ++ps) {
-                const int i = ps / JP, j0 = (ps % JP) * NJ;
-#pragma unroll
-                for (int jj = 0; jj < NJ; ++jj)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        float v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[e] = acc[i][j0 + jj][4 * g + e] + bv[j0 + jj][g][e];
-                            if (relu) v[e] = fmaxf(v[e], 0.f);
-                        }
-                        stage(jj, g, v);
-                    }
-                write_out(ps);
-            }
-        } else if constexpr (EPI == 1) {
-            // (g) ReLU gate alone (the FFN_suf dgrad, N = d_inner): a select commutes with the rounding, so the gate is
-            // applied to the ROUNDED tile in its row-contiguous staged form -- the gate operand is then read exactly like the
-            // output is written (16 bytes per lane, eight lanes per 128-byte row segment) instead of as 8-byte pieces of 32
-            // different rows per instruction (same box, interleaved, N2048.K512: 130.0 -> 96.0 us; the product without a gate 76-78 us;
-            // the remaining 20 us are the 134 MB of gate rows at the HBM rate).
-            // Chunks of pass ps + 1 are requested before the stores of pass ps.
-            chunk16 gq[2][4];
-            auto fetch_gate = [&](int ps, chunk16 (&q)[4]) __attribute__((always_inline)) {
-                const int i = ps / JP, j0 = (ps % JP) * NJ;
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int rr = it * 8 + (lane >> 3), ch = lane & 7;
-                    const int orow = min(m0 + wr * TM + i * 32 + rr, M - 1);
-                    const int col = min(n0 + wc * TN + j0 * 32 + ch * 8, N - 8);
-                    q[it] = ld_chunk(gate + (size_t)orow * ldgate + col);
-                }
-            };
-            fetch_gate(0, gq[0]);
-#pragma unroll
-            for (int ps = 0; ps < NP; ++ps) {
-                const int i = ps / JP, j0 = (ps % JP) * NJ;
-#pragma unroll
-                for (int jj = 0; jj < NJ; ++jj)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        float v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = acc[i][j0 + jj][4 * g + e];
-                        stage(jj, g, v);
-                    }
-                if (ps + 1 < NP) fetch_gate(ps + 1, gq[(ps + 1) & 1]);
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int rr = it * 8 + (lane >> 3), ch = lane & 7;
-                    chunk16 v = ld_chunk(stg + rr * 128 + ((ch ^ (rr & 7)) << 4));
-                    const T* gp = reinterpret_cast<const T*>(&gq[ps & 1][it]);
-                    T* vp = reinterpret_cast<T*>(&v);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) vp[e] = (float)gp[e] > 0.f ? vp[e] : (T)0.f;
-                    const int orow = m0 + wr * TM + i * 32 + rr;
-                    const int col = n0 + wc * TN + j0 * 32 + ch * 8;
-                    if (orow < M && col < N) st_chunk(reinterpret_cast<T*>(Cv) + (size_t)orow * ldc + col, v);
-                }
-            }
-        } else if constexpr (EPI == 2) {
-            // (r) residual add alone (the FFN_pre and qkv dgrads): the operand is read row-contiguously like the output is
-            // written (16 bytes per lane) and brought into the accumulators' layout through the wave's staging buffer --
-            // chunks in, 8-byte quads out, the mapping `stage` / `write_out` use in the other direction -- so the sum is still
-            // formed in f32 before the one rounding (bit-identical to the element-wise path b), but an instruction touches 8
-            // full 128-byte row segments instead of 16 bytes in each of 32 rows (same box, interleaved: +9.5 us -> see profiles).
-            chunk16 aq[2][4];
-            auto fetch_add = [&](int ps, chunk16 (&q)[4]) __attribute__((always_inline)) {
-                const int i = ps / JP, j0 = (ps % JP) * NJ;
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int rr = it * 8 + (lane >> 3), ch = lane & 7;
-                    const int orow = min(m0 + wr * TM + i * 32 + rr, M - 1);
-                    const int col = min(n0 + wc * TN + j0 * 32 + ch * 8, N - 8);
-                    q[it] = ld_chunk(add + (size_t)orow * ldadd + col);
-                }
-            };
-            fetch_add(0, aq[0]);
-#pragma unroll
-            for (int ps = 0; ps < NP; ++ps) {
-                const int i = ps / JP, j0 = (ps % JP) * NJ;
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int rr = it * 8 + (lane >> 3), ch = lane & 7;
-                    st_chunk(stg + rr * 128 + ((ch ^ (rr & 7)) << 4), aq[ps & 1][it]);
-                }
-                bf16x4_t av[NJ][4];
-#pragma unroll
-                for (int jj = 0; jj < NJ; ++jj)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        av[jj][g] = *reinterpret_cast<const bf16x4_t*>(stg + lr * 128 + (((jj * 4 + g) ^ (lr & 7)) << 4) + h * 8);
-                if (ps + 1 < NP) fetch_add(ps + 1, aq[(ps + 1) & 1]);
-#pragma unroll
-                for (int jj = 0; jj < NJ; ++jj)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int col = n0 + wc * TN + (j0 + jj) * 32 + 8 * g + 4 * h;
-                        float v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[e] = acc[i][j0 + jj][4 * g + e] + ((bias && col + e < N) ? bias[col + e] : 0.f);
-                            if (relu) v[e] = fmaxf(v[e], 0.f);
-                            v[e] += (float)av[jj][g][e];
-                        }
-                        stage(jj, g, v);
-                    }
-                write_out(ps);
-            }
-        } else {
-            // (b) residual add / ReLU gate (the backward GEMMs): their operands for the NEXT pass are fetched (8 bytes
-            // per quad) before this pass's stores are issued
-            const bool vec_add = add && (ldadd & 3) == 0 && (reinterpret_cast<uintptr_t>(add) & 7) == 0;
-            const bool vec_gate = gate && (ldgate & 3) == 0 && (reinterpret_cast<uintptr_t>(gate) & 7) == 0;
-            auto load4 = [&](const bf16_t* base, int ld, bool vec, int row, int col) __attribute__((always_inline)) -> bf16x4_t {
-                bf16x4_t r = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
-                if (base && row < M) {
-                    if (vec && col + 3 < N) r = *reinterpret_cast<const bf16x4_t*>(base + (size_t)row * ld + col);
-                    else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) if (col + e < N) r[e] = base[(size_t)row * ld + col + e];
-                    }
-                }
-                return r;
-            };
-            bf16x4_t av[NJ][4], gv[NJ][4];
-            auto fetch_ag = [&](int ps) __attribute__((always_inline)) {
-                const int i = ps / JP, j0 = (ps % JP) * NJ;
-                const int row = m0 + wr * TM + i * 32 + lr;
-#pragma unroll
-                for (int jj = 0; jj < NJ; ++jj)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int col = n0 + wc * TN + (j0 + jj) * 32 + 8 * g + 4 * h;
-                        if (add) av[jj][g] = load4(add, ldadd, vec_add, row, col);
-                        if (gate) gv[jj][g] = load4(gate, ldgate, vec_gate, row, col);
-                    }
-            };
-            fetch_ag(0);
-#pragma unroll
-            for (int ps = 0; ps < NP; ++ps) {
-                const int i = ps / JP, j0 = (ps % JP) * NJ;
-#pragma unroll
-                for (int jj = 0; jj < NJ; ++jj)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int col = n0 + wc * TN + (j0 + jj) * 32 + 8 * g + 4 * h;
-                        float v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[e] = acc[i][j0 + jj][4 * g + e] + ((bias && col + e < N) ? bias[col + e] : 0.f);
-                            if (relu) v[e] = fmaxf(v[e], 0.f);
-                            if (add) v[e] += (float)av[jj][g][e];
-                            if (gate) v[e] = (float)gv[jj][g][e] > 0.f ? v[e] : 0.f;
-                        }
-                        stage(jj, g, v);
-                    }
-                if (ps + 1 < NP) fetch_ag(ps + 1);
-                write_out(ps);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < AI; ++i)
-#pragma unroll
-            for (int j = 0; j < BJ; ++j) acc_zero(acc[i][j]);
+        nt256_write_tile<OUT_F32, WR, WC, EPI>(acc, smem, m0, n0, wid, lane, Cv, ldc, bias, add, ldadd, gate, ldgate, M, N, relu, vec_c);
     };
 
     // ---- prologue: slab 0 into LDS, slab 1 into the registers
@@ -496,6 +510,235 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_nt256_kernel(
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // my stores of slab step+1 are in LDS
         slot_barrier();                                                    // everybody's; slab `step` fully consumed
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 256x256 tile, 8 waves (2 x 4, 128 x 64 per wave), bf16, K % 64 == 0 -- PING-PONG main loop (round 5).
+// Same tile, same LDS slab images, same accumulator layout, same k order per accumulator (bit-identical results)
+// and same write-out as gemm_nt256_kernel; what differs is how the matrix pipe is kept busy:
+//   * the two waves of a SIMD (wave w and w + 4 = the two row groups wr = 0 / 1) never compete for it.  A slab is cut
+//     into four PHASES (a 64 x 32 quadrant of the wave tile x the slab's 64 k: 8 MFMAs = 256 matrix-pipe cycles); each
+//     phase is an L segment (fragment ds_reads for the phase + the operand feed) and an M segment (MFMAs only, at
+//     s_setprio 1), separated by s_barriers.  Group 1 runs one barrier behind group 0, so in every barrier interval
+//     one wave of each SIMD multiplies while the other one loads.
+//   * operand feed = direct-to-LDS loads (global_load_lds_dwordx4, no registers, no ds_write: the LDS store path was
+//     830 of the 1600 LDS cycles per slab of the register-staged kernel).  A slab is fed as four UNITS of 128 rows
+//     (16 KB = 2 pieces of 8 rows x 128 B per wave): A rows of quadrant half 0, B half 0, B half 1, A half 1 -- in the
+//     order the phases first read them.  L segment s (= 4 slab + phase) issues unit s + 6 and then waits with a
+//     COUNTED vmcnt(8) for unit s + 2: eight to ten 1 KB pieces per wave stay in flight across the barriers, nothing in the
+//     loop ever drains the queue.  Hazards: a unit is read in segment >= u - 1, i.e. at least one barrier after every
+//     wave's wait for it (RAW); unit u overwrites the slot of unit u - 8, last read in segment <= u - 8, six segments
+//     and two lgkmcnt(0)-before-barrier waits earlier (WAR).
+// Fragment registers: one A half (2 atoms x 4 k-phases) + both B atoms (4 k-phases each) = 64; reads per phase 12 / 4 / 8 / 0.
+// ---------------------------------------------------------------------------------------------
+template <bool OUT_F32, int EPI, int VAR = 0>
+__global__ __launch_bounds__(512) void gemm_nt8p_kernel(
+    const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc,
+    const float* __restrict__ bias, const bf16_t* __restrict__ add, int ldadd, const bf16_t* __restrict__ gate,
+    int ldgate, int M, int N, int K, int flags) {
+    typedef bf16_t T;
+    constexpr int WR = 2, WC = 4, AI = 4, BJ = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // [2 buffers][A 32 KB | B 32 KB] | staging
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;                                // wr = ping-pong group
+    const int ntn = (N + 255) / 256, ntiles = ntn * ((M + 255) / 256);
+    const int nk = K / 64;
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nsteps = my_tiles * nk;
+    if (nsteps <= 0) return;
+    const int NU = 4 * nsteps;                                            // feed units of this block
+    auto tile_origin = [&](int it, int& m0, int& n0) __attribute__((always_inline)) {
+        int t = it * gridDim.x + blockIdx.x;
+        if ((ntiles & 7) == 0) t = (t & 7) * (ntiles >> 3) + (t >> 3);      // contiguous tile range per XCD
+        m0 = (t / ntn) * 256;
+        n0 = (t % ntn) * 256;
+    };
+
+    // ---- operand feed.  Unit `which` of a slab: 0 = A rows {0..63} + 128 g, 1 = B rows {0..31} + 64 c, 2 = B rows {32..63} + 64 c,
+    // 3 = A rows {64..127} + 128 g (g = row group, c = wave column): the rows the phases read, in first-use order.
+    // Wave w moves pieces 2 w and 2 w + 1 of the unit's 16; a piece is 8 consecutive slab rows = 1 KB of the linear slab
+    // image (LDS address = wave-uniform base + 16 lane); the swizzle is applied to the SOURCE chunk of every lane.
+    const uint32_t lda2 = (uint32_t)lda * 2u, ldb2 = (uint32_t)ldb * 2u;
+    const char* Ab = reinterpret_cast<const char*>(A);
+    const char* Bb = reinterpret_cast<const char*>(B);
+    struct Cur { int m0, n0, k, tile; };
+    auto cur_next = [&](Cur& c) __attribute__((always_inline)) {
+        c.k += 64;
+        if (c.k == K) { c.k = 0; ++c.tile; tile_origin(c.tile, c.m0, c.n0); }
+    };
+    // Per-lane part of a source address: row offset + swizzled chunk column of the wave's first piece of a unit (4 registers
+    // for A and B); the other pieces differ by a wave-uniform row distance (added to the scalar base) and by a constant
+    // XOR of the chunk column (swz(r) = lrow ^ ((r >> 3) & 7) and the pieces start at multiples of 8 rows).  Tiles cut by
+    // the matrix edge clamp their rows and recompute everything from `lane` at the issue (the empty asm keeps hipcc from
+    // hoisting that: it would hold sixteen more registers across the loop and spill).
+    const int lrow = lane >> 3;
+    const int rA0 = (wid >> 2) * 128 + 16 * (wid & 3) + lrow, rB0 = (wid >> 1) * 64 + 16 * (wid & 1) + lrow;
+    const uint32_t rowoffA = (uint32_t)rA0 * lda2, rowoffB = (uint32_t)rB0 * ldb2;
+    const uint32_t colA = (uint32_t)(((lane & 7) ^ ((rA0 ^ (rA0 >> 3)) & 7)) << 4);
+    const uint32_t colB = (uint32_t)(((lane & 7) ^ ((rB0 ^ (rB0 >> 3)) & 7)) << 4);
+    auto stage = [&](int which, const Cur& c, int slab) __attribute__((always_inline)) {
+        const bool isA = which == 0 || which == 3;
+        const int half = which >> 1;
+        const bool interior = isA ? c.m0 + 256 <= M : c.n0 + 256 <= N;
+        if (interior && !(VAR & 512)) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int dr = isA ? 64 * half + 8 * e : 32 * half + 8 * e;             // rows from the wave's first piece
+                const uint32_t x = isA ? 16u * e : 16u * e + 64u * half;                  // its chunk XOR
+                const char* sb = isA ? Ab + ((size_t)(uint32_t)(c.m0 + dr) * lda2 + (uint32_t)(c.k * 2))
+                                     : Bb + ((size_t)(uint32_t)(c.n0 + dr) * ldb2 + (uint32_t)(c.k * 2));
+                const uint32_t vo = isA ? rowoffA + (colA ^ x) : rowoffB + (colB ^ x);
+                const int rb = isA ? (wid >> 2) * 128 + 16 * (wid & 3) + dr : (wid >> 1) * 64 + 16 * (wid & 1) + dr;
+                char* dst = smem + (slab & 1) * 65536 + (isA ? 0 : 32768) + rb * 128;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + vo),
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            }
+        } else {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const int lr8 = ln >> 3;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                // wave-uniform first row of the piece inside the slab
+                const int rb = isA ? (wid >> 2) * 128 + 64 * half + 16 * (wid & 3) + 8 * e
+                                   : (wid >> 1) * 64 + 32 * half + 16 * (wid & 1) + 8 * e;
+                const int r = rb + lr8;
+                const uint32_t col = (uint32_t)((((ln & 7) ^ ((r ^ (r >> 3)) & 7)) << 4) + c.k * 2);
+                const char* src = isA ? Ab + ((uint32_t)min(c.m0 + r, M - 1) * lda2 + col)
+                                      : Bb + ((uint32_t)min(c.n0 + r, N - 1) * ldb2 + col);
+                char* dst = smem + (slab & 1) * 65536 + (isA ? 0 : 32768) + rb * 128;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            }
+        }
+    };
+
+    f32x16_t acc[AI][BJ];
+#pragma unroll
+    for (int i = 0; i < AI; ++i)
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) acc_zero(acc[i][j]);
+
+    const int frow = lane & 31, h = lane >> 5;
+    const bool relu = flags & ME_EPI_RELU;
+    const bool vec_c = (ldc % (OUT_F32 ? 4 : 8)) == 0 && (reinterpret_cast<uintptr_t>(Cv) & 15) == 0;
+    static_assert(!(OUT_F32 && (EPI == 1 || EPI == 2)), "the row paths stage bf16 rows");
+
+    // fragment addresses: see gemm_nt256_kernel (swz(r) = (r ^ r >> 3) & 7; rows r and r + 32 differ by XOR 64)
+    Frag<T> fa[2][4], fb[BJ][4];
+    uint32_t pa0, pb0;
+    { const int r = wr * 128 + frow; pa0 = r * 128 + ((h ^ ((r ^ (r >> 3)) & 7)) << 4); }
+    { const int r = wc * 64 + frow; pb0 = 32768 + r * 128 + ((h ^ ((r ^ (r >> 3)) & 7)) << 4); }
+    // (the eight XOR variants per operand are formed at the read, from one opaque base register: see `stage`)
+    auto lfragA = [&](uint32_t bufoff, int half) __attribute__((always_inline)) {
+        uint32_t a0 = pa0;
+        asm volatile("" : "+v"(a0));
+        a0 += bufoff;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const char* ae = smem + (a0 ^ (uint32_t)(kk << 5));
+            const char* ao = smem + (a0 ^ (uint32_t)((kk << 5) ^ 64));
+            frag_load(fa[0][kk], reinterpret_cast<const T*>(ae + (2 * half) * 4096));
+            frag_load(fa[1][kk], reinterpret_cast<const T*>(ao + (2 * half + 1) * 4096));
+        }
+    };
+    auto lfragB = [&](uint32_t bufoff, int j) __attribute__((always_inline)) {
+        uint32_t b0 = pb0;
+        asm volatile("" : "+v"(b0));
+        b0 += bufoff;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const char* b = smem + (b0 ^ (uint32_t)((kk << 5) ^ ((j & 1) ? 64 : 0)));
+            frag_load(fb[j][kk], reinterpret_cast<const T*>(b + j * 4096));
+        }
+    };
+    auto seg_barrier = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto epilogue = [&](int tile_it) __attribute__((always_inline)) {
+        int m0, n0;
+        tile_origin(tile_it, m0, n0);
+        nt256_write_tile<OUT_F32, WR, WC, EPI>(acc, smem, m0, n0, wid, lane, Cv, ldc, bias, add, ldadd, gate, ldgate, M, N, relu, vec_c);
+    };
+
+    // ---- prologue: units 0 .. 5 (slab 0 and the first half of slab 1) are issued; units 0 and 1 must have landed
+    Cur c1, c2;                                                           // slabs step + 1 and step + 2
+    c1.k = 0; c1.tile = 0; tile_origin(0, c1.m0, c1.n0);
+    {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) stage(w, c1, 0);
+        cur_next(c1);
+        c2 = c1;
+        if (NU > 4) {
+            stage(0, c1, 1);
+            stage(1, c1, 1);
+            cur_next(c2);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    seg_barrier();
+    if (wr == 1 && !(VAR & 256)) seg_barrier();                           // group 1 runs one barrier behind
+
+    for (int step = 0; step < nsteps; ++step) {
+        const uint32_t buf = (uint32_t)(step & 1) * 65536u;
+        const bool tile_end = (step + 1) % nk == 0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            // ---- L segment
+            if (!(VAR & 2)) {
+                if (p == 0) { lfragA(buf, 0); lfragB(buf, 0); }
+                if (p == 1) lfragB(buf, 1);
+                if (p == 2) lfragA(buf, 1);
+            }
+            if (!(VAR & 1)) {
+            if (4 * step + p + 6 < NU) {
+                if (p == 0) stage(2, c1, step + 1);
+                if (p == 1) stage(3, c1, step + 1);
+                if (p == 2) stage(0, c2, step + 2);
+                if (p == 3) stage(1, c2, step + 2);
+                if (VAR & 32) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+                else if (VAR & 64) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            }
+            if (!(VAR & 8)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // my reads are done before anybody restages
+            seg_barrier();
+            // ---- M segment
+            if (!(VAR & 16)) __builtin_amdgcn_s_setprio(1);
+            if (!(VAR & 4))
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (p == 0) mma32(acc[i][0], fb[0][kk], fa[i][kk]);
+                    if (p == 1) mma32(acc[i][1], fb[1][kk], fa[i][kk]);
+                    if (p == 2) mma32(acc[2 + i][1], fb[1][kk], fa[i][kk]);
+                    if (p == 3) mma32(acc[2 + i][0], fb[0][kk], fa[i][kk]);
+                }
+            if (!(VAR & 16)) __builtin_amdgcn_s_setprio(0);
+            // both groups write a finished tile out in the SAME barrier interval: group 1 (one interval behind) before the
+            // barrier that ends this M segment, group 0 after it
+            if (p == 3 && tile_end) {
+                if (wr == 0) seg_barrier();
+                epilogue(step / nk);
+                if (wr == 1) seg_barrier();
+            } else {
+                seg_barrier();
+            }
+        }
+        c1 = c2;
+        cur_next(c2);
+    }
+    if (wr == 0 && !(VAR & 256)) seg_barrier();
 }
 
 // C = A.B^T.  128x128 block tile, 4 waves (2x2) x 64x64.  K-slab BKT (64 bf16 / 32 f32) is
@@ -1194,6 +1437,12 @@ __global__ __launch_bounds__(256) void cast_transpose_multi_kernel(const me_ct_d
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static const bool g_disable_nt256 = getenv("MIDIEMO_NO_NT256") != nullptr;
+// main loop of the 256-tile NT kernel: 1 = ping-pong / direct-to-LDS feed (gemm_nt8p_kernel), 0 = register-staged single phase
+// (gemm_nt256_kernel); results are bit-identical.  MIDIEMO_NT_MAINLOOP overrides (development A/B).
+#ifndef ME_NT_MAINLOOP_DEFAULT
+#define ME_NT_MAINLOOP_DEFAULT 0
+#endif
+static const int g_nt_mainloop = getenv("MIDIEMO_NT_MAINLOOP") ? atoi(getenv("MIDIEMO_NT_MAINLOOP")) : ME_NT_MAINLOOP_DEFAULT;
 
 // CUs the persistent kernels may occupy on the current device: multiProcessorCount minus MIDIEMO_CU_RESERVE (CUs left
 // to a concurrent RCCL kernel when the gradient all-reduce overlaps the backward; default 0).  A query, not a
@@ -1239,6 +1488,12 @@ int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int 
                 (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, 2, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
                 (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<true, 2, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
                 (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<true, 2, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+                (void)hipFuncSetAttribute((const void*)gemm_nt8p_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+                (void)hipFuncSetAttribute((const void*)gemm_nt8p_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+                (void)hipFuncSetAttribute((const void*)gemm_nt8p_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+                (void)hipFuncSetAttribute((const void*)gemm_nt8p_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+                (void)hipFuncSetAttribute((const void*)gemm_nt8p_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+                (void)hipFuncSetAttribute((const void*)gemm_nt8p_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
                 if (dev >= 0 && dev < 16) attr_set[dev] = true;
             }
             unsigned g256 = (unsigned)(((N + 255) / 256) * ((M + 255) / 256));
@@ -1252,8 +1507,20 @@ int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int 
             if (!add && !gate) epi = 0;
             else if (!(flags & ME_EPI_OUT_F32) && gate && !add && !bias && !(flags & ME_EPI_RELU) && vec_c && (ldgate & 7) == 0 && aligned16(gate)) epi = 1;
             else if (!(flags & ME_EPI_OUT_F32) && add && !gate && vec_c && (ldadd & 7) == 0 && aligned16(add)) epi = 2;
-#define ME_NT256(F32, E) gemm_nt256_kernel<F32, 2, 4, E><<<g256, 512, NT256_LDS, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias, \
-                                                                                   (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags)
+#ifdef ME_NT_ABL
+            if (g_nt_mainloop == 1 && epi == 0 && !(flags & ME_EPI_OUT_F32)) {
+                static const int var = getenv("MIDIEMO_NT_VAR") ? atoi(getenv("MIDIEMO_NT_VAR")) : 0;
+#define ME_ABL(V) case V: (void)hipFuncSetAttribute((const void*)gemm_nt8p_kernel<false, 0, V>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS); \
+                          gemm_nt8p_kernel<false, 0, V><<<g256, 512, NT256_LDS, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias, (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags); break;
+                switch (var) { ME_ABL(0) ME_ABL(1) ME_ABL(2) ME_ABL(3) ME_ABL(4) ME_ABL(5) ME_ABL(6) ME_ABL(7) ME_ABL(8) ME_ABL(512) ME_ABL(518) ME_ABL(262) ME_ABL(294) ME_ABL(16) ME_ABL(38) ME_ABL(70) ME_ABL(134) ME_ABL(166) ME_ABL(32) ME_ABL(64) ME_ABL(128) default: return ME_ERR_BAD_SHAPE; }
+#undef ME_ABL
+                return me_launch_status();
+            }
+#endif
+#define ME_NT256(F32, E) do { if (g_nt_mainloop == 1 && E != 3) gemm_nt8p_kernel<F32, E><<<g256, 512, NT256_LDS, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias, \
+                                                                                   (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags); \
+                              else gemm_nt256_kernel<F32, 2, 4, E><<<g256, 512, NT256_LDS, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias, \
+                                                                                   (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags); } while (0)
             if (flags & ME_EPI_OUT_F32) { if (epi == 0) ME_NT256(true, 0); else ME_NT256(true, 3); }
             else if (epi == 0) ME_NT256(false, 0);
             else if (epi == 1) ME_NT256(false, 1);
