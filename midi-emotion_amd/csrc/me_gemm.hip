@@ -514,31 +514,38 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_nt256_kernel(
 
 // ---------------------------------------------------------------------------------------------
 // 256x256 tile, 8 waves (2 x 4, 128 x 64 per wave), bf16, K % 64 == 0 -- PING-PONG main loop (round 5).
-// Same tile, same LDS slab images, same accumulator layout, same k order per accumulator (bit-identical results)
-// and same write-out as gemm_nt256_kernel; what differs is how the matrix pipe is kept busy:
-//   * the two waves of a SIMD (wave w and w + 4 = the two row groups wr = 0 / 1) never compete for it.  A slab is cut
-//     into four PHASES (a 64 x 32 quadrant of the wave tile x the slab's 64 k: 8 MFMAs = 256 matrix-pipe cycles); each
-//     phase is an L segment (fragment ds_reads for the phase + the operand feed) and an M segment (MFMAs only, at
-//     s_setprio 1), separated by s_barriers.  Group 1 runs one barrier behind group 0, so in every barrier interval
-//     one wave of each SIMD multiplies while the other one loads.
-//   * operand feed = direct-to-LDS loads (global_load_lds_dwordx4, no registers, no ds_write: the LDS store path was
-//     830 of the 1600 LDS cycles per slab of the register-staged kernel).  A slab is fed as four UNITS of 128 rows
-//     (16 KB = 2 pieces of 8 rows x 128 B per wave): A rows of quadrant half 0, B half 0, B half 1, A half 1 -- in the
-//     order the phases first read them.  L segment s (= 4 slab + phase) issues unit s + 6 and then waits with a
-//     COUNTED vmcnt(8) for unit s + 2: eight to ten 1 KB pieces per wave stay in flight across the barriers, nothing in the
-//     loop ever drains the queue.  Hazards: a unit is read in segment >= u - 1, i.e. at least one barrier after every
-//     wave's wait for it (RAW); unit u overwrites the slot of unit u - 8, last read in segment <= u - 8, six segments
-//     and two lgkmcnt(0)-before-barrier waits earlier (WAR).
-// Fragment registers: one A half (2 atoms x 4 k-phases) + both B atoms (4 k-phases each) = 64; reads per phase 12 / 4 / 8 / 0.
+// Same tile, same accumulator layout, same k order per accumulator (bit-identical results) and same write-out as
+// gemm_nt256_kernel; what differs is how the matrix pipe and the vector-memory port are kept busy:
+//   * the two waves of a SIMD (wave w and w + 4 = the two row groups wr = 0 / 1) never compete for the matrix pipe.  A
+//     slab is cut into four PHASES (a 64 x 32 quadrant of the wave tile x the slab's 64 k: 8 MFMAs = 256 matrix-pipe
+//     cycles); each phase is an L segment and an M segment separated by s_barriers, and group 1 runs one barrier behind
+//     group 0: in every barrier interval one wave of each SIMD multiplies while the other one feeds.
+//   * operand feed = direct-to-LDS loads (global_load_lds_dwordx4: no registers, no ds_write -- the LDS store path was
+//     830 of the 1600 LDS cycles per slab of the register-staged kernel).  A CU accepts one such 1 KB instruction per
+//     ~23 cycles (measured: 64 per slab = 1500 of the 2048 matrix cycles), and a wave is blocked until its own is
+//     accepted, so a feeding wave must do nothing else: the L segment is 2 pieces + one counted wait, and the
+//     fragment ds_reads of the NEXT phase ride between the MFMAs of the M segment (4 or 8 per segment).
+//   * fragment registers: two A sets X, Y (a 64-row half, 2 atoms x 4 k-phases each) and two B sets P, Q (one atom).
+//     Quadrant order alternates between even and odd slabs so that every read finds a set that is free:
+//         even slab: (X,P) (X,Q) (Y,Q) (Y,P)      reads during the four M segments:  Q<-B1  Y<-A1  X<-A0'  Q<-B1'
+//         odd  slab: (X,Q) (X,P) (Y,P) (Y,Q)                                         P<-B0  Y<-A1  X<-A0'  P<-B0'
+//     (' = next slab): 24 reads per slab, each operand byte read once.
+//   * a slab is fed as four UNITS of 128 rows (16 KB = 2 pieces of 8 rows x 128 B per wave) in the order they are read
+//     (even: A0 B0 B1 A1, odd: A0 B1 B0 A1; A0 = rows {0..63} + 128 g, B0 = rows {0..31} + 64 c, ...).  With u = 4 slab + k:
+//     unit u is read during M segment u - 2; L segment m issues unit m + 8 (same LDS slot as unit m, whose reads were
+//     retired by every wave's lgkmcnt(0) at the start of its L segment m - 1 at the latest) and then waits with a COUNTED
+//     vmcnt(10) for unit m + 3, i.e. at least one barrier before any wave reads it: ten to twelve 1 KB pieces per wave
+//     stay in flight across the barriers, nothing in the loop ever drains the queue.
+// LDS: [A even 32 KB][A odd 32 KB][B even 32 KB][B odd 32 KB][write-out staging 32 KB]; slab images as in gemm_nt256_kernel.
 // ---------------------------------------------------------------------------------------------
-template <bool OUT_F32, int EPI, int VAR = 0>
+template <bool OUT_F32, int EPI>
 __global__ __launch_bounds__(512) void gemm_nt8p_kernel(
     const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc,
     const float* __restrict__ bias, const bf16_t* __restrict__ add, int ldadd, const bf16_t* __restrict__ gate,
     int ldgate, int M, int N, int K, int flags) {
     typedef bf16_t T;
     constexpr int WR = 2, WC = 4, AI = 4, BJ = 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];          // [2 buffers][A 32 KB | B 32 KB] | staging
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;                                // wr = ping-pong group
@@ -555,10 +562,14 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(
         n0 = (t % ntn) * 256;
     };
 
-    // ---- operand feed.  Unit `which` of a slab: 0 = A rows {0..63} + 128 g, 1 = B rows {0..31} + 64 c, 2 = B rows {32..63} + 64 c,
-    // 3 = A rows {64..127} + 128 g (g = row group, c = wave column): the rows the phases read, in first-use order.
-    // Wave w moves pieces 2 w and 2 w + 1 of the unit's 16; a piece is 8 consecutive slab rows = 1 KB of the linear slab
-    // image (LDS address = wave-uniform base + 16 lane); the swizzle is applied to the SOURCE chunk of every lane.
+    // ---- operand feed.  `which`: 0 = A half 0, 1 = B half 0, 2 = B half 1, 3 = A half 1.  Wave w moves pieces 2 w and 2 w + 1
+    // of a unit's 16; a piece is 8 consecutive slab rows = 1 KB of the linear slab image (LDS address = wave-uniform
+    // base + 16 lane); the swizzle is applied to the SOURCE chunk of every lane.
+    // Per-lane part of a source address: row offset + swizzled chunk column of the wave's first piece of a unit (4 registers
+    // for A and B); the other pieces differ by a wave-uniform row distance (added to the scalar base) and by a constant
+    // XOR of the chunk column (swz(r) = lrow ^ ((r >> 3) & 7) and the pieces start at multiples of 8 rows).  Tiles cut by
+    // the matrix edge clamp their rows and recompute everything from `lane` at the issue (the empty asm keeps hipcc from
+    // hoisting that: it would hold sixteen more registers across the loop and spill).
     const uint32_t lda2 = (uint32_t)lda * 2u, ldb2 = (uint32_t)ldb * 2u;
     const char* Ab = reinterpret_cast<const char*>(A);
     const char* Bb = reinterpret_cast<const char*>(B);
@@ -567,30 +578,26 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(
         c.k += 64;
         if (c.k == K) { c.k = 0; ++c.tile; tile_origin(c.tile, c.m0, c.n0); }
     };
-    // Per-lane part of a source address: row offset + swizzled chunk column of the wave's first piece of a unit (4 registers
-    // for A and B); the other pieces differ by a wave-uniform row distance (added to the scalar base) and by a constant
-    // XOR of the chunk column (swz(r) = lrow ^ ((r >> 3) & 7) and the pieces start at multiples of 8 rows).  Tiles cut by
-    // the matrix edge clamp their rows and recompute everything from `lane` at the issue (the empty asm keeps hipcc from
-    // hoisting that: it would hold sixteen more registers across the loop and spill).
     const int lrow = lane >> 3;
     const int rA0 = (wid >> 2) * 128 + 16 * (wid & 3) + lrow, rB0 = (wid >> 1) * 64 + 16 * (wid & 1) + lrow;
-    const uint32_t rowoffA = (uint32_t)rA0 * lda2, rowoffB = (uint32_t)rB0 * ldb2;
-    const uint32_t colA = (uint32_t)(((lane & 7) ^ ((rA0 ^ (rA0 >> 3)) & 7)) << 4);
-    const uint32_t colB = (uint32_t)(((lane & 7) ^ ((rB0 ^ (rB0 >> 3)) & 7)) << 4);
-    auto stage = [&](int which, const Cur& c, int slab) __attribute__((always_inline)) {
+    // (row pitch a multiple of 128 bytes: the chunk XOR can be applied to the sum)
+    const uint32_t offA = (uint32_t)rA0 * lda2 + (uint32_t)(((lane & 7) ^ ((rA0 ^ (rA0 >> 3)) & 7)) << 4);
+    const uint32_t offB = (uint32_t)rB0 * ldb2 + (uint32_t)(((lane & 7) ^ ((rB0 ^ (rB0 >> 3)) & 7)) << 4);
+    const bool pitch128 = ((lda2 | ldb2) & 127u) == 0;
+    auto stage = [&](int which, const Cur& c, int par) __attribute__((always_inline)) {
         const bool isA = which == 0 || which == 3;
         const int half = which >> 1;
-        const bool interior = isA ? c.m0 + 256 <= M : c.n0 + 256 <= N;
-        if (interior && !(VAR & 512)) {
+        const bool interior = pitch128 && (isA ? c.m0 + 256 <= M : c.n0 + 256 <= N);
+        if (interior) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int dr = isA ? 64 * half + 8 * e : 32 * half + 8 * e;             // rows from the wave's first piece
                 const uint32_t x = isA ? 16u * e : 16u * e + 64u * half;                  // its chunk XOR
                 const char* sb = isA ? Ab + ((size_t)(uint32_t)(c.m0 + dr) * lda2 + (uint32_t)(c.k * 2))
                                      : Bb + ((size_t)(uint32_t)(c.n0 + dr) * ldb2 + (uint32_t)(c.k * 2));
-                const uint32_t vo = isA ? rowoffA + (colA ^ x) : rowoffB + (colB ^ x);
+                const uint32_t vo = (isA ? offA : offB) ^ x;
                 const int rb = isA ? (wid >> 2) * 128 + 16 * (wid & 3) + dr : (wid >> 1) * 64 + 16 * (wid & 1) + dr;
-                char* dst = smem + (slab & 1) * 65536 + (isA ? 0 : 32768) + rb * 128;
+                char* dst = smem + par * 32768 + (isA ? 0 : 65536) + rb * 128;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + vo),
                                                  (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
             }
@@ -600,19 +607,20 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(
             const int lr8 = ln >> 3;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                // wave-uniform first row of the piece inside the slab
                 const int rb = isA ? (wid >> 2) * 128 + 64 * half + 16 * (wid & 3) + 8 * e
                                    : (wid >> 1) * 64 + 32 * half + 16 * (wid & 1) + 8 * e;
                 const int r = rb + lr8;
                 const uint32_t col = (uint32_t)((((ln & 7) ^ ((r ^ (r >> 3)) & 7)) << 4) + c.k * 2);
                 const char* src = isA ? Ab + ((uint32_t)min(c.m0 + r, M - 1) * lda2 + col)
                                       : Bb + ((uint32_t)min(c.n0 + r, N - 1) * ldb2 + col);
-                char* dst = smem + (slab & 1) * 65536 + (isA ? 0 : 32768) + rb * 128;
+                char* dst = smem + par * 32768 + (isA ? 0 : 65536) + rb * 128;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
             }
         }
     };
+    // unit k of a slab of parity par: even A0 B0 B1 A1, odd A0 B1 B0 A1
+    auto unit_which = [](int par, int k) __attribute__((always_inline)) { return (par && (k == 1 || k == 2)) ? 3 - k : k; };
 
     f32x16_t acc[AI][BJ];
 #pragma unroll
@@ -625,33 +633,24 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(
     const bool vec_c = (ldc % (OUT_F32 ? 4 : 8)) == 0 && (reinterpret_cast<uintptr_t>(Cv) & 15) == 0;
     static_assert(!(OUT_F32 && (EPI == 1 || EPI == 2)), "the row paths stage bf16 rows");
 
-    // fragment addresses: see gemm_nt256_kernel (swz(r) = (r ^ r >> 3) & 7; rows r and r + 32 differ by XOR 64)
-    Frag<T> fa[2][4], fb[BJ][4];
+    // fragment addresses: see gemm_nt256_kernel (swz(r) = (r ^ r >> 3) & 7; rows r and r + 32 differ by XOR 64).
+    // The XOR variants are formed at the read from one opaque base register each (see `stage`); buffer parity, atom and
+    // operand are immediate offsets.
+    Frag<T> FA[2][2][4], FB[2][4];                                        // [X|Y][atom][k-phase], [P|Q][k-phase]
     uint32_t pa0, pb0;
     { const int r = wr * 128 + frow; pa0 = r * 128 + ((h ^ ((r ^ (r >> 3)) & 7)) << 4); }
-    { const int r = wc * 64 + frow; pb0 = 32768 + r * 128 + ((h ^ ((r ^ (r >> 3)) & 7)) << 4); }
-    // (the eight XOR variants per operand are formed at the read, from one opaque base register: see `stage`)
-    auto lfragA = [&](uint32_t bufoff, int half) __attribute__((always_inline)) {
+    { const int r = wc * 64 + frow; pb0 = 65536 + r * 128 + ((h ^ ((r ^ (r >> 3)) & 7)) << 4); }
+    auto read_A1 = [&](int set, int par, int half, int kk, int i) __attribute__((always_inline)) {
         uint32_t a0 = pa0;
         asm volatile("" : "+v"(a0));
-        a0 += bufoff;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const char* ae = smem + (a0 ^ (uint32_t)(kk << 5));
-            const char* ao = smem + (a0 ^ (uint32_t)((kk << 5) ^ 64));
-            frag_load(fa[0][kk], reinterpret_cast<const T*>(ae + (2 * half) * 4096));
-            frag_load(fa[1][kk], reinterpret_cast<const T*>(ao + (2 * half + 1) * 4096));
-        }
+        const char* q = smem + (a0 ^ (uint32_t)((kk << 5) ^ (i ? 64 : 0)));
+        frag_load(FA[set][i][kk], reinterpret_cast<const T*>(q + (2 * half + i) * 4096 + par * 32768));
     };
-    auto lfragB = [&](uint32_t bufoff, int j) __attribute__((always_inline)) {
+    auto read_B1 = [&](int set, int par, int j, int kk) __attribute__((always_inline)) {
         uint32_t b0 = pb0;
         asm volatile("" : "+v"(b0));
-        b0 += bufoff;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const char* b = smem + (b0 ^ (uint32_t)((kk << 5) ^ ((j & 1) ? 64 : 0)));
-            frag_load(fb[j][kk], reinterpret_cast<const T*>(b + j * 4096));
-        }
+        const char* q = smem + (b0 ^ (uint32_t)((kk << 5) ^ ((j & 1) ? 64 : 0)));
+        frag_load(FB[set][kk], reinterpret_cast<const T*>(q + j * 4096 + par * 32768));
     };
     auto seg_barrier = [&]() __attribute__((always_inline)) {
         __builtin_amdgcn_sched_barrier(0);
@@ -663,82 +662,98 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(
     auto epilogue = [&](int tile_it) __attribute__((always_inline)) {
         int m0, n0;
         tile_origin(tile_it, m0, n0);
-        nt256_write_tile<OUT_F32, WR, WC, EPI>(acc, smem, m0, n0, wid, lane, Cv, ldc, bias, add, ldadd, gate, ldgate, M, N, relu, vec_c);
+        int ln = lane;                                                    // opaque: nothing of the write-out's address arithmetic
+        asm volatile("" : "+v"(ln));                                      // is hoisted into (and held across) the main loop
+        nt256_write_tile<OUT_F32, WR, WC, EPI>(acc, smem, m0, n0, wid, ln, Cv, ldc, bias, add, ldadd, gate, ldgate, M, N, relu, vec_c);
     };
 
-    // ---- prologue: units 0 .. 5 (slab 0 and the first half of slab 1) are issued; units 0 and 1 must have landed
-    Cur c1, c2;                                                           // slabs step + 1 and step + 2
-    c1.k = 0; c1.tile = 0; tile_origin(0, c1.m0, c1.n0);
-    {
+    // ---- prologue: units 0 .. 7 (slabs 0 and 1) are issued; units 0 .. 2 must have landed (vmcnt(10) with 16 issued)
+    Cur c2;                                                               // slab step + 2
+    c2.k = 0; c2.tile = 0; tile_origin(0, c2.m0, c2.n0);
 #pragma unroll
-        for (int w = 0; w < 4; ++w) stage(w, c1, 0);
-        cur_next(c1);
-        c2 = c1;
-        if (NU > 4) {
-            stage(0, c1, 1);
-            stage(1, c1, 1);
-            cur_next(c2);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    for (int k = 0; k < 4; ++k) stage(unit_which(0, k), c2, 0);
+    cur_next(c2);
+    if (NU > 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) stage(unit_which(1, k), c2, 1);
+        cur_next(c2);
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    seg_barrier();
+    // X <- A0(0), P <- B0(0)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { read_A1(0, 0, 0, kk, 0); read_A1(0, 0, 0, kk, 1); read_B1(0, 0, 0, kk); }
+    if (wr == 1) seg_barrier();                           // group 1 runs one barrier behind
+
+    // one M + L pair of slab parity E (compile-time), phase p (compile-time)
+    auto phase = [&](auto e_c, auto p_c, int step, bool tile_end) __attribute__((always_inline)) {
+        constexpr int e = decltype(e_c)::value, p = decltype(p_c)::value;
+        const int m = 4 * step + p;
+        // ---- L segment: retire my reads of the previous M segment, feed unit m + 8, wait for unit m + 3
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (m + 8 < NU) {
+            stage(unit_which(e, p), c2, e);
+            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-    }
-    seg_barrier();
-    if (wr == 1 && !(VAR & 256)) seg_barrier();                           // group 1 runs one barrier behind
-
-    for (int step = 0; step < nsteps; ++step) {
-        const uint32_t buf = (uint32_t)(step & 1) * 65536u;
-        const bool tile_end = (step + 1) % nk == 0;
+        seg_barrier();
+        // ---- M segment: 8 MFMAs of quadrant (aset, bset) with the reads of unit m + 2 between them
+        constexpr int aset = p >> 1;
+        constexpr int bset = e == 0 ? (p == 1 || p == 2) : (p == 0 || p == 3);
+        // Straight-line code: no branch may enclose an MFMA (hipcc then merges two accumulator copies at the join) or sit
+        // between two of them.  The reads are therefore unconditional: past the end of the stream they fetch stale slots
+        // nobody consumes, and the sets read during the last two M segments of a TILE are fetched again after the
+        // write-out, which so has their 48 registers to itself.
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            // ---- L segment
-            if (!(VAR & 2)) {
-                if (p == 0) { lfragA(buf, 0); lfragB(buf, 0); }
-                if (p == 1) lfragB(buf, 1);
-                if (p == 2) lfragA(buf, 1);
-            }
-            if (!(VAR & 1)) {
-            if (4 * step + p + 6 < NU) {
-                if (p == 0) stage(2, c1, step + 1);
-                if (p == 1) stage(3, c1, step + 1);
-                if (p == 2) stage(0, c2, step + 2);
-                if (p == 3) stage(1, c2, step + 2);
-                if (VAR & 32) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
-                else if (VAR & 64) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            }
-            if (!(VAR & 8)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // my reads are done before anybody restages
-            seg_barrier();
-            // ---- M segment
-            if (!(VAR & 16)) __builtin_amdgcn_s_setprio(1);
-            if (!(VAR & 4))
+        for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    if (p == 0) mma32(acc[i][0], fb[0][kk], fa[i][kk]);
-                    if (p == 1) mma32(acc[i][1], fb[1][kk], fa[i][kk]);
-                    if (p == 2) mma32(acc[2 + i][1], fb[1][kk], fa[i][kk]);
-                    if (p == 3) mma32(acc[2 + i][0], fb[0][kk], fa[i][kk]);
+            for (int i = 0; i < 2; ++i) {
+                mma32(acc[2 * aset + i][bset], FB[bset][kk], FA[aset][i][kk]);
+                {
+                    if (p == 0 && i == 0) read_B1(1 - e, e, 1 - e, kk);
+                    if (p == 3 && i == 0) read_B1(1 - e, 1 - e, 1 - e, kk);
+                    if (p == 1) read_A1(1, e, 1, kk, i);
+                    if (p == 2) read_A1(0, 1 - e, 0, kk, i);
                 }
-            if (!(VAR & 16)) __builtin_amdgcn_s_setprio(0);
-            // both groups write a finished tile out in the SAME barrier interval: group 1 (one interval behind) before the
-            // barrier that ends this M segment, group 0 after it
-            if (p == 3 && tile_end) {
-                if (wr == 0) seg_barrier();
-                epilogue(step / nk);
-                if (wr == 1) seg_barrier();
-            } else {
-                seg_barrier();
+                // pinned order: the fragment read after an MFMA may take the registers of the fragment that MFMA consumed
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        c1 = c2;
-        cur_next(c2);
+        __builtin_amdgcn_s_setprio(0);
+        // both groups write a finished tile out in the SAME barrier interval: group 1 (one interval behind) before the
+        // barrier that ends this M segment, group 0 after it
+        if (p == 3 && tile_end) {
+            if (wr == 0) seg_barrier();
+            epilogue(step / nk);
+            if (m + 1 < NU) {                                             // X <- A0', P|Q <- first B atom of the next slab
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) { read_A1(0, 1 - e, 0, kk, 0); read_A1(0, 1 - e, 0, kk, 1); read_B1(1 - e, 1 - e, 1 - e, kk); }
+            }
+            if (wr == 1) seg_barrier();
+            seg_barrier();        // group 0 feeds the slots just read only after group 1's post-write-out reads (same interval) were issued
+        } else {
+            seg_barrier();
+        }
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    for (int step = 0; step < nsteps; step += 2) {
+        {
+            const bool te = (step + 1) % nk == 0;
+            phase(I0{}, I0{}, step, te); phase(I0{}, I1{}, step, te); phase(I0{}, I2{}, step, te); phase(I0{}, I3{}, step, te);
+            cur_next(c2);
+        }
+        if (step + 1 < nsteps) {
+            const bool te = (step + 2) % nk == 0;
+            phase(I1{}, I0{}, step + 1, te); phase(I1{}, I1{}, step + 1, te); phase(I1{}, I2{}, step + 1, te); phase(I1{}, I3{}, step + 1, te);
+            cur_next(c2);
+        }
     }
-    if (wr == 0 && !(VAR & 256)) seg_barrier();
+    if (wr == 0) seg_barrier();
 }
 
 // C = A.B^T.  128x128 block tile, 4 waves (2x2) x 64x64.  K-slab BKT (64 bf16 / 32 f32) is
@@ -1490,10 +1505,7 @@ int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int 
                 (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<true, 2, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
                 (void)hipFuncSetAttribute((const void*)gemm_nt8p_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
                 (void)hipFuncSetAttribute((const void*)gemm_nt8p_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
-                (void)hipFuncSetAttribute((const void*)gemm_nt8p_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
-                (void)hipFuncSetAttribute((const void*)gemm_nt8p_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
                 (void)hipFuncSetAttribute((const void*)gemm_nt8p_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
-                (void)hipFuncSetAttribute((const void*)gemm_nt8p_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
                 if (dev >= 0 && dev < 16) attr_set[dev] = true;
             }
             unsigned g256 = (unsigned)(((N + 255) / 256) * ((M + 255) / 256));
@@ -1507,26 +1519,19 @@ int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int 
             if (!add && !gate) epi = 0;
             else if (!(flags & ME_EPI_OUT_F32) && gate && !add && !bias && !(flags & ME_EPI_RELU) && vec_c && (ldgate & 7) == 0 && aligned16(gate)) epi = 1;
             else if (!(flags & ME_EPI_OUT_F32) && add && !gate && vec_c && (ldadd & 7) == 0 && aligned16(add)) epi = 2;
-#ifdef ME_NT_ABL
-            if (g_nt_mainloop == 1 && epi == 0 && !(flags & ME_EPI_OUT_F32)) {
-                static const int var = getenv("MIDIEMO_NT_VAR") ? atoi(getenv("MIDIEMO_NT_VAR")) : 0;
-#define ME_ABL(V) case V: (void)hipFuncSetAttribute((const void*)gemm_nt8p_kernel<false, 0, V>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS); \
-                          gemm_nt8p_kernel<false, 0, V><<<g256, 512, NT256_LDS, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias, (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags); break;
-                switch (var) { ME_ABL(0) ME_ABL(1) ME_ABL(2) ME_ABL(3) ME_ABL(4) ME_ABL(5) ME_ABL(6) ME_ABL(7) ME_ABL(8) ME_ABL(512) ME_ABL(518) ME_ABL(262) ME_ABL(294) ME_ABL(16) ME_ABL(38) ME_ABL(70) ME_ABL(134) ME_ABL(166) ME_ABL(32) ME_ABL(64) ME_ABL(128) default: return ME_ERR_BAD_SHAPE; }
-#undef ME_ABL
-                return me_launch_status();
-            }
-#endif
-#define ME_NT256(F32, E) do { if (g_nt_mainloop == 1 && E != 3) gemm_nt8p_kernel<F32, E><<<g256, 512, NT256_LDS, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias, \
-                                                                                   (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags); \
-                              else gemm_nt256_kernel<F32, 2, 4, E><<<g256, 512, NT256_LDS, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias, \
-                                                                                   (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags); } while (0)
-            if (flags & ME_EPI_OUT_F32) { if (epi == 0) ME_NT256(true, 0); else ME_NT256(true, 3); }
-            else if (epi == 0) ME_NT256(false, 0);
-            else if (epi == 1) ME_NT256(false, 1);
-            else if (epi == 2) ME_NT256(false, 2);
-            else ME_NT256(false, 3);
-#undef ME_NT256
+            // main loop: the ping-pong kernel exists for the write-out paths that fit its registers (plain / bias / ReLU, gate rows)
+#define ME_NT256_OLD(F32, E) gemm_nt256_kernel<F32, 2, 4, E><<<g256, 512, NT256_LDS, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias, \
+                                                                                   (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags)
+#define ME_NT256_PP(F32, E) gemm_nt8p_kernel<F32, E><<<g256, 512, NT256_LDS, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias, \
+                                                                                   (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags)
+            const bool pp = g_nt_mainloop == 1;
+            if (flags & ME_EPI_OUT_F32) { if (epi == 0) { if (pp) ME_NT256_PP(true, 0); else ME_NT256_OLD(true, 0); } else ME_NT256_OLD(true, 3); }
+            else if (epi == 0) { if (pp) ME_NT256_PP(false, 0); else ME_NT256_OLD(false, 0); }
+            else if (epi == 1) { if (pp) ME_NT256_PP(false, 1); else ME_NT256_OLD(false, 1); }
+            else if (epi == 2) ME_NT256_OLD(false, 2);
+            else ME_NT256_OLD(false, 3);
+#undef ME_NT256_OLD
+#undef ME_NT256_PP
             return me_launch_status();
         }
     }

@@ -4,6 +4,7 @@ bf16 tier: error relative to the fp64 result bounded by bf16 rounding of the
 inputs (stated per test)."""
 import math
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -1089,3 +1090,17 @@ def test_rga_bwd_bidirectional(ops, dtype, B, H, L, dh, M):
         errs = {n: relerr(got[n], ref[n]) for n in ("O", "lse", "dq", "dk", "dv", "dE")}
         lims = attn_bounds(dtype, 3e-5, q, k, v, E, dO, use_pad, causal=False)
         assert attn_ok(errs, lims), (errs, lims, use_pad is not None)
+
+
+@pytest.mark.gpu
+def test_gemm_nt_main_loops_bit_identical():
+    """The two main loops of the 256-tile NT kernel (MIDIEMO_NT_MAINLOOP = 0 register-staged / 1 ping-pong + direct-to-LDS feed)
+    accumulate every output element in the same k order: 66 cases (ragged M / N, persistent multi-tile walks, every write-out
+    path, f32 out) must agree bit for bit.  Each setting needs its own copy of the library (the switch is read once per load),
+    so the comparison runs in a subprocess (tools/ab_nt_mainloop.py)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ab_nt_mainloop.py"), "--nobench"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "ALL BIT-IDENTICAL" in r.stdout, r.stdout[-3000:]
+    assert r.stdout.count("bit-identical=True") == 66
