@@ -122,13 +122,12 @@ def generate(model, maps, device, out_dir, conditioning, short_filename=False,
     repeat_counts = torch.zeros(batch_size, device=device)
     temp_note, temp_rest = float(temperatures[0]), float(temperatures[1])
     V = model.vocab_size
-    if V > 1024 and top_k != 1:
-        # the device sampling tail (me_sample_topk_topp / me_sample_step) sorts one row of at most 1024 (value, id) pairs in
-        # LDS; the reference's vocabularies have 1007 / 1017 symbols (data_processing.py get_maps, loader.py:58-75).  There is
-        # no second, non-HIP sampling path in this build: a larger vocabulary is refused, not silently served
-        # by torch ops.  Greedy decoding (--topk 1) has no such limit.
-        raise NotImplementedError("sampled generation supports vocabularies of at most 1024 symbols (got %d); "
-                                  "use top_k=1 (greedy) or extend sample_kernel's sort width" % V)
+    if V > 4096 and top_k != 1:
+        # the device sampling tail (me_sample_topk_topp / me_sample_step) sorts one row of (value, id) pairs in LDS: 1024,
+        # 2048 or 4096 wide (the reference's vocabularies have 1007 / 1017 / 1018 symbols).  There is no second, non-HIP
+        # sampling path in this build; greedy decoding (--topk 1) has no limit.
+        raise NotImplementedError("sampled generation supports vocabularies of at most 4096 symbols (got %d); "
+                                  "use top_k=1 (greedy) or add a wider instantiation of sample_kernel" % V)
 
     cache_ok = bool(use_cache) and varying_condition is None
     sess = None
@@ -148,7 +147,7 @@ def generate(model, maps, device, out_dir, conditioning, short_filename=False,
 
             if cache_ok and T <= max_input_len:
                 # ---- incremental path: absolute positions are stable
-                if (top_k != 1 and V <= 1024 and device_loop and sess is not None and fed == T - 1 and gen_len - i >= 2
+                if (top_k != 1 and V <= 4096 and device_loop and sess is not None and fed == T - 1 and gen_len - i >= 2
                         and max_input_len - T >= 2):
                     # ---- the rest of the cache-valid span entirely on the device (DecodeSession.sample_run): the
                     # uniforms are drawn here, one torch.rand(batch_size) per step exactly like the eager loop below, so

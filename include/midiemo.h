@@ -358,11 +358,12 @@ int me_dec_ln_proj(const float* s_in, const float* gamma, const float* beta, flo
 int me_greedy_pick(const float* logits, int ld, int V, const int32_t* special, int n_special,
                    int64_t* out_ids, int B, void* stream);
 
-/* Sampling tail of generate() for one step (generate.py:122-189), one launch for the whole batch, V <= 1024:
+/* Sampling tail of generate() for one step (generate.py:122-189), one launch for the whole batch, V <= 4096
+ * (one block per row sorts NP = 1024 / 2048 / 4096 (value, id) pairs in LDS, NP = the smallest of the three >= V):
  * NaN -> 0, ids in special[] -> -inf, log_softmax, / temp[b], keep the top_k largest (all if top_k <= 0), nucleus
  * cut at top_p (0 < top_p < 1; the first entry always stays), renormalise, draw by inverse CDF from the caller's
  * uniform u[b] in [0,1) -> out_ids[b]; n_choices[b] (may be NULL) = number of entries with probability > 0
- * (drives the repeat-penalty counter, generate.py:186-189).  dbg_p / dbg_i (may be NULL, f32 / int32 [B][1024]):
+ * (drives the repeat-penalty counter, generate.py:186-189).  dbg_p / dbg_i (may be NULL, f32 / int32 [B][NP]):
  * the final sorted probabilities and their vocabulary ids.  The reference draws with torch.multinomial, whose
  * random stream cannot be reproduced; the distribution is identical (tested), the draw is inverse-CDF. */
 int me_sample_topk_topp(const float* logits, int ld, int V, const int32_t* special, int n_special,

@@ -1281,14 +1281,17 @@ struct SampleStep {
     float temp_note, temp_rest, penalty;
 };
 
+// NP = sort width (power of two >= V: 1024 for the reference's vocabularies, up to 4096), EPT = NP / 256 sorted entries per thread
+template <int NP>
 __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ logits, int ld, int V,
                                                      const int32_t* __restrict__ special, int n_special,
                                                      const float* __restrict__ temp, int top_k, float top_p,
                                                      const float* __restrict__ u, int64_t* __restrict__ out_ids,
                                                      int32_t* __restrict__ n_choices, float* __restrict__ dbg_p,
                                                      int32_t* __restrict__ dbg_i, SampleStep st) {
-    __shared__ float key[1024];
-    __shared__ int idx[1024];
+    constexpr int EPT = NP / 256;
+    __shared__ float key[NP];
+    __shared__ int idx[NP];
     __shared__ float part[256];
     __shared__ float red[4];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, b = blockIdx.x;
@@ -1308,7 +1311,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
         return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     };
     // ---- load, NaN -> 0, specials -> -inf
-    for (int j = tid; j < 1024; j += 256) {
+    for (int j = tid; j < NP; j += 256) {
         float x = -INFINITY;
         if (j < V) { x = lg[j]; if (x != x) x = 0.f; }
         key[j] = x;
@@ -1319,10 +1322,10 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
     __syncthreads();
     // ---- log_softmax, / temperature
     float mx = -INFINITY;
-    for (int j = tid; j < 1024; j += 256) mx = fmaxf(mx, key[j]);
+    for (int j = tid; j < NP; j += 256) mx = fmaxf(mx, key[j]);
     mx = block_max(mx);
     float se = 0.f;
-    for (int j = tid; j < 1024; j += 256) se += expf(key[j] - mx);
+    for (int j = tid; j < NP; j += 256) se += expf(key[j] - mx);
     se = block_sum(se);
     float row_temp, row_u;
     if (st.prev_tok) {
@@ -1338,12 +1341,12 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
         row_u = u[b];
     }
     const float lse = mx + logf(se), inv_t = 1.f / row_temp;
-    for (int j = tid; j < 1024; j += 256) key[j] = (key[j] - lse) * inv_t;
+    for (int j = tid; j < NP; j += 256) key[j] = (key[j] - lse) * inv_t;
     __syncthreads();
     // ---- bitonic sort, descending by value, ascending index among equals
-    for (int k = 2; k <= 1024; k <<= 1)
+    for (int k = 2; k <= NP; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < 512; t += 256) {
+            for (int t = tid; t < NP / 2; t += 256) {
                 const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p2 = i | j;
                 const bool desc = (i & k) == 0;
                 const float a = key[i], c = key[p2];
@@ -1356,16 +1359,16 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
     // ---- top-k, softmax over the kept head, nucleus cut
     const int k_eff = (top_k <= 0 || top_k > V) ? V : top_k;
     const float y0 = key[0];
-    float e[4];
+    float e[EPT];
     float loc = 0.f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int i = tid * 4 + q;
+    for (int q = 0; q < EPT; ++q) {
+        const int i = tid * EPT + q;
         e[q] = i < k_eff ? expf(key[i] - y0) : 0.f;
         loc += e[q];
     }
     const float tot = block_sum(loc);
-    // inclusive prefix of the chunk sums (each thread owns 4 consecutive sorted entries)
+    // inclusive prefix of the chunk sums (each thread owns EPT consecutive sorted entries)
     part[tid] = loc;
     __syncthreads();
     for (int off = 1; off < 256; off <<= 1) {
@@ -1377,8 +1380,8 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
     float run = (part[tid] - loc) / tot;
     float loc2 = 0.f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int i = tid * 4 + q;
+    for (int q = 0; q < EPT; ++q) {
+        const int i = tid * EPT + q;
         run += e[q] / tot;                                                   // cumulative probability incl. entry i
         const bool cut = top_p > 0.f && top_p < 1.f && i > 0 && run > top_p;
         if (cut || i >= k_eff) e[q] = 0.f;
@@ -1399,14 +1402,14 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
     float c0 = part[tid] - loc2;
     int cnt = 0, pick = -1;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int i = tid * 4 + q;
+    for (int q = 0; q < EPT; ++q) {
+        const int i = tid * EPT + q;
         const float pq = e[q] / tot2;
         if (pq > 0.f) ++cnt;
         const float c1 = c0 + e[q];
         if (pick < 0 && e[q] > 0.f && target < c1 && target >= c0) pick = i;
         c0 = c1;
-        if (dbg_p) { dbg_p[(size_t)b * 1024 + i] = pq; dbg_i[(size_t)b * 1024 + i] = idx[i]; }
+        if (dbg_p) { dbg_p[(size_t)b * NP + i] = pq; dbg_i[(size_t)b * NP + i] = idx[i]; }
     }
     // number of choices and the (unique) picked position; fall back to the last positive entry for u ~ 1
     __shared__ int s_pick, s_cnt, s_last;
@@ -1415,7 +1418,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
     if (pick >= 0) atomicMin(&s_pick, pick);
     atomicAdd(&s_cnt, cnt);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) if (e[q] > 0.f) atomicMax(&s_last, tid * 4 + q);
+    for (int q = 0; q < EPT; ++q) if (e[q] > 0.f) atomicMax(&s_last, tid * EPT + q);
     __syncthreads();
     if (tid == 0) {
         const int pos = s_pick < (1 << 30) ? s_pick : s_last;
@@ -1647,7 +1650,7 @@ int me_sumsq(const float* g, int64_t n, float* out, void* ws, size_t ws_bytes, v
     if (!g || !out) return ME_ERR_NULL;
     if (n <= 0) return ME_OK;
     if (!aligned16(g)) return ME_ERR_ALIGNMENT;
-    if (ws && (ws_bytes < ME_SUMSQ_WS_BYTES || (reinterpret_cast<uintptr_t>(ws) & 3))) return ME_ERR_BAD_SHAPE;
+    if (ws && (ws_bytes < ME_SUMSQ_WS_BYTES || (reinterpret_cast<uintptr_t>(ws) & 3))) return ME_ERR_WORKSPACE;
     int64_t blocks = (n / 4 + 255) / 256;
     if (blocks > 256) blocks = 256;
     if (blocks < 1) blocks = 1;
@@ -1679,10 +1682,12 @@ int me_sample_topk_topp(const float* logits, int ld, int V, const int32_t* speci
                         int32_t* dbg_i, int B, void* stream) {
     me_clear_error();
     if (!logits || !temp || !u || !out_ids) return ME_ERR_NULL;
-    if (B <= 0 || V <= 0 || V > 1024 || ld < V || (dbg_p && !dbg_i)) return ME_ERR_BAD_SHAPE;
+    if (B <= 0 || V <= 0 || V > 4096 || ld < V || (dbg_p && !dbg_i)) return ME_ERR_BAD_SHAPE;
     SampleStep none = {};
-    sample_kernel<<<B, 256, 0, (hipStream_t)stream>>>(logits, ld, V, special, special ? n_special : 0, temp, top_k, top_p, u,
-                                                      out_ids, n_choices, dbg_p, dbg_i, none);
+#define ME_SAMPLE(NPV) sample_kernel<NPV><<<B, 256, 0, (hipStream_t)stream>>>(logits, ld, V, special, special ? n_special : 0, temp, top_k, top_p, u, \
+                                                      out_ids, n_choices, dbg_p, dbg_i, none)
+    if (V <= 1024) ME_SAMPLE(1024); else if (V <= 2048) ME_SAMPLE(2048); else ME_SAMPLE(4096);
+#undef ME_SAMPLE
     return me_launch_status();
 }
 
@@ -1692,10 +1697,12 @@ int me_sample_step(const float* logits, int ld, int V, const int32_t* special, i
                    int32_t* n_choices, int B, void* stream) {
     me_clear_error();
     if (!logits || !prev_tok || !is_timeshift || !repeat_counts || !u_table || !pos || !out_ids) return ME_ERR_NULL;
-    if (B <= 0 || V <= 0 || V > 1024 || ld < V || u_ld < B) return ME_ERR_BAD_SHAPE;
+    if (B <= 0 || V <= 0 || V > 4096 || ld < V || u_ld < B) return ME_ERR_BAD_SHAPE;
     SampleStep st = {prev_tok, is_timeshift, repeat_counts, pos, pos0, u_ld, temp_note, temp_rest, penalty_coeff};
-    sample_kernel<<<B, 256, 0, (hipStream_t)stream>>>(logits, ld, V, special, special ? n_special : 0, nullptr, top_k, top_p,
-                                                      u_table, out_ids, n_choices, nullptr, nullptr, st);
+#define ME_SAMPLE(NPV) sample_kernel<NPV><<<B, 256, 0, (hipStream_t)stream>>>(logits, ld, V, special, special ? n_special : 0, nullptr, top_k, top_p, \
+                                                      u_table, out_ids, n_choices, nullptr, nullptr, st)
+    if (V <= 1024) ME_SAMPLE(1024); else if (V <= 2048) ME_SAMPLE(2048); else ME_SAMPLE(4096);
+#undef ME_SAMPLE
     return me_launch_status();
 }
 

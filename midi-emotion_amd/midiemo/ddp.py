@@ -10,6 +10,8 @@ them in reverse order.  The sum is turned into a mean by folding 1/world_size
 into the optimiser's grad_scale (FusedAdamW.step(grad_scale=...)), so no extra
 pass over the gradients is needed and the global-norm clip sees averaged grads.
 """
+import collections
+
 import torch
 import torch.distributed as dist
 
@@ -43,7 +45,7 @@ class GradAllReducer:
         # exposed communication: device time the compute stream spends in finish() waiting for bucket work handles
         # (one event pair per step while `timing` is on; read with exposed_ms() after a synchronize)
         self.timing = False
-        self._wait_events = []
+        self._wait_events = collections.deque(maxlen=4096)     # bounded: timing may stay on without exposed_ms() calls
 
     @property
     def grad_scale(self):

@@ -58,8 +58,10 @@ class DecodeSession:
             raise RuntimeError("max_seq %d exceeds the cached decode's %d keys (8 splits of 2048)" % (m.max_seq, 8 * 2048))
         self.part = e(B * H, self.nsplit, dh + 2, dtype=f32)
         # fused qkv + attention stage (me_dec_ln_qkv_attn): the last split is the new key, so it needs >= 2 splits
-        self.fused = os.environ.get("MIDIEMO_DEC_UNFUSED", "0") in ("", "0") and d <= 1024 and self.nsplit >= 2 and \
-            -(-m.max_seq // (self.nsplit - 1)) <= 2048
+        # (the kernel's own preconditions, me_dec_ln_qkv_attn / me_dec_embed_qkv_attn: d % 8 == 0, d <= 1024, dh in {32, 48, 64};
+        # any other shape takes the separate me_dec_qkv + me_dec_attn launches)
+        self.fused = os.environ.get("MIDIEMO_DEC_UNFUSED", "0") in ("", "0") and d <= 1024 and d % 8 == 0 and dh in (32, 48, 64) and \
+            self.nsplit >= 2 and -(-m.max_seq // (self.nsplit - 1)) <= 2048
         self.logits = e(B, V, dtype=f32)
         self.t = 0                      # next model position to be written
         self._pos_dev = None            # device-side position: set while a step is issued for graph capture / replay
@@ -88,7 +90,7 @@ class DecodeSession:
             for i in range(m.num_layer):
                 W = m._prep["layers"][i]
                 p = f"enc_layers.{i}."
-                if i == 0 and tokens is not None and self.fused and d % 4 == 0 and (m.d_condition <= 0 or m.d_condition % 4 == 0):
+                if i == 0 and tokens is not None and self.fused and (m.d_condition <= 0 or (m.d_condition % 4 == 0 and m.d_condition < d)):
                     # first layer, fused like the others (round 4): embedding row -> q|k|v of a head -> cache append ->
                     # attention partials in ONE launch (me_dec_embed_qkv_attn): 26 launches per token at 6 layers
                     ops.dec_embed_qkv_attn(tokens[r0:r1], cond[r0:r1] if cw is not None else None, pv("embedding.weight"), cw, cb,
@@ -236,8 +238,8 @@ class DecodeSession:
         m = self.m
         dev = m.flat_params.device
         n_steps = int(n_steps)
-        if m.vocab_size > 1024:
-            raise RuntimeError("sample_run: the sampling kernel sorts at most 1024 logits (vocab %d)" % m.vocab_size)
+        if m.vocab_size > 4096:
+            raise RuntimeError("sample_run: the sampling kernel sorts at most 4096 logits (vocab %d)" % m.vocab_size)
         if self.t + n_steps > m.max_seq:
             raise RuntimeError("decode positions %d..%d exceed max_seq %d" % (self.t, self.t + n_steps, m.max_seq))
         if uniforms.shape[0] < n_steps or uniforms.shape[1] != self.B or uniforms.dtype != torch.float32:

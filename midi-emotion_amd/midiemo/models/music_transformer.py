@@ -474,7 +474,7 @@ class MusicTransformerHIP(nn.Module):
         # saved activations they pair with stay valid until the next layer's backward starts.)
         pending = []
 
-        def wgrad(role, dY, X, gW, gb, T, N, K, dtype):
+        def wgrad(dY, X, gW, gb, N, K):
             pending.append((dY, X, gW, gb, N, K))
 
         def flush_wgrads():
@@ -482,15 +482,9 @@ class MusicTransformerHIP(nn.Module):
                 ops.gemm_tn_acc_group(pending, T, dt, ws=tnws)
                 del pending[:]
 
-        def reuse(role):
-            pass
-
-        def join():
-            flush_wgrads()
-
         # (the head's product stays a launch of its own: grouped with the last layer it makes 56 tiles = 4 token ranges on
         # 224 of the 256 CUs -- measured no faster than 48 tiles x 5 ranges on 240 CUs plus the small head launch)
-        wgrad("dlogits", ws.dlogits, hN, gv(self._HEAD_W), None if head_bias_done else gv(self._HEAD_B), T=T, N=V, K=d, dtype=dt)
+        wgrad(ws.dlogits, hN, gv(self._HEAD_W), None if head_bias_done else gv(self._HEAD_B), N=V, K=d)
         flush_wgrads()
         ops.gemm_nt(ws.dlogits, head["WfT"], ws.dA, M=T, N=d, K=ldv, dtype=dt)
         if bucket_hook:
@@ -502,29 +496,24 @@ class MusicTransformerHIP(nn.Module):
             p = f"enc_layers.{i}."
             x = ws.h[i]
             # LN2 + FFN
-            reuse("dC")
             ops.resid_ln_bwd(dy, Lw.s2, Lw.st2, self._pview(f, p + "layernorm2.weight"), ws.dB, ws.dC,
                              gv(p + "layernorm2.weight"), gv(p + "layernorm2.bias"), T, d, p_drop, seed, 2 + 2 * i)
-            wgrad("dC", ws.dC, Lw.hid, gv(p + "FFN_suf.weight"), gv(p + "FFN_suf.bias"), T=T, N=d, K=di, dtype=dt)
-            reuse("dhid")
+            wgrad(ws.dC, Lw.hid, gv(p + "FFN_suf.weight"), gv(p + "FFN_suf.bias"), N=d, K=di)
             ops.gemm_nt(ws.dC, W["W2T"], ws.dhid, gate=Lw.hid, M=T, N=di, K=d, flags=ops.ME_EPI_RELU_BWD, dtype=dt)
-            wgrad("dhid", ws.dhid, Lw.o1, gv(p + "FFN_pre.weight"), gv(p + "FFN_pre.bias"), T=T, N=di, K=d, dtype=dt)
+            wgrad(ws.dhid, Lw.o1, gv(p + "FFN_pre.weight"), gv(p + "FFN_pre.bias"), N=di, K=d)
             ops.gemm_nt(ws.dhid, W["W1T"], ws.dA, add=ws.dB, M=T, N=d, K=di, dtype=dt)          # d(o1) total
             # LN1 + attention
-            reuse("dC2")
             ops.resid_ln_bwd(ws.dA, Lw.s1, Lw.st1, self._pview(f, p + "layernorm1.weight"), ws.dB, ws.dC2,
                              gv(p + "layernorm1.weight"), gv(p + "layernorm1.bias"), T, d, p_drop, seed, 1 + 2 * i)
-            wgrad("dC2", ws.dC2, Lw.att, gv(p + "rga.fc.weight"), gv(p + "rga.fc.bias"), T=T, N=d, K=d, dtype=dt)
+            wgrad(ws.dC2, Lw.att, gv(p + "rga.fc.weight"), gv(p + "rga.fc.bias"), N=d, K=d)
             ops.gemm_nt(ws.dC2, W["WoT"], ws.dA, M=T, N=d, K=d, dtype=dt)                        # d(att)
-            reuse("dqkv")
             if bucket_hook:
                 bucket_hook(-1)            # comm window: ~0.5 ms of attention-backward kernels follow (ddp.GradAllReducer)
             ops.rga_bwd(Lw.qkv, W["Epk"], Lw.att, Lw.lse, ws.dA, ws.dqkv, gv(p + "rga.E"), ws.delta, Lw.PT, Lw.MT, ws.dGT,
                         B, Lm, ws.Lp, H, dh, M, causal=self.causal)
             o, _, _ = self._slices[p + "rga.Wq.weight"]
             ob, _, _ = self._slices[p + "rga.Wq.bias"]
-            wgrad("dqkv", ws.dqkv, x, gflat[o:o + 3 * d * d].view(3 * d, d), gflat[ob:ob + 3 * d], T=T, N=3 * d, K=d,
-                  dtype=dt)
+            wgrad(ws.dqkv, x, gflat[o:o + 3 * d * d].view(3 * d, d), gflat[ob:ob + 3 * d], N=3 * d, K=d)
             ops.gemm_nt(ws.dqkv, W["WqkvT"], ws.dA, add=ws.dB, M=T, N=d, K=3 * d, dtype=dt)     # d(x) total
             dy = ws.dA
             flush_wgrads()
@@ -541,7 +530,7 @@ class MusicTransformerHIP(nn.Module):
             # behind; the "library leaves it zeroed" contract only holds for calls that returned 0
             self._emb_ws = None
             raise
-        join()                                             # optimizer / next forward see every gradient
+        flush_wgrads()                                     # optimizer / next forward see every gradient
         if bucket_hook:
             bucket_hook(0)
 

@@ -238,28 +238,31 @@ def test_fused_decode_stages_equal_the_separate_launches(conditioning, cd):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("top_k,top_p", [(-1, 0.7), (20, 1.0), (50, 0.9), (-1, 1.0), (3, 0.5)])
-def test_fused_sampling_tail_matches_torch_path(top_k, top_p):
+@pytest.mark.parametrize("top_k,top_p,V", [(-1, 0.7, 1007), (20, 1.0, 1007), (50, 0.9, 1007), (-1, 1.0, 1007), (3, 0.5, 1007),
+                                             (-1, 0.8, 1500), (40, 1.0, 2048), (-1, 0.9, 3000), (-1, 1.0, 4096)])
+def test_fused_sampling_tail_matches_torch_path(top_k, top_p, V):
     """me_sample_topk_topp == the torch restatement of generate.py:122-189 (same filtered distribution, same
-    n_choices; the draw is the inverse CDF of that distribution at the supplied uniform)."""
+    n_choices; the draw is the inverse CDF of that distribution at the supplied uniform).  V > 1024 runs the 2048- / 4096-wide
+    instantiations of the sort (the reference samples any vocabulary, generate.py:152-183)."""
     import torch
     import torch.nn.functional as F
     from midiemo import ops
     g = torch.Generator().manual_seed(11 + max(top_k, 0))
-    B, V, ld = 6, 1007, 1024
+    B, NP = 6, 1024 if V <= 1024 else (2048 if V <= 2048 else 4096)
+    ld = NP
     logits = torch.zeros(B, ld)
     logits[:, :V] = torch.randn(B, V, generator=g) * 3
     logits[0, 5] = float("nan")
     logits[1, :] = logits[1, :] * 0.01                    # nearly flat row: many choices
     logits[2, 100] = 40.0                                 # peaked row: one choice
-    special = torch.tensor([0, 1, 7, 1006], dtype=torch.int32)
+    special = torch.tensor([0, 1, 7, V - 1], dtype=torch.int32)
     temp = torch.tensor([1.2, 0.8, 1.0, 2.5, 1.2, 0.5])
     u = torch.rand(B, generator=g)
     dev = "cuda"
     out = torch.empty(B, dtype=torch.long, device=dev)
     nch = torch.empty(B, dtype=torch.int32, device=dev)
-    dp = torch.empty(B, 1024, device=dev)
-    di = torch.empty(B, 1024, dtype=torch.int32, device=dev)
+    dp = torch.empty(B, NP, device=dev)
+    di = torch.empty(B, NP, dtype=torch.int32, device=dev)
     ops.sample_topk_topp(logits.to(dev), V, special.to(dev), temp.to(dev), top_k, top_p, u.to(dev), out, nch, dp, di)
     # torch path (generate.py:122-189)
     o = logits[:, :V].clone()
@@ -276,9 +279,9 @@ def test_fused_sampling_tail_matches_torch_path(top_k, top_p):
     probs = F.softmax(o, dim=-1)
     dp, di, out, nch = dp.cpu(), di.cpu(), out.cpu(), nch.cpu()
     assert torch.allclose(dp[:, :k_eff], probs, atol=2e-6, rtol=1e-5), float((dp[:, :k_eff] - probs).abs().max())
-    assert float(dp[:, k_eff:].abs().max()) == 0.0 if k_eff < 1024 else True
+    assert float(dp[:, k_eff:].abs().max()) == 0.0 if k_eff < NP else True
     sup = probs > 0
-    dense_k = torch.zeros(B, V).scatter_add_(1, di[:, :1024].long().clamp(max=V - 1), dp * (di < V))
+    dense_k = torch.zeros(B, V).scatter_add_(1, di[:, :NP].long().clamp(max=V - 1), dp * (di < V))
     dense_t = torch.zeros(B, V).scatter_add_(1, top_inds, probs)
     assert torch.allclose(dense_k, dense_t, atol=2e-6, rtol=1e-5)       # same distribution over the vocabulary
     assert torch.equal(nch.long(), sup.sum(-1))
@@ -287,7 +290,7 @@ def test_fused_sampling_tail_matches_torch_path(top_k, top_p):
         pos = int(torch.searchsorted(cdf[b], torch.tensor(float(u[b]), dtype=torch.double), right=True))
         pos = min(pos, int(sup[b].sum()) - 1)
         cand = {int(di[b, pos])}
-        if pos + 1 < 1024 and dp[b, pos + 1] > 0:
+        if pos + 1 < NP and dp[b, pos + 1] > 0:
             cand.add(int(di[b, pos + 1]))                # f32 vs f64 prefix sums may differ by one slot at a boundary
         if pos > 0:
             cand.add(int(di[b, pos - 1]))

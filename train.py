@@ -87,12 +87,48 @@ def parse_args(argv=None):
                         "full_dataset_features_summarized.csv); giving it switches from synthetic to real batches")
     p.add_argument("--full_dataset", action="store_true", help="also train on songs without emotion labels")
     p.add_argument("--always_use_discrete_condition", action="store_true")
-    p.add_argument("--num_workers", type=int, default=4)
+    p.add_argument("--num_workers", type=int, default=8)
+    # reference flags the loaders honour (data/loader.py:24-31 defaults; the reference parses them, config.py:92-103, and then
+    # constructs its loaders without them, train.py:61-68 -- here they reach the loader, defaults unchanged)
+    p.add_argument("--overfit", action="store_true", help="work on a single sample (debug data folder, no workers)")
+    p.add_argument("--bar_start_prob", type=float, default=0.5, help="probability of a training sample starting at a bar")
+    p.add_argument("--max_transpose", type=int, default=3, help="maximum transposition in semitones")
+    p.add_argument("--n_samples", type=int, default=-1, help="limit the number of songs (faster debugging)")
+    p.add_argument("--no_pad", action="store_true", help="do not pad short sequences (they are filtered by the collate)")
+    p.add_argument("--overwrite_dropout", action="store_true", help="on restart: replace the checkpoint's dropout by --dropout")
+    # reference flags that the reference itself never reads after parsing (config.py:33-38,48-50,90-91): accepted for
+    # command-line compatibility, reported when set
+    p.add_argument("--n_bars", type=int, default=-1)
+    p.add_argument("--eval_tgt_len", type=int, default=-1)
+    p.add_argument("--arousal_feature", type=str, default="note_density", choices=["tempo", "note_density"])
+    p.add_argument("--find_lr", action="store_true")
+    # reference flags without a counterpart on this engine: accepted, answered with a notice
+    p.add_argument("--no_cuda", action="store_true", help="(reference: run on the CPU) -- this engine has no CPU path")
+    p.add_argument("--reset_scaler", action="store_true", help="(reference: reset the fp16 GradScaler) -- bf16, no scaler here")
+    p.add_argument("--regression_dir", type=str, default=None,
+                   help="(reference: regress emotions of a folder of generated MIDI files, train.py:70-73) -- needs the "
+                        "MIDI -> token direction, which is outside this build (DESIGN section 7)")
     p.add_argument("--exhaustive_eval", action="store_true",
                    help="evaluate on every chunk of every test song and exit (config.py:106, train.py:448-461); needs "
                         "--feature_file; --data_folder is then the root that holds maps.pt and lpd_5_full_transposable/")
     p.add_argument("--weight_decay", type=float, default=0.0, help="decoupled decay; 0 == reference Adam")
     args = p.parse_args(argv)
+    if args.regression_dir is not None:
+        raise SystemExit("--regression_dir: emotion regression over generated MIDI files needs the reference's MIDI -> token "
+                         "pipeline (pretty_midi / pypianoroll), which this build does not contain; --regression on the "
+                         "dataset (with --feature_file) is supported")
+    for flag, msg in (("no_cuda", "there is no CPU path: training runs on the HIP engine (cuda:LOCAL_RANK)"),
+                      ("reset_scaler", "bf16 / f32 tiers use no GradScaler: nothing to reset"),
+                      ("find_lr", "the reference parses --find_lr and never runs a finder; ignored here too")):
+        if getattr(args, flag):
+            print(f"[train.py] --{flag}: {msg}")
+    for flag, default in (("n_bars", -1), ("eval_tgt_len", -1), ("arousal_feature", "note_density")):
+        if getattr(args, flag) != default:
+            print(f"[train.py] --{flag}: parsed and unused by the reference (config.py), unused here")
+    if args.full_dataset and (args.conditioning not in ("discrete_token", "none") or args.regression):
+        raise SystemExit("--full_dataset: LPD-full has NaN features (config.py:123-124): conditioning must be discrete_token or none")
+    if args.debug or args.overfit:
+        args.num_workers = 0                                   # config.py:132-133
     if args.conditioning != "continuous_concat":
         args.d_condition = -1                                  # config.py:120-121
     if args.scheduler == "cyclic":
@@ -162,10 +198,14 @@ class LRSchedule:
             # restart: put the triangle where the interrupted run left it.  A run that completed start_step updates has
             # called on_step(0) .. on_step(start_step - 1); the scheduler stepped for those arguments that were not warm-up
             # steps -- counted with on_step's own predicate (one step ahead before).
-            for s in range(start_step):
-                if not self._in_warmup(s):
-                    self.shadow.step()
-                    self.sched.step()
+            # CyclicLR's only state is its call count (last_epoch) and its lr a function of it: jump there instead of
+            # replaying start_step iterations.
+            n_warm = min(start_step, args.warmup_step + 1) if args.warmup_step > 0 else 0
+            n = start_step - n_warm
+            if n > 0:
+                self.sched.last_epoch = n - 1
+                self.shadow.step()
+                self.sched.step()
 
     def _in_warmup(self, step):
         return self.args.warmup_step > 0 and step <= self.args.warmup_step
@@ -224,12 +264,14 @@ def main(argv=None):
         train_feats, test_feats = preprocess_features(args.feature_file, n_bins=n_bins,
                                                       conditional=args.conditioning != "none" or args.regression,
                                                       use_labeled_only=not args.full_dataset)
-        kw = dict(always_use_discrete_condition=args.always_use_discrete_condition, regression=args.regression)
+        kw = dict(always_use_discrete_condition=args.always_use_discrete_condition, regression=args.regression,
+                  pad=not args.no_pad, overfit=args.overfit, max_samples=args.n_samples if args.n_samples > 0 else None)
         if args.exhaustive_eval:                               # train.py:58-63
             from midiemo.data import LoaderExhaustive
             test_ds = LoaderExhaustive(args.data_folder, test_feats, args.tgt_len, args.conditioning, **kw)
             train_ds = test_ds                                 # never iterated: the run evaluates and exits
         else:
+            kw.update(bar_start_prob=args.bar_start_prob, max_transpose=args.max_transpose)
             train_ds = Loader(args.data_folder, train_feats, args.tgt_len, args.conditioning, **kw)
             test_ds = Loader(args.data_folder, test_feats, args.tgt_len, args.conditioning, **kw)
         if args.conditioning == "discrete_token" and not args.exhaustive_eval:
@@ -270,7 +312,7 @@ def main(argv=None):
         bad = {k: (config.get(k), v) for k, v in want.items() if k in config and config.get(k) != v}
         if bad:
             raise SystemExit("restart: model_config.pt disagrees with the command line (saved, requested): %s" % bad)
-        model, _ = build_model(None, load_config_dict=config)
+        model, _ = build_model(vars(args), load_config_dict=config)    # train.py:175 (args carry --overwrite_dropout / --dropout)
         model.load_state_dict(torch.load(os.path.join(restart, "model.pt"), map_location="cpu"))
         # work_dir stays the fresh time-stamped directory (train.py:173-180 writes there, never into restart_dir)
     else:
