@@ -265,6 +265,52 @@ def make_f4():
     np.savez_compressed(os.path.join(OUT, "f4_decode.npz"), **rec)
 
 
+# ---------------------------------------------------------------- F4h: the same at the HEADLINE geometry (BASELINE config 2 / 5 model)
+def make_f4h():
+    """Greedy ids of the reference's own generate() on the 6-layer d512 8-head (dh 64) d_inner 2048 continuous_concat model:
+    4 (valence, arousal) pairs x 128 tokens, no slide.  Weights = O.seeded_params(cfg, 43), regenerated by the test, not
+    stored.  Also stored: the top-1 / top-2 logit margin of every step (from a second pass through the reference model over
+    the generated sequences) -- the test's f32 criterion is bit-exact ids, and the margin says how much room that has."""
+    conds = [[-0.8, -0.8], [-0.8, 0.8], [0.8, -0.8], [0.8, 0.8]]          # train.py:361-366
+    cfg = O.Cfg(1007, 6, 8, 512, 2048, d_condition=128, conditioning="continuous_concat")
+    params = O.seeded_params(cfg, seed=43)
+    args = dict(vocab_size=1007, n_layer=6, n_head=8, d_model=512, d_inner=2048, dropout=0.0, d_condition=128,
+                conditioning="continuous_concat")
+    model, _ = ref_build_model(args)
+    model.load_state_dict(params, strict=True)
+    model.eval()
+    maps = decode_maps("continuous_concat")
+    gen_len = 128
+    captured = []
+    orig = ref_generate.ind_tensor_to_str
+
+    def spy(x, a, b, _c=captured, _o=orig):
+        _c.append(x.clone().cpu().numpy())
+        return _o(x, a, b)
+    ref_generate.ind_tensor_to_str = spy
+    try:
+        ref_generate.generate(model, maps, torch.device("cpu"), "/tmp/none", "continuous_concat", discrete_conditions=None,
+                              continuous_conditions=conds, max_input_len=gen_len, amp=False, gen_len=gen_len, top_k=1,
+                              debug=True, min_n_instruments=0, primers=[["<START>"]])
+    finally:
+        ref_generate.ind_tensor_to_str = orig
+    ids = np.stack(captured, axis=1)                        # [T, B], row 0 = <START>
+    assert ids.shape == (gen_len, 4), ids.shape
+    # margins: teacher-force the generated sequences through the reference model, mask what generate() masks
+    with torch.no_grad():
+        lg = model(torch.tensor(ids.T[:, :-1]), torch.tensor(conds, dtype=torch.float32)).double()     # [B, T-1, V]
+    for tok in ("<PAD>", "<START>", "<END>"):
+        if tok in maps["tuple2idx"]:
+            lg[:, :, maps["tuple2idx"][tok]] = -float("inf")
+    top2 = lg.topk(2, dim=-1)
+    assert bool((top2.indices[:, :, 0].numpy().T == ids[1:]).all()), "teacher-forced argmax != generated ids"
+    margin = (top2.values[:, :, 0] - top2.values[:, :, 1]).numpy().T            # [T-1, B]
+    scale = float(lg[torch.isfinite(lg)].abs().max())
+    print("F4h ok: ids", ids[:6, 0], "min margin %.3e (logit scale %.2f)" % (margin.min(), scale))
+    np.savez_compressed(os.path.join(OUT, "f4h_decode_cfg2.npz"), ids=ids.astype(np.int16), conds=np.array(conds, dtype=np.float32),
+                        weight_seed=np.array(43), margin=margin.astype(np.float32), logit_scale=np.array(scale))
+
+
 # ---------------------------------------------------------------- F5: attention core in fp64 through the reference's skewing code
 def make_f5():
     rs = np.random.RandomState(51)

@@ -141,8 +141,9 @@ def key_is_pad(cfg: Cfg, tokens: Tensor) -> Tensor:
     return pad
 
 
-def embed(cfg: Cfg, P: Dict[str, Tensor], tokens: Tensor, cond: Tensor) -> Tensor:
-    """Prologue.  music_multi.py:89-102 / music_continuous_token.py:77-100 (dropout off)."""
+def embed(cfg: Cfg, P: Dict[str, Tensor], tokens: Tensor, cond: Tensor, dropout: float = 0.0) -> Tensor:
+    """Prologue.  music_multi.py:89-102 / music_continuous_token.py:77-100.  dropout > 0: torch's own dropout at the
+    reference's site (:102, training mode); parity runs use 0 (its random stream is not part of any fixture)."""
     dt = P["embedding.weight"].dtype
     x = P["embedding.weight"][tokens] * math.sqrt(cfg.d_emb)           # :91-92
     if cfg.conditioning == "continuous_concat" and cfg.d_condition > 0:
@@ -155,7 +156,8 @@ def embed(cfg: Cfg, P: Dict[str, Tensor], tokens: Tensor, cond: Tensor) -> Tenso
     L = x.shape[1]
     assert L <= cfg.max_seq
     pe = sinusoid_pe(cfg.max_seq, cfg.d_model)[:L].to(dt)              # :160-164
-    return x + pe[None]
+    x = x + pe[None]
+    return F.dropout(x, dropout, training=True) if dropout > 0 else x     # :102
 
 
 def rga_scores_rel(q: Tensor, E: Tensor) -> Tensor:
@@ -200,8 +202,9 @@ def layer_norm(x: Tensor, w: Tensor, b: Tensor, eps: float = 1e-6) -> Tensor:
     return (x - mu) / torch.sqrt(var + eps) * w + b
 
 
-def encoder_layer(cfg: Cfg, P: Dict[str, Tensor], i: int, x: Tensor, pad: Optional[Tensor], causal: bool = True) -> Tensor:
-    """music_multi.py:126-135 (post-LN, ReLU FFN, dropout off)."""
+def encoder_layer(cfg: Cfg, P: Dict[str, Tensor], i: int, x: Tensor, pad: Optional[Tensor], causal: bool = True,
+                  dropout: float = 0.0) -> Tensor:
+    """music_multi.py:126-135 (post-LN, ReLU FFN; dropout1 / dropout2 at :128 / :133 when dropout > 0)."""
     p = f"enc_layers.{i}."
     B, L, d = x.shape
     H, dh = cfg.n_head, cfg.dh
@@ -212,20 +215,25 @@ def encoder_layer(cfg: Cfg, P: Dict[str, Tensor], i: int, x: Tensor, pad: Option
     o, _ = rga_attention_core(proj("Wq"), proj("Wk"), proj("Wv"), P[p + "rga.E"], pad, causal)
     o = o.permute(0, 2, 1, 3).reshape(B, L, d)                             # :234-235
     a = o @ P[p + "rga.fc.weight"].t() + P[p + "rga.fc.bias"]              # :237
+    if dropout > 0:
+        a = F.dropout(a, dropout, training=True)                           # :128
     o1 = layer_norm(a + x, P[p + "layernorm1.weight"], P[p + "layernorm1.bias"])   # :129
     f = torch.relu(o1 @ P[p + "FFN_pre.weight"].t() + P[p + "FFN_pre.bias"])       # :131
     f = f @ P[p + "FFN_suf.weight"].t() + P[p + "FFN_suf.bias"]                    # :132
+    if dropout > 0:
+        f = F.dropout(f, dropout, training=True)                                   # :133
     return layer_norm(o1 + f, P[p + "layernorm2.weight"], P[p + "layernorm2.bias"])  # :134
 
 
 def forward(cfg: Cfg, P: Dict[str, Tensor], tokens: Tensor, cond: Tensor,
-            return_hidden: bool = False):
-    """model(x, condition) -> logits [B, L(+2), V].  music_multi.py:84-108."""
-    x = embed(cfg, P, tokens, cond)
+            return_hidden: bool = False, dropout: float = 0.0):
+    """model(x, condition) -> logits [B, L(+2), V].  music_multi.py:84-108.  dropout: model.train() with that rate
+    (only the timed CPU baseline of bench.py uses it: BASELINE.md section 3 times the step with dropout 0.1 on)."""
+    x = embed(cfg, P, tokens, cond, dropout)
     pad = key_is_pad(cfg, tokens)
     hs = [x]
     for i in range(cfg.n_layer):
-        x = encoder_layer(cfg, P, i, x, pad)
+        x = encoder_layer(cfg, P, i, x, pad, dropout=dropout)
         hs.append(x)
     logits = x @ P["fc.weight"].t() + P["fc.bias"]                         # :106
     return (logits, hs) if return_hidden else logits
@@ -270,12 +278,12 @@ def adam_step(P, G, M1, M2, step: int, lr=2e-5, b1=0.9, b2=0.999, eps=1e-8,
     return total
 
 
-def loss_and_grads(cfg: Cfg, P: Dict[str, Tensor], tokens, cond, target):
+def loss_and_grads(cfg: Cfg, P: Dict[str, Tensor], tokens, cond, target, dropout: float = 0.0):
     """Forward + CE + backward through the restatement (torch autograd on the
     closed-form graph).  Embedding pad row receives no gradient
     (padding_idx, music_multi.py:57-59)."""
     Pg = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
-    logits = forward(cfg, Pg, tokens, cond)
+    logits = forward(cfg, Pg, tokens, cond, dropout=dropout)
     loss = ce_loss(cfg, logits, target)
     loss.backward()
     G = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in Pg.items()}

@@ -141,6 +141,22 @@ def test_f4_greedy_decode_ids(golden_dir, mode):
         assert np.array_equal(ids.numpy(), z[f"{mode}_{tag}_ids"]), (mode, tag)
 
 
+def test_f4h_headline_geometry_greedy_ids(golden_dir):
+    """The oracle against the reference's generate() at the headline geometry (6L d512 8H dh64, 4 pairs x 128 tokens):
+    teacher-forced with the reference's own ids, the oracle's arg-max (specials masked like generate.py:122-136) is the
+    reference's next token at every step, and its top-2 margins are the fixture's."""
+    z = load(golden_dir, "f4h_decode_cfg2.npz")
+    cfg = O.Cfg(1007, 6, 8, 512, 2048, d_condition=128, conditioning="continuous_concat")
+    P = O.seeded_params(cfg, int(z["weight_seed"]))
+    ids = torch.from_numpy(z["ids"].astype(np.int64))            # [128, 4]
+    lg = O.forward(cfg, P, ids.t()[:, :-1].contiguous(), torch.from_numpy(z["conds"])).double()
+    lg[:, :, :2] = -float("inf")                                 # <PAD>, <START> (the 1007-symbol vocabulary has no <END>)
+    top2 = lg.topk(2, dim=-1)
+    assert torch.equal(top2.indices[:, :, 0].t(), ids[1:])
+    margin = (top2.values[:, :, 0] - top2.values[:, :, 1]).t()
+    assert float((margin - torch.from_numpy(z["margin"]).double()).abs().max()) < 1e-4
+
+
 def test_f5_attention_core_fp64(golden_dir):
     z = load(golden_dir, "f5_attn_core.npz")
     q, k, v, E = (torch.tensor(z[n], requires_grad=True) for n in ("q", "k", "v", "E"))
