@@ -535,6 +535,7 @@ def main():
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         exposed_mean, exposed_p50 = float(tw[0]), float(tw[1])
 
+    ddp_state = (reducer.policy, reducer.decision)
     probe, hbm_table, gp, op_probe = None, None, None, None
     if not args.no_probe:
         # every rank runs the instrumented steps (they contain the gradient all-reduce); only rank 0 times its GEMMs
@@ -607,7 +608,8 @@ def main():
         # all-reduces (midiemo/ddp.py) and the CUs the persistent GEMM grids leave to RCCL (default 0: a reserve makes
         # EVERY 256-tile launch take a second tile round -- measured on one GPU: qkv 59.6 -> 70.8 us, proj 27.1 -> 43.9 us
         # with 64 CUs reserved -- so none is applied automatically)
-        out["ddp"] = {"policy": os.environ.get("MIDIEMO_DDP_POLICY", "window"),
+        out["ddp"] = {"policy": os.environ.get("MIDIEMO_DDP_POLICY", "window"), "policy_in_force": ddp_state[0],
+                      "policy_decision": ddp_state[1],          # "auto": the two measured spans and the choice (midiemo/ddp.py)
                       "cu_reserve": int(os.environ.get("MIDIEMO_CU_RESERVE", "0") or 0), "world": world,
                       "backend": backend if dist_on else None}
         if dist_on and exposed:

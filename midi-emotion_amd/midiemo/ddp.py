@@ -25,7 +25,16 @@ class GradAllReducer:
                  away makes one of their blocks wait for a whole tile round (up to 2x for that launch), whereas the
                  attention kernels just lose k/256 of their throughput.
       "eager"  -- launch in hook(i) as soon as the bucket is final (maximal overlap, GEMMs included).
-      "end"    -- one all-reduce over the whole flat buffer in finish() (no overlap, no contention)."""
+      "end"    -- one all-reduce over the whole flat buffer in finish() (no overlap, no contention).
+      "auto"   -- data-driven choice between "end" and "window" (round 5): the first AUTO_PROBE steps run under "end", the
+                 next AUTO_PROBE under "window"; each step's span from its first bucket hook (start of the backward) to the
+                 end of the waits in finish() is timed with device events, the first step of each phase is dropped, the
+                 means are MAX-reduced over the ranks (every rank decides from the same two numbers) and the cheaper policy
+                 runs from then on.  Measured on one MI355X: "window" costs 0.2 ms per step even with nothing to exchange
+                 (RCCL's channels take CUs from the attention backward, profiles/r04_measurements.txt), so it only pays
+                 when the exposed all-reduce of "end" is longer than that.  `decision` holds the numbers (bench.py prints
+                 them as ddp.policy_decision).  One host synchronisation, once, at the decision."""
+    AUTO_PROBE = 3
 
     def __init__(self, flat_grads_fn, bucket_ranges, group=None, policy=None):
         import os
@@ -37,8 +46,13 @@ class GradAllReducer:
         # path (asynchronous all-reduce on RCCL's stream, work handles, comm windows) can be exercised on a 1-GPU box
         self._active = self.world > 1 or (dist.is_initialized() and bool(os.environ.get("MIDIEMO_DDP_FORCE")))
         self.policy = policy or os.environ.get("MIDIEMO_DDP_POLICY", "window")
-        if self.policy not in ("window", "eager", "end"):
-            raise ValueError("MIDIEMO_DDP_POLICY must be window, eager or end")
+        if self.policy not in ("window", "eager", "end", "auto"):
+            raise ValueError("MIDIEMO_DDP_POLICY must be window, eager, end or auto")
+        self.decision = None
+        self._auto = None
+        if self.policy == "auto":
+            self._auto = {"step": 0, "spans": {"end": [], "window": []}, "t0": None}
+            self.policy = "end"
         self._works = []
         self._pending = []
         self._done = set()
@@ -73,6 +87,8 @@ class GradAllReducer:
         -1 -- a comm window opens (see the class docstring)."""
         if not self._active:
             return
+        if self._auto is not None and self._auto["t0"] is None:
+            self._auto["t0"] = self._stamp()                   # first hook of the step: the backward has just started
         if bucket_index < 0:
             if self.policy == "window":
                 self._flush()
@@ -104,6 +120,47 @@ class GradAllReducer:
             self._wait_events.append((a, b))
         self._works.clear()
         self._done.clear()
+        if self._auto is not None:
+            self._auto_step()
+
+    # ---- "auto" policy ------------------------------------------------------------------------------------------------
+    def _stamp(self):
+        """A point in time on the compute stream (device event) or, for host tensors (gloo tests), on the host clock."""
+        if self._flat().is_cuda:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            return e
+        import time
+        return time.perf_counter()
+
+    @staticmethod
+    def _span_ms(a, b):
+        return a.elapsed_time(b) if isinstance(a, torch.cuda.Event) else (b - a) * 1e3
+
+    def _auto_step(self):
+        st = self._auto
+        if st["t0"] is not None:
+            st["spans"][self.policy].append((st["t0"], self._stamp()))
+        st["t0"] = None
+        st["step"] += 1
+        n = self.AUTO_PROBE
+        if st["step"] == n:
+            self.policy = "window"
+        elif st["step"] == 2 * n:
+            if self._flat().is_cuda:
+                torch.cuda.synchronize()
+            mean = {}
+            for pol, sp in st["spans"].items():
+                ms = [self._span_ms(a, b) for a, b in sp[1:]] or [self._span_ms(a, b) for a, b in sp]
+                mean[pol] = sum(ms) / max(1, len(ms))
+            t = torch.tensor([mean["end"], mean["window"]], dtype=torch.float64, device=self._flat().device)
+            if dist.is_initialized() and self.world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            end_ms, window_ms = float(t[0]), float(t[1])
+            self.policy = "window" if window_ms < end_ms else "end"
+            self.decision = {"chosen": self.policy, "backward_plus_exchange_ms": {"end": round(end_ms, 4), "window": round(window_ms, 4)},
+                             "probe_steps_per_policy": n, "basis": "first bucket hook -> end of finish() waits, max over ranks"}
+            self._auto = None
 
     def exposed_ms(self, clear=True):
         """Per finish() call since timing was switched on: milliseconds between the compute stream reaching the waits and

@@ -161,6 +161,17 @@ def test_two_ranks_one_gpu_match_single_rank(tmp_path, policy, accumulate):
     check_against_single_rank(torch.load(out), 2, accumulate, "fp32", tag=policy)
 
 
+@pytest.mark.parametrize("policy", ["window", "auto"])
+def test_four_ranks_one_gpu_match_single_rank(tmp_path, policy):
+    """FOUR ranks (bucket order and the run-merging of parked buckets with more than two ranks; the sum
+    of four contributions, 1 / 4 folded into the optimiser) through the model's backward on one device (gloo), every
+    step's reduced gradient against the 1-rank gradient on the 8-sequence batch.  "auto" spends these three steps in its
+    probe phase under "end"."""
+    r, out = run_workers(tmp_path, policy, 1, "gloo", "fp32", 29591 + len(policy), nproc=4)
+    assert r.returncode == 0 and r.stdout.count("done") == 4, r.stdout[-3000:] + r.stderr[-3000:]
+    check_against_single_rank(torch.load(out), 4, 1, "fp32", tag="4 ranks " + policy)
+
+
 def test_two_ranks_bf16_headline_model_accumulate(tmp_path):
     """the tier and the model the benchmark times -- bf16 storage, hi + lo residual stream, bf16
     weight refresh after every reduced step, 6 layers d512 8 heads -- with world = 2 and --accumulate 2 through the

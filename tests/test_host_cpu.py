@@ -130,6 +130,27 @@ for policy in ("window", "eager", "end"):
     red.finish()
     assert torch.allclose(flat, sum(ref), atol=1e-6), policy
     assert abs(red.grad_scale - 1.0 / world) < 1e-12
+# "auto": AUTO_PROBE steps under "end", AUTO_PROBE under "window", then ONE decision every rank agrees on; every step of
+# the probe phases and after still produces the exact sum
+flat.copy_(base)
+red = GradAllReducer(lambda: flat, ranges, policy="auto")
+seen = []
+for s_ in range(2 * GradAllReducer.AUTO_PROBE + 2):
+    flat.copy_(base)
+    seen.append(red.policy)
+    red.hook(3)
+    for b in (2, 1):
+        red.hook(-1)
+        red.hook(b)
+    red.hook(0)
+    red.finish()
+    assert torch.allclose(flat, sum(ref), atol=1e-6), ("auto", s_)
+n = GradAllReducer.AUTO_PROBE
+assert seen[:2 * n] == ["end"] * n + ["window"] * n, seen
+assert red.decision is not None and red.decision["chosen"] in ("end", "window") and seen[-1] == red.decision["chosen"]
+chosen = [None] * world
+dist.all_gather_object(chosen, red.decision["chosen"])
+assert len(set(chosen)) == 1, chosen
 p0 = [torch.empty(2000) for _ in range(world)]
 dist.all_gather(p0, params)
 assert all(torch.equal(p0[0], q) for q in p0)
@@ -152,6 +173,19 @@ def test_gradient_allreduce_two_gloo_processes(tmp_path):
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+def test_gradient_allreduce_four_gloo_processes(tmp_path):
+    """The same worker with FOUR ranks (bucket order, run-merging in _flush and the "auto" decision with more than two
+    ranks)."""
+    script = tmp_path / "w4.py"
+    script.write_text(WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
+                        "--master-addr", "127.0.0.1", "--master-port", "29517", str(script)],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("ok") == 4
 
 
 def test_midi_writer_round_trip_and_reference_semantics():
