@@ -210,11 +210,12 @@ def decode_bench(cd, gen_len=2048):
     l_mid = sorted(mid)[len(mid) // 2] * 1e-3
     elt = 2 if cd == "bf16" else 4
     by = decode_bytes(CFG, t_mid, B, elt)
+    n_launch = sess.launches_per_token
     del sess, model
     torch.cuda.empty_cache()
     return {"dtype": cd, "batch": B, "gen_len": gen_len, "tokens_per_s": round(B * gen_len / wall, 1),
             "step_ms_p50": round(pct(0.5), 4), "step_ms_p90": round(pct(0.9), 4), "step_ms_mean_wall": round(1e3 * wall / gen_len, 4),
-            "launches_per_step": 26 if os.environ.get("MIDIEMO_DEC_UNFUSED", "0") in ("", "0") else 32, "replay": "one HIP graph per token, position in device memory",
+            "launches_per_step": n_launch, "replay": "one HIP graph per token, position in device memory",
             "roofline": {"bound": "hbm", "context": t_mid, "bytes_per_step": by, "step_ms": round(l_mid * 1e3, 4),
                          "achieved": round(by / l_mid / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": round(by / l_mid / 1e9 / PEAK_HBM_GBS, 4)},

@@ -27,6 +27,8 @@
  *   MIDIEMO_CU_RESERVE=n   persistent GEMM grids use (#CUs - n) blocks (CUs left to a concurrent RCCL kernel; default 0)
  *   MIDIEMO_NO_NT256=1     bf16 NT GEMMs run the generic 128 x 128 kernel instead of the persistent 256 x 256 one
  *   MIDIEMO_NO_TN256=1     likewise for the weight-gradient (TN) GEMMs
+ *   MIDIEMO_NT_MAINLOOP=1  256-tile NT GEMMs run the ping-pong / direct-to-LDS main loop (gemm_nt8p_kernel: bit-identical
+ *                          results, measured 4-9 % slower than the default register-staged loop, profiles/r05_nt_mainloop.txt)
  *   MIDIEMO_ATTN_V1=1      bf16 / head-dim-64 / causal attention runs the generic 32-key-step forward kernel
  *   MIDIEMO_DEC_CW=1|2|4, MIDIEMO_DEC_KS=0|1   column / K-split geometry of the decode GEMV kernels
  *   MIDIEMO_DEBUG=1        print the HIP error string when a launch fails
@@ -41,7 +43,8 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 18
+#define ME_ABI_VERSION 19
+#define ME_DEC_PART_REC(dh) ((dh) + 4)      /* floats per attention partial of the decode step (me_dec_attn) */
 #define ME_SUMSQ_WS_BYTES 1040   /* me_sumsq workspace: ticket counter + 256 block sums + padding */
 
 enum { ME_F32 = 0, ME_BF16 = 1 };
@@ -310,7 +313,8 @@ int me_dec_embed_qkv(const int64_t* tokens, const float* cond, const float* emb,
 
 /* me_dec_attn: for every (sequence, head) and each of nsplit key ranges of [0, t]:
  *   s_j = q.(K[j] + E[M-1-(t-j)]) / sqrt(dh)  (pad keys masked; music_multi.py:211-231 for a single query row),
- *   part[seq*H + head][split] = (max_j s_j, sum_j exp(s_j - max), sum_j exp(s_j - max) V[j])  -- f32 [dh + 2].
+ *   part[seq*H + head][split] = (max_j s_j, sum_j exp(s_j - max), 0, 0, sum_j exp(s_j - max) V[j])  -- f32 [ME_DEC_PART_REC(dh)
+ *   = dh + 4]: the P.V part starts 16-byte aligned (round 5: the combine reads it with 16-byte loads).
  * E: T [M][dh] natural layout.  nsplit <= 8.  grid = Mr*H x nsplit blocks; one key per 8-lane group, 16-byte coalesced K / V / E
  * reads.  The splits are combined by the prologue of me_dec_proj_resid. */
 int me_dec_attn(const void* q, const void* kcache, const void* vcache, const void* E, const uint8_t* key_pad, int ld_pad,
@@ -323,9 +327,12 @@ int me_dec_attn(const void* q, const void* kcache, const void* vcache, const voi
  * 0..nsplit-2 share the cached keys, partial nsplit-1 is the new key t, computed -- with k_t / v_t and their cache
  * append -- by two extra blocks per (row, head)).  part / nsplit as me_dec_attn (read by me_dec_proj_resid); x_out (f32
  * [Mr, d] or NULL) receives the LayerNorm rows.  d <= 1024, 2 <= nsplit <= 8.
+ * The input row is either s_in (f32 [Mr, d], npsum = 0) or, after me_dec_ffn, its split-K form (s_in = NULL):
+ * presid[m] + pbias + sum_{j < npsum} psum[j][m]  (psum f32 [npsum][Mr][d], summed in index order).
  * Replaces, per layer >= 1 of a cached decode step, music_multi.py:133-134 (layernorm2 of the previous layer) and
  * :196-232 for the one new position (generate.py:116-119). */
-int me_dec_ln_qkv_attn(const float* s_in, const float* gamma, const float* beta, float eps, const void* Wqkv, const float* bqkv,
+int me_dec_ln_qkv_attn(const float* s_in, const float* psum, int npsum, const float* presid, const float* pbias,
+                       const float* gamma, const float* beta, float eps, const void* Wqkv, const float* bqkv,
                        float* x_out, void* kcache, void* vcache, const void* E, const uint8_t* key_pad, int ld_pad, float* part,
                        int nsplit, int Mr, int d, int H, int dh, int M, int Mc, int t, const int32_t* t_dev, int dtype,
                        void* stream);
@@ -346,10 +353,24 @@ int me_dec_embed_qkv_attn(const int64_t* tokens, const float* cond, const float*
 int me_dec_proj_resid(const float* part, int nsplit, int H, int dh, const void* x_T, int ldx, const void* W, int ldw,
                       const float* bias, const float* resid, float* out, int Mr, int N, int K, int dtype, void* stream);
 
-/* me_dec_ln_proj: x = LayerNorm(s_in; gamma, beta, eps) -> x_out (f32, may be NULL); y = T(x).W^T + bias,
+/* me_dec_ffn (round 5): the feed-forward pair of a decode step in ONE launch, cut by the contraction index of FFN_suf:
+ *   x = LayerNorm(s_in; gamma, beta, eps) -> x_out (f32 [Mr][d], the residual of the consumer);
+ *   block j (64 hidden units): h_j = T(ReLU(T(x).W1[64 j .. 64 j + 63]^T + b1[..]))   (music_multi.py:129-131)
+ *                              part[j][m][0..d) = h_j . W2[:, 64 j .. 64 j + 63]^T    (music_multi.py:132, split over d_inner)
+ * part f32 [d_inner / 64][Mr][d] (caller-owned) is consumed by the LayerNorm prologue of the NEXT launch (me_dec_ln_qkv_attn /
+ * me_dec_ln_proj with psum = part, npsum = d_inner / 64, presid = x_out, pbias = the FFN_suf bias): the pre-norm sum of
+ * music_multi.py:133-134 is never stored.  W1 T [d_inner][d], W2 T [d][d_inner]; d % 16 == 0, d <= 1024 (bf16) / 512 (f32),
+ * d_inner % 64 == 0, Mr <= 8.  Replaces me_dec_ln_proj(FFN_pre) + me_dec_proj_resid(FFN_suf): 20 instead of 26 launches per
+ * token at 6 layers. */
+int me_dec_ffn(const float* s_in, const float* gamma, const float* beta, float eps, const void* W1, const float* b1,
+               const void* W2, float* x_out, float* part, int Mr, int d, int d_inner, int dtype, void* stream);
+
+/* me_dec_ln_proj: x = LayerNorm(row; gamma, beta, eps) -> x_out (f32, may be NULL), row = s_in or its split-K form (see
+ *   me_dec_ln_qkv_attn); y = T(x).W^T + bias,
  *   flags & ME_EPI_RELU: ReLU (FFN_pre, music_multi.py:129-131); flags & ME_EPI_OUT_F32: y is f32 [Mr][ldy] (the
  *   vocabulary head, music_multi.py:106), else T [Mr][ldy]. */
-int me_dec_ln_proj(const float* s_in, const float* gamma, const float* beta, float eps, const void* W, int ldw,
+int me_dec_ln_proj(const float* s_in, const float* psum, int npsum, const float* presid, const float* pbias,
+                   const float* gamma, const float* beta, float eps, const void* W, int ldw,
                    const float* bias, float* x_out, void* y, int ldy, int Mr, int N, int K, int flags, int dtype,
                    void* stream);
 

@@ -238,10 +238,19 @@ def adamw_step(p, g, m, v, sumsq_t, clip, grad_scale, lr, beta1, beta2, eps, wei
           "me_adamw_step")
 
 
+def _psum_args(psum):
+    """psum = None | (partials f32 [n][Mr][d], residual rows f32 [Mr][d], bias f32 [d]): the split-K form of a LayerNorm input row"""
+    if psum is None:
+        return None, 0, None, None
+    part, resid, bias = psum
+    return _ptr(part), int(part.shape[0]), _ptr(resid), _ptr(bias)
+
+
 def dec_ln_qkv_attn(s_in, gamma, beta, eps, Wqkv, bqkv, x_out, kcache, vcache, E, key_pad, ld_pad, part, nsplit, Mr, d, H, dh, M,
-                    Mc, t, t_dev, dtype):
-    """fused LayerNorm -> q|k|v of one head -> cache append -> key-split attention partials (me_dec_ln_qkv_attn)."""
-    check(lib().me_dec_ln_qkv_attn(_ptr(s_in), _ptr(gamma), _ptr(beta), float(eps), _ptr(Wqkv), _ptr(bqkv), _ptr(x_out),
+                    Mc, t, t_dev, dtype, psum=None):
+    """fused LayerNorm -> q|k|v of one head -> cache append -> key-split attention partials (me_dec_ln_qkv_attn).
+    psum: see _psum_args (then s_in must be None)."""
+    check(lib().me_dec_ln_qkv_attn(_ptr(s_in), *_psum_args(psum), _ptr(gamma), _ptr(beta), float(eps), _ptr(Wqkv), _ptr(bqkv), _ptr(x_out),
                                    _ptr(kcache), _ptr(vcache), _ptr(E), _ptr(key_pad), ld_pad, _ptr(part), nsplit, Mr, d, H, dh, M,
                                    Mc, int(t), _ptr(t_dev), _code(dtype), _stream()), "me_dec_ln_qkv_attn")
 
@@ -277,8 +286,14 @@ def dec_proj_resid(part, nsplit, H, dh, x_T, W, bias, resid, out, Mr, N, K, dtyp
           "me_dec_proj_resid")
 
 
-def dec_ln_proj(s_in, gamma, beta, eps, W, bias, x_out, y, Mr, N, K, flags, dtype):
-    check(lib().me_dec_ln_proj(_ptr(s_in), _ptr(gamma), _ptr(beta), float(eps), _ptr(W), W.stride(0), _ptr(bias), _ptr(x_out),
+def dec_ffn(s_in, gamma, beta, eps, W1, b1, W2, x_out, part, Mr, d, d_inner, dtype):
+    """fused LayerNorm1 -> FFN_pre + ReLU -> FFN_suf split over d_inner (me_dec_ffn): part f32 [d_inner / 64][Mr][d]"""
+    check(lib().me_dec_ffn(_ptr(s_in), _ptr(gamma), _ptr(beta), float(eps), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(x_out), _ptr(part),
+                           Mr, d, d_inner, _code(dtype), _stream()), "me_dec_ffn")
+
+
+def dec_ln_proj(s_in, gamma, beta, eps, W, bias, x_out, y, Mr, N, K, flags, dtype, psum=None):
+    check(lib().me_dec_ln_proj(_ptr(s_in), *_psum_args(psum), _ptr(gamma), _ptr(beta), float(eps), _ptr(W), W.stride(0), _ptr(bias), _ptr(x_out),
                                _ptr(y), y.stride(0), Mr, N, K, int(flags), _code(dtype), _stream()), "me_dec_ln_proj")
 
 

@@ -269,8 +269,9 @@ def test_device_resident_greedy_loop_matches_eager_steps(conditioning):
 @pytest.mark.parametrize("cd", ["fp32", "bf16"])
 @pytest.mark.parametrize("conditioning", ["none", "discrete_token", "continuous_concat"])
 def test_fused_decode_stages_equal_the_separate_launches(conditioning, cd):
-    """The fused decode stages (me_dec_embed_qkv_attn for the first layer -- round 4 --, me_dec_ln_qkv_attn for the others)
-    against the separate launches they replace (me_dec_embed_qkv / me_dec_qkv + me_dec_attn) over 70 positions (more than one
+    """The fused decode stages (me_dec_embed_qkv_attn for the first layer -- round 4 --, me_dec_ln_qkv_attn for the others, and
+    me_dec_ffn -- round 5: FFN_pre + FFN_suf in one launch, split over d_inner, its partials summed by the next LayerNorm
+    prologue --) against the separate launches they replace (me_dec_embed_qkv / me_dec_qkv + me_dec_attn) over 70 positions (more than one
     key-split chunk), sequences at different tokens.  Same operands rounded at the same places; what differs is f32 summation
     order (the fused stage keeps the newest key as a split of its own and sums the projection per head slice), so the bound
     is f32 rounding in the f32 tier (1e-5 of the logit scale) and ONE rounding unit of the stored type in the bf16 tier
@@ -291,16 +292,21 @@ def test_fused_decode_stages_equal_the_separate_launches(conditioning, cd):
     rel = lambda x, y: float((x.double() - y.double()).norm() / y.double().norm())
     worst = 0.0
     with torch.no_grad():
-        a, b = DecodeSession(model, B), DecodeSession(model, B)
-        assert a.fused
-        b.fused = False                                   # the round-2 form: one launch per piece
+        a, b, c = DecodeSession(model, B), DecodeSession(model, B), DecodeSession(model, B)
+        assert a.fused and a.ffn_fusable and not c.ffn_fused
+        a.ffn_fused = True                                # me_dec_ffn (opt-in: measured slower than its two launches)
+        assert a.launches_per_token == 3 * 3 + 2 and c.launches_per_token == 4 * 3 + 2
+        b.fused = b.ffn_fused = False                     # the round-2 form: one launch per piece; c = the default (round 4 form)
+        worst_c = 0.0
         for i in range(n):
-            la, lb = a.step(toks[i], cond).clone(), b.step(toks[i], cond).clone()
-            worst = max(worst, rel(la, lb))
-            assert rel(la, lb) <= tol, (i, rel(la, lb))
+            la, lb, lc = a.step(toks[i], cond).clone(), b.step(toks[i], cond).clone(), c.step(toks[i], cond).clone()
+            worst, worst_c = max(worst, rel(la, lb)), max(worst_c, rel(la, lc))
+            assert rel(la, lb) <= tol and rel(la, lc) <= tol, (i, rel(la, lb), rel(la, lc))
         for l in range(3):
             assert rel(a.kc[l][:, :, :n], b.kc[l][:, :, :n]) <= tol and rel(a.vc[l][:, :, :n], b.vc[l][:, :, :n]) <= tol, l
-    print("fused vs separate decode stages, %s %s: worst logits rel-L2 over %d steps %.2e (bound %.1e)" % (conditioning, cd, n, worst, tol))
+            assert rel(a.kc[l][:, :, :n], c.kc[l][:, :, :n]) <= tol and rel(a.vc[l][:, :, :n], c.vc[l][:, :, :n]) <= tol, l
+    print("fused vs separate decode stages, %s %s: worst logits rel-L2 over %d steps %.2e (all separate) / %.2e (me_dec_ffn vs its two "
+          "launches) (bound %.1e)" % (conditioning, cd, n, worst, worst_c, tol))
 
 
 @pytest.mark.gpu

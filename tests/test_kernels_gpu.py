@@ -640,7 +640,7 @@ def test_sumsq_ordered_is_bit_reproducible(ops):
     out = torch.full((1,), 2.0, device=DEV)
     ops.sumsq(g, out, ws=ws)
     assert abs(float(out) - 2.0 - float(ref)) <= 1e-6 * float(ref) + 1e-6
-    with pytest.raises(RuntimeError, match="ME_ERR_BAD_SHAPE"):
+    with pytest.raises(RuntimeError, match="ME_ERR_WORKSPACE"):
         ops.sumsq(g, out, ws=torch.zeros(16, dtype=torch.uint8, device=DEV))
 
 
@@ -948,7 +948,7 @@ def test_dec_attn_matches_full(ops, dtype, dh, nsplit):
     d = H * dh
     kc = torch.zeros(B, H, Mc, dh, dtype=dtype, device=DEV)
     vc = torch.zeros_like(kc)
-    part = torch.zeros(B * H, nsplit, dh + 2, dtype=torch.float32, device=DEV)
+    part = torch.zeros(B * H, nsplit, dh + 4, dtype=torch.float32, device=DEV)      # ME_DEC_PART_REC(dh)
     eye = torch.eye(d, dtype=dtype, device=DEV)
     zero = torch.zeros(B, d, dtype=torch.float32, device=DEV)
     out = torch.empty(B, d, dtype=torch.float32, device=DEV)
@@ -980,7 +980,7 @@ def test_dec_attn_pad_keys_and_fully_masked_row(ops):
     kc[:, :, :t + 1] = k.float().to(DEV)
     vc[:, :, :t + 1] = v.float().to(DEV)
     d = H * dh
-    part = torch.zeros(B * H, ns, dh + 2, device=DEV)
+    part = torch.zeros(B * H, ns, dh + 4, device=DEV)      # ME_DEC_PART_REC(dh)
     out = torch.empty(B, d, device=DEV)
     ops.dec_attn(q[:, :, t].reshape(B, d).contiguous().float().to(DEV), kc, vc, E.float().to(DEV), pad.to(DEV), t + 1, part, ns, B, H,
                  dh, M, Mc, t, None, torch.float32)

@@ -21,7 +21,7 @@ g, be = r(d, dtype=torch.float32), r(d, dtype=torch.float32)
 s_in, xres, s1, o1, s2 = (r(B, d, dtype=torch.float32) for _ in range(5))
 q, hid = r(B, d), r(B, di)
 kc, vc = r(B, H, M, dh), r(B, H, M, dh)
-part = torch.zeros(B * H, ns, dh + 2, device=dev)
+part = torch.zeros(B * H, ns, dh + 4, device=dev)
 logits = torch.zeros(B, V, device=dev)
 emb, pe = r(V, d - 128, dtype=torch.float32), r(M, d, dtype=torch.float32)
 cw, cb = r(128, 2, dtype=torch.float32), r(128, dtype=torch.float32)

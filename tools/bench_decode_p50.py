@@ -1,9 +1,7 @@
-"""development aid: p50 device step latency of the config-5 decode (bench.py's decode_bench) -- A/B runs with MIDIEMO_LIB."""
-import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "midi-emotion_amd"))
+"""decode step latency (BASELINE config 5, bf16 + f32) from bench.py's decode_bench; env switches select variants"""
+import json, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench
-for _ in range(2):
-    r = bench.decode_bench("bf16", 1024)
-    print("decode bf16: p50 %.4f ms  p90 %.4f ms  %.0f tok/s" % (r["step_ms_p50"], r["step_ms_p90"], r["tokens_per_s"]))
+for cd in (sys.argv[1:] or ["bf16"]):
+    d = bench.decode_bench(cd, 2048)
+    print(cd, json.dumps({k: d[k] for k in ("tokens_per_s", "step_ms_p50", "step_ms_p90", "launches_per_step", "ids_checksum")}), flush=True)
