@@ -16,6 +16,9 @@ timeout 900 python $R/bench.py > /tmp/rp_plain.log 2>&1
 grep "^{\"metric\"" /tmp/rp_plain.log | tail -1 > $OUT/${TAG}_bench.json
 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/rp_bench -o p -- python $R/bench.py --no_extra --no_decode --no_cpu_baseline --steps 20 --warmup 5 > /tmp/rp_bench.log 2>&1
 python $R/tools/rocpd_stats.py $(find /tmp/rp_bench -name "*.db" | head -1) > $OUT/${TAG}_bench_kernel_stats.txt 2>&1
+# 1b. the train steps alone (no probe steps, no back-to-back replays of the NT calls): per-step time of every kernel family
+timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/rp_step -o p -- python $R/bench.py --no_extra --no_decode --no_cpu_baseline --no_probe --steps 20 --warmup 5 > /tmp/rp_step.log 2>&1
+python $R/tools/rocpd_stats.py $(find /tmp/rp_step -name "*.db" | head -1) 25 > $OUT/${TAG}_step_kernel_stats.txt 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/rp_c4 -o p -- python $R/bench.py --only_config4 > /tmp/rp_c4.log 2>&1
 python $R/tools/rocpd_stats.py $(find /tmp/rp_c4 -name "*.db" | head -1) > $OUT/${TAG}_config4_kernel_stats.txt 2>&1
 python $R/tools/make_roofline.py > /tmp/rp_roof.log 2>&1
