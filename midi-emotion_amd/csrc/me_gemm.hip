@@ -756,6 +756,88 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(
     if (wr == 0) seg_barrier();
 }
 
+// ---------------------------------------------------------------------------------------------
+// 256x256 tile, FOUR waves (2 x 2, 128 x 128 per wave: one wave per SIMD, the 256 accumulators in a[0:255]), bf16, K % 128 == 0
+// -- hand-scheduled main loop (round 5, VERDICT r4 next-1: the wave tile of the vendor's kernel).  A wave tile of 128 x 128 reads
+// 128 KB of fragments per slab from LDS instead of 192 KB, but with ONE wave per SIMD nothing hides an instruction's issue
+// cost or a wait: the compiler-scheduled version of round 3 ran 84 vs 68 us.  Here the slab loop is one inline-asm body
+// generated by tools/gen_nt4w.py (me_gemm_nt4w.inc): 64 MFMAs per slab and wave with exactly ONE memory instruction in each of
+// the 64 gaps (the 8 fragment reads of the next k-phase in the order the MFMAs consume them; 16 ds_write_b128 of slab + 1;
+// 16 global_load_dwordx4 of slab + 2 into the registers just written), one s_barrier per slab, every s_waitcnt counted from
+// the periodic instruction stream.  Main loop alone (tools/ubench_nt_tile.hip, same box, us): N512.K2048 64.0 -> 53.8,
+// N512.K1536 49.9 -> 42.3, K = 512 shapes 20.1 / 52.5 / 67.8 -> 18.4 / 48.9 / 63.4.
+// Same slab images and swizzle, same k order per accumulator element as gemm_nt256_kernel: results are bit-identical.
+// The tile loop and the write-out stay C++ (nt256_write_tile with the 2 x 2 wave grid); no state crosses the write-out, every tile
+// runs its own prologue -- which is why this kernel only takes the launches with ONE tile per CU (see the launcher): in a
+// multi-tile launch the next tile's first loads queue behind the write-out's stores (vmcnt is in order), where the persistent
+// 8-wave kernel has them in flight before the write-out starts.  LDS: [A even 32 KB][A odd][B even][B odd][write-out staging 32 KB].
+// ---------------------------------------------------------------------------------------------
+#include "me_gemm_nt4w.inc"
+template <bool OUT_F32, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt4w_kernel(
+    const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc,
+    const float* __restrict__ bias, const bf16_t* __restrict__ add, int ldadd, const bf16_t* __restrict__ gate,
+    int ldgate, int M, int N, int K, int flags) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1;
+    const int ntn = (N + 255) / 256, ntiles = ntn * ((M + 255) / 256);
+    const bool relu = flags & ME_EPI_RELU;
+    const bool vec_c = (ldc % (OUT_F32 ? 4 : 8)) == 0 && (reinterpret_cast<uintptr_t>(Cv) & 15) == 0;
+    const int npair = K / 128;
+    // operand feed: waves 0, 1 stage the A slab (pieces 16 (wid & 1) + p), waves 2, 3 the B slab
+    const bool isA = wid < 2;
+    const uint32_t ld2 = (uint32_t)(isA ? lda : ldb) * 2u;
+    const int rows = isA ? M : N;
+    const int lrow = lane >> 3;
+    const uint32_t lwr = (isA ? 0u : 65536u) + (uint32_t)(wid & 1) * 16384u + (uint32_t)lane * 16u;
+    const int frow = lane & 31, h = lane >> 5;
+    uint32_t lra, lrb;
+    { const int r = wr * 128 + frow; lra = r * 128 + ((h ^ ((r ^ (r >> 3)) & 7)) << 4); }
+    { const int r = wc * 128 + frow; lrb = 65536 + r * 128 + ((h ^ ((r ^ (r >> 3)) & 7)) << 4); }
+    f32x16_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc_zero(acc[i][j]);
+    auto tile_origin = [&](int it, int& m0, int& n0) __attribute__((always_inline)) {
+        int t = it;
+        if ((ntiles & 7) == 0) t = (t & 7) * (ntiles >> 3) + (t >> 3);      // contiguous tile range per XCD
+        m0 = (t / ntn) * 256;
+        n0 = (t % ntn) * 256;
+    };
+    for (int it = blockIdx.x; it < ntiles; it += gridDim.x) {
+        int m0, n0;
+        tile_origin(it, m0, n0);
+        const int o0 = isA ? m0 : n0;
+        const char* sbase = reinterpret_cast<const char*>(isA ? A : B) + (size_t)(uint32_t)o0 * ld2;
+        uint32_t vo[16];
+        int lf = lane;                                                    // opaque per tile: the sixteen offsets are recomputed here, not
+        asm volatile("" : "+v"(lf));                                      // hoisted out of the tile loop and spilled around the asm body
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const int r = ((wid & 1) * 16 + p) * 8 + (lf >> 3);            // row inside the slab; rows past the matrix are clamped
+            vo[p] = (uint32_t)(min(o0 + r, rows - 1) - o0) * ld2 + (uint32_t)(((lf & 7) ^ ((r ^ (r >> 3)) & 7)) << 4);
+        }
+        asm volatile(ME_NT4W_BODY
+                     : [c0] "+a"(acc[0][0]), [c1] "+a"(acc[0][1]), [c2] "+a"(acc[0][2]), [c3] "+a"(acc[0][3]),
+                       [c4] "+a"(acc[1][0]), [c5] "+a"(acc[1][1]), [c6] "+a"(acc[1][2]), [c7] "+a"(acc[1][3]),
+                       [c8] "+a"(acc[2][0]), [c9] "+a"(acc[2][1]), [c10] "+a"(acc[2][2]), [c11] "+a"(acc[2][3]),
+                       [c12] "+a"(acc[3][0]), [c13] "+a"(acc[3][1]), [c14] "+a"(acc[3][2]), [c15] "+a"(acc[3][3])
+                     : [vo0] "v"(vo[0]), [vo1] "v"(vo[1]), [vo2] "v"(vo[2]), [vo3] "v"(vo[3]), [vo4] "v"(vo[4]), [vo5] "v"(vo[5]),
+                       [vo6] "v"(vo[6]), [vo7] "v"(vo[7]), [vo8] "v"(vo[8]), [vo9] "v"(vo[9]), [vo10] "v"(vo[10]), [vo11] "v"(vo[11]),
+                       [vo12] "v"(vo[12]), [vo13] "v"(vo[13]), [vo14] "v"(vo[14]), [vo15] "v"(vo[15]), [lwr] "v"(lwr), [lra] "v"(lra),
+                       [lrb] "v"(lrb), [sbase] "s"(sbase), [npair] "s"(npair)
+                     : ME_NT4W_CLOBBERS);
+        int ln = lane;                                                    // opaque: nothing of the write-out's address arithmetic
+        asm volatile("" : "+v"(ln));                                      // is hoisted out of the tile loop and held (spilled) across the asm body
+        nt256_write_tile<OUT_F32, 2, 2, EPI>(acc, smem, m0, n0, wid, ln, Cv, ldc, bias, add, ldadd, gate, ldgate, M, N, relu, vec_c);
+        // (no barrier: the staging area is private to the wave, the next prologue writes LDS buffer 0, which the last slab only
+        // touched with its never-consumed reads of "slab nk", and buffer 1 is written behind the prologue's own barrier)
+    }
+}
+
 // C = A.B^T.  128x128 block tile, 4 waves (2x2) x 64x64.  K-slab BKT (64 bf16 / 32 f32) is
 // double buffered in LDS: one barrier per slab, the slab after next is in flight in registers
 // while the current one is multiplied.  The 32x32 blocks are accumulated TRANSPOSED (mfma(B, A)):
@@ -1452,10 +1534,16 @@ __global__ __launch_bounds__(256) void cast_transpose_multi_kernel(const me_ct_d
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static const bool g_disable_nt256 = getenv("MIDIEMO_NO_NT256") != nullptr;
-// main loop of the 256-tile NT kernel: 1 = ping-pong / direct-to-LDS feed (gemm_nt8p_kernel), 0 = register-staged single phase
-// (gemm_nt256_kernel); results are bit-identical.  MIDIEMO_NT_MAINLOOP overrides (development A/B).
+// main loop of the 256-tile NT kernel (results are bit-identical across all of them; MIDIEMO_NT_MAINLOOP overrides for A/B):
+//   0  register-staged single phase, 8 waves (gemm_nt256_kernel)
+//   1  ping-pong / direct-to-LDS feed, 8 waves (gemm_nt8p_kernel; plain / bias / gate write-outs) -- measured 4-9 % slower
+//   2  hand-scheduled 4-wave loop (gemm_nt4w_kernel) wherever it is legal (K % 128 == 0, row write-outs)
+//   3  (default) measured choice: the 4-wave loop for launches with at most ONE tile per CU, K >= 2048 and the plain / bias /
+//      gate write-out (M32768.N512.K2048: plain 71.5 -> 62.9, bias 66.0 -> 61.9, gate 67.6 -> 62.5 us; M16384: 51.4 -> 45.3),
+//      gemm_nt256_kernel for everything else (K = 1024 draws level, multi-tile K = 512 launches run 8-22 % slower on the
+//      4-wave kernel, the residual-add write-out draws level; profiles/r05_nt_4wave.txt)
 #ifndef ME_NT_MAINLOOP_DEFAULT
-#define ME_NT_MAINLOOP_DEFAULT 0
+#define ME_NT_MAINLOOP_DEFAULT 3
 #endif
 static const int g_nt_mainloop = getenv("MIDIEMO_NT_MAINLOOP") ? atoi(getenv("MIDIEMO_NT_MAINLOOP")) : ME_NT_MAINLOOP_DEFAULT;
 
@@ -1524,7 +1612,28 @@ int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int 
                                                                                    (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags)
 #define ME_NT256_PP(F32, E) gemm_nt8p_kernel<F32, E><<<g256, 512, NT256_LDS, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias, \
                                                                                    (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags)
+#define ME_NT256_4W(F32, E) gemm_nt4w_kernel<F32, E><<<g256, 256, NT256_LDS, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias, \
+                                                                                   (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags)
             const bool pp = g_nt_mainloop == 1;
+            // hand-scheduled 4-wave main loop (slab pairs; the element-wise write-out spills beside it): forced (2) or where it measured faster (3)
+            const int ntiles256 = ((N + 255) / 256) * ((M + 255) / 256);
+            const bool w4 = K % 128 == 0 && epi < 3 &&
+                            (g_nt_mainloop == 2 || (g_nt_mainloop == 3 && ntiles256 <= (int)ncu && K >= 2048 && epi < 2));
+            if (w4) {
+                static bool attr4[16] = {false};
+                if (dev < 0 || dev >= 16 || !attr4[dev]) {
+                    (void)hipFuncSetAttribute((const void*)gemm_nt4w_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+                    (void)hipFuncSetAttribute((const void*)gemm_nt4w_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+                    (void)hipFuncSetAttribute((const void*)gemm_nt4w_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+                    (void)hipFuncSetAttribute((const void*)gemm_nt4w_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+                    if (dev >= 0 && dev < 16) attr4[dev] = true;
+                }
+                if (flags & ME_EPI_OUT_F32) ME_NT256_4W(true, 0);
+                else if (epi == 0) ME_NT256_4W(false, 0);
+                else if (epi == 1) ME_NT256_4W(false, 1);
+                else ME_NT256_4W(false, 2);
+                return me_launch_status();
+            }
             if (flags & ME_EPI_OUT_F32) { if (epi == 0) { if (pp) ME_NT256_PP(true, 0); else ME_NT256_OLD(true, 0); } else ME_NT256_OLD(true, 3); }
             else if (epi == 0) { if (pp) ME_NT256_PP(false, 0); else ME_NT256_OLD(false, 0); }
             else if (epi == 1) { if (pp) ME_NT256_PP(false, 1); else ME_NT256_OLD(false, 1); }
@@ -1532,6 +1641,7 @@ int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int 
             else ME_NT256_OLD(false, 3);
 #undef ME_NT256_OLD
 #undef ME_NT256_PP
+#undef ME_NT256_4W
             return me_launch_status();
         }
     }

@@ -1094,8 +1094,8 @@ def test_rga_bwd_bidirectional(ops, dtype, B, H, L, dh, M):
 
 @pytest.mark.gpu
 def test_gemm_nt_main_loops_bit_identical():
-    """The two main loops of the 256-tile NT kernel (MIDIEMO_NT_MAINLOOP = 0 register-staged / 1 ping-pong + direct-to-LDS feed)
-    accumulate every output element in the same k order: 66 cases (ragged M / N, persistent multi-tile walks, every write-out
+    """The main loops of the 256-tile NT kernel (MIDIEMO_NT_MAINLOOP = 0 register-staged / 1 ping-pong + direct-to-LDS feed /
+    2 hand-scheduled 4-wave loop / 3 the default mix of 0 and 2) accumulate every output element in the same k order: 66 cases (ragged M / N, persistent multi-tile walks, every write-out
     path, f32 out) must agree bit for bit.  Each setting needs its own copy of the library (the switch is read once per load),
     so the comparison runs in a subprocess (tools/ab_nt_mainloop.py)."""
     import subprocess

@@ -1,5 +1,5 @@
 """Same-process A/B of the two main loops of the 256-tile NT GEMM (MIDIEMO_NT_MAINLOOP = 0 register-staged single phase,
-1 ping-pong + direct-to-LDS feed): two private copies of the library, each initialised under its own setting; results must be
+1 ping-pong + direct-to-LDS feed, 2 hand-scheduled 4-wave loop): private copies of the library, each initialised under its own setting; results must be
 BIT-identical, timings are interleaved (round-robin, median) because the matrix pipe is power limited and the clocks drift."""
 import ctypes, os, shutil, sys, tempfile
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -9,7 +9,8 @@ from midiemo import _lib
 src = os.environ.get("MIDIEMO_LIB") or os.path.join(HERE, "..", "midi-emotion_amd", "midiemo", "libmidiemo_hip.so")
 tmp = tempfile.mkdtemp()
 libs = {}
-for ml in (0, 1):
+MLS = tuple(int(x) for x in os.environ.get("AB_ML", "0,1,2,3").split(","))
+for ml in MLS:
     dst = os.path.join(tmp, "lib_ml%d.so" % ml)
     shutil.copy(src, dst)
     os.environ["MIDIEMO_NT_MAINLOOP"] = str(ml)
@@ -30,7 +31,7 @@ def call(L, A, B, C, bias=None, add=None, gate=None, flags=0):
 warmed = {}
 r = lambda *s: torch.randn(*s, device=dev).to(dt)
 # first call of each copy under its own setting
-for ml in (0, 1):
+for ml in MLS:
     os.environ["MIDIEMO_NT_MAINLOOP"] = str(ml)
     call(libs[ml], r(256, 64), r(256, 64), torch.empty(256, 256, device=dev, dtype=dt))
 torch.cuda.synchronize()
@@ -43,34 +44,34 @@ def check(M, N, K, what, f32=False):
     kws = dict(kws)
     if f32: kws["flags"] = kws.get("flags", 0) | 2
     outs = []
-    for ml in (0, 1):
+    for ml in MLS:
         C = torch.full((M, N), float("nan"), device=dev, dtype=torch.float32 if f32 else dt)
         call(libs[ml], A, B, C, **kws)
         outs.append(C)
     torch.cuda.synchronize()
-    same = torch.equal(outs[0].view(torch.int32 if f32 else torch.int16), outs[1].view(torch.int32 if f32 else torch.int16))
+    same = all(torch.equal(outs[0].view(torch.int32 if f32 else torch.int16), o.view(torch.int32 if f32 else torch.int16)) for o in outs[1:])
     ref = A.float() @ B.float().t()
     base = outs[0].float()
-    print("check M%6d N%5d K%5d %-9s f32=%d  bit-identical=%s  finite=%s" % (M, N, K, what, f32, same, bool(torch.isfinite(outs[1].float()).all())), flush=True)
+    print("check M%6d N%5d K%5d %-9s f32=%d  bit-identical=%s  finite=%s" % (M, N, K, what, f32, same, bool(all(torch.isfinite(o.float()).all() for o in outs))), flush=True)
     return same
 
 def bench(M, N, K, what, rounds=12, iters=8):
     A, B, C = r(M, K), r(N, K), torch.empty(M, N, device=dev, dtype=dt)
     bias, addt, gatet = torch.randn(N, device=dev), r(M, N), r(M, N)
     kws = {"plain": {}, "bias": dict(bias=bias), "bias+relu": dict(bias=bias, flags=1), "add": dict(add=addt), "gate": dict(gate=gatet, flags=4)}[what]
-    ts = {0: [], 1: []}
-    for ml in (0, 1): call(libs[ml], A, B, C, **kws)
+    ts = {ml: [] for ml in MLS}
+    for ml in MLS: call(libs[ml], A, B, C, **kws)
     torch.cuda.synchronize()
     for _ in range(rounds):
-        for ml in (0, 1):
+        for ml in MLS:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(iters): call(libs[ml], A, B, C, **kws)
             e1.record(); torch.cuda.synchronize()
             ts[ml].append(e0.elapsed_time(e1) / iters * 1e3)
     med = lambda x: sorted(x)[len(x) // 2]
-    print("bench M%6d N%5d K%5d %-9s  old %.1f us  new %.1f us  (%+.1f %%)  new: %.0f TF/s" % (M, N, K, what, med(ts[0]), med(ts[1]), 100 * (med(ts[1]) / med(ts[0]) - 1),
-          2e-6 * M * N * K / med(ts[1])), flush=True)
+    print("bench M%6d N%5d K%5d %-9s  " % (M, N, K, what) + "  ".join("ml%d %.1f us (%+.1f %%)" % (ml, med(ts[ml]), 100 * (med(ts[ml]) / med(ts[MLS[0]]) - 1)) for ml in MLS) +
+          "  best %.0f TF/s" % (2e-6 * M * N * K / min(med(ts[ml]) for ml in MLS)), flush=True)
 
 ok = True
 if "--nocheck" not in sys.argv:
@@ -82,6 +83,7 @@ if "--nocheck" not in sys.argv:
     print("ALL BIT-IDENTICAL" if ok else "MISMATCH", flush=True)
 if "--nobench" not in sys.argv:
     M = 32768
-    for (N, K, whats) in ((512, 2048, ("plain", "bias", "add")), (2048, 512, ("plain", "bias+relu", "gate")), (1536, 512, ("bias",)), (512, 512, ("bias",)),
+    for (N, K, whats) in ((512, 2048, ("plain", "bias", "add", "gate")), (2048, 512, ("plain", "bias+relu", "gate")), (1536, 512, ("bias",)), (512, 512, ("bias",)),
                           (512, 1536, ("add",)), (1007, 512, ("bias",))):
         for w in whats: bench(M, N, K, w)
+    bench(16384, 512, 2048, "bias"); bench(16384, 1024, 1024, "bias"); bench(32768, 512, 1024, "bias")

@@ -120,6 +120,71 @@ __global__ __launch_bounds__(512) void nt_tile_kernel(const bf16_t* __restrict__
     out[(size_t)blockIdx.x * 512 + tid] = s;
 }
 
+// ---- hand-scheduled 4-wave variant (2 x 2 waves of 128 x 128, one wave per SIMD, accumulators in a[0:255]): the loop body is
+//      generated by tools/gen_nt4w.py (tools/nt4w_asm.inc); same slab images / swizzle, LDS [A even][A odd][B even][B odd]
+#include "nt4w_asm.inc"
+__global__ __launch_bounds__(256) void nt4w_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
+                                                   float* __restrict__ out, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1;
+    const int ntn = N / 256;
+    int t = blockIdx.x;
+    const int ntiles = ntn * (M / 256);
+    if ((ntiles & 7) == 0) t = (t & 7) * (ntiles >> 3) + (t >> 3);
+    const int m0 = (t / ntn) * 256, n0 = (t % ntn) * 256;
+    const bool isA = wid < 2;                                             // waves 0, 1 feed the A slab, waves 2, 3 the B slab
+    const uint32_t ld2 = (isA ? lda : ldb) * 2u;
+    const char* sbase = isA ? reinterpret_cast<const char*>(A) + (size_t)m0 * ld2 : reinterpret_cast<const char*>(B) + (size_t)n0 * ld2;
+    const int lrow = lane >> 3;
+    uint32_t vo[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        const int r = ((wid & 1) * 16 + p) * 8 + lrow;
+        vo[p] = (uint32_t)r * ld2 + (uint32_t)(((lane & 7) ^ ((r ^ (r >> 3)) & 7)) << 4);
+    }
+    const uint32_t lwr = (isA ? 0u : 65536u) + (uint32_t)(wid & 1) * 16384u + (uint32_t)lane * 16u;
+    const int frow = lane & 31, h = lane >> 5;
+    uint32_t lra, lrb;
+    { const int r = wr * 128 + frow; lra = r * 128 + ((h ^ ((r ^ (r >> 3)) & 7)) << 4); }
+    { const int r = wc * 128 + frow; lrb = 65536 + r * 128 + ((h ^ ((r ^ (r >> 3)) & 7)) << 4); }
+    const int npair = K / 128;
+    float osum;
+    asm volatile(NT4W_ASM_BODY
+                 : [osum] "=&v"(osum)
+                 : [vo0] "v"(vo[0]), [vo1] "v"(vo[1]), [vo2] "v"(vo[2]), [vo3] "v"(vo[3]), [vo4] "v"(vo[4]), [vo5] "v"(vo[5]), [vo6] "v"(vo[6]),
+                   [vo7] "v"(vo[7]), [vo8] "v"(vo[8]), [vo9] "v"(vo[9]), [vo10] "v"(vo[10]), [vo11] "v"(vo[11]), [vo12] "v"(vo[12]),
+                   [vo13] "v"(vo[13]), [vo14] "v"(vo[14]), [vo15] "v"(vo[15]), [lwr] "v"(lwr), [lra] "v"(lra), [lrb] "v"(lrb),
+                   [sbase] "s"(sbase), [npair] "s"(npair)
+                 : NT4W_ASM_CLOBBERS);
+    out[(size_t)blockIdx.x * 512 + tid] = osum;
+    out[(size_t)blockIdx.x * 512 + 256 + tid] = 0.f;
+}
+
+static float run4w(const bf16_t* A, const bf16_t* B, float* out, int M, int N, int K, int reps, double* sum) {
+    const int lds = 131072;
+    CK(hipFuncSetAttribute((const void*)nt4w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const int grid = (M / 256) * (N / 256);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < reps; ++r) { nt4w_kernel<<<grid, 256, lds>>>(A, K, B, K, out, M, N, K); CK(hipGetLastError()); }
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    CK(hipGetLastError());
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    if (sum) {
+        std::vector<float> h((size_t)grid * 512);
+        CK(hipMemcpy(h.data(), out, h.size() * 4, hipMemcpyDeviceToHost));
+        double t = 0;
+        for (float v : h) t += v;
+        *sum = t;
+    }
+    return ms * 1e3f / reps;
+}
+
 template <int BMT, int BNT, int WR, int WC>
 static float run(const bf16_t* A, const bf16_t* B, float* out, int M, int N, int K, int reps, double* sum) {
     auto kern = nt_tile_kernel<BMT, BNT, WR, WC>;
@@ -158,24 +223,27 @@ int main() {
         double ref = 0;
         for (int k = 0; k < K; ++k) ref += ca[k] * cb[k];
         bf16_t *A, *B; float* out;
-        CK(hipMalloc(&A, hA.size() * 2)); CK(hipMalloc(&B, hB.size() * 2)); CK(hipMalloc(&out, (size_t)4096 * 512 * 4));
+        CK(hipMalloc(&A, hA.size() * 2 + 65536)); CK(hipMalloc(&B, hB.size() * 2 + 65536));      // (the 4-wave loop reads two slabs past the end)
+        CK(hipMalloc(&out, (size_t)4096 * 512 * 4));
         CK(hipMemcpy(A, hA.data(), hA.size() * 2, hipMemcpyHostToDevice));
         CK(hipMemcpy(B, hB.data(), hB.size() * 2, hipMemcpyHostToDevice));
-        double s0, s1, s2;
+        double s0, s1, s2, s3;
+        run4w(A, B, out, M, N, K, 2, &s3);
         run<256, 256, 2, 4>(A, B, out, M, N, K, 2, &s0);
         run<128, 512, 1, 8>(A, B, out, M, N, K, 2, &s1);
         run<128, 512, 2, 4>(A, B, out, M, N, K, 2, &s2);
-        std::vector<float> t0, t1, t2;
+        std::vector<float> t0, t1, t2, t3;
         for (int r = 0; r < 10; ++r) {
             t0.push_back(run<256, 256, 2, 4>(A, B, out, M, N, K, 8, nullptr));
             t1.push_back(run<128, 512, 1, 8>(A, B, out, M, N, K, 8, nullptr));
             t2.push_back(run<128, 512, 2, 4>(A, B, out, M, N, K, 8, nullptr));
+            t3.push_back(run4w(A, B, out, M, N, K, 8, nullptr));
         }
-        std::sort(t0.begin(), t0.end()); std::sort(t1.begin(), t1.end()); std::sort(t2.begin(), t2.end());
+        std::sort(t0.begin(), t0.end()); std::sort(t1.begin(), t1.end()); std::sort(t2.begin(), t2.end()); std::sort(t3.begin(), t3.end());
         const double scale = fabs(ref) + 1e3 * sqrt((double)M * N);
         printf("N %4d K %4d: main loop only, us per launch (median of 10 x 8): 256x256 (2x4 waves) %.1f | 128x512 (1x8 waves of 128x64) %.1f | "
-               "128x512 (2x4 waves of 64x128) %.1f   [sum(C) %.6g %.6g %.6g ref %.6g: %s]\n", N, K, t0[5], t1[5], t2[5], s0, s1, s2, ref,
-               (fabs(s0 - ref) < 1e-3 * scale && fabs(s1 - ref) < 1e-3 * scale && fabs(s2 - ref) < 1e-3 * scale) ? "ok" : "MISMATCH");
+               "128x512 (2x4 waves of 64x128) %.1f | 256x256 hand-scheduled 4 waves of 128x128 %.1f   [sum(C) %.6g %.6g %.6g %.6g ref %.6g: %s]\n", N, K, t0[5], t1[5], t2[5], t3[5], s0, s1, s2, s3, ref,
+               (fabs(s0 - ref) < 1e-3 * scale && fabs(s1 - ref) < 1e-3 * scale && fabs(s2 - ref) < 1e-3 * scale && fabs(s3 - ref) < 1e-3 * scale) ? "ok" : "MISMATCH");
         CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(out));
     }
     return 0;
