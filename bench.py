@@ -339,28 +339,35 @@ class OpProbe:
 
 
 class GemmProbe:
-    """HIP-event timing of every NT-GEMM launch (me_gemm_nt; events recorded on the launch stream).
-    At the bench shapes all of them run gemm_nt256_kernel<bf16>."""
+    """HIP-event timing of every NT-GEMM launch (me_gemm_nt and me_gemm_nt_relu_mask; events recorded on the launch stream).
+    At the bench shapes all of them run the 256 x 256 tile kernels (gemm_nt256_kernel / gemm_nt4w_kernel <bf16>)."""
 
     def __init__(self, ops, steps=0):
-        self.ops, self.orig, self.rec, self.calls, self.steps = ops, ops.gemm_nt, [], [], steps
+        self.ops, self.rec, self.calls, self.steps = ops, [], [], steps
+        self.orig = {"gemm_nt": ops.gemm_nt, "gemm_nt_relu_mask": ops.gemm_nt_relu_mask}
 
     def __enter__(self):
-        def nt(A, B, C, **kw):
-            m = A.shape[0] if kw.get("M") is None else kw["M"]
-            k = A.shape[1] if kw.get("K") is None else kw["K"]
-            n = B.shape[0] if kw.get("N") is None else kw["N"]
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            self.orig(A, B, C, **kw)
-            e1.record()
-            self.rec.append((2.0 * m * n * k, e0, e1, (m * k + n * k) * A.element_size() + m * n * C.element_size()))
-            self.calls.append((A, B, C, dict(kw)))
-        self.ops.gemm_nt = nt
+        def make(name):
+            fn = self.orig[name]
+
+            def nt(A, B, C, *rest, **kw):
+                m = A.shape[0] if kw.get("M") is None else kw["M"]
+                k = A.shape[1] if kw.get("K") is None else kw["K"]
+                n = B.shape[0] if kw.get("N") is None else kw["N"]
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn(A, B, C, *rest, **kw)
+                e1.record()
+                self.rec.append((2.0 * m * n * k, e0, e1, (m * k + n * k) * A.element_size() + m * n * C.element_size()))
+                self.calls.append((fn, (A, B, C) + tuple(rest), dict(kw)))
+            return nt
+        for name in self.orig:
+            setattr(self.ops, name, make(name))
         return self
 
     def __exit__(self, *a):
-        self.ops.gemm_nt = self.orig
+        for name, fn in self.orig.items():
+            setattr(self.ops, name, fn)
 
     def summary(self):
         torch.cuda.synchronize()
@@ -375,13 +382,13 @@ class GemmProbe:
         overhead to every launch (VERDICT r4 weak #7).  Returns (sum of per-call average ms over one step's calls, calls)."""
         calls = self.calls[:len(self.calls) // max(1, self.steps)] if self.steps else self.calls
         total = 0.0
-        for (A, Bm, C, kw) in calls:
+        for (fn, a, kw) in calls:
             best = None
             for _ in range(rounds):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(reps):
-                    self.orig(A, Bm, C, **kw)
+                    fn(*a, **kw)
                 e1.record()
                 torch.cuda.synchronize()
                 t = e0.elapsed_time(e1) / reps

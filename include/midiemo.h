@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 19
+#define ME_ABI_VERSION 20
 #define ME_DEC_PART_REC(dh) ((dh) + 4)      /* floats per attention partial of the decode step (me_dec_attn) */
 #define ME_SUMSQ_WS_BYTES 1040   /* me_sumsq workspace: ticket counter + 256 block sums + padding */
 
@@ -146,6 +146,18 @@ int me_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                const float* bias, const void* add, int ldadd, const void* gate, int ldgate,
                int M, int N, int K, int flags, int dtype, void* stream);
 
+/* ---- FFN_pre forward / FFN_suf dgrad with the ReLU's sign pattern as a bit mask ------------------
+ * dir 0:  C = relu(A . B^T + bias)  and  mask <- (C > 0)          (FFN_pre + F.relu, music_multi.py:129-131)
+ * dir 1:  C = mask ? (A . B^T) : 0                                  (autograd of F.relu over FFN_suf's dX; bias ignored)
+ * Same results, bit for bit, as me_gemm_nt with ME_EPI_RELU / with gate = the activations and ME_EPI_RELU_BWD; the
+ * backward launch then reads 1 bit per element instead of the bf16 activations (134 MB per layer at the headline shape).
+ * mask: caller-owned, me_workspace_bytes(ME_WS_RELU_MASK, M, N, K, dtype) bytes, 16-byte aligned, opaque (1 bit per element
+ * in the order the kernel's write-out touches them: 1 KB per 128 rows x 64 columns, rows rounded up to 256); a size of
+ * 0 means the shape / dtype is not served (bf16, N % 64 == 0, the shapes the 256-tile kernel takes) -- callers then
+ * keep the gate operand; calling anyway returns ME_ERR_BAD_SHAPE.  C is T, ldc % 8 == 0, 16-byte aligned. */
+int me_gemm_nt_relu_mask(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
+                         void* mask, int M, int N, int K, int dir, int dtype, void* stream);
+
 /* ---- workspace sizes (caller supplies every workspace) -----------------
  * Bytes of scratch the entry point `op` needs for a call of the given shape and dtype (an upper bound;
  * 0 = none).  ME_WS_GEMM_TN: me_gemm_tn_acc with (M, N, K) = (T, N, K). */
@@ -156,7 +168,8 @@ enum {
     ME_WS_RGA_MT = 4,    /* me_rga_fwd / me_rga_bwd MT: (M, N, K) = (B*H, Lp, unused) */
     ME_WS_GEMM_TN_GROUP = 5, /* me_gemm_tn_acc_group: (M, N, K) = (T, sum over the items of ceil(N/256) * (K/256), unused) */
     ME_WS_EMBED_BWD = 6,     /* me_embed_bwd frequent-token list: 1024 bytes, zero before the first use */
-    ME_WS_SUMSQ = 7          /* me_sumsq ordered block sums: ME_SUMSQ_WS_BYTES, zero before the first use */
+    ME_WS_SUMSQ = 7,         /* me_sumsq ordered block sums: ME_SUMSQ_WS_BYTES, zero before the first use */
+    ME_WS_RELU_MASK = 8      /* me_gemm_nt_relu_mask sign mask: (M, N, K) = the product's; 0 = shape / dtype not served, use the gate */
 };
 size_t me_workspace_bytes(int op, int M, int N, int K, int dtype);
 

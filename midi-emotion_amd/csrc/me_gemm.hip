@@ -95,6 +95,16 @@ ME_DEV void epi_block_swapped(const f32x16_t& acc, int row_base, int col_base, i
     }
 }
 
+// ReLU sign mask (ME_WS_RELU_MASK): 1 bit per element, stored as the write-out sees the elements.  A REGION = 128 rows x 64
+// columns = 1 KB = [64 lanes][16 bytes]; bit e of byte b of lane l is element (row 32 (b / 4) + 8 (b % 4) + l / 8, column
+// 8 (l % 8) + e) of the region: the chunk lane l stores with instruction (i, it) = (b / 4, b % 4) of the region's write-out.
+// Regions are ordered [column group][row group] with the row count rounded up to 256: one 16-byte load / store per lane and
+// wave tile, nothing to gather.
+ME_DEV char* relu_mask_region(bf16_t* mask, int M, int row0, int col0) {
+    const size_t rb_total = (size_t)((M + 255) >> 8) * 32;
+    return reinterpret_cast<char*>(mask) + ((size_t)(col0 >> 6) * rb_total + (size_t)(row0 >> 3)) * 64;
+}
+
 // ---- tile write-out of the 256 x 256 kernels (shared by the main-loop variants): stage 32 rows x 128 B at a time through
 // the wave's private 4 KB so that every store instruction writes 8 full 128-byte row segments (per-lane 8-byte pieces
 // across 32 rows are L2-transaction bound).  bf16: a pass = 32 rows x 64 columns; f32: 32 rows x 32 columns.
@@ -102,11 +112,13 @@ ME_DEV void epi_block_swapped(const f32x16_t& acc, int row_base, int col_base, i
 template <bool OUT_F32, int WR, int WC, int EPI>
 ME_DEV void nt256_write_tile(f32x16_t (&acc)[256 / WR / 32][256 / WC / 32], char* smem, int m0, int n0, int wid, int lane,
                              void* __restrict__ Cv, int ldc, const float* __restrict__ bias, const bf16_t* __restrict__ add,
-                             int ldadd, const bf16_t* __restrict__ gate, int ldgate, int M, int N, bool relu, bool vec_c) {
+                             int ldadd, const bf16_t* __restrict__ gate, int ldgate, int M, int N, bool relu, bool vec_c,
+                             chunk16* mreg = nullptr) {
     typedef bf16_t T;
     constexpr int NW = WR * WC;
     constexpr int TM = 256 / WR, TN = 256 / WC;
     constexpr int AI = TM / 32, BJ = TN / 32;
+    static_assert(EPI < 4 || (TM == 128 && !OUT_F32), "the sign-mask region of a wave is 128 rows x 64 columns = 1 KB");
     const int wr = wid / WC, wc = wid % WC;
     const int h = lane >> 5;
     char* stg = smem + 2 * 65536 + wid * (32768 / NW);
@@ -135,6 +147,23 @@ ME_DEV void nt256_write_tile(f32x16_t (&acc)[256 / WR / 32][256 / WC / 32], char
             const int orow = m0 + wr * TM + i * 32 + rr;
             constexpr int EPC = OUT_F32 ? 4 : 8;                       // elements per chunk
             const int col = n0 + wc * TN + j0 * 32 + ch * EPC;
+            if constexpr (EPI == 4) {
+                // ReLU sign mask (layout: relu_mask_region): the 8 elements of this chunk are bit e of byte b = 4 i + it of the
+                // lane's 16 mask bytes.  Pure per-lane arithmetic on the rounded bf16 halves: x > 0 <=> the half, as a signed
+                // 16-bit integer, is > 0 (the ReLU left no NaN) -> packed clamp to {0, 1}, the two bits of a dword side by side
+                typedef short i16x2_t __attribute__((ext_vector_type(2)));
+                uint32_t byte = 0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const uint32_t dw = v.v[w];                          // (a bit_cast of the vector ELEMENT reads element 0: hipcc 7.2)
+                    i16x2_t x = __builtin_bit_cast(i16x2_t, dw);
+                    x = __builtin_elementwise_min(__builtin_elementwise_max(x, (i16x2_t){0, 0}), (i16x2_t){1, 1});
+                    const uint32_t u = __builtin_bit_cast(uint32_t, x);
+                    byte |= ((u | (u >> 15)) & 3u) << (2 * w);
+                }
+                const int b = i * 4 + it, grp = ps % JP;
+                mreg[grp].v[b >> 2] |= byte << (8 * (b & 3));
+            }
             if (orow < M && col < N) {
                 if (col + EPC <= N && vec_c) {
                     if constexpr (OUT_F32) st_chunk(reinterpret_cast<float*>(Cv) + (size_t)orow * ldc + col, v);
@@ -152,8 +181,8 @@ ME_DEV void nt256_write_tile(f32x16_t (&acc)[256 / WR / 32][256 / WC / 32], char
     };
     // vmcnt is in-order: a global load issued between two passes waits for the previous pass's STORES to retire
     // (measured: 20 us of an 80 us launch).  Hence two code paths (registers = max, not sum):
-    if constexpr (EPI == 0) {
-        // (a) bias (+ReLU): the wave's bias values are fetched once, before any store
+    if constexpr (EPI == 0 || EPI == 4) {
+        // (a) bias (+ReLU; EPI 4: + the ReLU's sign mask, written by write_out): the wave's bias values are fetched once, before any store
         f32x4_t bv[BJ][4];
         const bool vec_bias = (reinterpret_cast<uintptr_t>(bias) & 15) == 0;
 #pragma unroll
@@ -170,6 +199,10 @@ ME_DEV void nt256_write_tile(f32x16_t (&acc)[256 / WR / 32][256 / WC / 32], char
                     }
                 }
             }
+        if constexpr (EPI == 4) {
+#pragma unroll
+            for (int g = 0; g < BJ / 2; ++g) mreg[g] = zero_chunk();
+        }
 #pragma unroll
         for (int ps = 0; ps < NP; ++ps) {
             const int i = ps / JP, j0 = (ps % JP) * NJ;
@@ -186,6 +219,13 @@ ME_DEV void nt256_write_tile(f32x16_t (&acc)[256 / WR / 32][256 / WC / 32], char
                     stage(jj, g, v);
                 }
             write_out(ps);
+        }
+        if constexpr (EPI == 4) {
+#pragma unroll
+            for (int g = 0; g < BJ / 2; ++g) {
+                char* mp = relu_mask_region(const_cast<bf16_t*>(gate), M, m0 + wr * TM, n0 + wc * TN + g * 64);
+                if (m0 + wr * TM < M && n0 + wc * TN + g * 64 < N) st_chunk(mp + lane * 16, mreg[g]);      // one 1 KB store per wave
+            }
         }
     } else if constexpr (EPI == 1) {
         // (g) ReLU gate alone (the FFN_suf dgrad, N = d_inner): a select commutes with the rounding, so the gate is
@@ -227,6 +267,40 @@ ME_DEV void nt256_write_tile(f32x16_t (&acc)[256 / WR / 32][256 / WC / 32], char
                 T* vp = reinterpret_cast<T*>(&v);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) vp[e] = (float)gp[e] > 0.f ? vp[e] : (T)0.f;
+                const int orow = m0 + wr * TM + i * 32 + rr;
+                const int col = n0 + wc * TN + j0 * 32 + ch * 8;
+                if (orow < M && col < N) st_chunk(reinterpret_cast<T*>(Cv) + (size_t)orow * ldc + col, v);
+            }
+        }
+    } else if constexpr (EPI == 5) {
+        // (m) ReLU gate from the sign mask the forward's EPI 4 launch left: the wave's whole region (1 KB per 128 rows x 64
+        // columns instead of 16 KB of activations, the lane's own 16 bytes) arrived in mreg with ONE load issued a tile ahead
+        // (gemm_nt256_kernel); bit e of byte 4 i + it keeps element e of the lane's chunk.  No memory instruction besides
+        // the stores.
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            const int i = ps / JP, j0 = (ps % JP) * NJ, grp = ps % JP;
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j0 + jj][4 * g + e];
+                    stage(jj, g, v);
+                }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int rr = it * 8 + (lane >> 3), ch = lane & 7;
+                chunk16 v = ld_chunk(stg + rr * 128 + ((ch ^ (rr & 7)) << 4));
+                const int b = i * 4 + it;
+                const uint32_t bits = mreg[grp].v[b >> 2];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const uint32_t lo = (uint32_t)__builtin_amdgcn_sbfe((int)bits, 8 * (b & 3) + 2 * w, 1);          // 0 / 0xffffffff
+                    const uint32_t hi = (uint32_t)__builtin_amdgcn_sbfe((int)bits, 8 * (b & 3) + 2 * w + 1, 1);
+                    v.v[w] &= (hi & 0xffff0000u) | (lo & 0x0000ffffu);
+                }
                 const int orow = m0 + wr * TM + i * 32 + rr;
                 const int col = n0 + wc * TN + j0 * 32 + ch * 8;
                 if (orow < M && col < N) st_chunk(reinterpret_cast<T*>(Cv) + (size_t)orow * ldc + col, v);
@@ -471,11 +545,24 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_nt256_kernel(
         for (int j = 0; j < BJ; ++j) frag_load(fb[j], reinterpret_cast<const T*>(((j & 1) ? bo : be) + j * 4096));
     };
 
+    // sign-mask write-outs (EPI 4 / 5): the wave's 1 KB mask region(s) travel in registers; EPI 5 requests the region of the NEXT
+    // write-out a whole tile ahead (one 16-byte load per lane in the queue of the operand stream: no wait of its own)
+    chunk16 mreg[BJ / 2 > 0 ? BJ / 2 : 1];
+    auto mask_fetch = [&](int tile_it) __attribute__((always_inline)) {
+        int m0, n0;
+        tile_origin(tile_it, m0, n0);
+#pragma unroll
+        for (int g = 0; g < BJ / 2; ++g)
+            mreg[g] = ld_chunk(relu_mask_region(const_cast<bf16_t*>(gate), M, m0 + wr * TM, min(n0 + wc * TN + g * 64, N - 64)) + lane * 16);
+    };
     auto epilogue = [&](int tile_it) __attribute__((always_inline)) {
         int m0, n0;
         tile_origin(tile_it, m0, n0);
-        nt256_write_tile<OUT_F32, WR, WC, EPI>(acc, smem, m0, n0, wid, lane, Cv, ldc, bias, add, ldadd, gate, ldgate, M, N, relu, vec_c);
+        nt256_write_tile<OUT_F32, WR, WC, EPI>(acc, smem, m0, n0, wid, lane, Cv, ldc, bias, add, ldadd, gate, ldgate, M, N, relu, vec_c,
+                                               mreg);
+        if constexpr (EPI == 5) mask_fetch(min(tile_it + 1, my_tiles - 1));
     };
+    if constexpr (EPI == 5) mask_fetch(0);
 
     // ---- prologue: slab 0 into LDS, slab 1 into the registers
 #pragma unroll
@@ -1564,10 +1651,21 @@ static int persistent_cus() {
     return n;
 }
 
+// shapes the persistent 256 x 256 bf16 kernels take (me_workspace_bytes(ME_WS_RELU_MASK) answers with the same test).
+// Few tiles on many CUs (the sliding-window forward of generate(): M = 4 x 1024 rows): a launch costs one whole
+// 256 x 256 x K tile regardless, and 128 x 128 tiles finish sooner -- measured at M = 2048 .. 8192, N = 512 / 1007:
+// 15.0-16.2 vs 17.1-20.5 us (K = 512), 33.5 vs 45.6 us (K = 2048); below M = 2048 and above 64 tiles the big tile wins
+static bool nt256_shape_ok(int M, int N, int K) {
+    const long t256 = (long)((N + 255) / 256) * ((M + 255) / 256);
+    const bool few_tiles = M >= 2048 && t256 * 4 <= persistent_cus();
+    return K % 64 == 0 && M >= 256 && N >= 192 && !g_disable_nt256 && !few_tiles;
+}
+
 template <typename T>
 int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
                    const void* add, int ldadd, const void* gate, int ldgate, int M, int N, int K, int flags,
-                   hipStream_t st) {
+                   hipStream_t st, int mask_dir = -1) {
+    // mask_dir >= 0 (me_gemm_nt_relu_mask): `gate` is the ReLU sign mask, written (0, with bias + ReLU) or applied (1)
     constexpr int CH = ET<T>::CH;
     if (M <= 0 || N <= 0 || K <= 0) return ME_ERR_BAD_SHAPE;
     if (K % CH || lda % CH || ldb % CH) return ME_ERR_BAD_SHAPE;
@@ -1575,12 +1673,7 @@ int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int 
     if constexpr (sizeof(T) == 2) {
         // the 256-tile kernel addresses its operands with 32-bit byte offsets
         const bool off32 = (unsigned long long)M * lda * 2ull < (1ull << 32) && (unsigned long long)N * ldb * 2ull < (1ull << 32);
-        // few tiles on many CUs (the sliding-window forward of generate(): M = 4 x 1024 rows): a launch costs one whole
-        // 256 x 256 x K tile regardless, and 128 x 128 tiles finish sooner -- measured at M = 2048 .. 8192, N = 512 / 1007:
-        // 15.0-16.2 vs 17.1-20.5 us (K = 512), 33.5 vs 45.6 us (K = 2048); below M = 2048 and above 64 tiles the big tile wins
-        const long t256 = (long)((N + 255) / 256) * ((M + 255) / 256);
-        const bool few_tiles = M >= 2048 && t256 * 4 <= persistent_cus();
-        if (K % 64 == 0 && M >= 256 && N >= 192 && off32 && !g_disable_nt256 && !few_tiles) {
+        if (nt256_shape_ok(M, N, K) && off32) {
             static bool attr_set[16] = {false};
             int dev = 0;
             if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
@@ -1589,6 +1682,8 @@ int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int 
                 (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, 2, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
                 (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, 2, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
                 (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, 2, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, 2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, 2, 4, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
                 (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<true, 2, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
                 (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<true, 2, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
                 (void)hipFuncSetAttribute((const void*)gemm_nt8p_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
@@ -1604,7 +1699,12 @@ int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int 
             // write-out path (EPI): the row paths need 16-byte aligned operand rows, a vector-storable C and N % 8 == 0
             const bool vec_c = (ldc % 8) == 0 && aligned16(C) && (N & 7) == 0;
             int epi = 3;
-            if (!add && !gate) epi = 0;
+            if (mask_dir >= 0) {
+                // sign-mask write-outs: bf16 rows stored as whole 16-byte chunks, mask blocks of 64 columns, 8-byte aligned words
+                if ((flags & ME_EPI_OUT_F32) || add || !gate || !vec_c || (N & 63) || !aligned16(gate)) return ME_ERR_BAD_SHAPE;
+                if (mask_dir == 1 && (bias || (flags & ME_EPI_RELU))) return ME_ERR_BAD_SHAPE;
+                epi = mask_dir == 0 ? 4 : 5;
+            } else if (!add && !gate) epi = 0;
             else if (!(flags & ME_EPI_OUT_F32) && gate && !add && !bias && !(flags & ME_EPI_RELU) && vec_c && (ldgate & 7) == 0 && aligned16(gate)) epi = 1;
             else if (!(flags & ME_EPI_OUT_F32) && add && !gate && vec_c && (ldadd & 7) == 0 && aligned16(add)) epi = 2;
             // main loop: the ping-pong kernel exists for the write-out paths that fit its registers (plain / bias / ReLU, gate rows)
@@ -1614,7 +1714,7 @@ int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int 
                                                                                    (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags)
 #define ME_NT256_4W(F32, E) gemm_nt4w_kernel<F32, E><<<g256, 256, NT256_LDS, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias, \
                                                                                    (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags)
-            const bool pp = g_nt_mainloop == 1;
+            const bool pp = g_nt_mainloop == 1 && epi < 4;
             // hand-scheduled 4-wave main loop (slab pairs; the element-wise write-out spills beside it): forced (2) or where it measured faster (3)
             const int ntiles256 = ((N + 255) / 256) * ((M + 255) / 256);
             const bool w4 = K % 128 == 0 && epi < 3 &&
@@ -1638,6 +1738,8 @@ int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int 
             else if (epi == 0) { if (pp) ME_NT256_PP(false, 0); else ME_NT256_OLD(false, 0); }
             else if (epi == 1) { if (pp) ME_NT256_PP(false, 1); else ME_NT256_OLD(false, 1); }
             else if (epi == 2) ME_NT256_OLD(false, 2);
+            else if (epi == 4) ME_NT256_OLD(false, 4);
+            else if (epi == 5) ME_NT256_OLD(false, 5);
             else ME_NT256_OLD(false, 3);
 #undef ME_NT256_OLD
 #undef ME_NT256_PP
@@ -1645,6 +1747,7 @@ int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int 
             return me_launch_status();
         }
     }
+    if (mask_dir >= 0) return ME_ERR_BAD_SHAPE;                          // the sign-mask write-outs exist in the 256-tile kernel only
     const unsigned grid = (unsigned)(((N + BN - 1) / BN) * ((M + BM - 1) / BM));
     if (flags & ME_EPI_OUT_F32)
         gemm_nt_kernel<T, true><<<grid, NTHREADS, 0, st>>>((const T*)A, lda, (const T*)B, ldb, C, ldc, bias, (const T*)add, ldadd,
@@ -1755,6 +1858,16 @@ int me_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
     return ME_ERR_BAD_DTYPE;
 }
 
+int me_gemm_nt_relu_mask(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias, void* mask,
+                         int M, int N, int K, int dir, int dtype, void* stream) {
+    me_clear_error();
+    if (!A || !B || !C || !mask) return ME_ERR_NULL;
+    if (dir != 0 && dir != 1) return ME_ERR_BAD_SHAPE;
+    if (dtype != ME_BF16) return dtype == ME_F32 ? ME_ERR_BAD_SHAPE : ME_ERR_BAD_DTYPE;      // the f32 tier keeps the gate operand
+    return gemm_nt_launch<bf16_t>(A, lda, B, ldb, C, ldc, dir == 0 ? bias : nullptr, nullptr, 0, mask, 0, M, N, K,
+                                  dir == 0 ? ME_EPI_RELU : 0, (hipStream_t)stream, dir);
+}
+
 // bytes of partial-tile workspace a 256-tile launch over `ntile` tiles needs; 0 = no token split
 static size_t tn_ws_bytes_tiles(int Tn, int ntile) {
     if (Tn < 2048 || ntile <= 0) return 0;
@@ -1770,6 +1883,10 @@ static size_t tn_ws_bytes(int Tn, int N, int K) {
 }
 
 size_t me_workspace_bytes(int op, int M, int N, int K, int dtype) {
+    if (op == ME_WS_RELU_MASK)                                            // 64 bytes per 8 rows x 64 columns, rows rounded up to 256; 0 = use the gate operand
+        return (dtype == ME_BF16 && M > 0 && N > 0 && (N & 63) == 0 && nt256_shape_ok(M, N, K) &&
+                (unsigned long long)M * K * 2ull < (1ull << 32) && (unsigned long long)N * K * 2ull < (1ull << 32))
+                   ? (size_t)((M + 255) / 256) * 32 * (size_t)(N / 64) * 64 : 0;
     if (op == ME_WS_GEMM_TN) return dtype == ME_BF16 ? tn_ws_bytes(M, N, K) : 0;
     if (op == ME_WS_GEMM_TN_GROUP) return dtype == ME_BF16 ? tn_ws_bytes_tiles(M, N) : 0;      // N = total 256 x 256 tiles of the group
     if (op == ME_WS_RGA_PT || op == ME_WS_RGA_DGT) {

@@ -12,9 +12,9 @@ LIB_PATH = os.environ.get("MIDIEMO_LIB") or os.path.join(HERE, "libmidiemo_hip.s
 ME_F32, ME_BF16 = 0, 1
 ME_COND_NONE, ME_COND_CONCAT, ME_COND_TOKEN = 0, 1, 2
 ME_EPI_RELU, ME_EPI_OUT_F32, ME_EPI_RELU_BWD = 1, 2, 4
-ME_WS_GEMM_TN, ME_WS_RGA_PT, ME_WS_RGA_DGT, ME_WS_RGA_MT, ME_WS_GEMM_TN_GROUP, ME_WS_EMBED_BWD, ME_WS_SUMSQ = 1, 2, 3, 4, 5, 6, 7
+ME_WS_GEMM_TN, ME_WS_RGA_PT, ME_WS_RGA_DGT, ME_WS_RGA_MT, ME_WS_GEMM_TN_GROUP, ME_WS_EMBED_BWD, ME_WS_SUMSQ, ME_WS_RELU_MASK = 1, 2, 3, 4, 5, 6, 7, 8
 ME_TN_MAX_GROUP = 5
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 ERRORS = {0: "ME_OK", -1: "ME_ERR_BAD_DTYPE", -2: "ME_ERR_BAD_SHAPE", -3: "ME_ERR_ALIGNMENT",
           -4: "ME_ERR_LAUNCH", -5: "ME_ERR_NULL", -6: "ME_ERR_WORKSPACE"}
@@ -31,6 +31,7 @@ SIGNATURES = {
     "me_embed_bwd": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _p, ctypes.c_size_t, _p],
     "me_key_pad_mask": [_p, _p, _i, _i, _i, _i, _p],
     "me_gemm_nt": [_p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
+    "me_gemm_nt_relu_mask": [_p, _i, _p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p],
     "me_workspace_bytes": [_i, _i, _i, _i, _i],
     "me_gemm_tn_acc": [_p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _p, ctypes.c_size_t, _i, _p],
     "me_gemm_tn_acc_group": [_p, _i, _i, _p, ctypes.c_size_t, _i, _p],

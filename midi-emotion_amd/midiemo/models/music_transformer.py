@@ -362,8 +362,12 @@ class MusicTransformerHIP(nn.Module):
                 L.st1, L.st2 = e(T, 2, dtype=torch.float32), e(T, 2, dtype=torch.float32)
                 # what the attention forward leaves for its backward: unnormalised probability tiles + running maxima
                 L.PT, L.MT = ops.rga_saved_buffers(B, H, Lm, dt, dev, causal=self.causal)
+                # ReLU sign mask of the FFN (1 bit per hidden unit: the FFN_suf dgrad reads it instead of the activations);
+                # 0 bytes = this shape / dtype keeps the gate operand
+                nmask = 0 if os.environ.get("MIDIEMO_NO_RELU_MASK") else ops.workspace_bytes(ops.ME_WS_RELU_MASK, T, di, d, dt)
+                L.rmask = e(nmask, dtype=torch.uint8) if nmask else None
             else:
-                L.s1 = L.s2 = L.st1 = L.st2 = L.PT = L.MT = None
+                L.s1 = L.s2 = L.st1 = L.st2 = L.PT = L.MT = L.rmask = None
             ws.layers.append(L)
         ws.tmp = e(T, d)
         if save:
@@ -440,8 +444,11 @@ class MusicTransformerHIP(nn.Module):
             ops.gemm_nt(Lw.att, W["Wo"], ws.tmp, bias=self._pview(f, p + "rga.fc.bias"), M=T, N=d, K=d, dtype=dt)
             ops.resid_ln_fwd(x, ws.tmp, self._pview(f, p + "layernorm1.weight"), self._pview(f, p + "layernorm1.bias"),
                              Lw.o1, Lw.s1, Lw.st1, T, d, self.LN_EPS, p_drop, seed, 1 + 2 * i, x_lo=ws.hlo[0], y_lo=ws.hlo[1])
-            ops.gemm_nt(Lw.o1, W["W1"], Lw.hid, bias=self._pview(f, p + "FFN_pre.bias"), M=T, N=di, K=d,
-                        flags=ops.ME_EPI_RELU, dtype=dt)
+            if Lw.rmask is not None:
+                ops.gemm_nt_relu_mask(Lw.o1, W["W1"], Lw.hid, Lw.rmask, bias=self._pview(f, p + "FFN_pre.bias"), M=T, N=di, K=d, dtype=dt)
+            else:
+                ops.gemm_nt(Lw.o1, W["W1"], Lw.hid, bias=self._pview(f, p + "FFN_pre.bias"), M=T, N=di, K=d,
+                            flags=ops.ME_EPI_RELU, dtype=dt)
             ops.gemm_nt(Lw.hid, W["W2"], ws.tmp, bias=self._pview(f, p + "FFN_suf.bias"), M=T, N=d, K=di, dtype=dt)
             ops.resid_ln_fwd(Lw.o1, ws.tmp, self._pview(f, p + "layernorm2.weight"), self._pview(f, p + "layernorm2.bias"),
                              y, Lw.s2, Lw.st2, T, d, self.LN_EPS, p_drop, seed, 2 + 2 * i, x_lo=ws.hlo[1], y_lo=ws.hlo[0])
@@ -499,7 +506,10 @@ class MusicTransformerHIP(nn.Module):
             ops.resid_ln_bwd(dy, Lw.s2, Lw.st2, self._pview(f, p + "layernorm2.weight"), ws.dB, ws.dC,
                              gv(p + "layernorm2.weight"), gv(p + "layernorm2.bias"), T, d, p_drop, seed, 2 + 2 * i)
             wgrad(ws.dC, Lw.hid, gv(p + "FFN_suf.weight"), gv(p + "FFN_suf.bias"), N=d, K=di)
-            ops.gemm_nt(ws.dC, W["W2T"], ws.dhid, gate=Lw.hid, M=T, N=di, K=d, flags=ops.ME_EPI_RELU_BWD, dtype=dt)
+            if Lw.rmask is not None:
+                ops.gemm_nt_relu_mask(ws.dC, W["W2T"], ws.dhid, Lw.rmask, M=T, N=di, K=d, backward=True, dtype=dt)
+            else:
+                ops.gemm_nt(ws.dC, W["W2T"], ws.dhid, gate=Lw.hid, M=T, N=di, K=d, flags=ops.ME_EPI_RELU_BWD, dtype=dt)
             wgrad(ws.dhid, Lw.o1, gv(p + "FFN_pre.weight"), gv(p + "FFN_pre.bias"), N=di, K=d)
             ops.gemm_nt(ws.dhid, W["W1T"], ws.dA, add=ws.dB, M=T, N=d, K=di, dtype=dt)          # d(o1) total
             # LN1 + attention

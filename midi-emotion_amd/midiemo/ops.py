@@ -8,7 +8,7 @@ import torch
 from . import _lib
 from ._lib import (ME_BF16, ME_COND_CONCAT, ME_COND_NONE, ME_COND_TOKEN, ME_EPI_OUT_F32, ME_EPI_RELU,
                    ME_EPI_RELU_BWD, ME_F32, ME_TN_MAX_GROUP, ME_WS_EMBED_BWD, ME_WS_SUMSQ, ME_WS_GEMM_TN, ME_WS_GEMM_TN_GROUP, ME_WS_RGA_DGT, ME_WS_RGA_MT,
-                   ME_WS_RGA_PT, check)
+                   ME_WS_RGA_PT, ME_WS_RELU_MASK, check)
 
 DTYPE_CODE = {torch.float32: ME_F32, torch.bfloat16: ME_BF16}
 
@@ -104,6 +104,17 @@ def gemm_nt(A, B, C, bias=None, add=None, gate=None, M=None, N=None, K=None, fla
                            _ptr(add), add.stride(0) if add is not None else 0,
                            _ptr(gate), gate.stride(0) if gate is not None else 0,
                            M, N, K, flags, _code(dtype), _stream()), "me_gemm_nt")
+
+
+def gemm_nt_relu_mask(A, B, C, mask, bias=None, M=None, N=None, K=None, backward=False, dtype=None):
+    """forward: C = relu(A . B^T + bias), mask <- sign pattern; backward: C = mask ? A . B^T : 0.  mask: uint8 buffer of
+    workspace_bytes(ME_WS_RELU_MASK, M, N, K, dtype) bytes (0 bytes = shape not served: use gemm_nt with the gate operand)."""
+    dtype = dtype or A.dtype
+    M = A.shape[0] if M is None else M
+    K = A.shape[1] if K is None else K
+    N = B.shape[0] if N is None else N
+    check(lib().me_gemm_nt_relu_mask(_ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(C), C.stride(0), _ptr(bias), _ptr(mask),
+                                     M, N, K, 1 if backward else 0, _code(dtype), _stream()), "me_gemm_nt_relu_mask")
 
 
 def workspace_bytes(op, M, N, K, dtype):

@@ -1093,6 +1093,53 @@ def test_rga_bwd_bidirectional(ops, dtype, B, H, L, dh, M):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (777, 1024, 512), (2050, 2048, 512), (1024, 192, 128), (32768, 2048, 512)])
+def test_gemm_nt_relu_mask_equals_the_gate_operand(ops, M, N, K):
+    """me_gemm_nt_relu_mask (round 5): the FFN_pre forward leaves the ReLU's sign pattern as a bit mask and the FFN_suf dgrad
+    applies it -- both launches must agree BIT for bit with me_gemm_nt (ME_EPI_RELU / gate = the activations + ME_EPI_RELU_BWD),
+    ragged M included; the padding columns of C stay untouched; shapes the 256-tile kernel does not serve answer 0 bytes."""
+    dtype = torch.bfloat16
+    nbytes = ops.workspace_bytes(ops.ME_WS_RELU_MASK, M, N, K, dtype)
+    if N % 64:
+        assert nbytes == 0
+        return
+    assert nbytes == ((M + 255) // 256) * 32 * (N // 64) * 64
+    A = rnd(M, K, seed=41).to(dtype).to(DEV)
+    W1 = rnd(N, K, seed=42).to(dtype).to(DEV)
+    bias = rnd(N, seed=43).float().to(DEV)
+    ld = N + 16
+    hid_ref = torch.full((M, ld), float("nan"), dtype=dtype, device=DEV)
+    ops.gemm_nt(A, W1, hid_ref, bias=bias, flags=ops.ME_EPI_RELU, N=N)
+    hid = torch.full((M, ld), float("nan"), dtype=dtype, device=DEV)
+    mask = torch.full((nbytes,), 0xA5, dtype=torch.uint8, device=DEV)
+    ops.gemm_nt_relu_mask(A, W1, hid, mask, bias=bias, N=N)
+    assert torch.equal(hid[:, :N].view(torch.int16), hid_ref[:, :N].view(torch.int16)) and torch.isnan(hid[:, N:]).all()
+    assert 0.2 < float((hid_ref[:, :N] > 0).float().mean()) < 0.8           # the mask has both values to get wrong
+    # backward: dhid = (dC . W2T^T) where hid > 0
+    dC = rnd(M, K, seed=44).to(dtype).to(DEV)
+    W2T = rnd(N, K, seed=45).to(dtype).to(DEV)
+    d_ref = torch.full((M, ld), float("nan"), dtype=dtype, device=DEV)
+    ops.gemm_nt(dC, W2T, d_ref, gate=hid_ref, flags=ops.ME_EPI_RELU_BWD, N=N)
+    d = torch.full((M, ld), float("nan"), dtype=dtype, device=DEV)
+    ops.gemm_nt_relu_mask(dC, W2T, d, mask, N=N, backward=True)
+    assert torch.equal(d[:, :N].view(torch.int16), d_ref[:, :N].view(torch.int16)) and torch.isnan(d[:, N:]).all()
+    assert relerr(d[:, :N], (dC.double() @ W2T.double().t()).cpu() * (hid_ref[:, :N] > 0).cpu().double()) < 6e-3
+
+
+@pytest.mark.gpu
+def test_gemm_nt_relu_mask_refuses_what_it_does_not_serve(ops):
+    dtype = torch.bfloat16
+    assert ops.workspace_bytes(ops.ME_WS_RELU_MASK, 4096, 1007, 512, dtype) == 0            # N % 64
+    assert ops.workspace_bytes(ops.ME_WS_RELU_MASK, 128, 2048, 512, dtype) == 0             # below the 256-tile kernel's shapes
+    assert ops.workspace_bytes(ops.ME_WS_RELU_MASK, 4096, 2048, 512, torch.float32) == 0    # f32 tier keeps the gate
+    A, W = rnd(128, 512, seed=1).to(dtype).to(DEV), rnd(2048, 512, seed=2).to(dtype).to(DEV)
+    C = torch.empty(128, 2048, dtype=dtype, device=DEV)
+    mask = torch.zeros(1 << 16, dtype=torch.uint8, device=DEV)
+    with pytest.raises(RuntimeError):
+        ops.gemm_nt_relu_mask(A, W, C, mask)
+
+
+@pytest.mark.gpu
 def test_gemm_nt_main_loops_bit_identical():
     """The main loops of the 256-tile NT kernel (MIDIEMO_NT_MAINLOOP = 0 register-staged / 1 ping-pong + direct-to-LDS feed /
     2 hand-scheduled 4-wave loop / 3 the default mix of 0 and 2) accumulate every output element in the same k order: 66 cases (ragged M / N, persistent multi-tile walks, every write-out
