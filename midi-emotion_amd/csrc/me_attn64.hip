@@ -25,7 +25,7 @@ constexpr int LDR = 68;                        // G ring row (floats): 64-column
 constexpr int K_BYTES = 64 * LDK * 2;          // 9216
 constexpr int V_BYTES = 64 * LDV * 2;          // 12288
 constexpr int G_BYTES = 32 * LDR * 4;          // 8704 per wave
-constexpr int FWD_LDS = 2 * K_BYTES + 2 * V_BYTES + 4 * G_BYTES;                   // 77824
+constexpr int fwd_lds(int nw) { return 2 * K_BYTES + 2 * V_BYTES + nw * G_BYTES; }  // 4 waves: 77824, 8 waves: 112640
 
 // =====================================================================================
 // forward
@@ -36,20 +36,24 @@ constexpr int FWD_LDS = 2 * K_BYTES + 2 * V_BYTES + 4 * G_BYTES;                
 // MAIN steps (all four waves strictly below their diagonal in both tiles, no padded key in the sequence, the tiles of
 // step s + 2 entirely below L) contain no branch around a memory instruction and no per-element predicate; everything
 // else (diagonal tiles, ragged ends, pad masks) runs the general per-tile path.
-template <bool STORE_P>
-__global__ __launch_bounds__(256, 2) void rga_fwd64_kernel(const T* __restrict__ qkv, const T* __restrict__ Epk,
+// NW = waves per block: 4 (128 queries, two blocks per CU) or 8 (256 queries, one block per CU: every K / V tile is fetched
+// from L2 once per 256 queries -- round 5; measured, see profiles/r05_attn_qb256.txt)
+template <bool STORE_P, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void rga_fwd64_kernel(const T* __restrict__ qkv, const T* __restrict__ Epk,
                                                         const uint8_t* __restrict__ key_pad, T* __restrict__ out,
                                                         float* __restrict__ lse, T* __restrict__ PT, float* __restrict__ MT,
                                                         int B, int L, int Lp, int H, int M, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // the rings first: their 8 + 4 loop-invariant lane addresses then need no base constant (ds_read2_b32 offsets reach 1 KB)
-    float* const Gsm = reinterpret_cast<float*>(smem);                                   // [4][32 * LDR]
-    T* const Vsm = reinterpret_cast<T*>(smem + 4 * G_BYTES);                             // [2][64 * LDV]
-    T* const Ksm = reinterpret_cast<T*>(smem + 4 * G_BYTES + 2 * V_BYTES);               // [2][64 * LDK]
+    float* const Gsm = reinterpret_cast<float*>(smem);                                   // [NW][32 * LDR]
+    T* const Vsm = reinterpret_cast<T*>(smem + NW * G_BYTES);                            // [2][64 * LDV]
+    T* const Ksm = reinterpret_cast<T*>(smem + NW * G_BYTES + 2 * V_BYTES);              // [2][64 * LDK]
+    constexpr int QB = 32 * NW;                                                          // queries per block
+    constexpr int NI = 8 / NW;                                                           // 16-byte chunks per thread, operand and step
 
     const int tid = threadIdx.x, lane = tid & 63, a = lane & 31, h = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int BH = B * H, nqb = (L + 127) / 128;
+    const int BH = B * H, nqb = (L + QB - 1) / QB;
     const int bh = blockIdx.x % BH, qb = nqb - 1 - (int)(blockIdx.x / BH);             // heavy q-blocks first
     const int b = bh / H, head = bh % H;
     const int dm = H * DH;
@@ -57,19 +61,19 @@ __global__ __launch_bounds__(256, 2) void rga_fwd64_kernel(const T* __restrict__
     const T* qb_ = qkv + (size_t)b * L * ldq + head * DH;
     const T* kb_ = qb_ + dm;
     const T* vb_ = qb_ + 2 * dm;
-    const int q0 = qb * 128 + wid * 32;
+    const int q0 = qb * QB + wid * 32;
     const int q = q0 + a;
     const bool wave_on = q0 < L;
-    const int nkt = min((L + 31) / 32, qb * 4 + 4);
+    const int nkt = min((L + 31) / 32, qb * NW + NW);
     const int nst = (nkt + 1) >> 1;
-    const int my_last_kt = qb * 4 + wid;                  // diagonal tile of this wave
+    const int my_last_kt = qb * NW + wid;                 // diagonal tile of this wave
     const float c2 = scale * 1.4426950408889634f;         // logits are kept in log2 units
     const int nE = M >> 5;
 
     // ---- K / V tile stream: 64 rows x 128 B per operand and step = two 16-byte chunks per thread.  The pad flags of the
     // step's 64 keys travel with it: EVERY wave loads all 64 of them (one byte per lane), so the step's pad mask is a
     // wave-local ballot -- no scan of the sequence, no LDS flags, no block-wide reduction.
-    chunk16 rk[2], rv[2];
+    chunk16 rk[NI], rv[NI];
     uint32_t rp = 0;
     const int lrow = tid >> 3, lcc = (tid & 7) * 8;
     const uint8_t* kp_ = key_pad ? key_pad + (size_t)b * L : reinterpret_cast<const uint8_t*>(qkv);     // valid dummy when there is no mask
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void rga_fwd64_kernel(const T* __restrict__
     auto gload = [&](int s) __attribute__((always_inline)) {            // rows past L are zeros
         const int k0 = s * 64;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int row = k0 + lrow + 32 * i;
             rk[i] = row < L ? ld_chunk(kb_ + (size_t)row * ldq + lcc) : zero_chunk();
             rv[i] = row < L ? ld_chunk(vb_ + (size_t)row * ldq + lcc) : zero_chunk();
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void rga_fwd64_kernel(const T* __restrict__
         const T* kp2 = kb_ + (size_t)(s * 64 + lrow) * ldq + lcc;
         const T* vp2 = vb_ + (size_t)(s * 64 + lrow) * ldq + lcc;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NI; ++i) {
             rk[i] = ld_chunk(kp2 + (size_t)(32 * i) * ldq);
             rv[i] = ld_chunk(vp2 + (size_t)(32 * i) * ldq);
         }
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void rga_fwd64_kernel(const T* __restrict__
         T* kd = Ksm + buf * (64 * LDK) + lrow * LDK + lcc;
         T* vd = Vsm + buf * (64 * LDV) + lrow * LDV + lcc;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NI; ++i) {
             st_chunk(kd + 32 * i * LDK, rk[i]);
             st_chunk(vd + 32 * i * LDV, rv[i]);
         }
@@ -375,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void rga_fwd64_kernel(const T* __restrict__
 
     // MAIN: s < 2 qb (both tiles strictly below every wave's diagonal), all four waves on, tiles of step s + 2 whole,
     // no padded key among the step's 64 (the loop ends at the first step that has one)
-    const int nmain = (qb * 128 + 96 < L) ? max(0, min(2 * qb, (L >> 6) - 2)) : 0;
+    const int nmain = (qb * QB + QB - 32 < L) ? max(0, min((NW / 2) * qb, (L >> 6) - 2)) : 0;
     int s = 0;
     vm_drain();
     for (; s < nmain && pb_cur == 0ull; ++s) { step_main(s); pb_cur = pb_nxt; }
@@ -414,22 +418,31 @@ static void set_lds_limit(const void* fn, int bytes, bool* done) {
     done[dev] = true;
 }
 
-int fwd_launch(const void* qkv, const void* Epk, const uint8_t* key_pad, void* out, float* lse, void* PT, float* MT, int B,
-               int L, int H, int M, hipStream_t st) {
-    const int nqb = (L + 127) / 128, Lp = ((L + 31) / 32) * 32;
+static const bool g_qb256 = getenv("MIDIEMO_ATTN_QB256") != nullptr;      // 256-query forward blocks (A/B switch; default off)
+
+template <int NW>
+static int fwd_launch_nw(const void* qkv, const void* Epk, const uint8_t* key_pad, void* out, float* lse, void* PT, float* MT, int B,
+                         int L, int H, int M, hipStream_t st) {
+    const int nqb = (L + 32 * NW - 1) / (32 * NW), Lp = ((L + 31) / 32) * 32;
     const float scale = 1.f / sqrtf((float)DH);
     const dim3 grid(B * H * nqb);
     static bool done_t[16] = {false}, done_i[16] = {false};
     if (PT) {
-        set_lds_limit((const void*)rga_fwd64_kernel<true>, FWD_LDS, done_t);
-        rga_fwd64_kernel<true><<<grid, 256, FWD_LDS, st>>>((const T*)qkv, (const T*)Epk, key_pad, (T*)out, lse, (T*)PT, MT, B, L, Lp,
-                                                          H, M, scale);
+        set_lds_limit((const void*)rga_fwd64_kernel<true, NW>, fwd_lds(NW), done_t);
+        rga_fwd64_kernel<true, NW><<<grid, 64 * NW, fwd_lds(NW), st>>>((const T*)qkv, (const T*)Epk, key_pad, (T*)out, lse, (T*)PT, MT, B, L,
+                                                                       Lp, H, M, scale);
     } else {
-        set_lds_limit((const void*)rga_fwd64_kernel<false>, FWD_LDS, done_i);
-        rga_fwd64_kernel<false><<<grid, 256, FWD_LDS, st>>>((const T*)qkv, (const T*)Epk, key_pad, (T*)out, lse, nullptr, nullptr, B,
-                                                           L, Lp, H, M, scale);
+        set_lds_limit((const void*)rga_fwd64_kernel<false, NW>, fwd_lds(NW), done_i);
+        rga_fwd64_kernel<false, NW><<<grid, 64 * NW, fwd_lds(NW), st>>>((const T*)qkv, (const T*)Epk, key_pad, (T*)out, lse, nullptr, nullptr,
+                                                                        B, L, Lp, H, M, scale);
     }
     return me_launch_status();
+}
+
+int fwd_launch(const void* qkv, const void* Epk, const uint8_t* key_pad, void* out, float* lse, void* PT, float* MT, int B,
+               int L, int H, int M, hipStream_t st) {
+    if (g_qb256) return fwd_launch_nw<8>(qkv, Epk, key_pad, out, lse, PT, MT, B, L, H, M, st);
+    return fwd_launch_nw<4>(qkv, Epk, key_pad, out, lse, PT, MT, B, L, H, M, st);
 }
 
 }  // namespace me_attn64
