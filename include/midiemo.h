@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 20
+#define ME_ABI_VERSION 21
 #define ME_DEC_PART_REC(dh) ((dh) + 4)      /* floats per attention partial of the decode step (me_dec_attn) */
 #define ME_SUMSQ_WS_BYTES 1040   /* me_sumsq workspace: ticket counter + 256 block sums + padding */
 
@@ -244,6 +244,16 @@ int me_rga_pack_rel(const void* E, void* Epk, int M, int dh, int dtype, void* st
 int me_rga_bwd(const void* qkv, const void* Epk, const void* out, const float* lse, const void* dout,
                void* dqkv, float* dE, float* delta_ws, const void* PT, const float* MT, void* dGT,
                int B, int L, int Lp, int H, int dh, int M, int causal, int dtype, void* stream);
+
+/* The same backward, kernel by kernel.  phases: bit 0 = query-owned kernel (dQ part of dqkv, delta_ws, dGT), bit 1 =
+ * key-owned kernel (dK, dV parts of dqkv; needs delta_ws), bit 2 = E-row-owned kernel (dE += ; needs dGT), bit 3 = delta_ws
+ * alone (a small launch of its own), bit 4 = the query-owned kernel leaves delta_ws alone (bit 3 wrote it).  Within one
+ * call the selected kernels run in the order 3, 0, 1, 2.  The kernels of bits 1 and 2 do not depend on each other, and
+ * after bit 3 neither do those of bits 0 and 1: a caller that owns two streams may enqueue them side by side (its own events
+ * order them; the library never synchronises).  phases = 7 on one stream is me_rga_bwd. */
+int me_rga_bwd_phases(const void* qkv, const void* Epk, const void* out, const float* lse, const void* dout,
+                      void* dqkv, float* dE, float* delta_ws, const void* PT, const float* MT, void* dGT,
+                      int B, int L, int Lp, int H, int dh, int M, int causal, int phases, int dtype, void* stream);
 
 /* ---- residual + dropout + LayerNorm (post-LN, eps) ---------------------------
  *   s = x + dropout(a) ;  y = LN(s) * gamma + beta          (music_multi.py:128-129,133-134)

@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256, BQ_OCC) void rga_bwd_q_kernel(
 #pragma unroll
         for (int e = 0; e < 8; ++e) delta += frag_get(dof[kk], e) * frag_get(oof[kk], e);
     delta = half_sum(delta);
-    if (row_on && h == 0) delta_ws[((size_t)b * H + head) * L + q] = delta;
+    if (delta_ws && row_on && h == 0) delta_ws[((size_t)b * H + head) * L + q] = delta;
     tile_sstore<T, 32, DH, C::LDV>(rk0, Ks[0], tid);
     tile_sstore<T, 32, DH, C::LDN>(rv0, Vs[0], tid);
     if constexpr (ERING) {
@@ -558,6 +558,32 @@ __global__ __launch_bounds__(256, BQ_OCC) void rga_bwd_q_kernel(
             if (i * 32 + 8 * gq + 4 * h < DH)
                 st4<T>(dqp + i * 32 + 8 * gq + 4 * h, dq[i][4 * gq], dq[i][4 * gq + 1], dq[i][4 * gq + 2], dq[i][4 * gq + 3]);
 
+}
+
+// delta[b, head, q] = sum_d dO[q][d] O[q][d] alone -- the query-owned kernel's own prologue computation (same lanes, same
+// order of the multiply-adds), as a separate launch: with delta in memory first, the key-owned kernel no longer depends
+// on the query-owned one and a caller with two streams can run the two side by side (me_rga_bwd_phases, bit 3).
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void rga_delta_kernel(const T* __restrict__ out, const T* __restrict__ dout, float* __restrict__ delta_ws,
+                                                        int B, int L, int H) {
+    using C = ACfg<T, DH>;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, a = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.x % (B * H), qb = blockIdx.x / (B * H);
+    const int b = bh / H, head = bh % H;
+    const int dm = H * DH;
+    const int q = qb * 128 + wid * 32 + a;
+    const bool row_on = q < L;
+    const size_t orow = ((size_t)b * L + q) * dm + head * DH;
+    Frag<T> dof[C::KA], oof[C::KA];
+    row_frags<T, DH>(dof, dout + orow, row_on, h);
+    row_frags<T, DH>(oof, out + orow, row_on, h);
+    float delta = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < C::KA; ++kk)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) delta += frag_get(dof[kk], e) * frag_get(oof[kk], e);
+    delta = half_sum(delta);
+    if (row_on && h == 0) delta_ws[((size_t)b * H + head) * L + q] = delta;
 }
 
 // =====================================================================================
@@ -920,21 +946,35 @@ int fwd_launch(const void* qkv, const void* Epk, const uint8_t* key_pad, void* o
 template <typename T, int DH>
 int bwd_launch(const void* qkv, const void* Epk, const void* out, const float* lse, const void* dout, void* dqkv, float* dE,
                float* delta_ws, const void* PT, const float* MT, void* dGT, int B, int L, int Lp, int H, int M, int causal,
-               hipStream_t st) {
+               hipStream_t st, int phases = 7) {
+    // phases (me_rga_bwd_phases): bit 0 = query-owned kernel (dQ, delta, dG^T), bit 1 = key-owned kernel (dK, dV; needs delta),
+    // bit 2 = E-row-owned kernel (dE; needs dG^T), bit 3 = delta alone (rga_delta_kernel), bit 4 = the query-owned kernel does not
+    // write delta (bit 3 did).  The kernels of bits 1 and 2 are independent of each other, and with bit 3 first the kernels of
+    // bits 0 and 1 are too: a caller with two streams may run them side by side (ops.rga_bwd).
     // One launch of each kernel over the whole batch.  Splitting the batch so that a chunk's probability / dG^T tiles
     // stay in the 256 MB Infinity Cache between the three kernels was measured and is slower (B = 32 in chunks of
     // 16 / 8 / 4: 449 / 524 / 898 us against 424 us): these kernels are latency bound, not HBM bound, and smaller
     // launches leave CUs idle.
     const int nqb = (L + 127) / 128;
     const float scale = 1.f / sqrtf((float)DH);
+    int rc = 0;
+    if (phases & 8) {
+        rga_delta_kernel<T, DH><<<B * H * nqb, 256, 0, st>>>((const T*)out, (const T*)dout, delta_ws, B, L, H);
+        rc = me_launch_status();
+        if (rc) return rc;
+    }
+    float* const delta_q = (phases & 16) ? nullptr : delta_ws;          // bit 4: delta_ws is already in memory (bit 3 ran): leave it alone
+    if (phases & 1) {
     if (causal)
         rga_bwd_q_kernel<T, DH, true><<<B * H * nqb, 256, 0, st>>>((const T*)qkv, (const T*)Epk, (const T*)out, lse, (const T*)dout,
-                                                                  (T*)dqkv, delta_ws, (const T*)PT, MT, (T*)dGT, B, L, Lp, H, M, scale);
+                                                                  (T*)dqkv, delta_q, (const T*)PT, MT, (T*)dGT, B, L, Lp, H, M, scale);
     else
         rga_bwd_q_kernel<T, DH, false><<<B * H * nqb, 256, 0, st>>>((const T*)qkv, (const T*)Epk, (const T*)out, lse, (const T*)dout,
-                                                                   (T*)dqkv, delta_ws, (const T*)PT, MT, (T*)dGT, B, L, Lp, H, M, scale);
-    int rc = me_launch_status();
+                                                                   (T*)dqkv, delta_q, (const T*)PT, MT, (T*)dGT, B, L, Lp, H, M, scale);
+    rc = me_launch_status();
     if (rc) return rc;
+    }
+    if (phases & 2) {
     if (causal)
         rga_bwd_kv_kernel<T, DH, true><<<B * H * nqb, 256, 0, st>>>((const T*)PT, MT, (const T*)qkv, (const T*)dout, lse, delta_ws,
                                                                    (T*)dqkv, B, L, Lp, H, scale);
@@ -943,6 +983,8 @@ int bwd_launch(const void* qkv, const void* Epk, const void* out, const float* l
                                                                     (T*)dqkv, B, L, Lp, H, scale);
     rc = me_launch_status();
     if (rc) return rc;
+    }
+    if (!(phases & 4)) return rc;
     const int ngx = (Lp + 127) / 128;
     // grid sweep at C2 (us per launch, round 2 kernel): 768: 85.8, 1024: 90.8, 1280: 82.5, 1536: 85.4, 2048: 85.2, 4096: 85.9 -- flat:
     // the launch is bound by the per-step latency chain (Q slab -> LDS -> barrier -> transpose reads -> 4 MFMAs), not by the tail
@@ -999,6 +1041,19 @@ int me_rga_bwd(const void* qkv, const void* Epk, const void* out, const float* l
         return ME_ERR_ALIGNMENT;
     hipStream_t st = (hipStream_t)stream;
     ME_ATTN_DISPATCH((bwd_launch<T, DH>(qkv, Epk, out, lse, dout, dqkv, dE, delta_ws, PT, MT, dGT, B, L, Lp, H, M, causal, st)))
+}
+
+int me_rga_bwd_phases(const void* qkv, const void* Epk, const void* out, const float* lse, const void* dout, void* dqkv, float* dE,
+                      float* delta_ws, const void* PT, const float* MT, void* dGT, int B, int L, int Lp, int H, int dh, int M,
+                      int causal, int phases, int dtype, void* stream) {
+    me_clear_error();
+    if (!qkv || !Epk || !out || !lse || !dout || !dqkv || !dE || !delta_ws || !PT || !MT || !dGT) return ME_ERR_NULL;
+    if (B <= 0 || L <= 0 || H <= 0 || L > M || (M & 31) || Lp != ((L + 31) / 32) * 32 || Lp > M || phases < 1 || phases > 31) return ME_ERR_BAD_SHAPE;
+    if (!aligned16(qkv) || !aligned16(Epk) || !aligned16(out) || !aligned16(dout) || !aligned16(dqkv) ||
+        !aligned16(PT) || !aligned16(dGT))
+        return ME_ERR_ALIGNMENT;
+    hipStream_t st = (hipStream_t)stream;
+    ME_ATTN_DISPATCH((bwd_launch<T, DH>(qkv, Epk, out, lse, dout, dqkv, dE, delta_ws, PT, MT, dGT, B, L, Lp, H, M, causal, st, phases)))
 }
 
 }  // extern "C"

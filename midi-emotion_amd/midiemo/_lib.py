@@ -14,7 +14,7 @@ ME_COND_NONE, ME_COND_CONCAT, ME_COND_TOKEN = 0, 1, 2
 ME_EPI_RELU, ME_EPI_OUT_F32, ME_EPI_RELU_BWD = 1, 2, 4
 ME_WS_GEMM_TN, ME_WS_RGA_PT, ME_WS_RGA_DGT, ME_WS_RGA_MT, ME_WS_GEMM_TN_GROUP, ME_WS_EMBED_BWD, ME_WS_SUMSQ, ME_WS_RELU_MASK = 1, 2, 3, 4, 5, 6, 7, 8
 ME_TN_MAX_GROUP = 5
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 ERRORS = {0: "ME_OK", -1: "ME_ERR_BAD_DTYPE", -2: "ME_ERR_BAD_SHAPE", -3: "ME_ERR_ALIGNMENT",
           -4: "ME_ERR_LAUNCH", -5: "ME_ERR_NULL", -6: "ME_ERR_WORKSPACE"}
@@ -38,6 +38,7 @@ SIGNATURES = {
     "me_rga_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "me_rga_pack_rel": [_p, _p, _i, _i, _i, _p],
     "me_rga_bwd": [_p] * 11 + [_i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "me_rga_bwd_phases": [_p] * 11 + [_i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "me_resid_ln_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _f, _u64, _u32, _i, _p],
     "me_resid_ln_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _u64, _u32, _i, _p],
     "me_ce_fwd": [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p],

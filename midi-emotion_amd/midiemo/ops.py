@@ -3,6 +3,8 @@
 Every wrapper takes torch CUDA tensors, passes raw device pointers and the
 current HIP stream, and raises RuntimeError on any non-zero status.  Nothing
 here computes on the host."""
+import ctypes
+
 import torch
 
 from . import _lib
@@ -190,15 +192,55 @@ def rga_bwd_workspace(B, H, L, dtype, device):
     return torch.empty(workspace_bytes(ME_WS_RGA_DGT, B * H, Lp, 0, dtype) // es, dtype=dtype, device=device)
 
 
-def rga_bwd(qkv, Epk, out, lse, dout, dqkv, dE, delta_ws, PT, MT, dGT, B, L, Lp, H, dh, M, causal=True):
+_side = {}
+
+
+def _side_stream(device):
+    """second stream + two events per device for rga_bwd(overlap=True) (created once; the library itself owns no stream)."""
+    key = torch.device(device).index or 0
+    if key not in _side:
+        _side[key] = (torch.cuda.Stream(device=device), torch.cuda.Event(), torch.cuda.Event())
+    return _side[key]
+
+
+def rga_bwd(qkv, Epk, out, lse, dout, dqkv, dE, delta_ws, PT, MT, dGT, B, L, Lp, H, dh, M, causal=True, overlap=False):
+    """overlap=True: the key-owned kernel (dK, dV) stays on the current stream, the E-row-owned kernel (dE) runs beside it on a
+    second stream (me_rga_bwd_phases; both only depend on the query-owned kernel); the current stream then waits for it."""
     es = PT.element_size()
     if (PT.numel() * es < workspace_bytes(ME_WS_RGA_PT, B * H, Lp, 1 if causal else 0, qkv.dtype) or
             MT.numel() * 4 < workspace_bytes(ME_WS_RGA_MT, B * H, Lp, 0, qkv.dtype) or
             dGT.numel() * es < workspace_bytes(ME_WS_RGA_DGT, B * H, Lp, 0, qkv.dtype)):
         raise RuntimeError("rga_bwd: PT / MT / dGT smaller than me_workspace_bytes")
-    check(lib().me_rga_bwd(_ptr(qkv), _ptr(Epk), _ptr(out), _ptr(lse), _ptr(dout), _ptr(dqkv), _ptr(dE), _ptr(delta_ws),
-                           _ptr(PT), _ptr(MT), _ptr(dGT), B, L, Lp, H, dh, M, 1 if causal else 0, _code(qkv.dtype), _stream()),
-          "me_rga_bwd")
+    if not overlap:
+        check(lib().me_rga_bwd(_ptr(qkv), _ptr(Epk), _ptr(out), _ptr(lse), _ptr(dout), _ptr(dqkv), _ptr(dE), _ptr(delta_ws),
+                               _ptr(PT), _ptr(MT), _ptr(dGT), B, L, Lp, H, dh, M, 1 if causal else 0, _code(qkv.dtype), _stream()),
+              "me_rga_bwd")
+        return
+    side, ev_q, ev_e = _side_stream(qkv.device)
+    main = torch.cuda.current_stream(qkv.device)
+
+    def phase(bits, stream):
+        check(lib().me_rga_bwd_phases(_ptr(qkv), _ptr(Epk), _ptr(out), _ptr(lse), _ptr(dout), _ptr(dqkv), _ptr(dE), _ptr(delta_ws),
+                                      _ptr(PT), _ptr(MT), _ptr(dGT), B, L, Lp, H, dh, M, 1 if causal else 0, bits, _code(qkv.dtype),
+                                      ctypes.c_void_p(stream.cuda_stream)), "me_rga_bwd_phases")
+    if overlap == 2:
+        # delta first, then the key-owned kernel on the second stream beside the query-owned and the E-row-owned ones
+        phase(8, main)
+        ev_q.record(main)
+        side.wait_event(ev_q)
+        phase(2, side)
+        ev_e.record(side)
+        phase(1 | 16, main)
+        phase(4, main)
+        main.wait_event(ev_e)
+        return
+    phase(1, main)
+    ev_q.record(main)
+    side.wait_event(ev_q)
+    phase(4, side)                  # dE first: the short streaming kernel gets its blocks in beside the long one
+    ev_e.record(side)
+    phase(2, main)
+    main.wait_event(ev_e)
 
 
 def resid_ln_fwd(x, a, gamma, beta, y, s_out, stats, rows, d, eps, p, seed, site, x_lo=None, y_lo=None):

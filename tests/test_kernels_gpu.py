@@ -1093,6 +1093,42 @@ def test_rga_bwd_bidirectional(ops, dtype, B, H, L, dh, M):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype,B,H,L,dh", [(torch.bfloat16, 4, 8, 1024, 64), (torch.bfloat16, 2, 2, 300, 64), (torch.float32, 2, 2, 200, 32)])
+def test_rga_bwd_phases_on_two_streams_equal_the_single_call(ops, dtype, B, H, L, dh):
+    """me_rga_bwd_phases (round 5): the backward kernel by kernel.  (1) key-owned and E-row-owned kernels side by side on two
+    streams, (2) delta as its own launch and the key-owned kernel beside the query-owned one -- dQ / dK / dV must be BIT-identical
+    to me_rga_bwd (every element has one writer and the same arithmetic), dE equal up to the order of its f32 atomics."""
+    M = 2048
+    Lp = ((L + 31) // 32) * 32
+    g = torch.Generator().manual_seed(5)
+    qkv = (torch.randn(B, L, 3, H, dh, generator=g) * 0.7).to(dtype).to(DEV)
+    E = (torch.randn(M, dh, generator=g) * 0.5).to(dtype).to(DEV)
+    dout = torch.randn(B, L, H, dh, generator=g).to(dtype).to(DEV)
+    kp = torch.zeros(B, L, dtype=torch.uint8, device=DEV)
+    kp[0, L - 7:] = 1
+    Epk = ops.rga_pack_rel(E)
+    out = torch.empty(B, L, H, dh, device=DEV, dtype=dtype)
+    lse = torch.empty(B, H, L, device=DEV)
+    PT, MT = ops.rga_saved_buffers(B, H, L, dtype, DEV)
+    dGT = ops.rga_bwd_workspace(B, H, L, dtype, DEV)
+    ops.rga_fwd(qkv, Epk, kp, out, lse, B, L, H, dh, M, PT=PT, MT=MT)
+    res = {}
+    for ov in (False, True, 2):
+        dqkv = torch.full_like(qkv, float("nan"))
+        dE = torch.zeros(M, dh, device=DEV)
+        delta = torch.full((B, H, L), float("nan"), device=DEV)
+        ops.rga_bwd(qkv, Epk, out, lse, dout, dqkv, dE, delta, PT, MT, dGT, B, L, Lp, H, dh, M, overlap=ov)
+        torch.cuda.synchronize()
+        res[ov] = (dqkv, dE, delta)
+    it = torch.int16 if dtype == torch.bfloat16 else torch.int32
+    for ov in (True, 2):
+        assert torch.equal(res[ov][0].view(it), res[False][0].view(it)), ov
+        assert torch.equal(res[ov][2], res[False][2]), ov                      # delta: same lanes, same order of the multiply-adds
+        assert float((res[ov][1] - res[False][1]).abs().max()) <= 2e-5 * float(res[False][1].abs().max()), ov
+    assert torch.isfinite(res[False][0]).all()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (777, 1024, 512), (2050, 2048, 512), (1024, 192, 128), (32768, 2048, 512)])
 def test_gemm_nt_relu_mask_equals_the_gate_operand(ops, M, N, K):
     """me_gemm_nt_relu_mask (round 5): the FFN_pre forward leaves the ReLU's sign pattern as a bit mask and the FFN_suf dgrad

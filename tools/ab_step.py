@@ -1,4 +1,4 @@
-"""Same-process, interleaved A/B of the whole train step (bench.py's workload) with and without the ReLU sign mask
+"""AB_WHAT=relu_mask (default) | attn_overlap.  Same-process, interleaved A/B of the whole train step (bench.py's workload) with and without the ReLU sign mask
 (MIDIEMO_NO_RELU_MASK is read when a workspace is created: the workspace cache is dropped between the arms).
 Median of per-step device times, ROUNDS rounds x STEPS steps per arm."""
 import os, sys
@@ -22,12 +22,17 @@ def step(i):
     opt.step()
     return loss
 ROUNDS, STEPS = 6, 12
-res = {"mask": [], "gate": []}
+WHAT = os.environ.get("AB_WHAT", "relu_mask")
+ARMS = ("gate", "mask") if WHAT == "relu_mask" else ("serial", "overlap")
+res = {a: [] for a in ARMS}
 for r in range(ROUNDS):
-    for arm in ("gate", "mask"):
-        if arm == "gate": os.environ["MIDIEMO_NO_RELU_MASK"] = "1"
-        else: os.environ.pop("MIDIEMO_NO_RELU_MASK", None)
-        model._ws.clear()
+    for arm in ARMS:
+        if WHAT == "relu_mask":
+            if arm == "gate": os.environ["MIDIEMO_NO_RELU_MASK"] = "1"
+            else: os.environ.pop("MIDIEMO_NO_RELU_MASK", None)
+            model._ws.clear()
+        else:
+            model.attn_bwd_overlap = arm == "overlap"
         for i in range(3): step(i)
         torch.cuda.synchronize()
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(STEPS + 1)]
