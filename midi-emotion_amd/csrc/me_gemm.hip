@@ -152,15 +152,15 @@ ME_DEV void nt256_write_tile(f32x16_t (&acc)[256 / WR / 32][256 / WC / 32], char
                 // lane's 16 mask bytes.  Pure per-lane arithmetic on the rounded bf16 halves: x > 0 <=> the half, as a signed
                 // 16-bit integer, is > 0 (the ReLU left no NaN) -> packed clamp to {0, 1}, the two bits of a dword side by side
                 typedef short i16x2_t __attribute__((ext_vector_type(2)));
-                uint32_t byte = 0;
+                uint32_t t = 0;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
                     const uint32_t dw = v.v[w];                          // (a bit_cast of the vector ELEMENT reads element 0: hipcc 7.2)
                     i16x2_t x = __builtin_bit_cast(i16x2_t, dw);
                     x = __builtin_elementwise_min(__builtin_elementwise_max(x, (i16x2_t){0, 0}), (i16x2_t){1, 1});
-                    const uint32_t u = __builtin_bit_cast(uint32_t, x);
-                    byte |= ((u | (u >> 15)) & 3u) << (2 * w);
+                    t |= __builtin_bit_cast(uint32_t, x) << (2 * w);     // even elements at bits 0 2 4 6, odd ones at 16 18 20 22
                 }
+                const uint32_t byte = (t | (t >> 15)) & 0xffu;
                 const int b = i * 4 + it, grp = ps % JP;
                 mreg[grp].v[b >> 2] |= byte << (8 * (b & 3));
             }
