@@ -589,12 +589,14 @@ def main():
             tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")
             if args.compute_dtype == "bf16" and (B, L) == (32, 1024) and os.path.exists(tj):
                 tjd = json.load(open(tj))
-                k = tjd.get("gemm_nt256_kernel") or tjd.get("gemm_nt256_kernel<false>")
+                # the NT family runs two kernels since round 5 (8-wave and hand-scheduled 4-wave main loop): launch-weighted mean
+                ks = [tjd[n_] for n_ in ("gemm_nt256_kernel", "gemm_nt256_kernel<false>", "gemm_nt4w_kernel") if n_ in tjd]
                 if tjd.get("_source_sha256") != source_hash():
                     traffic_note = "profiles/hbm_traffic.json was measured on other kernel sources (hash mismatch): not quoted"
-                elif k:
-                    traffic = int(round((k["read_MB"] + k["write_MB"]) * 1e6))
-                    traffic_note = "HBM bytes per launch (rocprofv3 PMC passes FETCH_SIZE x2 + WRITE_SIZE, %s)" % tjd.get("_profile", "profiles/")
+                elif ks:
+                    nl = sum(k["launches"] for k in ks)
+                    traffic = int(round(sum((k["read_MB"] + k["write_MB"]) * k["launches"] for k in ks) / nl * 1e6))
+                    traffic_note = "HBM bytes per launch, mean over the family's %d traced launches (rocprofv3 PMC passes FETCH_SIZE x2 + WRITE_SIZE, %s)" % (nl, tjd.get("_profile", "profiles/"))
             # achieved = algorithmic FLOPs of one step's launches / their back-to-back replay durations (two events around
             # >= 24 launches per call); the per-launch event pairs inside the live step are kept as `in_step_*`
             in_step_ms, in_step_n = ms, n
