@@ -28,10 +28,10 @@
  *   MIDIEMO_NO_NT256=1     bf16 NT GEMMs run the generic 128 x 128 kernel instead of the persistent 256 x 256 one
  *   MIDIEMO_NO_TN256=1     likewise for the weight-gradient (TN) GEMMs
  *   MIDIEMO_NT_MAINLOOP=0|1|2|3  main loop of the 256-tile NT GEMM; results are bit-identical across all four settings.
- *                          3 (default): the hand-scheduled 4-wave loop (gemm_nt4w_kernel) for launches with one tile per CU,
- *                          K >= 2048 and the plain / bias / gate write-out, the register-staged 8-wave loop otherwise
- *                          (profiles/r05_nt_4wave.txt); 0: 8-wave loop everywhere; 2: 4-wave loop wherever it is legal;
- *                          1: ping-pong / direct-to-LDS loop (gemm_nt8p_kernel, 4-9 % slower, profiles/r05_nt_mainloop.txt)
+ *                          0 (default): register-staged 8-wave loop; 2: hand-scheduled 4-wave loop (gemm_nt4w_kernel) wherever
+ *                          it is legal; 3: the 4-wave loop for one-tile-per-CU launches with K >= 2048 (6-12 % faster in a
+ *                          warm replay, 19 % slower inside the train step: profiles/r05_nt_4wave.txt); 1: ping-pong /
+ *                          direct-to-LDS loop (gemm_nt8p_kernel, 4-9 % slower, profiles/r05_nt_mainloop.txt)
  *   MIDIEMO_ATTN_V1=1      bf16 / head-dim-64 / causal attention runs the generic 32-key-step forward kernel
  *   MIDIEMO_DEC_CW=1|2|4, MIDIEMO_DEC_KS=0|1   column / K-split geometry of the decode GEMV kernels
  *   MIDIEMO_DEBUG=1        print the HIP error string when a launch fails

@@ -855,9 +855,9 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(
 // N512.K1536 49.9 -> 42.3, K = 512 shapes 20.1 / 52.5 / 67.8 -> 18.4 / 48.9 / 63.4.
 // Same slab images and swizzle, same k order per accumulator element as gemm_nt256_kernel: results are bit-identical.
 // The tile loop and the write-out stay C++ (nt256_write_tile with the 2 x 2 wave grid); no state crosses the write-out, every tile
-// runs its own prologue -- which is why this kernel only takes the launches with ONE tile per CU (see the launcher): in a
-// multi-tile launch the next tile's first loads queue behind the write-out's stores (vmcnt is in order), where the persistent
-// 8-wave kernel has them in flight before the write-out starts.  LDS: [A even 32 KB][A odd][B even][B odd][write-out staging 32 KB].
+// runs its own prologue: in a multi-tile launch the next tile's first loads queue behind the write-out's stores (vmcnt is in
+// order), where the persistent 8-wave kernel has them in flight before the write-out starts.  Opt-in (MIDIEMO_NT_MAINLOOP=2 / 3):
+// with operands that are not cache-warm the one-slab latency cover of this pipeline loses more than the loop gains (launcher).  LDS: [A even 32 KB][A odd][B even][B odd][write-out staging 32 KB].
 // ---------------------------------------------------------------------------------------------
 #include "me_gemm_nt4w.inc"
 template <bool OUT_F32, int EPI>
@@ -1621,16 +1621,18 @@ __global__ __launch_bounds__(256) void cast_transpose_multi_kernel(const me_ct_d
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static const bool g_disable_nt256 = getenv("MIDIEMO_NO_NT256") != nullptr;
-// main loop of the 256-tile NT kernel (results are bit-identical across all of them; MIDIEMO_NT_MAINLOOP overrides for A/B):
-//   0  register-staged single phase, 8 waves (gemm_nt256_kernel)
+// main loop of the 256-tile NT kernel (results are bit-identical across all of them; MIDIEMO_NT_MAINLOOP selects):
+//   0  (default) register-staged single phase, 8 waves (gemm_nt256_kernel)
 //   1  ping-pong / direct-to-LDS feed, 8 waves (gemm_nt8p_kernel; plain / bias / gate write-outs) -- measured 4-9 % slower
 //   2  hand-scheduled 4-wave loop (gemm_nt4w_kernel) wherever it is legal (K % 128 == 0, row write-outs)
-//   3  (default) measured choice: the 4-wave loop for launches with at most ONE tile per CU, K >= 2048 and the plain / bias /
-//      gate write-out (M32768.N512.K2048: plain 71.5 -> 62.9, bias 66.0 -> 61.9, gate 67.6 -> 62.5 us; M16384: 51.4 -> 45.3),
-//      gemm_nt256_kernel for everything else (K = 1024 draws level, multi-tile K = 512 launches run 8-22 % slower on the
-//      4-wave kernel, the residual-add write-out draws level; profiles/r05_nt_4wave.txt)
+//   3  the 4-wave loop for launches with at most ONE tile per CU, K >= 2048 and the plain / bias / gate write-out, the 8-wave
+//      kernel otherwise.  In a warm back-to-back replay those launches run 6-12 % faster on the 4-wave kernel (M32768.N512.K2048
+//      bias 66.0 -> 61.9 us); INSIDE the train step, where the 134 MB activation operand comes from HBM, they run 19 %
+//      slower (68.4 -> 81.4 us, tools/instep_nt_shapes.py): one wave per SIMD with one register stage covers one slab time
+//      (1.5 us) of load latency and nothing else runs on the SIMD while it waits.  Hence not the default
+//      (profiles/r05_nt_4wave.txt).
 #ifndef ME_NT_MAINLOOP_DEFAULT
-#define ME_NT_MAINLOOP_DEFAULT 3
+#define ME_NT_MAINLOOP_DEFAULT 0
 #endif
 static const int g_nt_mainloop = getenv("MIDIEMO_NT_MAINLOOP") ? atoi(getenv("MIDIEMO_NT_MAINLOOP")) : ME_NT_MAINLOOP_DEFAULT;
 
