@@ -1178,7 +1178,7 @@ def test_gemm_nt_relu_mask_refuses_what_it_does_not_serve(ops):
 @pytest.mark.gpu
 def test_gemm_nt_main_loops_bit_identical():
     """The main loops of the 256-tile NT kernel (MIDIEMO_NT_MAINLOOP = 0 register-staged / 1 ping-pong + direct-to-LDS feed /
-    2 hand-scheduled 4-wave loop / 3 the default mix of 0 and 2) accumulate every output element in the same k order: 66 cases (ragged M / N, persistent multi-tile walks, every write-out
+    2 hand-scheduled 4-wave loop / 3 the mix of 0 and 2 by launch shape) accumulate every output element in the same k order: 66 cases (ragged M / N, persistent multi-tile walks, every write-out
     path, f32 out) must agree bit for bit.  Each setting needs its own copy of the library (the switch is read once per load),
     so the comparison runs in a subprocess (tools/ab_nt_mainloop.py)."""
     import subprocess
