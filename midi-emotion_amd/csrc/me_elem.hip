@@ -1290,9 +1290,10 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
                                                      int32_t* __restrict__ n_choices, float* __restrict__ dbg_p,
                                                      int32_t* __restrict__ dbg_i, SampleStep st) {
     constexpr int EPT = NP / 256;
-    __shared__ float key[NP];
-    __shared__ int idx[NP];
-    __shared__ float part[256];
+    // key / idx double as the exchange buffer of the sort's three cross-wave stages (one 64-bit word per entry)
+    __shared__ unsigned long long xbuf[NP];
+    float* const key = reinterpret_cast<float*>(xbuf);
+    int* const idx = reinterpret_cast<int*>(xbuf) + NP;
     __shared__ float red[4];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, b = blockIdx.x;
     const float* lg = logits + (size_t)b * ld;
@@ -1302,6 +1303,21 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
         if (lane == 0) red[wid] = v;
         __syncthreads();
         return red[0] + red[1] + red[2] + red[3];
+    };
+    // inclusive prefix over the block's 256 threads: shuffle scan inside the wave, the three wave totals in front added in order
+    auto block_scan = [&](float v) -> float {
+        float x = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float y = __shfl_up(x, off);
+            if (lane >= off) x += y;
+        }
+        __syncthreads();
+        if (lane == 63) red[wid] = x;
+        __syncthreads();
+        float base = 0.f;
+        for (int w = 0; w < wid; ++w) base += red[w];
+        return x + base;
     };
     auto block_max = [&](float v) -> float {
         v = wave_max(v);
@@ -1343,19 +1359,69 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
     const float lse = mx + logf(se), inv_t = 1.f / row_temp;
     for (int j = tid; j < NP; j += 256) key[j] = (key[j] - lse) * inv_t;
     __syncthreads();
-    // ---- bitonic sort, descending by value, ascending index among equals
-    for (int k = 2; k <= NP; k <<= 1)
+    // ---- bitonic sort, descending by value, ascending index among equals -- in REGISTERS (round 5: the LDS version took a
+    // barrier per compare stage, 55 at NP = 1024, ~25 of the kernel's 33 us).  Thread tid owns entries tid EPT .. + EPT - 1; an entry
+    // is ONE 64-bit word (order-preserving image of the float << 32 | ~index: "greater word" = "earlier in the order", ties
+    // included), a stage with partner distance j < EPT is a compare-exchange inside the thread, j < 64 EPT a lane shuffle
+    // (partner lane ^ (j / EPT)), and only the last three stage groups (j >= 64 EPT: partner in another wave) go through LDS.
+    unsigned long long sv[EPT];
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int i = tid * EPT + q;
+        uint32_t bts = __float_as_uint(key[i] + 0.f);                       // + 0: one zero
+        bts ^= (bts >> 31) ? 0xffffffffu : 0x80000000u;
+        sv[q] = ((unsigned long long)bts << 32) | (uint32_t)(0xffffffffu - (uint32_t)i);
+    }
+    __syncthreads();                                                        // key / idx are free: the exchange buffer from here on
+#pragma unroll
+    for (int k = 2; k <= NP; k <<= 1) {
+#pragma unroll
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < NP / 2; t += 256) {
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p2 = i | j;
-                const bool desc = (i & k) == 0;
-                const float a = key[i], c = key[p2];
-                const int ia = idx[i], ic = idx[p2];
-                const bool a_first = a > c || (a == c && ia < ic);          // a belongs before c in descending order
-                if (a_first != desc) { key[i] = c; key[p2] = a; idx[i] = ic; idx[p2] = ia; }
+            if (j < EPT) {
+#pragma unroll
+                for (int q = 0; q < EPT; ++q) {
+                    if (q & j) continue;
+                    const bool desc = ((tid * EPT + q) & k) == 0;
+                    const unsigned long long a = sv[q], c = sv[q | j];
+                    const unsigned long long hi = a > c ? a : c, lo = a > c ? c : a;
+                    sv[q] = desc ? hi : lo;
+                    sv[q | j] = desc ? lo : hi;
+                }
+            } else {
+                unsigned long long ot[EPT];
+                if (j < 64 * EPT) {
+#pragma unroll
+                    for (int q = 0; q < EPT; ++q) {
+                        const uint32_t olo = (uint32_t)__shfl_xor((int)(uint32_t)sv[q], j / EPT);
+                        const uint32_t ohi = (uint32_t)__shfl_xor((int)(uint32_t)(sv[q] >> 32), j / EPT);
+                        ot[q] = ((unsigned long long)ohi << 32) | olo;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < EPT; ++q) xbuf[tid * EPT + q] = sv[q];
+                    __syncthreads();
+#pragma unroll
+                    for (int q = 0; q < EPT; ++q) ot[q] = xbuf[(tid ^ (j / EPT)) * EPT + q];
+                    __syncthreads();
+                }
+#pragma unroll
+                for (int q = 0; q < EPT; ++q) {
+                    const int i = tid * EPT + q;
+                    const bool keep_max = ((i & j) == 0) == ((i & k) == 0);   // the lower position of a descending pair keeps the greater word
+                    const bool mine_gt = sv[q] > ot[q];
+                    sv[q] = (keep_max == mine_gt) ? sv[q] : ot[q];
+                }
             }
-            __syncthreads();
         }
+    }
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        uint32_t bts = (uint32_t)(sv[q] >> 32);
+        bts ^= (bts >> 31) ? 0x80000000u : 0xffffffffu;
+        key[tid * EPT + q] = __uint_as_float(bts);
+        idx[tid * EPT + q] = (int)(0xffffffffu - (uint32_t)sv[q]);
+    }
+    __syncthreads();
     // ---- top-k, softmax over the kept head, nucleus cut
     const int k_eff = (top_k <= 0 || top_k > V) ? V : top_k;
     const float y0 = key[0];
@@ -1369,15 +1435,8 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
     }
     const float tot = block_sum(loc);
     // inclusive prefix of the chunk sums (each thread owns EPT consecutive sorted entries)
-    part[tid] = loc;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const float v = tid >= off ? part[tid - off] : 0.f;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    float run = (part[tid] - loc) / tot;
+    const float incl1 = block_scan(loc);
+    float run = (incl1 - loc) / tot;
     float loc2 = 0.f;
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
@@ -1389,17 +1448,9 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
     }
     const float tot2 = block_sum(loc2);
     // ---- renormalised CDF and inverse-CDF draw
-    __syncthreads();
-    part[tid] = loc2;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const float v = tid >= off ? part[tid - off] : 0.f;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
+    const float incl2 = block_scan(loc2);
     const float target = row_u * tot2;
-    float c0 = part[tid] - loc2;
+    float c0 = incl2 - loc2;
     int cnt = 0, pick = -1;
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
@@ -1415,10 +1466,17 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
     __shared__ int s_pick, s_cnt, s_last;
     if (tid == 0) { s_pick = 1 << 30; s_cnt = 0; s_last = 0; }
     __syncthreads();
-    if (pick >= 0) atomicMin(&s_pick, pick);
-    atomicAdd(&s_cnt, cnt);
+    // one LDS atomic of each kind per WAVE (a thousand atomicMax on one word cost ~8 us with every entry surviving)
+    int w_pick = pick >= 0 ? pick : (1 << 30), w_cnt = cnt, w_last = 0;
 #pragma unroll
-    for (int q = 0; q < EPT; ++q) if (e[q] > 0.f) atomicMax(&s_last, tid * EPT + q);
+    for (int q = 0; q < EPT; ++q) if (e[q] > 0.f) w_last = tid * EPT + q;      // ascending in q: the thread's last positive entry
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        w_pick = min(w_pick, __shfl_xor(w_pick, m));
+        w_cnt += __shfl_xor(w_cnt, m);
+        w_last = max(w_last, __shfl_xor(w_last, m));
+    }
+    if (lane == 0) { atomicMin(&s_pick, w_pick); atomicAdd(&s_cnt, w_cnt); atomicMax(&s_last, w_last); }
     __syncthreads();
     if (tid == 0) {
         const int pos = s_pick < (1 << 30) ? s_pick : s_last;
