@@ -33,6 +33,23 @@ def test_library_exports_every_declared_symbol():
         assert len(args) == len(_lib.SIGNATURES[name]), name
 
 
+def test_workspace_sizes_are_host_side_arithmetic():
+    """me_workspace_bytes is pure host code (no device needed): the caller-owned buffers of the entry points added in round 5.
+    ReLU sign mask: 1 bit per element, rows rounded up to 256; 0 = the shape / dtype keeps the gate operand."""
+    from midiemo import _lib
+    lib = _lib.load()
+    ws = lambda op, M, N, K, dt: int(lib.me_workspace_bytes(op, M, N, K, dt))
+    assert ws(_lib.ME_WS_RELU_MASK, 32768, 2048, 512, _lib.ME_BF16) == 32768 * 2048 // 8
+    assert ws(_lib.ME_WS_RELU_MASK, 777, 1024, 512, _lib.ME_BF16) == 1024 * 1024 // 8        # rows -> 1024
+    assert ws(_lib.ME_WS_RELU_MASK, 32768, 1007, 512, _lib.ME_BF16) == 0                     # N % 64
+    assert ws(_lib.ME_WS_RELU_MASK, 32768, 2048, 512, _lib.ME_F32) == 0                      # exact tier keeps the activations
+    assert ws(_lib.ME_WS_RELU_MASK, 128, 2048, 512, _lib.ME_BF16) == 0                       # below the 256-tile kernel
+    # attention tiles: packed causal triangle of 32 x 32 tiles per (batch, head)
+    nq = 1024 // 32
+    assert ws(_lib.ME_WS_RGA_PT, 256, 1024, 1, _lib.ME_BF16) == 256 * (nq * (nq + 1) // 2) * 1024 * 2
+    assert ws(_lib.ME_WS_RGA_DGT, 256, 1024, 0, _lib.ME_BF16) == 256 * (nq * (nq + 1) // 2) * 1024 * 2
+
+
 @pytest.mark.parametrize("mode", ["none", "discrete_token", "continuous_token", "continuous_concat"])
 def test_build_model_contract(mode):
     from midiemo.models.build_model import build_model
