@@ -95,6 +95,26 @@ ME_DEV void epi_block_swapped(const f32x16_t& acc, int row_base, int col_base, i
     }
 }
 
+// C rows may leave with the streaming (non-temporal) hint (development switch ME_NT_C_STREAM: 0 never, 1 always, 2 for outputs of
+// at least ME_NT_C_MIN_N columns): kept out of L2 the output does not evict the operand rows the other column tiles of the XCD
+// are about to re-read -- but the NEXT kernel then finds less of it in the caches (measured, see profiles/r05_nt_c_stream.txt)
+#ifndef ME_NT_C_STREAM
+#define ME_NT_C_STREAM 0
+#endif
+#ifndef ME_NT_C_MIN_N
+#define ME_NT_C_MIN_N 1536
+#endif
+ME_DEV void st_chunk_c(void* p, const chunk16& c, int N) {
+#if ME_NT_C_STREAM == 1
+    __builtin_nontemporal_store(c.v, reinterpret_cast<u32x4_t*>(p));
+#elif ME_NT_C_STREAM == 2
+    if (N >= ME_NT_C_MIN_N) __builtin_nontemporal_store(c.v, reinterpret_cast<u32x4_t*>(p));
+    else st_chunk(p, c);
+#else
+    st_chunk(p, c);
+#endif
+}
+
 // ReLU sign mask (ME_WS_RELU_MASK): 1 bit per element, stored as the write-out sees the elements.  A REGION = 128 rows x 64
 // columns = 1 KB = [64 lanes][16 bytes]; bit e of byte b of lane l is element (row 32 (b / 4) + 8 (b % 4) + l / 8, column
 // 8 (l % 8) + e) of the region: the chunk lane l stores with instruction (i, it) = (b / 4, b % 4) of the region's write-out.
@@ -167,7 +187,7 @@ ME_DEV void nt256_write_tile(f32x16_t (&acc)[256 / WR / 32][256 / WC / 32], char
             if (orow < M && col < N) {
                 if (col + EPC <= N && vec_c) {
                     if constexpr (OUT_F32) st_chunk(reinterpret_cast<float*>(Cv) + (size_t)orow * ldc + col, v);
-                    else st_chunk(reinterpret_cast<T*>(Cv) + (size_t)orow * ldc + col, v);
+                    else st_chunk_c(reinterpret_cast<T*>(Cv) + (size_t)orow * ldc + col, v, N);
                 } else {
 #pragma unroll
                     for (int e = 0; e < EPC; ++e)
@@ -269,7 +289,7 @@ ME_DEV void nt256_write_tile(f32x16_t (&acc)[256 / WR / 32][256 / WC / 32], char
                 for (int e = 0; e < 8; ++e) vp[e] = (float)gp[e] > 0.f ? vp[e] : (T)0.f;
                 const int orow = m0 + wr * TM + i * 32 + rr;
                 const int col = n0 + wc * TN + j0 * 32 + ch * 8;
-                if (orow < M && col < N) st_chunk(reinterpret_cast<T*>(Cv) + (size_t)orow * ldc + col, v);
+                if (orow < M && col < N) st_chunk_c(reinterpret_cast<T*>(Cv) + (size_t)orow * ldc + col, v, N);
             }
         }
     } else if constexpr (EPI == 5) {
@@ -303,7 +323,7 @@ ME_DEV void nt256_write_tile(f32x16_t (&acc)[256 / WR / 32][256 / WC / 32], char
                 }
                 const int orow = m0 + wr * TM + i * 32 + rr;
                 const int col = n0 + wc * TN + j0 * 32 + ch * 8;
-                if (orow < M && col < N) st_chunk(reinterpret_cast<T*>(Cv) + (size_t)orow * ldc + col, v);
+                if (orow < M && col < N) st_chunk_c(reinterpret_cast<T*>(Cv) + (size_t)orow * ldc + col, v, N);
             }
         }
     } else if constexpr (EPI == 2) {

@@ -3,7 +3,8 @@ sys.path.insert(0, "/root/repo/midi-emotion_amd"); sys.path.insert(0, os.path.jo
 import torch
 from midiemo import _lib
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
-cfgs = [("old", "midi-emotion_amd/midiemo/libmidiemo_hip.so", 0), ("4w", "midi-emotion_amd/midiemo/libmidiemo_hip.so", 2)] + [(n, "abl_tmp/lib_%s.so" % n, 2) for n in sys.argv[1:]]
+ML = int(os.environ.get("AB_LIB_ML", "2"))
+cfgs = [("old", "midi-emotion_amd/midiemo/libmidiemo_hip.so", 0)] + ([("4w", "midi-emotion_amd/midiemo/libmidiemo_hip.so", 2)] if ML == 2 else []) + [(n, "abl_tmp/lib_%s.so" % n, ML) for n in sys.argv[1:]]
 import shutil, tempfile
 tmp = tempfile.mkdtemp(); libs = []
 st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
