@@ -546,6 +546,39 @@ def test_cpu_model_fails_loudly():
         m(torch.randint(2, 97, (1, 8)), None)
 
 
+def test_round5_paths_leave_the_gradients_bit_identical(monkeypatch):
+    """The two train-step changes of round 5 are re-orderings / re-encodings, not new arithmetic: the ReLU sign mask (1 bit
+    instead of the activations for the FFN_suf dX gate) and the attention backward's key-owned / E-row-owned kernels on two
+    streams.  With both switched off the same batch must give the same loss and the same gradients: bit-identical for the
+    projection / FFN weight matrices (T = 8192 rows: their products sum the token ranges in a fixed order), to f32 summation
+    order for the tensors that are accumulated with atomics (LayerNorm, biases, embedding, the relative-position table).
+    dropout on: the masks depend on (seed, counter) only."""
+    cfg = O.Cfg(1007, 2, 4, 256, 1024, d_condition=64, conditioning="continuous_concat")
+    tok, cond, tgt = O.synthetic_batch(cfg, 8, 1024, seed=3)
+    tok, cond, tgt = tok.to(DEV), cond.to(DEV), tgt.to(DEV)
+    res = {}
+    for arm in ("new", "old"):
+        if arm == "old":
+            monkeypatch.setenv("MIDIEMO_NO_RELU_MASK", "1")
+            monkeypatch.setenv("MIDIEMO_ATTN_BWD_OVERLAP", "0")
+        model = make_model(cfg, O.seeded_params(cfg, 9), "bf16", dropout=0.1).train()
+        model.seed_dropout(21)
+        loss = model.loss_and_backward(tok, cond, tgt)
+        ws = next(iter(model._ws.values()))
+        assert (ws.layers[0].rmask is not None) == (arm == "new") and model.attn_bwd_overlap == (arm == "new")
+        model.link_grads()
+        res[arm] = (float(loss), {k: p.grad.clone() for k, p in model.named_parameters()})
+    assert abs(res["new"][0] - res["old"][0]) < 1e-5
+    exact = 0
+    for k, g in res["new"][1].items():
+        if g.dim() == 2 and k.endswith(".weight") and ("rga.W" in k or "rga.fc" in k or "FFN_" in k):
+            assert torch.equal(g, res["old"][1][k]), k
+            exact += 1
+        elif not k.endswith("Wk.bias"):
+            assert relerr(g, res["old"][1][k]) < 1e-5, k
+    assert exact == 2 * 6
+
+
 def test_full_size_c2_properties_bf16():
     """BASELINE config 2 at its full size (B = 32 x L = 1024, bf16), through properties that need no oracle run:
     batch independence (bit-exact), causality (bit-exact), gradient additivity over a batch split, and the
