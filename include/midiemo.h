@@ -33,6 +33,7 @@
  *                          warm replay, 19 % slower inside the train step: profiles/r05_nt_4wave.txt); 1: ping-pong /
  *                          direct-to-LDS loop (gemm_nt8p_kernel, 4-9 % slower, profiles/r05_nt_mainloop.txt)
  *   MIDIEMO_ATTN_V1=1      bf16 / head-dim-64 / causal attention runs the generic 32-key-step forward kernel
+ *   MIDIEMO_ATTN_QB256=1   that forward kernel runs 256-query blocks (8 waves) instead of 128 (measured 2-10 % slower)
  *   MIDIEMO_DEC_CW=1|2|4, MIDIEMO_DEC_KS=0|1   column / K-split geometry of the decode GEMV kernels
  *   MIDIEMO_DEBUG=1        print the HIP error string when a launch fails
  */
