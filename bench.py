@@ -17,10 +17,12 @@ p50 / p90 device step latency and the HBM roofline fraction of a step at context
 HBM-bound kernel of the train step from in-run HIP events.  `extra.config4` = discrete_token V1017 L2048 B16 train step.
 `roofline` is the dominant kernel family
 (the NT GEMM gemm_nt256_kernel<bf16>: every nn.Linear forward and dX product): algorithmic FLOPs of its launches /
-their HIP-event durations, measured on the launch stream in instrumented steps after the
-timed region.  `cpu_baseline` is the oracle (oracle/ref_model.py, a port) timed on the
+their HIP-event durations INSIDE live train steps (events on the launch stream around every launch, in instrumented steps
+after the timed region, minus the cost of an empty event pair measured at the same place); the committed rocprofv3 step trace
+of the same sources is quoted beside it (`rocprof_step_trace`), and a warm back-to-back replay only as `warm_replay_*`.  `cpu_baseline` is the oracle (oracle/ref_model.py, a port) timed on the
 host cores on a bounded sample (B = 2, same model / seq, dropout 0.1 on, 1 warm-up + >= 3 timed steps),
-rank 0, N=1 only.  `extra.fp32_tier` = the same workload on the exact-f32 tier (the tier inside north_star's 1e-3 logits bound).
+rank 0, N=1 only.  `extra.fp16_tier` = the same workload on the f16 tier (the reference's own autocast dtype, with its GradScaler
+on the device: the 16-bit tier inside north_star's 1e-3 logits bound); `extra.fp32_tier` = the exact-f32 tier.
 """
 import argparse
 import json
@@ -108,36 +110,51 @@ def cpu_baseline(c, L, budget_s=30.0):
                       "median %.2f s (min %.2f s)" % (c["dropout"], B, L, len(timed), med, timed[0])}
 
 
-def fp32_tier_bench(B, L, steps=5, warmup=2):
-    """The tier that meets north_star's "logits within 1e-3 rel" (VERDICT r4 weak #1): the SAME C2 workload with the exact-f32
-    engine (--compute_dtype fp32): tokens/s and ms per step, plus the logits rel-L2 of that tier against the oracle on a
-    bounded sample (B = 1, L = 256 of the same model: seconds on the host)."""
-    from oracle import ref_model as O
+def tier_bench(cd, B, L, steps=5, warmup=2):
+    """The SAME C2 workload on another tier of the engine: "fp16" (the reference's own autocast dtype + its GradScaler on the
+    device: the 16-bit tier that meets north_star's "logits within 1e-3 rel") or "fp32" (exact-f32 MFMA): tokens/s and ms per
+    step of the full train step."""
     from midiemo.models.build_model import build_model
-    from midiemo.optim import FusedAdamW
+    from midiemo.optim import FusedAdamW, LossScaler
     torch.manual_seed(0)
-    model, _ = build_model(dict(CFG, compute_dtype="fp32"))
+    model, _ = build_model(dict(CFG, compute_dtype=cd))
     model = model.cuda().train()
     model.seed_dropout(1000)
-    opt = FusedAdamW(model, lr=2e-5, clip=1.0)
-    batches = [synthetic_batch(CFG, B, L, 1234 + 7919 * i, "cuda") for i in range(2)]
+    scaler = LossScaler("cuda") if cd == "fp16" else None
+    opt = FusedAdamW(model, lr=2e-5, clip=1.0, scaler=scaler)
+    ls = scaler.scale_tensor if scaler is not None else None
+    batches = [synthetic_batch(CFG, B, L, 1234 + 7919 * i, "cuda") for i in range(4)]
     for i in range(warmup):
-        model.loss_and_backward(*batches[i % 2])
+        model.loss_and_backward(*batches[i % 4], loss_scale=ls)
         opt.step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        loss = model.loss_and_backward(*batches[i % 2])
+        loss = model.loss_and_backward(*batches[(warmup + i) % 4], loss_scale=ls)
         opt.step()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    res = {"workload": "the headline C2 workload (batch %d, seq %d, dropout 0.1) on the exact-f32 MFMA tier" % (B, L), "dtype": "f32",
-           "tokens_per_s": round(B * L * steps / el, 1), "ms_per_step": round(1e3 * el / steps, 3), "steps": steps,
+    res = {"workload": "the headline C2 workload (batch %d, seq %d, dropout 0.1, fwd+CE+bwd+clip+AdamW) on the %s tier" %
+                       (B, L, {"fp16": "f16 (v_mfma_f32_32x32x16_f16, dynamic loss scale)", "fp32": "exact-f32 MFMA"}[cd]),
+           "dtype": {"fp16": "f16", "fp32": "f32"}[cd],
+           "tokens_per_s": round(B * L * steps / el, 1), "ms_per_step": round(1e3 * el / steps, 3), "steps": steps, "warmup": warmup,
            "final_loss": round(float(loss.item()), 4),
-           "step_tflops_algorithmic": round(B * L * steps / el * train_flop_per_token(CFG, L) / 1e12, 2), "peak_f32_mfma_tflops": 157.3}
+           "step_tflops_algorithmic": round(B * L * steps / el * train_flop_per_token(CFG, L) / 1e12, 2)}
+    if cd == "fp32":
+        res["peak_f32_mfma_tflops"] = 157.3
+    if scaler is not None:
+        res["loss_scaler"] = {"scale": scaler.get_scale(), "steps_taken": scaler.steps_taken(), "steps_skipped": scaler.steps_skipped(),
+                              "semantics": "torch.cuda.amp.GradScaler defaults (65536, x2 / 2000 finite steps, x0.5 + skipped step on inf / nan), state on the device"}
     del opt, model
     torch.cuda.empty_cache()
-    # parity of the tier on a bounded sample, against the oracle (dropout off on both sides)
+    return res
+
+
+def tier_parity_sample():
+    """Logits rel-L2 of every tier against the oracle on a bounded sample (B = 1, L = 256 of the headline model, seeded weights,
+    dropout off on both sides: seconds on the host) -- north_star's bound is 1e-3."""
+    from oracle import ref_model as O
+    from midiemo.models.build_model import build_model
     c = CFG
     cfg = O.Cfg(c["vocab_size"], c["n_layer"], c["n_head"], c["d_model"], c["d_inner"], d_condition=c["d_condition"],
                 conditioning=c["conditioning"])
@@ -146,7 +163,7 @@ def fp32_tier_bench(B, L, steps=5, warmup=2):
     with torch.no_grad():
         ref = O.forward(cfg, P, tok, cond).double()
         out = {}
-        for cd in ("fp32", "bf16"):
+        for cd in ("fp32", "bf16", "fp16"):
             m, _ = build_model(dict(CFG, dropout=0.0, compute_dtype=cd))
             m.load_state_dict(P)
             m = m.cuda().eval()
@@ -154,9 +171,8 @@ def fp32_tier_bench(B, L, steps=5, warmup=2):
             out[cd] = float((lg - ref).norm() / ref.norm())
             del m
     torch.cuda.empty_cache()
-    res["logits_rel_l2_vs_oracle"] = {"f32_tier": float("%.3e" % out["fp32"]), "bf16_tier": float("%.3e" % out["bf16"]),
-                                      "sample": "seeded weights (seed 31), B=1 L=256, dropout off", "north_star_bound": 1e-3}
-    return res
+    return {"f32_tier": float("%.3e" % out["fp32"]), "bf16_tier": float("%.3e" % out["bf16"]), "f16_tier": float("%.3e" % out["fp16"]),
+            "sample": "seeded weights (seed 31), B=1 L=256, dropout off", "north_star_bound": 1e-3}
 
 
 def source_hash():
@@ -208,7 +224,7 @@ def decode_bench(cd, gen_len=2048):
     mid = lat[gen_len // 2 - 32: gen_len // 2 + 32] if gen_len >= 128 else lat
     t_mid = gen_len // 2
     l_mid = sorted(mid)[len(mid) // 2] * 1e-3
-    elt = 2 if cd == "bf16" else 4
+    elt = 4 if cd == "fp32" else 2
     by = decode_bytes(CFG, t_mid, B, elt)
     n_launch = sess.launches_per_token
     del sess, model
@@ -293,7 +309,7 @@ class OpProbe:
         self.ops, self.rec, self.orig = ops, {}, {}
         d, V = model.embedding_dim, model.head_size
         T = B * L
-        es = 2 if model.compute_dtype == torch.bfloat16 else 4
+        es = 4 if model.compute_dtype == torch.float32 else 2
         lo = es if (model.resid_lo and es == 2) else 0
         n = model.flat_params.numel()
         ldv = ((V + 63) // 64) * 64
@@ -340,11 +356,19 @@ class OpProbe:
 
 class GemmProbe:
     """HIP-event timing of every NT-GEMM launch (me_gemm_nt and me_gemm_nt_relu_mask; events recorded on the launch stream).
-    At the bench shapes all of them run the 256 x 256 tile kernels (gemm_nt256_kernel / gemm_nt4w_kernel <bf16>)."""
+    At the bench shapes all of them run the 256 x 256 tile kernel (gemm_nt256_kernel<T, ...>).  Every launch is followed by an
+    EMPTY event pair (e1 -> e2, nothing between): what the two event packets themselves add to elapsed(e0, e1) at that place
+    of the live stream; summary() subtracts it."""
 
-    def __init__(self, ops, steps=0):
+    def __init__(self, ops, steps=0, pool=720):
         self.ops, self.rec, self.calls, self.steps = ops, [], [], steps
         self.orig = {"gemm_nt": ops.gemm_nt, "gemm_nt_relu_mask": ops.gemm_nt_relu_mask}
+        # events are created BEFORE the instrumented steps: hipEventCreate inside the loop (three per launch) made the host the
+        # bottleneck of those steps, and an e0 recorded on an idle stream then times the host's launch gap, not the kernel
+        self.pool = [torch.cuda.Event(enable_timing=True) for _ in range(pool)]
+
+    def _ev(self):
+        return self.pool.pop() if self.pool else torch.cuda.Event(enable_timing=True)
 
     def __enter__(self):
         def make(name):
@@ -354,11 +378,12 @@ class GemmProbe:
                 m = A.shape[0] if kw.get("M") is None else kw["M"]
                 k = A.shape[1] if kw.get("K") is None else kw["K"]
                 n = B.shape[0] if kw.get("N") is None else kw["N"]
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0, e1, e2 = self._ev(), self._ev(), self._ev()
                 e0.record()
                 fn(A, B, C, *rest, **kw)
                 e1.record()
-                self.rec.append((2.0 * m * n * k, e0, e1, (m * k + n * k) * A.element_size() + m * n * C.element_size()))
+                e2.record()
+                self.rec.append((2.0 * m * n * k, e0, e1, (m * k + n * k) * A.element_size() + m * n * C.element_size(), e2))
                 self.calls.append((fn, (A, B, C) + tuple(rest), dict(kw)))
             return nt
         for name in self.orig:
@@ -373,13 +398,16 @@ class GemmProbe:
         torch.cuda.synchronize()
         flops = sum(r[0] for r in self.rec)
         ms = sum(r[1].elapsed_time(r[2]) for r in self.rec)
+        self.empty_pair_ms = sum(r[2].elapsed_time(r[4]) for r in self.rec)       # cost of the event packets themselves, in situ
         self.alg_bytes = sum(r[3] for r in self.rec) / max(1, len(self.rec))
         return flops, ms, len(self.rec)
 
     def replay(self, reps=24, rounds=3):
         """Duration of every distinct NT call of ONE step from a back-to-back replay: `reps` launches of the call (same
         operands, same write-out path) between TWO events, best of `rounds` -- per-launch event pairs add 2-6 us of event
-        overhead to every launch (VERDICT r4 weak #7).  Returns (sum of per-call average ms over one step's calls, calls)."""
+        overhead to every launch.  A WARM number: after the first launch the operands sit in L2 / Infinity Cache, which the live
+        step's activation operands do not -- reported as `warm_replay_*` only, never as roofline.achieved.
+        Returns (sum of per-call average ms over one step's calls, calls)."""
         calls = self.calls[:len(self.calls) // max(1, self.steps)] if self.steps else self.calls
         total = 0.0
         for (fn, a, kw) in calls:
@@ -441,7 +469,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=BATCH, help="sequences per GPU (weak scaling)")
     ap.add_argument("--seq", type=int, default=SEQ)
-    ap.add_argument("--compute_dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--compute_dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_probe", action="store_true")
     ap.add_argument("--no_decode", action="store_true")
@@ -488,7 +516,7 @@ def main():
     from midiemo import ops
     from midiemo.ddp import GradAllReducer, broadcast_params
     from midiemo.models.build_model import build_model
-    from midiemo.optim import FusedAdamW
+    from midiemo.optim import FusedAdamW, LossScaler
 
     torch.manual_seed(0)                                   # identical random-init weights on every rank
     margs = dict(CFG, compute_dtype=args.compute_dtype)
@@ -496,14 +524,16 @@ def main():
     model = model.to(dev).train()
     broadcast_params(model.flat_params)
     model.seed_dropout(1000 + rank)
-    opt = FusedAdamW(model, lr=2e-5, clip=1.0)             # == Adam(lr) + clip_grad_norm_(1.0), train.py:182,321
+    scaler = LossScaler(dev) if args.compute_dtype == "fp16" else None      # GradScaler of the reference's fp16 path (train.py:108)
+    opt = FusedAdamW(model, lr=2e-5, clip=1.0, scaler=scaler)             # == Adam(lr) + clip_grad_norm_(1.0), train.py:182,321
     reducer = GradAllReducer(lambda: model.flat_grads, model.bucket_ranges())
     B, L = args.batch, args.seq
     batches = [synthetic_batch(CFG, B, L, 1234 + rank + 7919 * i, dev) for i in range(4)]
 
     def step(i):
         tok, cond, tgt = batches[i % len(batches)]
-        loss = model.loss_and_backward(tok, cond, tgt, bucket_hook=reducer.hook if dist_on else None)
+        loss = model.loss_and_backward(tok, cond, tgt, bucket_hook=reducer.hook if dist_on else None,
+                                       loss_scale=scaler.scale_tensor if scaler is not None else None)
         reducer.finish()
         opt.step(grad_scale=reducer.grad_scale)
         return loss
@@ -549,9 +579,12 @@ def main():
         # every rank runs the instrumented steps (they contain the gradient all-reduce); only rank 0 times its GEMMs
         if rank == 0:
             with GemmProbe(ops, steps=3) as gp:
+                torch.cuda.synchronize()
+                t_i = time.perf_counter()
                 for i in range(3):
                     step(i)
                 probe = gp.summary()
+                gp.instrumented_step_ms = 1e3 * (time.perf_counter() - t_i) / 3
             replay_ms, replay_calls = gp.replay()          # the workspace buffers of the last step are still alive
             with OpProbe(ops, model, B, L) as op_probe:
                 for i in range(3):
@@ -589,31 +622,46 @@ def main():
             tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")
             if args.compute_dtype == "bf16" and (B, L) == (32, 1024) and os.path.exists(tj):
                 tjd = json.load(open(tj))
-                # the NT family runs two kernels since round 5 (8-wave and hand-scheduled 4-wave main loop): launch-weighted mean
-                ks = [tjd[n_] for n_ in ("gemm_nt256_kernel", "gemm_nt256_kernel<false>", "gemm_nt4w_kernel") if n_ in tjd]
+                # launch-weighted mean over the family's instantiations
+                ks = [tjd[n_] for n_ in tjd if n_.startswith("gemm_nt256_kernel")]
                 if tjd.get("_source_sha256") != source_hash():
                     traffic_note = "profiles/hbm_traffic.json was measured on other kernel sources (hash mismatch): not quoted"
                 elif ks:
                     nl = sum(k["launches"] for k in ks)
                     traffic = int(round(sum((k["read_MB"] + k["write_MB"]) * k["launches"] for k in ks) / nl * 1e6))
                     traffic_note = "HBM bytes per launch, mean over the family's %d traced launches (rocprofv3 PMC passes FETCH_SIZE x2 + WRITE_SIZE, %s)" % (nl, tjd.get("_profile", "profiles/"))
-            # achieved = algorithmic FLOPs of one step's launches / their back-to-back replay durations (two events around
-            # >= 24 launches per call); the per-launch event pairs inside the live step are kept as `in_step_*`
-            in_step_ms, in_step_n = ms, n
-            flops, ms, n = flops / 3.0, replay_ms, replay_calls
-            ach = flops / (ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": ("gemm_nt256_kernel<bf16>" if args.compute_dtype == "bf16" else "gemm_nt_kernel<float>"),
-                               "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS if args.compute_dtype == "bf16" else 157.3,
-                               "unit": "TFLOP/s",
-                               "frac": round(ach / (PEAK_BF16_TFLOPS if args.compute_dtype == "bf16" else 157.3), 4),
+            # achieved = algorithmic FLOPs of the launches of 3 LIVE steps / (their HIP-event durations - the empty event pairs
+            # recorded right behind each of them): the kernel as the timed region runs it (cold activation operands)
+            peak = PEAK_BF16_TFLOPS if args.compute_dtype != "fp32" else 157.3
+            ms_live = ms - gp.empty_pair_ms
+            ach = flops / (ms_live * 1e-3) / 1e12
+            kname = {"bf16": "gemm_nt256_kernel<bf16>", "fp16": "gemm_nt256_kernel<f16>", "fp32": "gemm_nt_kernel<float>"}[args.compute_dtype]
+            out["roofline"] = {"bound": "mfma", "kernel": kname,
+                               "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                                "traffic": traffic, "traffic_unit": traffic_note,
-                               "algorithmic_bytes_per_launch": int(gp.alg_bytes), "launches_per_step": n,
-                               "avg_launch_us": round(1000.0 * ms / n, 2),
-                               "gemm_nt_ms_per_step": round(ms, 3),
-                               "timing": "back-to-back replay of each of the step's %d NT calls (24 launches between two HIP events, best of 3)" % n,
-                               "in_step_avg_launch_us": round(1000.0 * in_step_ms / in_step_n, 2),
-                               "in_step_gemm_nt_ms_per_step": round(in_step_ms / 3, 3),
+                               "algorithmic_bytes_per_launch": int(gp.alg_bytes), "launches_per_step": n // 3,
+                               "avg_launch_us": round(1000.0 * ms_live / n, 2),
+                               "gemm_nt_ms_per_step": round(ms_live / 3, 3),
+                               "timing": "HIP events on the launch stream around every NT launch of 3 live train steps (%d launches), minus the "
+                                         "empty event pair recorded behind each launch (%.2f us per pair)" % (n, 1000.0 * gp.empty_pair_ms / n),
+                               "raw_event_avg_launch_us": round(1000.0 * ms / n, 2),
+                               "instrumented_step_ms": round(gp.instrumented_step_ms, 3),     # must stay device-bound: ~ ms_per_step + the event packets
+                               "warm_replay_avg_launch_us": round(1000.0 * replay_ms / replay_calls, 2),
+                               "warm_replay_frac": round(flops / 3.0 / (replay_ms * 1e-3) / 1e12 / peak, 4),
+                               "warm_replay_note": "24 back-to-back launches of each call on L2 / Infinity-Cache-warm operands, best of 3: an upper bound, not the step",
                                "step_frac_of_peak": round(tps * fpt / 1e12 / world / PEAK_BF16_TFLOPS, 4)}
+            # the committed rocprofv3 kernel trace of the train steps alone (tools/round_profiles.sh -> profiles/step_trace.json),
+            # quoted only for the sources it was measured on: the profile's average launch duration of the same family
+            sj = os.path.join(ROOT, "profiles", "step_trace.json")
+            if args.compute_dtype == "bf16" and (B, L) == (32, 1024) and os.path.exists(sj):
+                sjd = json.load(open(sj))
+                if sjd.get("_source_sha256") == source_hash() and "gemm_nt" in sjd.get("families", {}):
+                    fam = sjd["families"]["gemm_nt"]
+                    out["roofline"]["rocprof_step_trace"] = {
+                        "avg_launch_us": fam["avg_us"], "ms_per_step": fam["ms_per_step"], "launches_per_step": fam["launches_per_step"],
+                        "frac": round(flops / 3.0 / (fam["ms_per_step"] * 1e-3) / 1e12 / peak, 4), "profile": sjd.get("_profile")}
+                else:
+                    out["roofline"]["rocprof_step_trace"] = "profiles/step_trace.json was measured on other kernel sources (hash mismatch): not quoted"
         # multi-GPU knobs of this run (SCALE runs are only interpretable with them): the overlap policy of the bucket
         # all-reduces (midiemo/ddp.py) and the CUs the persistent GEMM grids leave to RCCL (default 0: a reserve makes
         # EVERY 256-tile launch take a second tile round -- measured on one GPU: qkv 59.6 -> 70.8 us, proj 27.1 -> 43.9 us
@@ -638,12 +686,20 @@ def main():
             if args.compute_dtype == "bf16":
                 model = opt = reducer = gp = op_probe = None        # (the probes hold the step's workspace tensors)
                 torch.cuda.empty_cache()
-                out["extra"]["fp32_tier"] = fp32_tier_bench(B, L)
+                # the 16-bit tier inside north_star's tolerance, with the headline run's own step count, beside the headline number
+                out["extra"]["fp16_tier"] = tier_bench("fp16", B, L, steps=args.steps, warmup=args.warmup)
+                out["extra"]["fp16_tier"]["ms_per_step_vs_bf16"] = round(out["extra"]["fp16_tier"]["ms_per_step"] / (1000.0 * elapsed / args.steps), 4)
+                out["extra"]["fp32_tier"] = tier_bench("fp32", B, L)
+                par = tier_parity_sample()
+                out["extra"]["logits_rel_l2_vs_oracle"] = par
+                out["extra"]["fp16_tier"]["logits_rel_l2_vs_oracle"] = par["f16_tier"]
+                out["extra"]["fp32_tier"]["logits_rel_l2_vs_oracle"] = par
         if world == 1 and not args.no_decode:
             model = opt = None
             torch.cuda.empty_cache()
             dec = decode_bench("bf16")
             dec["fp32"] = {k: v for k, v in decode_bench("fp32").items() if k in ("tokens_per_s", "step_ms_p50", "step_ms_p90", "roofline")}
+            dec["fp16"] = {k: v for k, v in decode_bench("fp16").items() if k in ("tokens_per_s", "step_ms_p50", "step_ms_p90", "roofline", "ids_checksum")}
             if not args.no_cpu_baseline:
                 dec["cpu_baseline"] = decode_cpu_baseline()
             dec["slide"] = decode_slide_bench("bf16")

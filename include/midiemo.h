@@ -18,6 +18,9 @@
  *   - `dtype` selects the activation/weight storage type T of the call:
  *       ME_F32  : exact-f32 MFMA (v_mfma_f32_32x32x2_f32), parity tier
  *       ME_BF16 : bf16 storage, f32 accumulate (v_mfma_f32_32x32x16_bf16)
+ *       ME_F16  : f16 storage, f32 accumulate (v_mfma_f32_32x32x16_f16; same rate and bytes as bf16, 10 mantissa bits) -- the
+ *                 reference's own mixed precision (torch.cuda.amp.autocast + GradScaler, train.py:101,108,281,317-324;
+ *                 generate.py:116); gradients need the loss scale (me_scaler_step, me_ce_bwd, me_adamw_step)
  *     master parameters, gradients, optimiser state, statistics are always f32;
  *   - return value: ME_OK or a negative ME_ERR_* code; nothing throws/aborts.
  *
@@ -25,15 +28,8 @@
  * count / "LDS limit raised" flags, and these environment variables, each read ONCE (getenv at first use) -- development
  * and measurement aids, never needed for correct results:
  *   MIDIEMO_CU_RESERVE=n   persistent GEMM grids use (#CUs - n) blocks (CUs left to a concurrent RCCL kernel; default 0)
- *   MIDIEMO_NO_NT256=1     bf16 NT GEMMs run the generic 128 x 128 kernel instead of the persistent 256 x 256 one
+ *   MIDIEMO_NO_NT256=1     16-bit NT GEMMs run the generic 128 x 128 kernel instead of the persistent 256 x 256 one
  *   MIDIEMO_NO_TN256=1     likewise for the weight-gradient (TN) GEMMs
- *   MIDIEMO_NT_MAINLOOP=0|1|2|3  main loop of the 256-tile NT GEMM; results are bit-identical across all four settings.
- *                          0 (default): register-staged 8-wave loop; 2: hand-scheduled 4-wave loop (gemm_nt4w_kernel) wherever
- *                          it is legal; 3: the 4-wave loop for one-tile-per-CU launches with K >= 2048 (6-12 % faster in a
- *                          warm replay, 19 % slower inside the train step: profiles/r05_nt_4wave.txt); 1: ping-pong /
- *                          direct-to-LDS loop (gemm_nt8p_kernel, 4-9 % slower, profiles/r05_nt_mainloop.txt)
- *   MIDIEMO_ATTN_V1=1      bf16 / head-dim-64 / causal attention runs the generic 32-key-step forward kernel
- *   MIDIEMO_ATTN_QB256=1   that forward kernel runs 256-query blocks (8 waves) instead of 128 (measured 2-10 % slower)
  *   MIDIEMO_DEC_CW=1|2|4, MIDIEMO_DEC_KS=0|1   column / K-split geometry of the decode GEMV kernels
  *   MIDIEMO_DEBUG=1        print the HIP error string when a launch fails
  */
@@ -47,11 +43,11 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 21
+#define ME_ABI_VERSION 22
 #define ME_DEC_PART_REC(dh) ((dh) + 4)      /* floats per attention partial of the decode step (me_dec_attn) */
 #define ME_SUMSQ_WS_BYTES 1040   /* me_sumsq workspace: ticket counter + 256 block sums + padding */
 
-enum { ME_F32 = 0, ME_BF16 = 1 };
+enum { ME_F32 = 0, ME_BF16 = 1, ME_F16 = 2 };
 
 enum {
     ME_OK = 0,
@@ -154,7 +150,7 @@ int me_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
  * backward launch then reads 1 bit per element instead of the bf16 activations (134 MB per layer at the headline shape).
  * mask: caller-owned, me_workspace_bytes(ME_WS_RELU_MASK, M, N, K, dtype) bytes, 16-byte aligned, opaque (1 bit per element
  * in the order the kernel's write-out touches them: 1 KB per 128 rows x 64 columns, rows rounded up to 256); a size of
- * 0 means the shape / dtype is not served (bf16, N % 64 == 0, the shapes the 256-tile kernel takes) -- callers then
+ * 0 means the shape / dtype is not served (16-bit types, N % 64 == 0, the shapes the 256-tile kernel takes) -- callers then
  * keep the gate operand; calling anyway returns ME_ERR_BAD_SHAPE.  C is T, ldc % 8 == 0, 16-byte aligned. */
 int me_gemm_nt_relu_mask(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
                          void* mask, int M, int N, int K, int dir, int dtype, void* stream);
@@ -190,7 +186,7 @@ int me_gemm_tn_acc(const void* A, int lda, const void* B, int ldb, float* dW, in
  * results as n_items calls of me_gemm_tn_acc up to the summation order (still fixed, bit-reproducible); the token
  * dimension is split #CUs / (tiles of ALL items) ways instead of once per product, which at the headline shapes cuts the
  * partial-tile traffic to a quarter and replaces eight launches by two.  `items` is a HOST array (read during the call
- * only).  bf16, every N readable up to a multiple of 256 columns (lda), K % 256 == 0, T >= 2048 run the grouped kernel
+ * only).  16-bit types, every N readable up to a multiple of 256 columns (lda), K % 256 == 0, T >= 2048 run the grouped kernel
  * (workspace: me_workspace_bytes(ME_WS_GEMM_TN_GROUP, T, total tiles, 0, dtype)); anything else is executed as
  * separate me_gemm_tn_acc calls with the same workspace. */
 #define ME_TN_MAX_GROUP 5
@@ -247,11 +243,10 @@ int me_rga_bwd(const void* qkv, const void* Epk, const void* out, const float* l
                int B, int L, int Lp, int H, int dh, int M, int causal, int dtype, void* stream);
 
 /* The same backward, kernel by kernel.  phases: bit 0 = query-owned kernel (dQ part of dqkv, delta_ws, dGT), bit 1 =
- * key-owned kernel (dK, dV parts of dqkv; needs delta_ws), bit 2 = E-row-owned kernel (dE += ; needs dGT), bit 3 = delta_ws
- * alone (a small launch of its own), bit 4 = the query-owned kernel leaves delta_ws alone (bit 3 wrote it).  Within one
- * call the selected kernels run in the order 3, 0, 1, 2.  The kernels of bits 1 and 2 do not depend on each other, and
- * after bit 3 neither do those of bits 0 and 1: a caller that owns two streams may enqueue them side by side (its own events
- * order them; the library never synchronises).  phases = 7 on one stream is me_rga_bwd. */
+ * key-owned kernel (dK, dV parts of dqkv; needs delta_ws), bit 2 = E-row-owned kernel (dE += ; needs dGT).  Within one
+ * call the selected kernels run in the order 0, 1, 2.  The kernels of bits 1 and 2 do not depend on each other: a caller
+ * that owns two streams may enqueue them side by side (its own events order them; the library never synchronises).
+ * phases = 7 on one stream is me_rga_bwd. */
 int me_rga_bwd_phases(const void* qkv, const void* Epk, const void* out, const float* lse, const void* dout,
                       void* dqkv, float* dE, float* delta_ws, const void* PT, const float* MT, void* dGT,
                       int B, int L, int Lp, int H, int dh, int M, int causal, int phases, int dtype, void* stream);
@@ -275,22 +270,25 @@ int me_resid_ln_bwd(const void* dy, const void* s, const float* stats, const flo
                     float p_drop, uint64_t seed, uint32_t site, int dtype, void* stream);
 
 /* ---- cross-entropy head ------------------------------------------------------
- * logits [rows, ld] (V valid columns) in logits_dtype: ME_F32, or ME_BF16 -- the bf16 tier's head GEMM writes T
- * logits (what the reference's autocast F.linear produces; no 4-byte logits tensor exists then); target int64 [rows].
+ * logits [rows, ld] (V valid columns) in logits_dtype: ME_F32, or the 16-bit tier's own type (ME_BF16 / ME_F16 == dtype) -- the
+ * 16-bit tiers' head GEMM writes T logits (what the reference's autocast F.linear produces; no 4-byte logits tensor exists
+ * then); target int64 [rows].
  * The loss arithmetic is f32 either way.
  * me_ce_fwd:  row_lse[r] = logsumexp(logits[r, :V]);
  *             *loss_sum += sum over target != ignore of (row_lse - logit[target]);
  *             *n_valid  += count(target != ignore)          (both f32 device scalars)
  * me_ce_bwd:  dlogits (T [rows, ld_d]) = (exp(logit - row_lse) - onehot) * (target != ignore)
- *             * extra_scale / *n_valid ; columns V..ld_d-1 are written as 0.
+ *             * extra_scale * (loss_scale_dev ? *loss_scale_dev : 1) / *n_valid ; columns V..ld_d-1 are written as 0.
+ *             loss_scale_dev (f32 device scalar, may be NULL): the dynamic loss scale of the f16 tier = state[ME_SCALER_SCALE]
+ *             of me_scaler_step (GradScaler.scale(loss), train.py:317) -- read on the device, so a step never syncs.
  *             dbias (f32 [V] or NULL): dbias[j] += sum over rows of the f32 dlogits[:, j] BEFORE the rounding to T -- the
  *             vocabulary head's bias gradient (music_multi.py:71,106), which would otherwise be summed from the bf16
- *             dlogits by me_gemm_tn_acc (bf16 logits and dlogits, ld_d <= 2048 only; anything else: ME_ERR_BAD_SHAPE).
+ *             dlogits by me_gemm_tn_acc (16-bit logits and dlogits, ld_d <= 2048 only; anything else: ME_ERR_BAD_SHAPE).
  * Replaces CrossEntropyLoss(ignore_index=pad) + its autograd (train.py:124,288-290). */
 int me_ce_fwd(const void* logits, int ld, const int64_t* target, float* row_lse,
               float* loss_sum, float* n_valid, int rows, int V, int ignore_index, int logits_dtype, void* stream);
 int me_ce_bwd(const void* logits, int ld, const int64_t* target, const float* row_lse,
-              void* dlogits, int ld_d, const float* n_valid, float extra_scale, float* dbias,
+              void* dlogits, int ld_d, const float* n_valid, float extra_scale, const float* loss_scale_dev, float* dbias,
               int rows, int V, int ignore_index, int logits_dtype, int dtype, void* stream);
 
 /* ---- optimiser: global-norm clip + Adam(W) -----------------------------------
@@ -305,12 +303,30 @@ int me_ce_bwd(const void* logits, int ld, const int64_t* target, const float* ro
  *   p = p*(1 - lr*wd) - (lr/bias_corr1) * m / (sqrt(v)/sqrt(bias_corr2) + eps)
  * with bias_corr{1,2} = 1 - beta^step computed by the caller.  weight_decay = 0 is
  * exactly torch.optim.Adam.  If zero_grad != 0 the gradient is zeroed in the same pass.
- * Replaces clip_grad_norm_ + optim.Adam.step + zero_grad (train.py:320-325). */
+ * scaler_state (may be NULL; f16 tier): the state me_scaler_step just updated -- the gradients (and *sumsq) carry the loss
+ *   scale: g' additionally * state[ME_SCALER_INV]; if state[ME_SCALER_FOUND_INF] != 0 nothing is updated (the gradients are
+ *   still zeroed): GradScaler.step skipping optimizer.step (train.py:322); bias_corr{1,2} are then recomputed on the device
+ *   from state[ME_SCALER_STEP] (the count of steps actually taken), the by-value ones are ignored.
+ * Replaces clip_grad_norm_ + optim.Adam.step + zero_grad (train.py:320-325).
+ *
+ * me_scaler_step: torch.cuda.amp.GradScaler (train.py:101,108,317-324: scale(loss), unscale_, step, update) on the device,
+ *   one launch after me_sumsq and before me_adamw_step, no host sync.  state: f32 [ME_SCALER_WORDS], caller-owned:
+ *     [ME_SCALER_SCALE]     the loss scale the NEXT backward multiplies into dlogits (initialise to 65536 = GradScaler's init_scale)
+ *     [ME_SCALER_INV]       1 / (the scale the gradients just summed were produced with)      (written)
+ *     [ME_SCALER_TRACKER]   consecutive finite steps since the last change of the scale      (initialise 0)
+ *     [ME_SCALER_STEP]      optimiser steps actually taken                                     (initialise 0 or the resumed count)
+ *     [ME_SCALER_FOUND_INF] 1 if *sumsq (squared norm of the SCALED gradients) is inf / nan    (written)
+ *     [ME_SCALER_SKIPPED]   number of skipped steps so far                                     (initialise 0)
+ *   found_inf: scale *= backoff_factor, tracker = 0, skipped += 1; else step += 1, tracker += 1 and, at growth_interval,
+ *   scale *= growth_factor (never to inf), tracker = 0 -- GradScaler.update() with its defaults 2.0 / 0.5 / 2000. */
+enum { ME_SCALER_SCALE = 0, ME_SCALER_INV = 1, ME_SCALER_TRACKER = 2, ME_SCALER_STEP = 3, ME_SCALER_FOUND_INF = 4,
+       ME_SCALER_SKIPPED = 5, ME_SCALER_WORDS = 8 };
+int me_scaler_step(float* state, const float* sumsq, float growth_factor, float backoff_factor, int growth_interval, void* stream);
 int me_sumsq(const float* g, int64_t n, float* out, void* ws, size_t ws_bytes, void* stream);
 int me_adamw_step(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq,
                   float clip, float grad_scale, float lr, float beta1, float beta2, float eps,
                   float weight_decay, float bias_corr1, float bias_corr2, int zero_grad,
-                  void* stream);
+                  const float* scaler_state, void* stream);
 
 /* ---- KV-cached decode step (generate.py:92-122 with the model call made incremental) --------------------
  * One new position `t` for each of Mr <= 8 sequences; the reference recomputes the whole window for every token
@@ -353,13 +369,10 @@ int me_dec_attn(const void* q, const void* kcache, const void* vcache, const voi
  * attention needs only that head's q and the keys 0..t-1 already cached, so the two launches had no real seam; splits
  * 0..nsplit-2 share the cached keys, partial nsplit-1 is the new key t, computed -- with k_t / v_t and their cache
  * append -- by two extra blocks per (row, head)).  part / nsplit as me_dec_attn (read by me_dec_proj_resid); x_out (f32
- * [Mr, d] or NULL) receives the LayerNorm rows.  d <= 1024, 2 <= nsplit <= 8.
- * The input row is either s_in (f32 [Mr, d], npsum = 0) or, after me_dec_ffn, its split-K form (s_in = NULL):
- * presid[m] + pbias + sum_{j < npsum} psum[j][m]  (psum f32 [npsum][Mr][d], summed in index order).
+ * [Mr, d] or NULL) receives the LayerNorm rows.  d <= 1024, 2 <= nsplit <= 8.  s_in: f32 [Mr, d].
  * Replaces, per layer >= 1 of a cached decode step, music_multi.py:133-134 (layernorm2 of the previous layer) and
  * :196-232 for the one new position (generate.py:116-119). */
-int me_dec_ln_qkv_attn(const float* s_in, const float* psum, int npsum, const float* presid, const float* pbias,
-                       const float* gamma, const float* beta, float eps, const void* Wqkv, const float* bqkv,
+int me_dec_ln_qkv_attn(const float* s_in, const float* gamma, const float* beta, float eps, const void* Wqkv, const float* bqkv,
                        float* x_out, void* kcache, void* vcache, const void* E, const uint8_t* key_pad, int ld_pad, float* part,
                        int nsplit, int Mr, int d, int H, int dh, int M, int Mc, int t, const int32_t* t_dev, int dtype,
                        void* stream);
@@ -380,24 +393,10 @@ int me_dec_embed_qkv_attn(const int64_t* tokens, const float* cond, const float*
 int me_dec_proj_resid(const float* part, int nsplit, int H, int dh, const void* x_T, int ldx, const void* W, int ldw,
                       const float* bias, const float* resid, float* out, int Mr, int N, int K, int dtype, void* stream);
 
-/* me_dec_ffn (round 5): the feed-forward pair of a decode step in ONE launch, cut by the contraction index of FFN_suf:
- *   x = LayerNorm(s_in; gamma, beta, eps) -> x_out (f32 [Mr][d], the residual of the consumer);
- *   block j (64 hidden units): h_j = T(ReLU(T(x).W1[64 j .. 64 j + 63]^T + b1[..]))   (music_multi.py:129-131)
- *                              part[j][m][0..d) = h_j . W2[:, 64 j .. 64 j + 63]^T    (music_multi.py:132, split over d_inner)
- * part f32 [d_inner / 64][Mr][d] (caller-owned) is consumed by the LayerNorm prologue of the NEXT launch (me_dec_ln_qkv_attn /
- * me_dec_ln_proj with psum = part, npsum = d_inner / 64, presid = x_out, pbias = the FFN_suf bias): the pre-norm sum of
- * music_multi.py:133-134 is never stored.  W1 T [d_inner][d], W2 T [d][d_inner]; d % 16 == 0, d <= 1024 (bf16) / 512 (f32),
- * d_inner % 64 == 0, Mr <= 8.  Replaces me_dec_ln_proj(FFN_pre) + me_dec_proj_resid(FFN_suf): 20 instead of 26 launches per
- * token at 6 layers. */
-int me_dec_ffn(const float* s_in, const float* gamma, const float* beta, float eps, const void* W1, const float* b1,
-               const void* W2, float* x_out, float* part, int Mr, int d, int d_inner, int dtype, void* stream);
-
-/* me_dec_ln_proj: x = LayerNorm(row; gamma, beta, eps) -> x_out (f32, may be NULL), row = s_in or its split-K form (see
- *   me_dec_ln_qkv_attn); y = T(x).W^T + bias,
+/* me_dec_ln_proj: x = LayerNorm(s_in; gamma, beta, eps) -> x_out (f32, may be NULL); y = T(x).W^T + bias,
  *   flags & ME_EPI_RELU: ReLU (FFN_pre, music_multi.py:129-131); flags & ME_EPI_OUT_F32: y is f32 [Mr][ldy] (the
  *   vocabulary head, music_multi.py:106), else T [Mr][ldy]. */
-int me_dec_ln_proj(const float* s_in, const float* psum, int npsum, const float* presid, const float* pbias,
-                   const float* gamma, const float* beta, float eps, const void* W, int ldw,
+int me_dec_ln_proj(const float* s_in, const float* gamma, const float* beta, float eps, const void* W, int ldw,
                    const float* bias, float* x_out, void* y, int ldy, int Mr, int N, int K, int flags, int dtype,
                    void* stream);
 

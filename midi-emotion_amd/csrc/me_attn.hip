@@ -288,15 +288,12 @@ __global__ __launch_bounds__(256, 3) void rga_fwd_kernel(const T* __restrict__ q
 // goes through the dG ring (LDS) and gives the relative part dQ^T += E^T dG^T (2 DB atoms) and the dG^T tile for dE.
 // CAUSAL = false: backward of the bidirectional forward (MusicRegression): every key tile is visited; tiles above the
 // diagonal have no relative term (no dG, no E^T product).
-template <typename T> struct PHalf;
-template <> struct PHalf<bf16_t> { typedef bf16x8_t type; static constexpr int N = 8; };     // two 16-byte loads per lane and tile
+template <typename T> struct PHalf { typedef typename V16<T>::x8 type; static constexpr int N = 8; };     // two 16-byte loads per lane and tile
 template <> struct PHalf<float> { typedef f32x4_t type; static constexpr int N = 4; };
 
-#ifndef BQ_OCC
-#define BQ_OCC 2        // 186 registers; a cap of 168 (three waves per SIMD) spills 152 bytes per lane: 411 vs 388 us per backward
-#endif
+// (186 registers, two waves per SIMD; a cap of 168 for three spills 152 bytes per lane: 411 vs 388 us per backward)
 template <typename T, int DH, bool CAUSAL = true>
-__global__ __launch_bounds__(256, BQ_OCC) void rga_bwd_q_kernel(
+__global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
     const T* __restrict__ qkv, const T* __restrict__ Epk, const T* __restrict__ out, const float* __restrict__ lse,
     const T* __restrict__ dout, T* __restrict__ dqkv, float* __restrict__ delta_ws, const T* __restrict__ PT,
     const float* __restrict__ MT, T* __restrict__ dGT, int B, int L, int Lp, int H, int M, float scale) {
@@ -560,32 +557,6 @@ __global__ __launch_bounds__(256, BQ_OCC) void rga_bwd_q_kernel(
 
 }
 
-// delta[b, head, q] = sum_d dO[q][d] O[q][d] alone -- the query-owned kernel's own prologue computation (same lanes, same
-// order of the multiply-adds), as a separate launch: with delta in memory first, the key-owned kernel no longer depends
-// on the query-owned one and a caller with two streams can run the two side by side (me_rga_bwd_phases, bit 3).
-template <typename T, int DH>
-__global__ __launch_bounds__(256) void rga_delta_kernel(const T* __restrict__ out, const T* __restrict__ dout, float* __restrict__ delta_ws,
-                                                        int B, int L, int H) {
-    using C = ACfg<T, DH>;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, a = lane & 31, h = lane >> 5;
-    const int bh = blockIdx.x % (B * H), qb = blockIdx.x / (B * H);
-    const int b = bh / H, head = bh % H;
-    const int dm = H * DH;
-    const int q = qb * 128 + wid * 32 + a;
-    const bool row_on = q < L;
-    const size_t orow = ((size_t)b * L + q) * dm + head * DH;
-    Frag<T> dof[C::KA], oof[C::KA];
-    row_frags<T, DH>(dof, dout + orow, row_on, h);
-    row_frags<T, DH>(oof, out + orow, row_on, h);
-    float delta = 0.f;
-#pragma unroll
-    for (int kk = 0; kk < C::KA; ++kk)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) delta += frag_get(dof[kk], e) * frag_get(oof[kk], e);
-    delta = half_sum(delta);
-    if (row_on && h == 0) delta_ws[((size_t)b * H + head) * L + q] = delta;
-}
-
 // =====================================================================================
 // backward 2/3 (key-owned):  dV[key] = sum_q P[q][key] dO[q],  dK[key] = sum_q dS[q][key] Q[q]
 // =====================================================================================
@@ -600,13 +571,10 @@ __global__ __launch_bounds__(256) void rga_delta_kernel(const T* __restrict__ ou
 // frag_load_tr for a probability tile in register-image order: the lane's operand column is KEY lane & 31, which sits at
 // position p_col(key) of every row; a 4-key group stays a contiguous 4-element group (key group j -> position group
 // 4 (j & 1) + (j >> 1)), so the 16-bit transpose read only needs the permuted group address.
-ME_DEV void p_frag_tr(Frag<bf16_t>& f, const bf16_t* tile, int ld, int rA, int rB, int lane) {
-    typedef short v4s __attribute__((ext_vector_type(4)));
+template <typename T> ME_DEV void p_frag_tr(Frag<T>& f, const T* tile, int ld, int rA, int rB, int lane) {
     const int l16 = lane & 15, j = (l16 & 3) + 4 * ((lane >> 4) & 1);
-    const bf16_t* p = tile + (l16 >> 2) * ld + 4 * (4 * (j & 1) + (j >> 1));
-    v4s x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p + rA * ld));
-    v4s y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p + rB * ld));
-    f.v = __builtin_shufflevector(__builtin_bit_cast(bf16x4_t, x), __builtin_bit_cast(bf16x4_t, y), 0, 1, 2, 3, 4, 5, 6, 7);
+    const T* p = tile + (l16 >> 2) * ld + 4 * (4 * (j & 1) + (j >> 1));
+    f.v = __builtin_shufflevector(lds_tr4(p + rA * ld), lds_tr4(p + rB * ld), 0, 1, 2, 3, 4, 5, 6, 7);
 }
 ME_DEV void p_frag_tr(Frag<float>& f, const float* tile, int ld, int rA, int rB, int lane) {
     const float* p = tile + p_col(lane & 31);
@@ -923,15 +891,12 @@ int pack_launch(const void* E, void* Epk, int M, hipStream_t st) {
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-// debug switch (documented in include/midiemo.h): MIDIEMO_ATTN_V1=1 routes the bf16 / dh 64 / causal shapes through the
-// generic 32-key-step kernels as well (A/B measurements, parity cross-checks)
-static const int g_attn_v1 = getenv("MIDIEMO_ATTN_V1") ? atoi(getenv("MIDIEMO_ATTN_V1")) : 0;
 
 template <typename T, int DH>
 int fwd_launch(const void* qkv, const void* Epk, const uint8_t* key_pad, void* out, float* lse, void* PT, float* MT, int B,
                int L, int H, int M, int causal, hipStream_t st) {
-    if constexpr (std::is_same<T, bf16_t>::value && DH == 64) {
-        if (causal && !g_attn_v1) return me_attn64::fwd_launch(qkv, Epk, key_pad, out, lse, PT, MT, B, L, H, M, st);
+    if constexpr (sizeof(T) == 2 && DH == 64) {
+        if (causal) return me_attn64::fwd_launch<T>(qkv, Epk, key_pad, out, lse, PT, MT, B, L, H, M, st);
     }
     const int nqb = (L + 127) / 128, Lp = ((L + 31) / 32) * 32;
     const float scale = 1.f / sqrtf((float)DH);
@@ -948,9 +913,8 @@ int bwd_launch(const void* qkv, const void* Epk, const void* out, const float* l
                float* delta_ws, const void* PT, const float* MT, void* dGT, int B, int L, int Lp, int H, int M, int causal,
                hipStream_t st, int phases = 7) {
     // phases (me_rga_bwd_phases): bit 0 = query-owned kernel (dQ, delta, dG^T), bit 1 = key-owned kernel (dK, dV; needs delta),
-    // bit 2 = E-row-owned kernel (dE; needs dG^T), bit 3 = delta alone (rga_delta_kernel), bit 4 = the query-owned kernel does not
-    // write delta (bit 3 did).  The kernels of bits 1 and 2 are independent of each other, and with bit 3 first the kernels of
-    // bits 0 and 1 are too: a caller with two streams may run them side by side (ops.rga_bwd).
+    // bit 2 = E-row-owned kernel (dE; needs dG^T).  The kernels of bits 1 and 2 are independent of each other: a caller with
+    // two streams may run them side by side (ops.rga_bwd).
     // One launch of each kernel over the whole batch.  Splitting the batch so that a chunk's probability / dG^T tiles
     // stay in the 256 MB Infinity Cache between the three kernels was measured and is slower (B = 32 in chunks of
     // 16 / 8 / 4: 449 / 524 / 898 us against 424 us): these kernels are latency bound, not HBM bound, and smaller
@@ -958,12 +922,7 @@ int bwd_launch(const void* qkv, const void* Epk, const void* out, const float* l
     const int nqb = (L + 127) / 128;
     const float scale = 1.f / sqrtf((float)DH);
     int rc = 0;
-    if (phases & 8) {
-        rga_delta_kernel<T, DH><<<B * H * nqb, 256, 0, st>>>((const T*)out, (const T*)dout, delta_ws, B, L, H);
-        rc = me_launch_status();
-        if (rc) return rc;
-    }
-    float* const delta_q = (phases & 16) ? nullptr : delta_ws;          // bit 4: delta_ws is already in memory (bit 3 ran): leave it alone
+    float* const delta_q = delta_ws;
     if (phases & 1) {
     if (causal)
         rga_bwd_q_kernel<T, DH, true><<<B * H * nqb, 256, 0, st>>>((const T*)qkv, (const T*)Epk, (const T*)out, lse, (const T*)dout,
@@ -1006,6 +965,10 @@ int bwd_launch(const void* qkv, const void* Epk, const void* out, const float* l
         if (dh == 64) { typedef bf16_t T; constexpr int DH = 64; return CALL; }  \
         if (dh == 48) { typedef bf16_t T; constexpr int DH = 48; return CALL; }  \
         if (dh == 32) { typedef bf16_t T; constexpr int DH = 32; return CALL; }  \
+    } else if (dtype == ME_F16) {                                                \
+        if (dh == 64) { typedef f16_t T; constexpr int DH = 64; return CALL; }   \
+        if (dh == 48) { typedef f16_t T; constexpr int DH = 48; return CALL; }   \
+        if (dh == 32) { typedef f16_t T; constexpr int DH = 32; return CALL; }   \
     } else return ME_ERR_BAD_DTYPE;                                              \
     return ME_ERR_BAD_SHAPE;
 
@@ -1048,7 +1011,7 @@ int me_rga_bwd_phases(const void* qkv, const void* Epk, const void* out, const f
                       int causal, int phases, int dtype, void* stream) {
     me_clear_error();
     if (!qkv || !Epk || !out || !lse || !dout || !dqkv || !dE || !delta_ws || !PT || !MT || !dGT) return ME_ERR_NULL;
-    if (B <= 0 || L <= 0 || H <= 0 || L > M || (M & 31) || Lp != ((L + 31) / 32) * 32 || Lp > M || phases < 1 || phases > 31) return ME_ERR_BAD_SHAPE;
+    if (B <= 0 || L <= 0 || H <= 0 || L > M || (M & 31) || Lp != ((L + 31) / 32) * 32 || Lp > M || phases < 1 || phases > 7) return ME_ERR_BAD_SHAPE;
     if (!aligned16(qkv) || !aligned16(Epk) || !aligned16(out) || !aligned16(dout) || !aligned16(dqkv) ||
         !aligned16(PT) || !aligned16(dGT))
         return ME_ERR_ALIGNMENT;

@@ -1,4 +1,4 @@
-// Relative global attention, hot-path instantiation: bf16, head dim 64, causal (BASELINE configs 2-4).
+// Relative global attention, hot-path instantiation: 16-bit storage (bf16 or f16), head dim 64, causal (BASELINE configs 2-4).
 //
 // Same algorithm and the same saved-tile formats as the generic kernels of me_attn.hip (which remain the f32 tier, the
 // other head dims and the bidirectional variant); what changes is the step: a wave still owns 32 queries, but one step
@@ -17,7 +17,6 @@ namespace me_attn64 {
 using namespace me_attn;
 
 
-typedef bf16_t T;
 constexpr int DH = 64, KA = 4, DB = 2;
 constexpr int LDK = 72;                        // K tile row (elements): 144 B, conflict-free ds_read_b128 fragments
 constexpr int LDV = 96;                        // V tile row: 192 B, conflict-free ds_read_b64_tr_b16
@@ -25,7 +24,8 @@ constexpr int LDR = 68;                        // G ring row (floats): 64-column
 constexpr int K_BYTES = 64 * LDK * 2;          // 9216
 constexpr int V_BYTES = 64 * LDV * 2;          // 12288
 constexpr int G_BYTES = 32 * LDR * 4;          // 8704 per wave
-constexpr int fwd_lds(int nw) { return 2 * K_BYTES + 2 * V_BYTES + nw * G_BYTES; }  // 4 waves: 77824, 8 waves: 112640
+constexpr int NW = 4;                         // waves per block: 128 queries, two blocks per CU (256-query blocks of 8 waves measured 2-10 % slower: profiles/r05_attn_qb256.txt)
+constexpr int FWD_LDS = 2 * K_BYTES + 2 * V_BYTES + NW * G_BYTES;      // 77824
 
 // =====================================================================================
 // forward
@@ -36,10 +36,8 @@ constexpr int fwd_lds(int nw) { return 2 * K_BYTES + 2 * V_BYTES + nw * G_BYTES;
 // MAIN steps (all four waves strictly below their diagonal in both tiles, no padded key in the sequence, the tiles of
 // step s + 2 entirely below L) contain no branch around a memory instruction and no per-element predicate; everything
 // else (diagonal tiles, ragged ends, pad masks) runs the general per-tile path.
-// NW = waves per block: 4 (128 queries, two blocks per CU) or 8 (256 queries, one block per CU: every K / V tile is fetched
-// from L2 once per 256 queries -- round 5; measured, see profiles/r05_attn_qb256.txt)
-template <bool STORE_P, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void rga_fwd64_kernel(const T* __restrict__ qkv, const T* __restrict__ Epk,
+template <typename T, bool STORE_P>
+__global__ __launch_bounds__(64 * NW, 2) void rga_fwd64_kernel(const T* __restrict__ qkv, const T* __restrict__ Epk,
                                                         const uint8_t* __restrict__ key_pad, T* __restrict__ out,
                                                         float* __restrict__ lse, T* __restrict__ PT, float* __restrict__ MT,
                                                         int B, int L, int Lp, int H, int M, float scale) {
@@ -167,7 +165,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void rga_fwd64_kernel(con
             frag_from_acc(pf, p, t);
             if constexpr (STORE_P) {
                 // written once, read by the backward much later: streaming (non-temporal) stores
-                if (store) __builtin_nontemporal_store(pf.v, reinterpret_cast<bf16x8_t*>(ptile + 8 * t));
+                if (store) __builtin_nontemporal_store(pf.v, reinterpret_cast<typename V16<T>::x8*>(ptile + 8 * t));
             }
 #pragma unroll
             for (int i = 0; i < DB; ++i) {
@@ -418,31 +416,25 @@ static void set_lds_limit(const void* fn, int bytes, bool* done) {
     done[dev] = true;
 }
 
-static const bool g_qb256 = getenv("MIDIEMO_ATTN_QB256") != nullptr;      // 256-query forward blocks (A/B switch; default off)
-
-template <int NW>
-static int fwd_launch_nw(const void* qkv, const void* Epk, const uint8_t* key_pad, void* out, float* lse, void* PT, float* MT, int B,
-                         int L, int H, int M, hipStream_t st) {
+template <typename T>
+int fwd_launch(const void* qkv, const void* Epk, const uint8_t* key_pad, void* out, float* lse, void* PT, float* MT, int B,
+               int L, int H, int M, hipStream_t st) {
     const int nqb = (L + 32 * NW - 1) / (32 * NW), Lp = ((L + 31) / 32) * 32;
     const float scale = 1.f / sqrtf((float)DH);
     const dim3 grid(B * H * nqb);
     static bool done_t[16] = {false}, done_i[16] = {false};
     if (PT) {
-        set_lds_limit((const void*)rga_fwd64_kernel<true, NW>, fwd_lds(NW), done_t);
-        rga_fwd64_kernel<true, NW><<<grid, 64 * NW, fwd_lds(NW), st>>>((const T*)qkv, (const T*)Epk, key_pad, (T*)out, lse, (T*)PT, MT, B, L,
-                                                                       Lp, H, M, scale);
+        set_lds_limit((const void*)rga_fwd64_kernel<T, true>, FWD_LDS, done_t);
+        rga_fwd64_kernel<T, true><<<grid, 64 * NW, FWD_LDS, st>>>((const T*)qkv, (const T*)Epk, key_pad, (T*)out, lse, (T*)PT, MT, B, L, Lp, H, M,
+                                                                 scale);
     } else {
-        set_lds_limit((const void*)rga_fwd64_kernel<false, NW>, fwd_lds(NW), done_i);
-        rga_fwd64_kernel<false, NW><<<grid, 64 * NW, fwd_lds(NW), st>>>((const T*)qkv, (const T*)Epk, key_pad, (T*)out, lse, nullptr, nullptr,
-                                                                        B, L, Lp, H, M, scale);
+        set_lds_limit((const void*)rga_fwd64_kernel<T, false>, FWD_LDS, done_i);
+        rga_fwd64_kernel<T, false><<<grid, 64 * NW, FWD_LDS, st>>>((const T*)qkv, (const T*)Epk, key_pad, (T*)out, lse, nullptr, nullptr, B, L,
+                                                                  Lp, H, M, scale);
     }
     return me_launch_status();
 }
-
-int fwd_launch(const void* qkv, const void* Epk, const uint8_t* key_pad, void* out, float* lse, void* PT, float* MT, int B,
-               int L, int H, int M, hipStream_t st) {
-    if (g_qb256) return fwd_launch_nw<8>(qkv, Epk, key_pad, out, lse, PT, MT, B, L, H, M, st);
-    return fwd_launch_nw<4>(qkv, Epk, key_pad, out, lse, PT, MT, B, L, H, M, st);
-}
+template int fwd_launch<bf16_t>(const void*, const void*, const uint8_t*, void*, float*, void*, float*, int, int, int, int, hipStream_t);
+template int fwd_launch<f16_t>(const void*, const void*, const uint8_t*, void*, float*, void*, float*, int, int, int, int, hipStream_t);
 
 }  // namespace me_attn64

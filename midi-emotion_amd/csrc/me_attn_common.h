@@ -1,5 +1,5 @@
 // Helpers shared by the relative-global-attention translation units (me_attn.hip: generic kernels + C entry points,
-// me_attn64.hip: the bf16 / head-dim-64 / causal kernels of the training hot path).
+// me_attn64.hip: the 16-bit / head-dim-64 / causal kernels of the training hot path).
 #pragma once
 #include "me_common.h"
 #include <type_traits>
@@ -110,7 +110,7 @@ template <typename V> ME_DEV V nt_load(const V* p) {
 template <typename V> ME_DEV void nt_store(V v, V* p) {
     __builtin_nontemporal_store(v, p);
 }
-ME_DEV void frag_load_nt(Frag<bf16_t>& f, const bf16_t* p) { f.v = nt_load(reinterpret_cast<const bf16x8_t*>(p)); }
+template <typename T> ME_DEV void frag_load_nt(Frag<T>& f, const T* p) { f.v = nt_load(reinterpret_cast<const typename V16<T>::x8*>(p)); }
 ME_DEV void frag_load_nt(Frag<float>& f, const float* p) {
     f.lo = nt_load(reinterpret_cast<const f32x4_t*>(p));
     f.hi = nt_load(reinterpret_cast<const f32x4_t*>(p + 4));
@@ -119,19 +119,11 @@ ME_DEV void frag_load_nt(Frag<float>& f, const float* p) {
 // v_exp_f32 without the denormal-range fix-up of exp2f (arguments here are <= 0: tiny results may flush to 0)
 ME_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-template <typename T> ME_DEV void st4(T* p, float a, float b, float c, float d);
-template <> ME_DEV void st4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
-    bf16x4_t v; v[0] = (bf16_t)a; v[1] = (bf16_t)b; v[2] = (bf16_t)c; v[3] = (bf16_t)d;
-    *reinterpret_cast<bf16x4_t*>(p) = v;
-}
-template <> ME_DEV void st4<float>(float* p, float a, float b, float c, float d) {
-    *reinterpret_cast<f32x4_t*>(p) = (f32x4_t){a, b, c, d};
-}
-
 }  // namespace me_attn
 
-// bf16 / head dim 64 / causal instantiations (me_attn64.hip); same arguments and workspace formats as the generic launchers
+// 16-bit / head dim 64 / causal instantiations (me_attn64.hip); same arguments and workspace formats as the generic launchers
 namespace me_attn64 {
+template <typename T>
 int fwd_launch(const void* qkv, const void* Epk, const uint8_t* key_pad, void* out, float* lse, void* PT, float* MT, int B,
                int L, int H, int M, hipStream_t st);
 }

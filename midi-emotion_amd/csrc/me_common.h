@@ -4,6 +4,7 @@
 // where lane = (i | h<<5) supplies 8 contraction elements of row i of A and
 // lane = (j | h<<5) supplies 8 contraction elements of column j of B.
 //   bf16 : one v_mfma_f32_32x32x16_bf16            (8 bf16 per lane, 16 B)
+//   f16  : one v_mfma_f32_32x32x16_f16             (8 halves per lane, 16 B; same rate, 10 mantissa bits)
 //   f32  : eight v_mfma_f32_32x32x2_f32 (exact f32) (8 floats per lane, 32 B)
 // Because A and B always use the same (h,e)->k map, the hardware's own k
 // ordering never matters; only the C/D map does:
@@ -19,6 +20,9 @@
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 f16_t;
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
@@ -42,12 +46,24 @@ template <> struct ET<bf16_t> {
     ME_DEV static bf16_t from_f(float x) { return (bf16_t)x; }
     ME_DEV static float fexp(float x) { return __expf(x); }
 };
+template <> struct ET<f16_t> {
+    static constexpr int CH = 8;
+    ME_DEV static float to_f(f16_t x) { return (float)x; }
+    ME_DEV static f16_t from_f(float x) { return (f16_t)x; }
+    ME_DEV static float fexp(float x) { return __expf(x); }
+};
 template <> struct ET<float> {
     static constexpr int CH = 4;
     ME_DEV static float to_f(float x) { return x; }
     ME_DEV static float from_f(float x) { return x; }
     ME_DEV static float fexp(float x) { return expf(x); }
 };
+
+// vector types of the two 16-bit element types (every 16-bit kernel is a template over T in {bf16_t, f16_t}: the data
+// movement is identical, only the MFMA opcode and the conversions differ)
+template <typename T> struct V16;
+template <> struct V16<bf16_t> { typedef bf16x4_t x4; typedef bf16x8_t x8; };
+template <> struct V16<f16_t> { typedef f16x4_t x4; typedef f16x8_t x8; };
 
 // 16-byte chunk moved as one unit between global memory, registers and LDS
 struct __attribute__((aligned(16))) chunk16 { u32x4_t v; };
@@ -58,20 +74,20 @@ ME_DEV void st_chunk(void* p, const chunk16& c) { *reinterpret_cast<chunk16*>(p)
 // ---------------------------------------------------------------------------
 // MFMA operand fragment: 8 contraction elements for one row/column
 // ---------------------------------------------------------------------------
-template <typename T> struct Frag;
-template <> struct Frag<bf16_t> { bf16x8_t v; };
+template <typename T> struct Frag { typename V16<T>::x8 v; };
 template <> struct Frag<float> { f32x4_t lo, hi; };
 
 // 8 contiguous elements (16-byte aligned for bf16, 16-byte aligned halves for f32)
-ME_DEV void frag_load(Frag<bf16_t>& f, const bf16_t* p) { f.v = *reinterpret_cast<const bf16x8_t*>(p); }
+template <typename T> ME_DEV void frag_load(Frag<T>& f, const T* p) { f.v = *reinterpret_cast<const typename V16<T>::x8*>(p); }
 ME_DEV void frag_load(Frag<float>& f, const float* p) {
     f.lo = *reinterpret_cast<const f32x4_t*>(p);
     f.hi = *reinterpret_cast<const f32x4_t*>(p + 4);
 }
 // two groups of 4 contiguous elements (used with the accumulator-as-operand k map)
-ME_DEV void frag_load_4x2(Frag<bf16_t>& f, const bf16_t* p0, const bf16_t* p1) {
-    bf16x4_t a = *reinterpret_cast<const bf16x4_t*>(p0);
-    bf16x4_t b = *reinterpret_cast<const bf16x4_t*>(p1);
+template <typename T> ME_DEV void frag_load_4x2(Frag<T>& f, const T* p0, const T* p1) {
+    typedef typename V16<T>::x4 x4;
+    x4 a = *reinterpret_cast<const x4*>(p0);
+    x4 b = *reinterpret_cast<const x4*>(p1);
     f.v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 ME_DEV void frag_load_4x2(Frag<float>& f, const float* p0, const float* p1) {
@@ -84,42 +100,44 @@ ME_DEV void frag_load_4x2(Frag<float>& f, const float* p0, const float* p1) {
 // address of 4 contiguous elements and lane i receives element i%4 of the chunks of lanes i/4 + 4j (measured
 // on gfx950), so with lane l pointing at row r + l/4, columns 4*(l%4).., lane i gets column i for 4
 // consecutive rows.  f32: plain element gather (the exact tier is not performance critical).
-ME_DEV void frag_load_tr(Frag<bf16_t>& f, const bf16_t* tile, int ld, int rA, int rB, int cbase, int lane) {
-    typedef short v4s __attribute__((ext_vector_type(4)));
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+template <typename T> ME_DEV typename V16<T>::x4 lds_tr4(const T* p) {        // one ds_read_b64_tr_b16 (type agnostic: 16-bit elements)
+    v4s_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(p));
+    return __builtin_bit_cast(typename V16<T>::x4, r);
+}
+template <typename T> ME_DEV void frag_load_tr(Frag<T>& f, const T* tile, int ld, int rA, int rB, int cbase, int lane) {
     const int l16 = lane & 15;
-    const bf16_t* p = tile + (l16 >> 2) * ld + cbase + ((lane >> 4) & 1) * 16 + 4 * (l16 & 3);
-    v4s a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p + rA * ld));
-    v4s b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p + rB * ld));
-    f.v = __builtin_shufflevector(__builtin_bit_cast(bf16x4_t, a), __builtin_bit_cast(bf16x4_t, b), 0, 1, 2, 3, 4, 5, 6, 7);
+    const T* p = tile + (l16 >> 2) * ld + cbase + ((lane >> 4) & 1) * 16 + 4 * (l16 & 3);
+    f.v = __builtin_shufflevector(lds_tr4(p + rA * ld), lds_tr4(p + rB * ld), 0, 1, 2, 3, 4, 5, 6, 7);
 }
 ME_DEV void frag_load_tr(Frag<float>& f, const float* tile, int ld, int rA, int rB, int cbase, int lane) {
     const float* p = tile + cbase + (lane & 31);
 #pragma unroll
     for (int e = 0; e < 4; ++e) { f.lo[e] = p[(rA + e) * ld]; f.hi[e] = p[(rB + e) * ld]; }
 }
-ME_DEV void frag_zero(Frag<bf16_t>& f) { f.v = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0}; }
+template <typename T> ME_DEV void frag_zero(Frag<T>& f) { f.v = (typename V16<T>::x8){0, 0, 0, 0, 0, 0, 0, 0}; }
 ME_DEV void frag_zero(Frag<float>& f) { f.lo = (f32x4_t){0, 0, 0, 0}; f.hi = f.lo; }
-ME_DEV void frag_set(Frag<bf16_t>& f, int e, float x) { f.v[e] = (bf16_t)x; }
+template <typename T> ME_DEV void frag_set(Frag<T>& f, int e, float x) { f.v[e] = (T)x; }
 ME_DEV void frag_set(Frag<float>& f, int e, float x) { if (e < 4) f.lo[e] = x; else f.hi[e - 4] = x; }
 // the 8 elements of a fragment as one 16-byte (bf16) / two 16-byte (f32) stores
-ME_DEV void frag_store(bf16_t* p, const Frag<bf16_t>& f) { *reinterpret_cast<bf16x8_t*>(p) = f.v; }
+template <typename T> ME_DEV void frag_store(T* p, const Frag<T>& f) { *reinterpret_cast<typename V16<T>::x8*>(p) = f.v; }
 ME_DEV void frag_store(float* p, const Frag<float>& f) {
     *reinterpret_cast<f32x4_t*>(p) = f.lo;
     *reinterpret_cast<f32x4_t*>(p + 4) = f.hi;
 }
 // elements 4 half .. 4 half + 3 of a fragment as one 8-byte (bf16) / 16-byte (f32) store
-ME_DEV void frag_store_half(bf16_t* p, const Frag<bf16_t>& f, int half) {
-    bf16x4_t v = half ? __builtin_shufflevector(f.v, f.v, 4, 5, 6, 7) : __builtin_shufflevector(f.v, f.v, 0, 1, 2, 3);
-    *reinterpret_cast<bf16x4_t*>(p) = v;
+template <typename T> ME_DEV void frag_store_half(T* p, const Frag<T>& f, int half) {
+    typename V16<T>::x4 v = half ? __builtin_shufflevector(f.v, f.v, 4, 5, 6, 7) : __builtin_shufflevector(f.v, f.v, 0, 1, 2, 3);
+    *reinterpret_cast<typename V16<T>::x4*>(p) = v;
 }
 ME_DEV void frag_store_half(float* p, const Frag<float>& f, int half) { *reinterpret_cast<f32x4_t*>(p) = half ? f.hi : f.lo; }
-ME_DEV float frag_get(const Frag<bf16_t>& f, int e) { return (float)f.v[e]; }
+template <typename T> ME_DEV float frag_get(const Frag<T>& f, int e) { return (float)f.v[e]; }
 ME_DEV float frag_get(const Frag<float>& f, int e) { return e < 4 ? f.lo[e] : f.hi[e - 4]; }
 
 // accumulator registers [8*t .. 8*t+7] -> operand fragment (k map = c_row of those registers)
-ME_DEV void frag_from_acc(Frag<bf16_t>& f, const f32x16_t& a, int t) {
+template <typename T> ME_DEV void frag_from_acc(Frag<T>& f, const f32x16_t& a, int t) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) f.v[e] = (bf16_t)a[8 * t + e];
+    for (int e = 0; e < 8; ++e) f.v[e] = (T)a[8 * t + e];
 }
 ME_DEV void frag_from_acc(Frag<float>& f, const f32x16_t& a, int t) {
 #pragma unroll
@@ -129,12 +147,29 @@ ME_DEV void frag_from_acc(Frag<float>& f, const f32x16_t& a, int t) {
 ME_DEV void mma32(f32x16_t& acc, const Frag<bf16_t>& a, const Frag<bf16_t>& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
 }
+ME_DEV void mma32(f32x16_t& acc, const Frag<f16_t>& a, const Frag<f16_t>& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.v, b.v, acc, 0, 0, 0);
+}
 ME_DEV void mma32(f32x16_t& acc, const Frag<float>& a, const Frag<float>& b) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo[e], b.lo[e], acc, 0, 0, 0);
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi[e], b.hi[e], acc, 0, 0, 0);
 }
+// four consecutive elements of T from four floats (one 8-byte / 16-byte store)
+template <typename T> ME_DEV void st4(T* p, float a, float b, float c, float d) {
+    typename V16<T>::x4 v; v[0] = (T)a; v[1] = (T)b; v[2] = (T)c; v[3] = (T)d;
+    *reinterpret_cast<typename V16<T>::x4*>(p) = v;
+}
+template <> ME_DEV void st4<float>(float* p, float a, float b, float c, float d) { *reinterpret_cast<f32x4_t*>(p) = (f32x4_t){a, b, c, d}; }
+// the low / high 16-bit half of a dword as a float (element 2 w / 2 w + 1 of a chunk of T)
+template <typename T> ME_DEV float lo16_f(uint32_t u);
+template <typename T> ME_DEV float hi16_f(uint32_t u);
+template <> ME_DEV float lo16_f<bf16_t>(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
+template <> ME_DEV float hi16_f<bf16_t>(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+template <> ME_DEV float lo16_f<f16_t>(uint32_t u) { return (float)__builtin_bit_cast(f16_t, (uint16_t)(u & 0xffffu)); }
+template <> ME_DEV float hi16_f<f16_t>(uint32_t u) { return (float)__builtin_bit_cast(f16_t, (uint16_t)(u >> 16)); }
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also makes the compiler wait vmcnt(0), i.e. for
 // every global load just issued as a prefetch and for every global store still draining (vmcnt is in-order on
 // gfx950); inside pipelined loops only the LDS hand-over needs the barrier.

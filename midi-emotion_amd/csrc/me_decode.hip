@@ -47,12 +47,6 @@ struct DecArgs {
     const float* pe;
     int dc;
     float* x_out;           // f32 [Mr][K] (may be NULL): the prologue's unrounded result (residual of a later kernel)
-    // PRO_LN with npsum > 0: the pre-norm row is not stored anywhere, it is  presid[m] + pbias + sum_j psum[j][m]  (the
-    // split-K partials of the fused FFN kernel, summed in index order: deterministic), psum f32 [npsum][Mr][K]
-    const float* psum;
-    const float* presid;
-    const float* pbias;
-    int npsum;
     // projection
     const void* W;          // T [N][ldw]
     int ldw;
@@ -68,22 +62,6 @@ struct DecArgs {
     int Mc, t;
     const int32_t* t_dev;
 };
-
-// ---- tools-only phase timers (-DME_DEC_PROF, tools/prof_decode_phases.py): lane 0 of wave 0 of every block stamps s_memtime at
-// the phase boundaries of its kernel; never part of the shipped library
-#ifdef ME_DEC_PROF
-constexpr int PROF_SLOTS = 256, PROF_BLOCKS = 320, PROF_ST = 8;
-__device__ unsigned long long g_prof[PROF_SLOTS][PROF_BLOCKS][PROF_ST];
-__device__ int g_prof_kind[PROF_SLOTS];
-__device__ int g_prof_launch;
-#define PROF_DECL(kind) const int prof_slot_ = g_prof_launch; const int prof_bid_ = blockIdx.x + gridDim.x * blockIdx.y; const int prof_kind_ = (kind);
-#define PROF(i) do { if (threadIdx.x == 0 && prof_slot_ < PROF_SLOTS && prof_bid_ < PROF_BLOCKS) g_prof[prof_slot_][prof_bid_][i] = __builtin_amdgcn_s_memtime(); } while (0)
-#define PROF_END() do { if (threadIdx.x == 0 && prof_bid_ == 0 && prof_slot_ < PROF_SLOTS) { g_prof_kind[prof_slot_] = prof_kind_ | (int)(gridDim.x * gridDim.y) << 8; atomicAdd(&g_prof_launch, 1); } } while (0)
-#else
-#define PROF_DECL(kind)
-#define PROF(i)
-#define PROF_END()
-#endif
 
 template <typename T> ME_DEV float round_to(float x) { return ET<T>::to_f(ET<T>::from_f(x)); }
 template <typename T> ME_DEV void chunk_to_f32(const chunk16& c, float* f) {
@@ -142,23 +120,6 @@ template <int NV> ME_DEV void reduce_scatter64(float* v) {
     }
 }
 
-// four consecutive elements k .. k + 3 of pre-norm row m in its partial-sum form (DecArgs.psum): eight partials in flight
-ME_DEV f32x4_t ln_row_from_partials(const DecArgs& a, int m, int k) {
-    const size_t slab = (size_t)a.Mr * a.K;
-    const float* p = a.psum + (size_t)m * a.K + k;
-    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    for (int j0 = 0; j0 < a.npsum; j0 += 8) {
-        f32x4_t t[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const f32x4_t*>(p + (size_t)min(j0 + u, a.npsum - 1) * slab);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) if (j0 + u < a.npsum) acc += t[u];
-    }
-    const f32x4_t b = *reinterpret_cast<const f32x4_t*>(a.pbias + k);
-    const f32x4_t r = *reinterpret_cast<const f32x4_t*>(a.presid + (size_t)m * a.K + k);
-    return (acc + b) + r;
-}
-
 template <typename T, int MR, int CW>
 ME_DEV void dec_fma_chunks(float (&acc)[CW][MR], const chunk16 (&w)[CW], bool ok, const float* xs, int K, int chc) {
     constexpr int CH = ET<T>::CH;
@@ -214,8 +175,6 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(const DecArgs a) {
     const T* W = reinterpret_cast<const T*>(a.W) + (size_t)ch_lo * CH;
     const float* xw = xs + ch_lo * CH;                                  // this wave's slice of every input row
     const int n0 = KS ? blockIdx.x * CW : (blockIdx.x * 4 + wid) * CW;
-    PROF_DECL(PRO * 4 + EPI)
-    PROF(0);
 
     // ---- the prologue's OWN loads go out first (round 5, tools/prof_decode_phases.py): loads return in order per wave, so a
     //      prologue whose few input loads queue behind 4-16 cold weight loads waits for the weights' round trip before it
@@ -230,7 +189,7 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(const DecArgs a) {
         for (int i = 0; i < 4; ++i) {
             const int k = lane * 4 + 256 * i;
             pre_ln[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            if (wid < MR && wid < Mr && k < K) pre_ln[i] = a.npsum > 0 ? ln_row_from_partials(a, wid, k) : *reinterpret_cast<const f32x4_t*>(a.s_in + (size_t)wid * K + k);
+            if (wid < MR && wid < Mr && k < K) pre_ln[i] = *reinterpret_cast<const f32x4_t*>(a.s_in + (size_t)wid * K + k);
         }
     } else if constexpr (PRO == PRO_HILO || PRO == PRO_PLAIN) {
         const T* hi = reinterpret_cast<const T*>(a.x_hi);
@@ -287,7 +246,6 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(const DecArgs a) {
         if constexpr (EPI == EPI_RESID) resid_v = a.resid[(size_t)(oidx % MR) * a.N + n0 + oidx / MR];
     }
 
-    PROF(1);
     // ---- prologue: input rows into LDS
     if constexpr (PRO == PRO_LN) {
         // one wave per row, the row stays in registers (K <= 1024): mean, centred variance, normalise
@@ -299,7 +257,7 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(const DecArgs a) {
                 const int k = lane * 4 + 256 * i;
                 v[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
                 if (m == wid) v[i] = pre_ln[i];                          // requested before the weights
-                else if (m < Mr && k < K) v[i] = a.npsum > 0 ? ln_row_from_partials(a, m, k) : *reinterpret_cast<const f32x4_t*>(a.s_in + (size_t)m * K + k);
+                else if (m < Mr && k < K) v[i] = *reinterpret_cast<const f32x4_t*>(a.s_in + (size_t)m * K + k);
             }
             float sum = 0.f;
 #pragma unroll
@@ -462,10 +420,9 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(const DecArgs a) {
         }
     }
     __syncthreads();
-    PROF(2);
 
     // ---- projection
-    if (n0 >= a.N) { PROF_END(); return; }
+    if (n0 >= a.N) return;
     float acc[CW][MR];
 #pragma unroll
     for (int c = 0; c < CW; ++c)
@@ -476,7 +433,6 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(const DecArgs a) {
         const int ch = lane + 64 * u;
         if (64 * u < nch) dec_fma_chunks<T, MR, CW>(acc, wp[u], ch < nch, xw, K, ch < nch ? ch : 0);
     }
-    PROF(3);
     constexpr int U = 2;                                    // further chunk positions: two in flight
     for (int ch0 = lane + 64 * PF; ch0 < nch; ch0 += 64 * U) {
         chunk16 w[U][CW];
@@ -492,7 +448,6 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(const DecArgs a) {
             dec_fma_chunks<T, MR, CW>(acc, w[u], ch < nch, xw, K, ch < nch ? ch : ch0);
         }
     }
-    PROF(4);
     // ---- reduce over the lanes: lane (row r = lane >> 4, i = lane & 15 < NV/4) ends up with output i + (NV/4) r
     float red[NV];
 #pragma unroll
@@ -514,8 +469,6 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(const DecArgs a) {
             mine = (ks[o_] + ks[NV + o_]) + (ks[2 * NV + o_] + ks[3 * NV + o_]);
         }
     }
-    PROF(5);
-    PROF_END();
     if (!owner) return;
     const int c = oidx / MR, m = oidx % MR, n = n0 + c;
     float v = mine + bias_v;
@@ -535,164 +488,6 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(const DecArgs a) {
             T* cache = reinterpret_cast<T*>(which == 1 ? a.kcache : a.vcache);
             cache[(((size_t)m * H + nn / dh) * a.Mc + t) * dh + nn % dh] = ET<T>::from_f(v);
         }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Fused feed-forward stage (round 5): LayerNorm1 -> FFN_pre + bias + ReLU -> FFN_suf, ONE launch instead of two.
-// The hidden vector is an all-to-all seam only if FFN_suf is cut by OUTPUT columns; cut by the CONTRACTION index it is not:
-// block j owns FFS hidden units, computes them (FFS rows of W1, all of x) and at once their contribution to all d outputs
-// (the FFS columns of W2): part[j][m][0..d) -- split-K partials that the NEXT launch's LayerNorm prologue (which reads its
-// input row anyway) sums in index order together with bias and residual (DecArgs.psum).  Both weight slices (2 x FFS x d
-// elements) are requested before anything else, so the block still has ONE weight round trip; the hidden slice crosses the
-// waves through LDS.  The pre-norm sum s2 is never stored.
-//   phase A: wave w computes hidden units w FFS/4 .. (lanes walk the contraction in 16-byte chunks, like dec_gemv_kernel);
-//   phase B: wave w computes outputs w d/4 ..: a lane group of FFS / CH lanes holds one 128-byte (bf16) row piece of W2.
-// ---------------------------------------------------------------------------------------------------------
-constexpr int FFS = 64;             // hidden units per block
-
-template <typename T, int MR>
-__global__ __launch_bounds__(256) void dec_ffn_kernel(const DecArgs a, const T* __restrict__ W2, int ldw2, const float* __restrict__ b1,
-                                                      float* __restrict__ part) {
-    constexpr int CH = ET<T>::CH;
-    constexpr int CWA = FFS / 4;                                         // hidden units per wave (phase A columns)
-    constexpr int CPRW = FFS / CH;                                       // lanes per W2 row piece (8 bf16 / 16 f32)
-    constexpr int RPI = 64 / CPRW;                                       // W2 rows per wave instruction
-    constexpr int GA = 64 / MR / 4 * 4 >= CWA ? CWA : 64 / MR;           // phase-A columns per lane reduction (NV = GA * MR <= 64)
-    extern __shared__ __attribute__((aligned(16))) float xs[];          // [MR][K] LayerNorm rows (T-rounded) | [MR][FFS] hidden slice
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int K = a.K, Mr = a.Mr, j = blockIdx.x;
-    float* hs = xs + MR * K;
-    const int nch = K / CH;
-    // ---- both weight slices, requested first.  W1 rows j FFS + wid CWA + c, chunk positions lane (+ 64)
-    const T* W1 = reinterpret_cast<const T*>(a.W) + (size_t)(j * FFS + wid * CWA) * a.ldw;
-    const int npos = (nch + 63) / 64;                                    // 1 or 2 (K <= 1024 bf16 / 512 f32 ... checked by the launcher)
-    chunk16 w1[2][CWA];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int ch = lane + 64 * u, chc = ch < nch ? ch : 0;
-        if (u < npos) {
-#pragma unroll
-            for (int c = 0; c < CWA; ++c) w1[u][c] = ld_w(W1 + (size_t)c * a.ldw + (size_t)chc * CH);
-        }
-    }
-    // W2: outputs n = wid (N/4) + it RPI + lane / CPRW, columns j FFS + (lane % CPRW) CH ..; the first PFB iterations now
-    const int N = a.N, nq = N / 4;
-    const int rr = lane / CPRW, cc = lane % CPRW;
-    const int nit = (nq + RPI - 1) / RPI;
-    constexpr int PFB = 16;
-    chunk16 w2[PFB];
-    const T* W2p = W2 + (size_t)j * FFS + (size_t)cc * CH;
-#pragma unroll
-    for (int it = 0; it < PFB; ++it) {
-        const int n = wid * nq + min(it * RPI + rr, nq - 1);
-        if (it < nit) w2[it] = ld_w(W2p + (size_t)n * ldw2);
-    }
-    // ---- LayerNorm1 rows into LDS (one wave per row, as PRO_LN of dec_gemv_kernel)
-    for (int m = wid; m < MR; m += 4) {
-        f32x4_t v[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = lane * 4 + 256 * i;
-            v[i] = (m < Mr && k < K) ? *reinterpret_cast<const f32x4_t*>(a.s_in + (size_t)m * K + k) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        }
-        float sum = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
-        const float mean = wave_sum(sum) / K;
-        float vs = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (lane * 4 + 256 * i < K) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { const float d_ = v[i][e] - mean; vs += d_ * d_; }
-            }
-        }
-        const float rstd = rsqrtf(wave_sum(vs) / K + a.eps);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = lane * 4 + 256 * i;
-            if (k < K) {
-                f32x4_t o = {0.f, 0.f, 0.f, 0.f}, r = o;
-                if (m < Mr) {
-                    const f32x4_t g = *reinterpret_cast<const f32x4_t*>(a.gamma + k);
-                    const f32x4_t be = *reinterpret_cast<const f32x4_t*>(a.beta + k);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { o[e] = (v[i][e] - mean) * rstd * g[e] + be[e]; r[e] = round_to<T>(o[e]); }
-                    if (a.x_out && j == 0) *reinterpret_cast<f32x4_t*>(a.x_out + (size_t)m * K + k) = o;
-                }
-                *reinterpret_cast<f32x4_t*>(&xs[m * K + k]) = r;
-            }
-        }
-    }
-    __syncthreads();
-    // ---- phase A: hidden units of this wave, GA columns per lane reduction
-#pragma unroll
-    for (int g0 = 0; g0 < CWA; g0 += GA) {
-        float acc[GA][MR];
-#pragma unroll
-        for (int c = 0; c < GA; ++c)
-#pragma unroll
-            for (int m = 0; m < MR; ++m) acc[c][m] = 0.f;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (u < npos) {
-                const int ch = lane + 64 * u;
-                chunk16 wsub[GA];
-#pragma unroll
-                for (int c = 0; c < GA; ++c) wsub[c] = w1[u][g0 + c];
-                dec_fma_chunks<T, MR, GA>(acc, wsub, ch < nch, xs, K, ch < nch ? ch : 0);
-            }
-        }
-        constexpr int NV = GA * MR;
-        float red[NV];
-#pragma unroll
-        for (int c = 0; c < GA; ++c)
-#pragma unroll
-            for (int m = 0; m < MR; ++m) red[c * MR + m] = acc[c][m];
-        reduce_scatter64<NV>(red);
-        float mine = 0.f;
-#pragma unroll
-        for (int i = 0; i < NV / 4; ++i) if ((lane & 15) == i) mine = red[i];
-        if ((lane & 15) < NV / 4) {
-            const int o_ = (lane & 15) + (NV / 4) * (lane >> 4), c = o_ / MR, m = o_ % MR;
-            const int hu = wid * CWA + g0 + c;                            // hidden unit inside the slice
-            const float hv = fmaxf(mine + b1[j * FFS + hu], 0.f);
-            hs[m * FFS + hu] = round_to<T>(hv);                           // the training forward stores the hidden tensor in T
-        }
-    }
-    __syncthreads();
-    // ---- phase B: this block's contribution to every output
-    float hv[MR][CH];
-#pragma unroll
-    for (int m = 0; m < MR; ++m)
-#pragma unroll
-        for (int e = 0; e < CH; ++e) hv[m][e] = hs[m * FFS + cc * CH + e];
-    float* pj = part + (size_t)j * Mr * N;
-    auto finish = [&](const chunk16& w, int it) __attribute__((always_inline)) {
-        const T* we = reinterpret_cast<const T*>(&w);
-        float o[MR];
-#pragma unroll
-        for (int m = 0; m < MR; ++m) {
-            float s_ = 0.f;
-#pragma unroll
-            for (int e = 0; e < CH; ++e) s_ = fmaf(ET<T>::to_f(we[e]), hv[m][e], s_);
-            o[m] = group_sum<CPRW>(s_);
-        }
-        float mine = 0.f;
-#pragma unroll
-        for (int m = 0; m < MR; ++m) if (cc == m) mine = o[m];            // lane cc of the group stores row m = cc
-        const int q = it * RPI + rr;
-        if (cc < Mr && q < nq) pj[(size_t)cc * N + wid * nq + q] = mine;
-    };
-#pragma unroll
-    for (int it = 0; it < PFB; ++it) if (it < nit) finish(w2[it], it);
-    for (int it0 = PFB; it0 < nit; it0 += 4) {                            // wider models: four further row groups in flight
-        chunk16 w[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) w[u] = ld_w(W2p + (size_t)(wid * nq + min((it0 + u) * RPI + rr, nq - 1)) * ldw2);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) if (it0 + u < nit) finish(w[u], it0 + u);
     }
 }
 
@@ -861,9 +656,6 @@ __global__ __launch_bounds__(256) void dec_ln_qkv_attn_kernel(const DecArgs a, c
     per = (per + KPI - 1) / KPI * KPI;
     const int j0 = role * per, j1 = min(t, j0 + per);                   // cached keys of a split block
     float* pout = part + ((size_t)mh * nsplit + min(role, nsplit - 1)) * ME_DEC_PART_REC(DH);
-    PROF_DECL(100 + (EMBED ? 1 : 0))
-    PROF(0);
-    if (role == 0 && mh == 0) PROF_END();
     if (!part_a && !part_b && j0 >= j1) {                               // empty split (short contexts)
         if (tid < DH + 4) pout[tid] = tid == 0 ? -INFINITY : 0.f;
         return;
@@ -873,13 +665,7 @@ __global__ __launch_bounds__(256) void dec_ln_qkv_attn_kernel(const DecArgs a, c
     constexpr int NVR = 4;
     f32x4_t v[NVR];
     if constexpr (!EMBED) {
-        const float* row = a.s_in ? a.s_in + (size_t)m * K : ps;
-        if (a.npsum > 0) {
-            // the row arrives as split-K partials of the fused FFN kernel: the block's threads sum four elements each (all
-            // partials of a thread in flight), the waves then read the finished row from LDS (the score buffer, free until pass 1)
-            if (tid * 4 < K) *reinterpret_cast<f32x4_t*>(&ps[tid * 4]) = ln_row_from_partials(a, m, tid * 4);
-            __syncthreads();
-        }
+        const float* row = a.s_in + (size_t)m * K;
 #pragma unroll
         for (int i = 0; i < NVR; ++i) {
             const int k = lane * 4 + 256 * i;
@@ -909,7 +695,6 @@ __global__ __launch_bounds__(256) void dec_ln_qkv_attn_kernel(const DecArgs a, c
     const T* vc = reinterpret_cast<const T*>(a.vcache) + (size_t)mh * Mc * DH;
     const T* er = E + (size_t)(M - 1 - t) * DH;              // relative row of key j: E[M-1-(t-j)] = er + j * DH
     chunk16 v0[U];
-    PROF(1);
     if constexpr (EMBED) {
         // ---- embedding row of sequence m (music_multi.py:89-101 for one position), same arithmetic as PRO_EMBED of dec_gemv_kernel
         const int dc = a.dc, de = K - dc;
@@ -964,7 +749,6 @@ __global__ __launch_bounds__(256) void dec_ln_qkv_attn_kernel(const DecArgs a, c
         }
     }
     __syncthreads();
-    PROF(2);
     // ---- projection of this wave's CWQ columns; result (T-rounded) times `mul` to LDS / memory
     auto project = [&](const T* Wrow, chunk16 (&first)[CWQ], const float* bias, float* dst_lds, T* dst_cache, float* dst_f32, float mul)
                        __attribute__((always_inline)) {
@@ -1001,7 +785,6 @@ __global__ __launch_bounds__(256) void dec_ln_qkv_attn_kernel(const DecArgs a, c
         return;
     }
     project(W0, w0, a.bias + head * DH, qs, nullptr, nullptr, scale);
-    PROF(3);
     const uint8_t* kp = key_pad ? key_pad + (size_t)m * ld_pad : nullptr;
     if (part_a) {                                                       // k_t: cache row; (max, sum) = (s_t, 1)
         T* kcr = reinterpret_cast<T*>(a.kcache) + ((size_t)mh * Mc + t) * DH;
@@ -1054,7 +837,6 @@ __global__ __launch_bounds__(256) void dec_ln_qkv_attn_kernel(const DecArgs a, c
     mx = wave_max(mx);
     if (lane == 0) red[wid] = mx;
     __syncthreads();
-    PROF(4);
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     const float m_safe = mx == -INFINITY ? 0.f : mx;
     float o[CH], lsum = 0.f;
@@ -1089,7 +871,6 @@ __global__ __launch_bounds__(256) void dec_ln_qkv_attn_kernel(const DecArgs a, c
     lsum = wave_sum(lsum);
     if (lane == 0) red[4 + wid] = lsum;
     __syncthreads();
-    PROF(5);
     if (tid < DH) {
         float s_ = 0.f;
 #pragma unroll
@@ -1184,6 +965,7 @@ int attn_launch(const void* q, const void* kc, const void* vc, const void* E, co
 #define ME_DEC_T(CALL)                                          \
     if (dtype == ME_F32) { typedef float T; return CALL; }      \
     if (dtype == ME_BF16) { typedef bf16_t T; return CALL; }    \
+    if (dtype == ME_F16) { typedef f16_t T; return CALL; }      \
     return ME_ERR_BAD_DTYPE;
 
 extern "C" {
@@ -1244,22 +1026,18 @@ int me_dec_attn(const void* q, const void* kcache, const void* vcache, const voi
     return ME_ERR_BAD_SHAPE;
 }
 
-int me_dec_ln_qkv_attn(const float* s_in, const float* psum, int npsum, const float* presid, const float* pbias,
-                       const float* gamma, const float* beta, float eps, const void* Wqkv, const float* bqkv,
+int me_dec_ln_qkv_attn(const float* s_in, const float* gamma, const float* beta, float eps, const void* Wqkv, const float* bqkv,
                        float* x_out, void* kcache, void* vcache, const void* E, const uint8_t* key_pad, int ld_pad, float* part,
                        int nsplit, int Mr, int d, int H, int dh, int M, int Mc, int t, const int32_t* t_dev, int dtype,
                        void* stream) {
     me_clear_error();
-    if (!gamma || !beta || !Wqkv || !bqkv || !kcache || !vcache || !E || !part) return ME_ERR_NULL;
-    if (npsum > 0 ? (!psum || !presid || !pbias || s_in) : !s_in) return ME_ERR_NULL;           // exactly one form of the input row
-    if (npsum > 0 && (!aligned16(psum) || !aligned16(presid) || !aligned16(pbias))) return ME_ERR_ALIGNMENT;
+    if (!s_in || !gamma || !beta || !Wqkv || !bqkv || !kcache || !vcache || !E || !part) return ME_ERR_NULL;
     if (Mr <= 0 || H <= 0 || dh <= 0 || H * dh != d || d > 1024 || d % 8 || nsplit < 2 || nsplit > DEC_NSMAX || Mc <= 0 || M <= 0)
         return ME_ERR_BAD_SHAPE;
     if (!t_dev && (t < 0 || t >= Mc || t >= M)) return ME_ERR_BAD_SHAPE;
     if ((Mc + nsplit - 2) / (nsplit - 1) + 64 > 2048 + 64) return ME_ERR_BAD_SHAPE;   // score buffer: 2048 keys per split
-    if (!aligned16(Wqkv) || !aligned16(kcache) || !aligned16(vcache) || !aligned16(E) || (s_in && !aligned16(s_in))) return ME_ERR_ALIGNMENT;
+    if (!aligned16(Wqkv) || !aligned16(kcache) || !aligned16(vcache) || !aligned16(E) || !aligned16(s_in)) return ME_ERR_ALIGNMENT;
     DecArgs a = {};
-    a.psum = psum; a.npsum = npsum > 0 ? npsum : 0; a.presid = presid; a.pbias = pbias;
     a.s_in = s_in; a.gamma = gamma; a.beta = beta; a.eps = eps; a.x_out = x_out; a.W = Wqkv; a.ldw = d; a.bias = bqkv; a.Mr = Mr;
     a.N = 3 * d; a.K = d; a.kcache = kcache; a.vcache = vcache; a.Mc = Mc; a.t = t; a.t_dev = t_dev; a.H = H; a.dh = dh;
     hipStream_t st = (hipStream_t)stream;
@@ -1305,29 +1083,6 @@ int me_dec_embed_qkv_attn(const int64_t* tokens, const float* cond, const float*
     return ME_ERR_BAD_SHAPE;
 }
 
-int me_dec_ffn(const float* s_in, const float* gamma, const float* beta, float eps, const void* W1, const float* b1, const void* W2,
-               float* x_out, float* part, int Mr, int d, int d_inner, int dtype, void* stream) {
-    me_clear_error();
-    if (!s_in || !gamma || !beta || !W1 || !b1 || !W2 || !part) return ME_ERR_NULL;
-    const int ch = dtype == ME_BF16 ? 8 : 4;
-    if (Mr < 1 || Mr > 8 || d <= 0 || d > 1024 || d % 16 || d / ch > 128 || d_inner <= 0 || d_inner % FFS) return ME_ERR_BAD_SHAPE;
-    if (!aligned16(W1) || !aligned16(W2) || !aligned16(s_in) || !aligned16(part)) return ME_ERR_ALIGNMENT;
-    DecArgs a = {};
-    a.s_in = s_in; a.gamma = gamma; a.beta = beta; a.eps = eps; a.x_out = x_out; a.W = W1; a.ldw = d; a.Mr = Mr; a.N = d; a.K = d;
-    hipStream_t st = (hipStream_t)stream;
-    const unsigned grid = (unsigned)(d_inner / FFS);
-#define ME_DEC_FFN(TT)                                                                                                     \
-    {                                                                                                                       \
-        if (Mr <= 4) dec_ffn_kernel<TT, 4><<<grid, 256, (size_t)(4 * d + 4 * FFS) * sizeof(float), st>>>(a, (const TT*)W2, d_inner, b1, part); \
-        else dec_ffn_kernel<TT, 8><<<grid, 256, (size_t)(8 * d + 8 * FFS) * sizeof(float), st>>>(a, (const TT*)W2, d_inner, b1, part);         \
-        return me_launch_status();                                                                                          \
-    }
-    if (dtype == ME_F32) ME_DEC_FFN(float)
-    if (dtype == ME_BF16) ME_DEC_FFN(bf16_t)
-#undef ME_DEC_FFN
-    return ME_ERR_BAD_DTYPE;
-}
-
 int me_dec_proj_resid(const float* part, int nsplit, int H, int dh, const void* x_T, int ldx, const void* W, int ldw,
                       const float* bias, const float* resid, float* out, int Mr, int N, int K, int dtype, void* stream) {
     me_clear_error();
@@ -1341,34 +1096,17 @@ int me_dec_proj_resid(const float* part, int nsplit, int H, int dh, const void* 
     ME_DEC_T((gemv_launch<T, PRO_PLAIN, EPI_RESID>(a, st)))
 }
 
-int me_dec_ln_proj(const float* s_in, const float* psum, int npsum, const float* presid, const float* pbias,
-                   const float* gamma, const float* beta, float eps, const void* W, int ldw,
+int me_dec_ln_proj(const float* s_in, const float* gamma, const float* beta, float eps, const void* W, int ldw,
                    const float* bias, float* x_out, void* y, int ldy, int Mr, int N, int K, int flags, int dtype,
                    void* stream) {
     me_clear_error();
-    if (!gamma || !beta || !W || !y) return ME_ERR_NULL;
-    if (npsum > 0 ? (!psum || !presid || !pbias || s_in) : !s_in) return ME_ERR_NULL;
-    if (npsum > 0 && (!aligned16(psum) || !aligned16(presid) || !aligned16(pbias))) return ME_ERR_ALIGNMENT;
+    if (!s_in || !gamma || !beta || !W || !y) return ME_ERR_NULL;
     DecArgs a = {};
-    a.psum = psum; a.npsum = npsum > 0 ? npsum : 0; a.presid = presid; a.pbias = pbias;
     a.s_in = s_in; a.gamma = gamma; a.beta = beta; a.eps = eps; a.x_out = x_out; a.W = W; a.ldw = ldw; a.bias = bias;
     a.Mr = Mr; a.N = N; a.K = K; a.y = y; a.ldy = ldy; a.relu = (flags & ME_EPI_RELU) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     if (flags & ME_EPI_OUT_F32) { ME_DEC_T((gemv_launch<T, PRO_LN, EPI_F32>(a, st))) }
     ME_DEC_T((gemv_launch<T, PRO_LN, EPI_T>(a, st)))
 }
-
-#ifdef ME_DEC_PROF
-// tools-only: copy the phase stamps out (dst: PROF_SLOTS x PROF_BLOCKS x PROF_ST u64, kinds: PROF_SLOTS i32); returns the launch count
-int me_debug_dec_prof_read(void* dst, void* kinds, int reset) {
-    int n = 0;
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_prof_launch), sizeof(int));
-    if (dst) (void)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * PROF_SLOTS * PROF_BLOCKS * PROF_ST);
-    if (kinds) (void)hipMemcpyFromSymbol(kinds, HIP_SYMBOL(g_prof_kind), sizeof(int) * PROF_SLOTS);
-    if (reset) { int z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof_launch), &z, sizeof(int)); }
-    return n;
-}
-#endif
 
 }  // extern "C"

@@ -908,7 +908,7 @@ __global__ __launch_bounds__(CE_NW * 64) void ce_fwd_kernel(const LT* __restrict
                 for (int i = 0; i < EP; ++i) {
                     float x;
                     if constexpr (sizeof(LT) == 4) x = reinterpret_cast<const float*>(&nv[q])[i];
-                    else x = (float)reinterpret_cast<const bf16_t*>(&nv[q])[i];
+                    else x = (float)reinterpret_cast<const LT*>(&nv[q])[i];
                     v[q][i] = j + i < V ? x : -INFINITY;
                 }
             }
@@ -973,10 +973,12 @@ template <typename T, typename LT, bool HAS_DBIAS>
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const LT* __restrict__ logits, int ld,
                                                      const int64_t* __restrict__ target, const float* __restrict__ row_lse,
                                                      T* __restrict__ dlogits, int ld_d, const float* __restrict__ n_valid,
-                                                     float extra_scale, int rows, int V, int ignore_index, float* __restrict__ dbias) {
+                                                     float extra_scale, const float* __restrict__ loss_scale, int rows, int V,
+                                                     int ignore_index, float* __restrict__ dbias) {
     __shared__ float red[HAS_DBIAS ? 4 : 1][HAS_DBIAS ? 64 * 33 : 1];     // dbias: [wave][lane][32 partial sums], +1 padding
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const float scale = extra_scale / fmaxf(*n_valid, 0.f);   // n_valid == 0 -> inf/nan like torch's 0/0 mean
+    // n_valid == 0 -> inf/nan like torch's 0/0 mean; loss_scale: the dynamic loss scale of the f16 tier (me_scaler_step), device resident
+    const float scale = extra_scale * (loss_scale ? *loss_scale : 1.f) / fmaxf(*n_valid, 0.f);
     float bs[HAS_DBIAS ? 4 : 1][8];
 #pragma unroll
     for (int c = 0; c < (HAS_DBIAS ? 4 : 1); ++c)
@@ -997,17 +999,17 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const LT* __restrict__ logi
             const float lse = row_lse[row];
             const bool valid = t != ignore_index;
             for (int j = lane * 8; j < ld_d; j += 512) {
-                const chunk16 in = ld_chunk(reinterpret_cast<const bf16_t*>(logits) + row * ld + j);
+                const chunk16 in = ld_chunk(logits + row * ld + j);
                 chunk16 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float g = 0.f;
                     if (valid && j + e < V)
-                        g = (__builtin_amdgcn_exp2f(((float)reinterpret_cast<const bf16_t*>(&in)[e] - lse) * 1.4426950408889634f) -
+                        g = (__builtin_amdgcn_exp2f(((float)reinterpret_cast<const LT*>(&in)[e] - lse) * 1.4426950408889634f) -
                              (j + e == t ? 1.f : 0.f)) * scale;
-                    reinterpret_cast<bf16_t*>(&o)[e] = (bf16_t)g;
+                    reinterpret_cast<T*>(&o)[e] = ET<T>::from_f(g);
                 }
-                st_chunk(reinterpret_cast<bf16_t*>(dlogits) + row * ld_d + j, o);
+                st_chunk(dlogits + row * ld_d + j, o);
             }
         }
     } else if (fast) {
@@ -1027,7 +1029,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const LT* __restrict__ logi
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int j = lane * 8 + 512 * c;
-                    if (j < ld_d) ch[u][c] = ld_chunk(reinterpret_cast<const bf16_t*>(logits) + rc * ld + j);
+                    if (j < ld_d) ch[u][c] = ld_chunk(logits + rc * ld + j);
                 }
             }
 #pragma unroll
@@ -1044,12 +1046,12 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const LT* __restrict__ logi
                     for (int e = 0; e < 8; ++e) {
                         float g = 0.f;
                         if (valid && j + e < V)
-                            g = (__builtin_amdgcn_exp2f(((float)reinterpret_cast<const bf16_t*>(&ch[u][c])[e] - ls[u]) * 1.4426950408889634f) -
+                            g = (__builtin_amdgcn_exp2f(((float)reinterpret_cast<const LT*>(&ch[u][c])[e] - ls[u]) * 1.4426950408889634f) -
                                  (j + e == tg[u] ? 1.f : 0.f)) * scale;
                         if constexpr (HAS_DBIAS) bs[c][e] += g;
-                        reinterpret_cast<bf16_t*>(&o)[e] = (bf16_t)g;
+                        reinterpret_cast<T*>(&o)[e] = ET<T>::from_f(g);
                     }
-                    st_chunk(reinterpret_cast<bf16_t*>(dlogits) + row * ld_d + j, o);
+                    st_chunk(dlogits + row * ld_d + j, o);
                 }
             }
         }
@@ -1130,10 +1132,49 @@ __global__ __launch_bounds__(1024) void sumsq_kernel(const float* __restrict__ g
     }
 }
 
+// GradScaler.update() on the device (torch/cuda/amp/grad_scaler.py semantics; train.py:101,317-324): one thread.
+// state: see ME_SCALER_* in midiemo.h.  sumsq = squared norm of the SCALED gradients (me_sumsq).
+__global__ void scaler_step_kernel(float* __restrict__ state, const float* __restrict__ sumsq, float growth, float backoff, int interval) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float scale = state[ME_SCALER_SCALE];
+    const float ss = *sumsq;
+    const bool bad = !(ss == ss) || ss == INFINITY || ss == -INFINITY;
+    state[ME_SCALER_INV] = 1.f / scale;
+    state[ME_SCALER_FOUND_INF] = bad ? 1.f : 0.f;
+    if (bad) {
+        state[ME_SCALER_SCALE] = scale * backoff;
+        state[ME_SCALER_TRACKER] = 0.f;
+        state[ME_SCALER_SKIPPED] += 1.f;
+    } else {
+        state[ME_SCALER_STEP] += 1.f;
+        const float tr = state[ME_SCALER_TRACKER] + 1.f;
+        if (tr >= (float)interval) {
+            const float grown = scale * growth;
+            state[ME_SCALER_SCALE] = (grown == INFINITY) ? scale : grown;       // torch: the scale never grows to inf
+            state[ME_SCALER_TRACKER] = 0.f;
+        } else state[ME_SCALER_TRACKER] = tr;
+    }
+}
+
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, int64_t n, const float* __restrict__ sumsq,
                                                     float clip, float grad_scale, float lr, float b1, float b2, float eps,
-                                                    float wd, float bc1, float bc2, int zero_grad) {
+                                                    float wd, float bc1, float bc2, int zero_grad, const float* __restrict__ scaler) {
+    // scaler (f16 tier, me_scaler_step ran just before): the gradients carry the loss scale -> unscale with ME_SCALER_INV; a
+    // non-finite gradient norm (ME_SCALER_FOUND_INF) skips the update like GradScaler.step (train.py:322), only the
+    // gradients are cleared; the bias corrections come from the device-side count of the steps actually taken
+    if (scaler) {
+        grad_scale *= scaler[ME_SCALER_INV];
+        const double t = (double)scaler[ME_SCALER_STEP];
+        bc1 = (float)(1.0 - pow((double)b1, t));
+        bc2 = (float)(1.0 - pow((double)b2, t));
+        if (scaler[ME_SCALER_FOUND_INF] != 0.f) {
+            if (zero_grad) {
+                for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) g[i] = 0.f;
+            }
+            return;
+        }
+    }
     float coef = grad_scale;
     if (clip > 0.f && sumsq) {
         const float total = sqrtf(*sumsq) * fabsf(grad_scale);
@@ -1246,6 +1287,7 @@ inline int row_grid(int64_t rows, int cap) { int64_t g = (rows + 3) / 4; return 
 #define ME_DISPATCH(dtype, CALL)                         \
     if ((dtype) == ME_F32) { typedef float T; CALL; }    \
     else if ((dtype) == ME_BF16) { typedef bf16_t T; CALL; } \
+    else if ((dtype) == ME_F16) { typedef f16_t T; CALL; } \
     else return ME_ERR_BAD_DTYPE;
 
 
@@ -1656,7 +1698,7 @@ int me_ce_fwd(const void* logits, int ld, const int64_t* target, float* row_lse,
               int rows, int V, int ignore_index, int logits_dtype, void* stream) {
     me_clear_error();
     if (!logits || !target || !loss_sum || !n_valid) return ME_ERR_NULL;
-    if (logits_dtype != ME_F32 && logits_dtype != ME_BF16) return ME_ERR_BAD_DTYPE;
+    if (logits_dtype != ME_F32 && logits_dtype != ME_BF16 && logits_dtype != ME_F16) return ME_ERR_BAD_DTYPE;
     if (rows <= 0) return ME_OK;
     if (V <= 0 || ld < V) return ME_ERR_BAD_SHAPE;
     const int64_t gb = ((int64_t)rows + CE_NW - 1) / CE_NW;
@@ -1666,25 +1708,30 @@ int me_ce_fwd(const void* logits, int ld, const int64_t* target, float* row_lse,
         const float* lg = (const float*)logits;
         if (V <= 1024) ce_fwd_kernel<float, 4><<<grid, CE_NW * 64, 0, st>>>(lg, ld, target, row_lse, loss_sum, n_valid, rows, V, ignore_index);
         else ce_fwd_kernel<float, 8><<<grid, CE_NW * 64, 0, st>>>(lg, ld, target, row_lse, loss_sum, n_valid, rows, V, ignore_index);
-    } else {
+    } else if (logits_dtype == ME_BF16) {
         const bf16_t* lg = (const bf16_t*)logits;
         if (V <= 1024) ce_fwd_kernel<bf16_t, 2><<<grid, CE_NW * 64, 0, st>>>(lg, ld, target, row_lse, loss_sum, n_valid, rows, V, ignore_index);
         else ce_fwd_kernel<bf16_t, 4><<<grid, CE_NW * 64, 0, st>>>(lg, ld, target, row_lse, loss_sum, n_valid, rows, V, ignore_index);
+    } else {
+        const f16_t* lg = (const f16_t*)logits;
+        if (V <= 1024) ce_fwd_kernel<f16_t, 2><<<grid, CE_NW * 64, 0, st>>>(lg, ld, target, row_lse, loss_sum, n_valid, rows, V, ignore_index);
+        else ce_fwd_kernel<f16_t, 4><<<grid, CE_NW * 64, 0, st>>>(lg, ld, target, row_lse, loss_sum, n_valid, rows, V, ignore_index);
     }
     return me_launch_status();
 }
 
 int me_ce_bwd(const void* logits, int ld, const int64_t* target, const float* row_lse, void* dlogits, int ld_d,
-              const float* n_valid, float extra_scale, float* dbias, int rows, int V, int ignore_index, int logits_dtype,
-              int dtype, void* stream) {
+              const float* n_valid, float extra_scale, const float* loss_scale_dev, float* dbias, int rows, int V, int ignore_index,
+              int logits_dtype, int dtype, void* stream) {
     me_clear_error();
     if (!logits || !target || !row_lse || !dlogits || !n_valid) return ME_ERR_NULL;
-    if (logits_dtype != ME_F32 && logits_dtype != ME_BF16) return ME_ERR_BAD_DTYPE;
+    if (logits_dtype != ME_F32 && logits_dtype != ME_BF16 && logits_dtype != ME_F16) return ME_ERR_BAD_DTYPE;
+    if (logits_dtype != ME_F32 && logits_dtype != dtype) return ME_ERR_BAD_DTYPE;      // 16-bit logits: the tier's own type
     if (rows <= 0) return ME_OK;
     if (V <= 0 || ld < V || ld_d < V) return ME_ERR_BAD_SHAPE;
     if (dbias) {
         // fused bias gradient: 16-bit logits and dlogits, 16-byte rows, at most 2048 columns (four chunks per lane)
-        const bool ok = logits_dtype == ME_BF16 && dtype == ME_BF16 && (ld & 7) == 0 && (ld_d & 7) == 0 && ld >= ld_d && ld_d <= 2048 &&
+        const bool ok = logits_dtype != ME_F32 && (ld & 7) == 0 && (ld_d & 7) == 0 && ld >= ld_d && ld_d <= 2048 &&
                         ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits)) & 15) == 0;
         if (!ok) return ME_ERR_BAD_SHAPE;
     }
@@ -1692,13 +1739,13 @@ int me_ce_bwd(const void* logits, int ld, const int64_t* target, const float* ro
     const int cap = dbias ? 512 : 2048;                     // dbias: one atomic per column and block
     if (logits_dtype == ME_F32) {
         ME_DISPATCH(dtype, (ce_bwd_kernel<T, float, false><<<row_grid(rows, cap), 256, 0, st>>>((const float*)logits, ld, target, row_lse,
-                                                                                              (T*)dlogits, ld_d, n_valid, extra_scale, rows, V, ignore_index, nullptr)));
+                                                                                              (T*)dlogits, ld_d, n_valid, extra_scale, loss_scale_dev, rows, V, ignore_index, nullptr)));
     } else if (dbias) {
-        ME_DISPATCH(dtype, (ce_bwd_kernel<T, bf16_t, true><<<row_grid(rows, cap), 256, 0, st>>>((const bf16_t*)logits, ld, target, row_lse,
-                                                                                              (T*)dlogits, ld_d, n_valid, extra_scale, rows, V, ignore_index, dbias)));
+        ME_DISPATCH(dtype, (ce_bwd_kernel<T, T, true><<<row_grid(rows, cap), 256, 0, st>>>((const T*)logits, ld, target, row_lse,
+                                                                                         (T*)dlogits, ld_d, n_valid, extra_scale, loss_scale_dev, rows, V, ignore_index, dbias)));
     } else {
-        ME_DISPATCH(dtype, (ce_bwd_kernel<T, bf16_t, false><<<row_grid(rows, cap), 256, 0, st>>>((const bf16_t*)logits, ld, target, row_lse,
-                                                                                               (T*)dlogits, ld_d, n_valid, extra_scale, rows, V, ignore_index, nullptr)));
+        ME_DISPATCH(dtype, (ce_bwd_kernel<T, T, false><<<row_grid(rows, cap), 256, 0, st>>>((const T*)logits, ld, target, row_lse,
+                                                                                          (T*)dlogits, ld_d, n_valid, extra_scale, loss_scale_dev, rows, V, ignore_index, nullptr)));
     }
     return me_launch_status();
 }
@@ -1719,9 +1766,17 @@ int me_sumsq(const float* g, int64_t n, float* out, void* ws, size_t ws_bytes, v
     return me_launch_status();
 }
 
+int me_scaler_step(float* state, const float* sumsq, float growth_factor, float backoff_factor, int growth_interval, void* stream) {
+    me_clear_error();
+    if (!state || !sumsq) return ME_ERR_NULL;
+    if (!(growth_factor > 1.f) || !(backoff_factor > 0.f && backoff_factor < 1.f) || growth_interval <= 0) return ME_ERR_BAD_SHAPE;
+    scaler_step_kernel<<<1, 64, 0, (hipStream_t)stream>>>(state, sumsq, growth_factor, backoff_factor, growth_interval);
+    return me_launch_status();
+}
+
 int me_adamw_step(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq, float clip, float grad_scale,
                   float lr, float beta1, float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,
-                  int zero_grad, void* stream) {
+                  int zero_grad, const float* scaler_state, void* stream) {
     me_clear_error();
     if (!p || !g || !m || !v) return ME_ERR_NULL;
     if (n <= 0) return ME_OK;
@@ -1730,8 +1785,9 @@ int me_adamw_step(float* p, float* g, float* m, float* v, int64_t n, const float
     int64_t blocks = (n / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
+    if (scaler_state && !sumsq) return ME_ERR_NULL;
     adamw_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, sumsq, clip, grad_scale, lr, beta1, beta2, eps,
-                                                                   weight_decay, bias_corr1, bias_corr2, zero_grad);
+                                                                   weight_decay, bias_corr1, bias_corr2, zero_grad, scaler_state);
     return me_launch_status();
 }
 

@@ -16,13 +16,6 @@ namespace {
 
 constexpr int BM = 128, BN = 128, NTHREADS = 256;
 
-template <typename T> ME_DEV void st4_t(T* p, float a, float b, float c, float d);
-template <> ME_DEV void st4_t<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
-    bf16x4_t v; v[0] = (bf16_t)a; v[1] = (bf16_t)b; v[2] = (bf16_t)c; v[3] = (bf16_t)d;
-    *reinterpret_cast<bf16x4_t*>(p) = v;
-}
-template <> ME_DEV void st4_t<float>(float* p, float a, float b, float c, float d) { *reinterpret_cast<f32x4_t*>(p) = (f32x4_t){a, b, c, d}; }
-
 
 ME_DEV void acc_zero_quad(f32x16_t& a, int g) {
 #pragma unroll
@@ -86,7 +79,7 @@ ME_DEV void epi_block_swapped(const f32x16_t& acc, int row_base, int col_base, i
             }
         } else {
             T* cp = reinterpret_cast<T*>(Cv) + (size_t)row * ldc + col;
-            if (full && vec_c) st4_t<T>(cp, v[0], v[1], v[2], v[3]);
+            if (full && vec_c) st4<T>(cp, v[0], v[1], v[2], v[3]);
             else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) if (col + e < N) cp[e] = ET<T>::from_f(v[e]);
@@ -95,46 +88,26 @@ ME_DEV void epi_block_swapped(const f32x16_t& acc, int row_base, int col_base, i
     }
 }
 
-// C rows may leave with the streaming (non-temporal) hint (development switch ME_NT_C_STREAM: 0 never, 1 always, 2 for outputs of
-// at least ME_NT_C_MIN_N columns): kept out of L2 the output does not evict the operand rows the other column tiles of the XCD
-// are about to re-read -- but the NEXT kernel then finds less of it in the caches (measured, see profiles/r05_nt_c_stream.txt)
-#ifndef ME_NT_C_STREAM
-#define ME_NT_C_STREAM 0
-#endif
-#ifndef ME_NT_C_MIN_N
-#define ME_NT_C_MIN_N 1536
-#endif
-ME_DEV void st_chunk_c(void* p, const chunk16& c, int N) {
-#if ME_NT_C_STREAM == 1
-    __builtin_nontemporal_store(c.v, reinterpret_cast<u32x4_t*>(p));
-#elif ME_NT_C_STREAM == 2
-    if (N >= ME_NT_C_MIN_N) __builtin_nontemporal_store(c.v, reinterpret_cast<u32x4_t*>(p));
-    else st_chunk(p, c);
-#else
-    st_chunk(p, c);
-#endif
-}
-
 // ReLU sign mask (ME_WS_RELU_MASK): 1 bit per element, stored as the write-out sees the elements.  A REGION = 128 rows x 64
 // columns = 1 KB = [64 lanes][16 bytes]; bit e of byte b of lane l is element (row 32 (b / 4) + 8 (b % 4) + l / 8, column
 // 8 (l % 8) + e) of the region: the chunk lane l stores with instruction (i, it) = (b / 4, b % 4) of the region's write-out.
 // Regions are ordered [column group][row group] with the row count rounded up to 256: one 16-byte load / store per lane and
 // wave tile, nothing to gather.
-ME_DEV char* relu_mask_region(bf16_t* mask, int M, int row0, int col0) {
+ME_DEV char* relu_mask_region(const void* mask, int M, int row0, int col0) {
     const size_t rb_total = (size_t)((M + 255) >> 8) * 32;
-    return reinterpret_cast<char*>(mask) + ((size_t)(col0 >> 6) * rb_total + (size_t)(row0 >> 3)) * 64;
+    return reinterpret_cast<char*>(const_cast<void*>(mask)) + ((size_t)(col0 >> 6) * rb_total + (size_t)(row0 >> 3)) * 64;
 }
 
 // ---- tile write-out of the 256 x 256 kernels (shared by the main-loop variants): stage 32 rows x 128 B at a time through
 // the wave's private 4 KB so that every store instruction writes 8 full 128-byte row segments (per-lane 8-byte pieces
 // across 32 rows are L2-transaction bound).  bf16: a pass = 32 rows x 64 columns; f32: 32 rows x 32 columns.
 // Ends with the accumulators zeroed for the next tile.
-template <bool OUT_F32, int WR, int WC, int EPI>
+template <typename T, bool OUT_F32, int WR, int WC, int EPI>
 ME_DEV void nt256_write_tile(f32x16_t (&acc)[256 / WR / 32][256 / WC / 32], char* smem, int m0, int n0, int wid, int lane,
-                             void* __restrict__ Cv, int ldc, const float* __restrict__ bias, const bf16_t* __restrict__ add,
-                             int ldadd, const bf16_t* __restrict__ gate, int ldgate, int M, int N, bool relu, bool vec_c,
+                             void* __restrict__ Cv, int ldc, const float* __restrict__ bias, const T* __restrict__ add,
+                             int ldadd, const T* __restrict__ gate, int ldgate, int M, int N, bool relu, bool vec_c,
                              chunk16* mreg = nullptr) {
-    typedef bf16_t T;
+    typedef typename V16<T>::x4 Tx4;
     constexpr int NW = WR * WC;
     constexpr int TM = 256 / WR, TN = 256 / WC;
     constexpr int AI = TM / 32, BJ = TN / 32;
@@ -154,7 +127,7 @@ ME_DEV void nt256_write_tile(f32x16_t (&acc)[256 / WR / 32][256 / WC / 32], char
             *reinterpret_cast<f32x4_t*>(stg + lr * 128 + (slot << 4)) = (f32x4_t){v[0], v[1], v[2], v[3]};
         } else {
             const int slot = (jj * 4 + g) ^ (lr & 7);
-            st4_t<T>(reinterpret_cast<T*>(stg + lr * 128 + (slot << 4) + h * 8), v[0], v[1], v[2], v[3]);
+            st4<T>(reinterpret_cast<T*>(stg + lr * 128 + (slot << 4) + h * 8), v[0], v[1], v[2], v[3]);
         }
     };
     // read back: lane -> (row it*8 + lane/8, 16-byte chunk lane%8): full-row coalesced stores
@@ -169,7 +142,7 @@ ME_DEV void nt256_write_tile(f32x16_t (&acc)[256 / WR / 32][256 / WC / 32], char
             const int col = n0 + wc * TN + j0 * 32 + ch * EPC;
             if constexpr (EPI == 4) {
                 // ReLU sign mask (layout: relu_mask_region): the 8 elements of this chunk are bit e of byte b = 4 i + it of the
-                // lane's 16 mask bytes.  Pure per-lane arithmetic on the rounded bf16 halves: x > 0 <=> the half, as a signed
+                // lane's 16 mask bytes.  Pure per-lane arithmetic on the rounded 16-bit halves (bf16 and f16 alike: sign-magnitude): x > 0 <=> the half, as a signed
                 // 16-bit integer, is > 0 (the ReLU left no NaN) -> packed clamp to {0, 1}, the two bits of a dword side by side
                 typedef short i16x2_t __attribute__((ext_vector_type(2)));
                 uint32_t t = 0;
@@ -187,7 +160,7 @@ ME_DEV void nt256_write_tile(f32x16_t (&acc)[256 / WR / 32][256 / WC / 32], char
             if (orow < M && col < N) {
                 if (col + EPC <= N && vec_c) {
                     if constexpr (OUT_F32) st_chunk(reinterpret_cast<float*>(Cv) + (size_t)orow * ldc + col, v);
-                    else st_chunk_c(reinterpret_cast<T*>(Cv) + (size_t)orow * ldc + col, v, N);
+                    else st_chunk(reinterpret_cast<T*>(Cv) + (size_t)orow * ldc + col, v);
                 } else {
 #pragma unroll
                     for (int e = 0; e < EPC; ++e)
@@ -243,7 +216,7 @@ ME_DEV void nt256_write_tile(f32x16_t (&acc)[256 / WR / 32][256 / WC / 32], char
         if constexpr (EPI == 4) {
 #pragma unroll
             for (int g = 0; g < BJ / 2; ++g) {
-                char* mp = relu_mask_region(const_cast<bf16_t*>(gate), M, m0 + wr * TM, n0 + wc * TN + g * 64);
+                char* mp = relu_mask_region(gate, M, m0 + wr * TM, n0 + wc * TN + g * 64);
                 if (m0 + wr * TM < M && n0 + wc * TN + g * 64 < N) st_chunk(mp + lane * 16, mreg[g]);      // one 1 KB store per wave
             }
         }
@@ -289,7 +262,7 @@ ME_DEV void nt256_write_tile(f32x16_t (&acc)[256 / WR / 32][256 / WC / 32], char
                 for (int e = 0; e < 8; ++e) vp[e] = (float)gp[e] > 0.f ? vp[e] : (T)0.f;
                 const int orow = m0 + wr * TM + i * 32 + rr;
                 const int col = n0 + wc * TN + j0 * 32 + ch * 8;
-                if (orow < M && col < N) st_chunk_c(reinterpret_cast<T*>(Cv) + (size_t)orow * ldc + col, v, N);
+                if (orow < M && col < N) st_chunk(reinterpret_cast<T*>(Cv) + (size_t)orow * ldc + col, v);
             }
         }
     } else if constexpr (EPI == 5) {
@@ -323,7 +296,7 @@ ME_DEV void nt256_write_tile(f32x16_t (&acc)[256 / WR / 32][256 / WC / 32], char
                 }
                 const int orow = m0 + wr * TM + i * 32 + rr;
                 const int col = n0 + wc * TN + j0 * 32 + ch * 8;
-                if (orow < M && col < N) st_chunk_c(reinterpret_cast<T*>(Cv) + (size_t)orow * ldc + col, v, N);
+                if (orow < M && col < N) st_chunk(reinterpret_cast<T*>(Cv) + (size_t)orow * ldc + col, v);
             }
         }
     } else if constexpr (EPI == 2) {
@@ -352,12 +325,12 @@ ME_DEV void nt256_write_tile(f32x16_t (&acc)[256 / WR / 32][256 / WC / 32], char
                 const int rr = it * 8 + (lane >> 3), ch = lane & 7;
                 st_chunk(stg + rr * 128 + ((ch ^ (rr & 7)) << 4), aq[ps & 1][it]);
             }
-            bf16x4_t av[NJ][4];
+            Tx4 av[NJ][4];
 #pragma unroll
             for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    av[jj][g] = *reinterpret_cast<const bf16x4_t*>(stg + lr * 128 + (((jj * 4 + g) ^ (lr & 7)) << 4) + h * 8);
+                    av[jj][g] = *reinterpret_cast<const Tx4*>(stg + lr * 128 + (((jj * 4 + g) ^ (lr & 7)) << 4) + h * 8);
             if (ps + 1 < NP) fetch_add(ps + 1, aq[(ps + 1) & 1]);
 #pragma unroll
             for (int jj = 0; jj < NJ; ++jj)
@@ -380,10 +353,10 @@ ME_DEV void nt256_write_tile(f32x16_t (&acc)[256 / WR / 32][256 / WC / 32], char
         // per quad) before this pass's stores are issued
         const bool vec_add = add && (ldadd & 3) == 0 && (reinterpret_cast<uintptr_t>(add) & 7) == 0;
         const bool vec_gate = gate && (ldgate & 3) == 0 && (reinterpret_cast<uintptr_t>(gate) & 7) == 0;
-        auto load4 = [&](const bf16_t* base, int ld, bool vec, int row, int col) __attribute__((always_inline)) -> bf16x4_t {
-            bf16x4_t r = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+        auto load4 = [&](const T* base, int ld, bool vec, int row, int col) __attribute__((always_inline)) -> Tx4 {
+            Tx4 r = {(T)0.f, (T)0.f, (T)0.f, (T)0.f};
             if (base && row < M) {
-                if (vec && col + 3 < N) r = *reinterpret_cast<const bf16x4_t*>(base + (size_t)row * ld + col);
+                if (vec && col + 3 < N) r = *reinterpret_cast<const Tx4*>(base + (size_t)row * ld + col);
                 else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) if (col + e < N) r[e] = base[(size_t)row * ld + col + e];
@@ -391,7 +364,7 @@ ME_DEV void nt256_write_tile(f32x16_t (&acc)[256 / WR / 32][256 / WC / 32], char
             }
             return r;
         };
-        bf16x4_t av[NJ][4], gv[NJ][4];
+        Tx4 av[NJ][4], gv[NJ][4];
         auto fetch_ag = [&](int ps) __attribute__((always_inline)) {
             const int i = ps / JP, j0 = (ps % JP) * NJ;
             const int row = m0 + wr * TM + i * 32 + lr;
@@ -471,12 +444,11 @@ ME_DEV void slot_barrier() {
 //   3 = the general element-wise path (b: any combination, any alignment).
 // One path per instantiation because the kernel sits at the 256-register limit: with all four in one body hipcc spilled an
 // operand piece per slab inside the main loop (round 4).
-template <bool OUT_F32, int WR, int WC, int EPI>
+template <typename T, bool OUT_F32, int WR, int WC, int EPI>
 __global__ __launch_bounds__(WR * WC * 64) void gemm_nt256_kernel(
-    const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc,
-    const float* __restrict__ bias, const bf16_t* __restrict__ add, int ldadd, const bf16_t* __restrict__ gate,
+    const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc,
+    const float* __restrict__ bias, const T* __restrict__ add, int ldadd, const T* __restrict__ gate,
     int ldgate, int M, int N, int K, int flags) {
-    typedef bf16_t T;
     constexpr int NW = WR * WC;
     constexpr int TM = 256 / WR, TN = 256 / WC;                           // wave tile
     constexpr int AI = TM / 32, BJ = TN / 32;                             // macro-atoms per wave tile
@@ -573,12 +545,12 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_nt256_kernel(
         tile_origin(tile_it, m0, n0);
 #pragma unroll
         for (int g = 0; g < BJ / 2; ++g)
-            mreg[g] = ld_chunk(relu_mask_region(const_cast<bf16_t*>(gate), M, m0 + wr * TM, min(n0 + wc * TN + g * 64, N - 64)) + lane * 16);
+            mreg[g] = ld_chunk(relu_mask_region(gate, M, m0 + wr * TM, min(n0 + wc * TN + g * 64, N - 64)) + lane * 16);
     };
     auto epilogue = [&](int tile_it) __attribute__((always_inline)) {
         int m0, n0;
         tile_origin(tile_it, m0, n0);
-        nt256_write_tile<OUT_F32, WR, WC, EPI>(acc, smem, m0, n0, wid, lane, Cv, ldc, bias, add, ldadd, gate, ldgate, M, N, relu, vec_c,
+        nt256_write_tile<T, OUT_F32, WR, WC, EPI>(acc, smem, m0, n0, wid, lane, Cv, ldc, bias, add, ldadd, gate, ldgate, M, N, relu, vec_c,
                                                mreg);
         if constexpr (EPI == 5) mask_fetch(min(tile_it + 1, my_tiles - 1));
     };
@@ -616,332 +588,6 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_nt256_kernel(
         if ((step + 1) % nk == 0) epilogue(step / nk);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // my stores of slab step+1 are in LDS
         slot_barrier();                                                    // everybody's; slab `step` fully consumed
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// 256x256 tile, 8 waves (2 x 4, 128 x 64 per wave), bf16, K % 64 == 0 -- PING-PONG main loop (round 5).
-// Same tile, same accumulator layout, same k order per accumulator (bit-identical results) and same write-out as
-// gemm_nt256_kernel; what differs is how the matrix pipe and the vector-memory port are kept busy:
-//   * the two waves of a SIMD (wave w and w + 4 = the two row groups wr = 0 / 1) never compete for the matrix pipe.  A
-//     slab is cut into four PHASES (a 64 x 32 quadrant of the wave tile x the slab's 64 k: 8 MFMAs = 256 matrix-pipe
-//     cycles); each phase is an L segment and an M segment separated by s_barriers, and group 1 runs one barrier behind
-//     group 0: in every barrier interval one wave of each SIMD multiplies while the other one feeds.
-//   * operand feed = direct-to-LDS loads (global_load_lds_dwordx4: no registers, no ds_write -- the LDS store path was
-//     830 of the 1600 LDS cycles per slab of the register-staged kernel).  A CU accepts one such 1 KB instruction per
-//     ~23 cycles (measured: 64 per slab = 1500 of the 2048 matrix cycles), and a wave is blocked until its own is
-//     accepted, so a feeding wave must do nothing else: the L segment is 2 pieces + one counted wait, and the
-//     fragment ds_reads of the NEXT phase ride between the MFMAs of the M segment (4 or 8 per segment).
-//   * fragment registers: two A sets X, Y (a 64-row half, 2 atoms x 4 k-phases each) and two B sets P, Q (one atom).
-//     Quadrant order alternates between even and odd slabs so that every read finds a set that is free:
-//         even slab: (X,P) (X,Q) (Y,Q) (Y,P)      reads during the four M segments:  Q<-B1  Y<-A1  X<-A0'  Q<-B1'
-//         odd  slab: (X,Q) (X,P) (Y,P) (Y,Q)                                         P<-B0  Y<-A1  X<-A0'  P<-B0'
-//     (' = next slab): 24 reads per slab, each operand byte read once.
-//   * a slab is fed as four UNITS of 128 rows (16 KB = 2 pieces of 8 rows x 128 B per wave) in the order they are read
-//     (even: A0 B0 B1 A1, odd: A0 B1 B0 A1; A0 = rows {0..63} + 128 g, B0 = rows {0..31} + 64 c, ...).  With u = 4 slab + k:
-//     unit u is read during M segment u - 2; L segment m issues unit m + 8 (same LDS slot as unit m, whose reads were
-//     retired by every wave's lgkmcnt(0) at the start of its L segment m - 1 at the latest) and then waits with a COUNTED
-//     vmcnt(10) for unit m + 3, i.e. at least one barrier before any wave reads it: ten to twelve 1 KB pieces per wave
-//     stay in flight across the barriers, nothing in the loop ever drains the queue.
-// LDS: [A even 32 KB][A odd 32 KB][B even 32 KB][B odd 32 KB][write-out staging 32 KB]; slab images as in gemm_nt256_kernel.
-// ---------------------------------------------------------------------------------------------
-template <bool OUT_F32, int EPI>
-__global__ __launch_bounds__(512) void gemm_nt8p_kernel(
-    const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc,
-    const float* __restrict__ bias, const bf16_t* __restrict__ add, int ldadd, const bf16_t* __restrict__ gate,
-    int ldgate, int M, int N, int K, int flags) {
-    typedef bf16_t T;
-    constexpr int WR = 2, WC = 4, AI = 4, BJ = 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wid >> 2, wc = wid & 3;                                // wr = ping-pong group
-    const int ntn = (N + 255) / 256, ntiles = ntn * ((M + 255) / 256);
-    const int nk = K / 64;
-    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int nsteps = my_tiles * nk;
-    if (nsteps <= 0) return;
-    const int NU = 4 * nsteps;                                            // feed units of this block
-    auto tile_origin = [&](int it, int& m0, int& n0) __attribute__((always_inline)) {
-        int t = it * gridDim.x + blockIdx.x;
-        if ((ntiles & 7) == 0) t = (t & 7) * (ntiles >> 3) + (t >> 3);      // contiguous tile range per XCD
-        m0 = (t / ntn) * 256;
-        n0 = (t % ntn) * 256;
-    };
-
-    // ---- operand feed.  `which`: 0 = A half 0, 1 = B half 0, 2 = B half 1, 3 = A half 1.  Wave w moves pieces 2 w and 2 w + 1
-    // of a unit's 16; a piece is 8 consecutive slab rows = 1 KB of the linear slab image (LDS address = wave-uniform
-    // base + 16 lane); the swizzle is applied to the SOURCE chunk of every lane.
-    // Per-lane part of a source address: row offset + swizzled chunk column of the wave's first piece of a unit (4 registers
-    // for A and B); the other pieces differ by a wave-uniform row distance (added to the scalar base) and by a constant
-    // XOR of the chunk column (swz(r) = lrow ^ ((r >> 3) & 7) and the pieces start at multiples of 8 rows).  Tiles cut by
-    // the matrix edge clamp their rows and recompute everything from `lane` at the issue (the empty asm keeps hipcc from
-    // hoisting that: it would hold sixteen more registers across the loop and spill).
-    const uint32_t lda2 = (uint32_t)lda * 2u, ldb2 = (uint32_t)ldb * 2u;
-    const char* Ab = reinterpret_cast<const char*>(A);
-    const char* Bb = reinterpret_cast<const char*>(B);
-    struct Cur { int m0, n0, k, tile; };
-    auto cur_next = [&](Cur& c) __attribute__((always_inline)) {
-        c.k += 64;
-        if (c.k == K) { c.k = 0; ++c.tile; tile_origin(c.tile, c.m0, c.n0); }
-    };
-    const int lrow = lane >> 3;
-    const int rA0 = (wid >> 2) * 128 + 16 * (wid & 3) + lrow, rB0 = (wid >> 1) * 64 + 16 * (wid & 1) + lrow;
-    // (row pitch a multiple of 128 bytes: the chunk XOR can be applied to the sum)
-    const uint32_t offA = (uint32_t)rA0 * lda2 + (uint32_t)(((lane & 7) ^ ((rA0 ^ (rA0 >> 3)) & 7)) << 4);
-    const uint32_t offB = (uint32_t)rB0 * ldb2 + (uint32_t)(((lane & 7) ^ ((rB0 ^ (rB0 >> 3)) & 7)) << 4);
-    const bool pitch128 = ((lda2 | ldb2) & 127u) == 0;
-    auto stage = [&](int which, const Cur& c, int par) __attribute__((always_inline)) {
-        const bool isA = which == 0 || which == 3;
-        const int half = which >> 1;
-        const bool interior = pitch128 && (isA ? c.m0 + 256 <= M : c.n0 + 256 <= N);
-        if (interior) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int dr = isA ? 64 * half + 8 * e : 32 * half + 8 * e;             // rows from the wave's first piece
-                const uint32_t x = isA ? 16u * e : 16u * e + 64u * half;                  // its chunk XOR
-                const char* sb = isA ? Ab + ((size_t)(uint32_t)(c.m0 + dr) * lda2 + (uint32_t)(c.k * 2))
-                                     : Bb + ((size_t)(uint32_t)(c.n0 + dr) * ldb2 + (uint32_t)(c.k * 2));
-                const uint32_t vo = (isA ? offA : offB) ^ x;
-                const int rb = isA ? (wid >> 2) * 128 + 16 * (wid & 3) + dr : (wid >> 1) * 64 + 16 * (wid & 1) + dr;
-                char* dst = smem + par * 32768 + (isA ? 0 : 65536) + rb * 128;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + vo),
-                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-            }
-        } else {
-            int ln = lane;
-            asm volatile("" : "+v"(ln));
-            const int lr8 = ln >> 3;
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int rb = isA ? (wid >> 2) * 128 + 64 * half + 16 * (wid & 3) + 8 * e
-                                   : (wid >> 1) * 64 + 32 * half + 16 * (wid & 1) + 8 * e;
-                const int r = rb + lr8;
-                const uint32_t col = (uint32_t)((((ln & 7) ^ ((r ^ (r >> 3)) & 7)) << 4) + c.k * 2);
-                const char* src = isA ? Ab + ((uint32_t)min(c.m0 + r, M - 1) * lda2 + col)
-                                      : Bb + ((uint32_t)min(c.n0 + r, N - 1) * ldb2 + col);
-                char* dst = smem + par * 32768 + (isA ? 0 : 65536) + rb * 128;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-            }
-        }
-    };
-    // unit k of a slab of parity par: even A0 B0 B1 A1, odd A0 B1 B0 A1
-    auto unit_which = [](int par, int k) __attribute__((always_inline)) { return (par && (k == 1 || k == 2)) ? 3 - k : k; };
-
-    f32x16_t acc[AI][BJ];
-#pragma unroll
-    for (int i = 0; i < AI; ++i)
-#pragma unroll
-        for (int j = 0; j < BJ; ++j) acc_zero(acc[i][j]);
-
-    const int frow = lane & 31, h = lane >> 5;
-    const bool relu = flags & ME_EPI_RELU;
-    const bool vec_c = (ldc % (OUT_F32 ? 4 : 8)) == 0 && (reinterpret_cast<uintptr_t>(Cv) & 15) == 0;
-    static_assert(!(OUT_F32 && (EPI == 1 || EPI == 2)), "the row paths stage bf16 rows");
-
-    // fragment addresses: see gemm_nt256_kernel (swz(r) = (r ^ r >> 3) & 7; rows r and r + 32 differ by XOR 64).
-    // The XOR variants are formed at the read from one opaque base register each (see `stage`); buffer parity, atom and
-    // operand are immediate offsets.
-    Frag<T> FA[2][2][4], FB[2][4];                                        // [X|Y][atom][k-phase], [P|Q][k-phase]
-    uint32_t pa0, pb0;
-    { const int r = wr * 128 + frow; pa0 = r * 128 + ((h ^ ((r ^ (r >> 3)) & 7)) << 4); }
-    { const int r = wc * 64 + frow; pb0 = 65536 + r * 128 + ((h ^ ((r ^ (r >> 3)) & 7)) << 4); }
-    auto read_A1 = [&](int set, int par, int half, int kk, int i) __attribute__((always_inline)) {
-        uint32_t a0 = pa0;
-        asm volatile("" : "+v"(a0));
-        const char* q = smem + (a0 ^ (uint32_t)((kk << 5) ^ (i ? 64 : 0)));
-        frag_load(FA[set][i][kk], reinterpret_cast<const T*>(q + (2 * half + i) * 4096 + par * 32768));
-    };
-    auto read_B1 = [&](int set, int par, int j, int kk) __attribute__((always_inline)) {
-        uint32_t b0 = pb0;
-        asm volatile("" : "+v"(b0));
-        const char* q = smem + (b0 ^ (uint32_t)((kk << 5) ^ ((j & 1) ? 64 : 0)));
-        frag_load(FB[set][kk], reinterpret_cast<const T*>(q + j * 4096 + par * 32768));
-    };
-    auto seg_barrier = [&]() __attribute__((always_inline)) {
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto epilogue = [&](int tile_it) __attribute__((always_inline)) {
-        int m0, n0;
-        tile_origin(tile_it, m0, n0);
-        int ln = lane;                                                    // opaque: nothing of the write-out's address arithmetic
-        asm volatile("" : "+v"(ln));                                      // is hoisted into (and held across) the main loop
-        nt256_write_tile<OUT_F32, WR, WC, EPI>(acc, smem, m0, n0, wid, ln, Cv, ldc, bias, add, ldadd, gate, ldgate, M, N, relu, vec_c);
-    };
-
-    // ---- prologue: units 0 .. 7 (slabs 0 and 1) are issued; units 0 .. 2 must have landed (vmcnt(10) with 16 issued)
-    Cur c2;                                                               // slab step + 2
-    c2.k = 0; c2.tile = 0; tile_origin(0, c2.m0, c2.n0);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) stage(unit_which(0, k), c2, 0);
-    cur_next(c2);
-    if (NU > 4) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) stage(unit_which(1, k), c2, 1);
-        cur_next(c2);
-        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    seg_barrier();
-    // X <- A0(0), P <- B0(0)
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) { read_A1(0, 0, 0, kk, 0); read_A1(0, 0, 0, kk, 1); read_B1(0, 0, 0, kk); }
-    if (wr == 1) seg_barrier();                           // group 1 runs one barrier behind
-
-    // one M + L pair of slab parity E (compile-time), phase p (compile-time)
-    auto phase = [&](auto e_c, auto p_c, int step, bool tile_end) __attribute__((always_inline)) {
-        constexpr int e = decltype(e_c)::value, p = decltype(p_c)::value;
-        const int m = 4 * step + p;
-        // ---- L segment: retire my reads of the previous M segment, feed unit m + 8, wait for unit m + 3
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (m + 8 < NU) {
-            stage(unit_which(e, p), c2, e);
-            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        seg_barrier();
-        // ---- M segment: 8 MFMAs of quadrant (aset, bset) with the reads of unit m + 2 between them
-        constexpr int aset = p >> 1;
-        constexpr int bset = e == 0 ? (p == 1 || p == 2) : (p == 0 || p == 3);
-        // Straight-line code: no branch may enclose an MFMA (hipcc then merges two accumulator copies at the join) or sit
-        // between two of them.  The reads are therefore unconditional: past the end of the stream they fetch stale slots
-        // nobody consumes, and the sets read during the last two M segments of a TILE are fetched again after the
-        // write-out, which so has their 48 registers to itself.
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                mma32(acc[2 * aset + i][bset], FB[bset][kk], FA[aset][i][kk]);
-                {
-                    if (p == 0 && i == 0) read_B1(1 - e, e, 1 - e, kk);
-                    if (p == 3 && i == 0) read_B1(1 - e, 1 - e, 1 - e, kk);
-                    if (p == 1) read_A1(1, e, 1, kk, i);
-                    if (p == 2) read_A1(0, 1 - e, 0, kk, i);
-                }
-                // pinned order: the fragment read after an MFMA may take the registers of the fragment that MFMA consumed
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        __builtin_amdgcn_s_setprio(0);
-        // both groups write a finished tile out in the SAME barrier interval: group 1 (one interval behind) before the
-        // barrier that ends this M segment, group 0 after it
-        if (p == 3 && tile_end) {
-            if (wr == 0) seg_barrier();
-            epilogue(step / nk);
-            if (m + 1 < NU) {                                             // X <- A0', P|Q <- first B atom of the next slab
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) { read_A1(0, 1 - e, 0, kk, 0); read_A1(0, 1 - e, 0, kk, 1); read_B1(1 - e, 1 - e, 1 - e, kk); }
-            }
-            if (wr == 1) seg_barrier();
-            seg_barrier();        // group 0 feeds the slots just read only after group 1's post-write-out reads (same interval) were issued
-        } else {
-            seg_barrier();
-        }
-    };
-    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-    for (int step = 0; step < nsteps; step += 2) {
-        {
-            const bool te = (step + 1) % nk == 0;
-            phase(I0{}, I0{}, step, te); phase(I0{}, I1{}, step, te); phase(I0{}, I2{}, step, te); phase(I0{}, I3{}, step, te);
-            cur_next(c2);
-        }
-        if (step + 1 < nsteps) {
-            const bool te = (step + 2) % nk == 0;
-            phase(I1{}, I0{}, step + 1, te); phase(I1{}, I1{}, step + 1, te); phase(I1{}, I2{}, step + 1, te); phase(I1{}, I3{}, step + 1, te);
-            cur_next(c2);
-        }
-    }
-    if (wr == 0) seg_barrier();
-}
-
-// ---------------------------------------------------------------------------------------------
-// 256x256 tile, FOUR waves (2 x 2, 128 x 128 per wave: one wave per SIMD, the 256 accumulators in a[0:255]), bf16, K % 128 == 0
-// -- hand-scheduled main loop (round 5, VERDICT r4 next-1: the wave tile of the vendor's kernel).  A wave tile of 128 x 128 reads
-// 128 KB of fragments per slab from LDS instead of 192 KB, but with ONE wave per SIMD nothing hides an instruction's issue
-// cost or a wait: the compiler-scheduled version of round 3 ran 84 vs 68 us.  Here the slab loop is one inline-asm body
-// generated by tools/gen_nt4w.py (me_gemm_nt4w.inc): 64 MFMAs per slab and wave with exactly ONE memory instruction in each of
-// the 64 gaps (the 8 fragment reads of the next k-phase in the order the MFMAs consume them; 16 ds_write_b128 of slab + 1;
-// 16 global_load_dwordx4 of slab + 2 into the registers just written), one s_barrier per slab, every s_waitcnt counted from
-// the periodic instruction stream.  Main loop alone (tools/ubench_nt_tile.hip, same box, us): N512.K2048 64.0 -> 53.8,
-// N512.K1536 49.9 -> 42.3, K = 512 shapes 20.1 / 52.5 / 67.8 -> 18.4 / 48.9 / 63.4.
-// Same slab images and swizzle, same k order per accumulator element as gemm_nt256_kernel: results are bit-identical.
-// The tile loop and the write-out stay C++ (nt256_write_tile with the 2 x 2 wave grid); no state crosses the write-out, every tile
-// runs its own prologue: in a multi-tile launch the next tile's first loads queue behind the write-out's stores (vmcnt is in
-// order), where the persistent 8-wave kernel has them in flight before the write-out starts.  Opt-in (MIDIEMO_NT_MAINLOOP=2 / 3):
-// with operands that are not cache-warm the one-slab latency cover of this pipeline loses more than the loop gains (launcher).  LDS: [A even 32 KB][A odd][B even][B odd][write-out staging 32 KB].
-// ---------------------------------------------------------------------------------------------
-#include "me_gemm_nt4w.inc"
-template <bool OUT_F32, int EPI>
-__global__ __launch_bounds__(256) void gemm_nt4w_kernel(
-    const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc,
-    const float* __restrict__ bias, const bf16_t* __restrict__ add, int ldadd, const bf16_t* __restrict__ gate,
-    int ldgate, int M, int N, int K, int flags) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wid >> 1, wc = wid & 1;
-    const int ntn = (N + 255) / 256, ntiles = ntn * ((M + 255) / 256);
-    const bool relu = flags & ME_EPI_RELU;
-    const bool vec_c = (ldc % (OUT_F32 ? 4 : 8)) == 0 && (reinterpret_cast<uintptr_t>(Cv) & 15) == 0;
-    const int npair = K / 128;
-    // operand feed: waves 0, 1 stage the A slab (pieces 16 (wid & 1) + p), waves 2, 3 the B slab
-    const bool isA = wid < 2;
-    const uint32_t ld2 = (uint32_t)(isA ? lda : ldb) * 2u;
-    const int rows = isA ? M : N;
-    const int lrow = lane >> 3;
-    const uint32_t lwr = (isA ? 0u : 65536u) + (uint32_t)(wid & 1) * 16384u + (uint32_t)lane * 16u;
-    const int frow = lane & 31, h = lane >> 5;
-    uint32_t lra, lrb;
-    { const int r = wr * 128 + frow; lra = r * 128 + ((h ^ ((r ^ (r >> 3)) & 7)) << 4); }
-    { const int r = wc * 128 + frow; lrb = 65536 + r * 128 + ((h ^ ((r ^ (r >> 3)) & 7)) << 4); }
-    f32x16_t acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc_zero(acc[i][j]);
-    auto tile_origin = [&](int it, int& m0, int& n0) __attribute__((always_inline)) {
-        int t = it;
-        if ((ntiles & 7) == 0) t = (t & 7) * (ntiles >> 3) + (t >> 3);      // contiguous tile range per XCD
-        m0 = (t / ntn) * 256;
-        n0 = (t % ntn) * 256;
-    };
-    for (int it = blockIdx.x; it < ntiles; it += gridDim.x) {
-        int m0, n0;
-        tile_origin(it, m0, n0);
-        const int o0 = isA ? m0 : n0;
-        const char* sbase = reinterpret_cast<const char*>(isA ? A : B) + (size_t)(uint32_t)o0 * ld2;
-        uint32_t vo[16];
-        int lf = lane;                                                    // opaque per tile: the sixteen offsets are recomputed here, not
-        asm volatile("" : "+v"(lf));                                      // hoisted out of the tile loop and spilled around the asm body
-#pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            const int r = ((wid & 1) * 16 + p) * 8 + (lf >> 3);            // row inside the slab; rows past the matrix are clamped
-            vo[p] = (uint32_t)(min(o0 + r, rows - 1) - o0) * ld2 + (uint32_t)(((lf & 7) ^ ((r ^ (r >> 3)) & 7)) << 4);
-        }
-        asm volatile(ME_NT4W_BODY
-                     : [c0] "+a"(acc[0][0]), [c1] "+a"(acc[0][1]), [c2] "+a"(acc[0][2]), [c3] "+a"(acc[0][3]),
-                       [c4] "+a"(acc[1][0]), [c5] "+a"(acc[1][1]), [c6] "+a"(acc[1][2]), [c7] "+a"(acc[1][3]),
-                       [c8] "+a"(acc[2][0]), [c9] "+a"(acc[2][1]), [c10] "+a"(acc[2][2]), [c11] "+a"(acc[2][3]),
-                       [c12] "+a"(acc[3][0]), [c13] "+a"(acc[3][1]), [c14] "+a"(acc[3][2]), [c15] "+a"(acc[3][3])
-                     : [vo0] "v"(vo[0]), [vo1] "v"(vo[1]), [vo2] "v"(vo[2]), [vo3] "v"(vo[3]), [vo4] "v"(vo[4]), [vo5] "v"(vo[5]),
-                       [vo6] "v"(vo[6]), [vo7] "v"(vo[7]), [vo8] "v"(vo[8]), [vo9] "v"(vo[9]), [vo10] "v"(vo[10]), [vo11] "v"(vo[11]),
-                       [vo12] "v"(vo[12]), [vo13] "v"(vo[13]), [vo14] "v"(vo[14]), [vo15] "v"(vo[15]), [lwr] "v"(lwr), [lra] "v"(lra),
-                       [lrb] "v"(lrb), [sbase] "s"(sbase), [npair] "s"(npair)
-                     : ME_NT4W_CLOBBERS);
-        int ln = lane;                                                    // opaque: nothing of the write-out's address arithmetic
-        asm volatile("" : "+v"(ln));                                      // is hoisted out of the tile loop and held (spilled) across the asm body
-        nt256_write_tile<OUT_F32, 2, 2, EPI>(acc, smem, m0, n0, wid, ln, Cv, ldc, bias, add, ldadd, gate, ldgate, M, N, relu, vec_c);
-        // (no barrier: the staging area is private to the wave, the next prologue writes LDS buffer 0, which the last slab only
-        // touched with its never-consumed reads of "slab nk", and buffer 1 is written behind the prologue's own barrier)
     }
 }
 
@@ -1142,16 +788,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(
 // (A 256x256 direct-to-LDS variant reaches 757 TF in its main loop but loses end to end: the split-K
 // flush costs blocks x tile-area f32 atomics either way, and only this 3-blocks-per-CU kernel overlaps
 // it with other blocks' MFMA work.  Measured: 173 vs 123 us on dW1.)
-ME_DEV bf16x4_t lds_tr4(const bf16_t* p) {
-    typedef short v4s __attribute__((ext_vector_type(4)));
-    v4s r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p));
-    return __builtin_bit_cast(bf16x4_t, r);
-}
-
-__global__ __launch_bounds__(NTHREADS) void gemm_tn_bf16_kernel(
-    const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, float* __restrict__ dW, int lddw,
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void gemm_tn16_kernel(
+    const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb, float* __restrict__ dW, int lddw,
     float* __restrict__ dbias, int Tn, int N, int K, int t_per_block, int tn, int tk, int nsplit) {
-    typedef bf16_t T;
     constexpr int LDN_ = 160;                      // LDS row stride (elements)
     constexpr int NCH = BT * 16 / NTHREADS;        // 16-byte chunks per thread per operand (2)
     __shared__ __attribute__((aligned(16))) T As[2][BT * LDN_];
@@ -1273,16 +913,15 @@ constexpr int TN256_LDS = 4 * TN256_OP;                         // two buffers x
 // #CUs / (total tiles) instead of #CUs / (tiles of one product) -- at the headline shapes 5 ranges instead of 16-64, i.e.
 // a quarter of the partial-tile bytes written here and read by the reduce pass, one flush and one launch instead of four.
 struct tn_prod {
-    const bf16_t* A; const bf16_t* B; float* dW; float* dbias;
+    const void* A; const void* B; float* dW; float* dbias;
     int lda, ldb, lddw, N, tn, tk, tile0, pad_;
 };
 struct tn_group { tn_prod p[ME_TN_MAX_GROUP]; int np, ntile, nsplit, t_per_block, Tn, pad_; };
 
 // RAGGED = false: every slab of every range is whole (Tn % t_per_block == 0, t_per_block % 64 == 0): the operand feed has
 // no clamp, no zero-fill select and no per-piece address multiply (73 -> ~35 VALU instructions per slab and wave).
-template <bool RAGGED>
+template <typename T, bool RAGGED>
 __global__ __launch_bounds__(512) void gemm_tn256_kernel(const tn_group G, float* __restrict__ ws) {
-    typedef bf16_t T;
     extern __shared__ __attribute__((aligned(16))) char smem[];          // [2 buffers][A slab | B slab]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1300,8 +939,8 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const tn_group G, float
     const int z = g / ntile, gtile = g % ntile;
     int pi = 0;
     while (pi + 1 < G.np && gtile >= G.p[pi + 1].tile0) ++pi;
-    const bf16_t* __restrict__ A = G.p[pi].A;
-    const bf16_t* __restrict__ B = G.p[pi].B;
+    const T* __restrict__ A = reinterpret_cast<const T*>(G.p[pi].A);
+    const T* __restrict__ B = reinterpret_cast<const T*>(G.p[pi].B);
     float* __restrict__ dW = G.p[pi].dW;
     float* __restrict__ dbias = G.p[pi].dbias;
     const int lda = G.p[pi].lda, ldb = G.p[pi].ldb, lddw = G.p[pi].lddw, N = G.p[pi].N, tn = G.p[pi].tn;
@@ -1364,8 +1003,8 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const tn_group G, float
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             const uint32_t u = R[i].v[w];
-            bs8[2 * w] += __builtin_bit_cast(float, u << 16);
-            bs8[2 * w + 1] += __builtin_bit_cast(float, u & 0xffff0000u);
+            bs8[2 * w] += lo16_f<T>(u);
+            bs8[2 * w + 1] += hi16_f<T>(u);
         }
     };
 
@@ -1580,7 +1219,7 @@ __global__ __launch_bounds__(256) void cast_transpose_multi_kernel(const me_ct_d
                         for (int e = 0; e < 4; ++e) if (c + e < cols) v[e] = dsc.src[(size_t)r * cols + c + e];
                     }
                     if (dst) {
-                        if (vdst && c + 3 < cols) st4_t<T>(dst + (size_t)r * dsc.ld_dst + c, v[0], v[1], v[2], v[3]);
+                        if (vdst && c + 3 < cols) st4<T>(dst + (size_t)r * dsc.ld_dst + c, v[0], v[1], v[2], v[3]);
                         else {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) if (c + e < cols) dst[(size_t)r * dsc.ld_dst + c + e] = ET<T>::from_f(v[e]);
@@ -1625,8 +1264,8 @@ __global__ __launch_bounds__(256) void cast_transpose_multi_kernel(const me_ct_d
                         for (int j = 0; j < 8; ++j) v[j] = tile[rg + j][cl];
                         T* o = dstT + (size_t)c * dsc.ld_dstT + r;
                         if (vT && r + 7 < rows) {
-                            st4_t<T>(o, v[0], v[1], v[2], v[3]);
-                            st4_t<T>(o + 4, v[4], v[5], v[6], v[7]);
+                            st4<T>(o, v[0], v[1], v[2], v[3]);
+                            st4<T>(o + 4, v[4], v[5], v[6], v[7]);
                         } else {
 #pragma unroll
                             for (int j = 0; j < 8; ++j) if (r + j < rows) o[j] = ET<T>::from_f(v[j]);
@@ -1641,21 +1280,6 @@ __global__ __launch_bounds__(256) void cast_transpose_multi_kernel(const me_ct_d
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static const bool g_disable_nt256 = getenv("MIDIEMO_NO_NT256") != nullptr;
-// main loop of the 256-tile NT kernel (results are bit-identical across all of them; MIDIEMO_NT_MAINLOOP selects):
-//   0  (default) register-staged single phase, 8 waves (gemm_nt256_kernel)
-//   1  ping-pong / direct-to-LDS feed, 8 waves (gemm_nt8p_kernel; plain / bias / gate write-outs) -- measured 4-9 % slower
-//   2  hand-scheduled 4-wave loop (gemm_nt4w_kernel) wherever it is legal (K % 128 == 0, row write-outs)
-//   3  the 4-wave loop for launches with at most ONE tile per CU, K >= 2048 and the plain / bias / gate write-out, the 8-wave
-//      kernel otherwise.  In a warm back-to-back replay those launches run 6-12 % faster on the 4-wave kernel (M32768.N512.K2048
-//      bias 66.0 -> 61.9 us); INSIDE the train step, where the 134 MB activation operand comes from HBM, they run 19 %
-//      slower (68.4 -> 81.4 us, tools/instep_nt_shapes.py): one wave per SIMD with one register stage covers one slab time
-//      (1.5 us) of load latency and nothing else runs on the SIMD while it waits.  Hence not the default
-//      (profiles/r05_nt_4wave.txt).
-#ifndef ME_NT_MAINLOOP_DEFAULT
-#define ME_NT_MAINLOOP_DEFAULT 0
-#endif
-static const int g_nt_mainloop = getenv("MIDIEMO_NT_MAINLOOP") ? atoi(getenv("MIDIEMO_NT_MAINLOOP")) : ME_NT_MAINLOOP_DEFAULT;
-
 // CUs the persistent kernels may occupy on the current device: multiProcessorCount minus MIDIEMO_CU_RESERVE (CUs left
 // to a concurrent RCCL kernel when the gradient all-reduce overlaps the backward; default 0).  A query, not a
 // synchronisation; cached per device; 256 (MI355X) when no device is visible (host-only symbol checks).
@@ -1696,28 +1320,23 @@ int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int 
         // the 256-tile kernel addresses its operands with 32-bit byte offsets
         const bool off32 = (unsigned long long)M * lda * 2ull < (1ull << 32) && (unsigned long long)N * ldb * 2ull < (1ull << 32);
         if (nt256_shape_ok(M, N, K) && off32) {
-            static bool attr_set[16] = {false};
+            static bool attr_set[16] = {false};                               // (one flag array per instantiation of this launcher, i.e. per T)
             int dev = 0;
             if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
             if (dev < 0 || dev >= 16 || !attr_set[dev]) {                   // the attribute is per device
-                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, 2, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
-                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, 2, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
-                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, 2, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
-                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, 2, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
-                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, 2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
-                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<false, 2, 4, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
-                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<true, 2, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
-                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<true, 2, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
-                (void)hipFuncSetAttribute((const void*)gemm_nt8p_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
-                (void)hipFuncSetAttribute((const void*)gemm_nt8p_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
-                (void)hipFuncSetAttribute((const void*)gemm_nt8p_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<T, false, 2, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<T, false, 2, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<T, false, 2, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<T, false, 2, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<T, false, 2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<T, false, 2, 4, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<T, true, 2, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<T, true, 2, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
                 if (dev >= 0 && dev < 16) attr_set[dev] = true;
             }
             unsigned g256 = (unsigned)(((N + 255) / 256) * ((M + 255) / 256));
             const unsigned ncu = (unsigned)persistent_cus();
             if (g256 > ncu) g256 = ncu;              // persistent: one block per CU
-            // 2 x 4 waves.  The 2 x 2 instantiation (128 x 128 per wave, one wave per SIMD, accumulators in the 256
-            // AGPRs) is correct but hipcc spills the 16 prefetch pieces to scratch inside the main loop: 45 TF/s.
             // write-out path (EPI): the row paths need 16-byte aligned operand rows, a vector-storable C and N % 8 == 0
             const bool vec_c = (ldc % 8) == 0 && aligned16(C) && (N & 7) == 0;
             int epi = 3;
@@ -1729,43 +1348,16 @@ int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int 
             } else if (!add && !gate) epi = 0;
             else if (!(flags & ME_EPI_OUT_F32) && gate && !add && !bias && !(flags & ME_EPI_RELU) && vec_c && (ldgate & 7) == 0 && aligned16(gate)) epi = 1;
             else if (!(flags & ME_EPI_OUT_F32) && add && !gate && vec_c && (ldadd & 7) == 0 && aligned16(add)) epi = 2;
-            // main loop: the ping-pong kernel exists for the write-out paths that fit its registers (plain / bias / ReLU, gate rows)
-#define ME_NT256_OLD(F32, E) gemm_nt256_kernel<F32, 2, 4, E><<<g256, 512, NT256_LDS, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias, \
-                                                                                   (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags)
-#define ME_NT256_PP(F32, E) gemm_nt8p_kernel<F32, E><<<g256, 512, NT256_LDS, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias, \
-                                                                                   (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags)
-#define ME_NT256_4W(F32, E) gemm_nt4w_kernel<F32, E><<<g256, 256, NT256_LDS, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, bias, \
-                                                                                   (const bf16_t*)add, ldadd, (const bf16_t*)gate, ldgate, M, N, K, flags)
-            const bool pp = g_nt_mainloop == 1 && epi < 4;
-            // hand-scheduled 4-wave main loop (slab pairs; the element-wise write-out spills beside it): forced (2) or where it measured faster (3)
-            const int ntiles256 = ((N + 255) / 256) * ((M + 255) / 256);
-            const bool w4 = K % 128 == 0 && epi < 3 &&
-                            (g_nt_mainloop == 2 || (g_nt_mainloop == 3 && ntiles256 <= (int)ncu && K >= 2048 && epi < 2));
-            if (w4) {
-                static bool attr4[16] = {false};
-                if (dev < 0 || dev >= 16 || !attr4[dev]) {
-                    (void)hipFuncSetAttribute((const void*)gemm_nt4w_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
-                    (void)hipFuncSetAttribute((const void*)gemm_nt4w_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
-                    (void)hipFuncSetAttribute((const void*)gemm_nt4w_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
-                    (void)hipFuncSetAttribute((const void*)gemm_nt4w_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
-                    if (dev >= 0 && dev < 16) attr4[dev] = true;
-                }
-                if (flags & ME_EPI_OUT_F32) ME_NT256_4W(true, 0);
-                else if (epi == 0) ME_NT256_4W(false, 0);
-                else if (epi == 1) ME_NT256_4W(false, 1);
-                else ME_NT256_4W(false, 2);
-                return me_launch_status();
-            }
-            if (flags & ME_EPI_OUT_F32) { if (epi == 0) { if (pp) ME_NT256_PP(true, 0); else ME_NT256_OLD(true, 0); } else ME_NT256_OLD(true, 3); }
-            else if (epi == 0) { if (pp) ME_NT256_PP(false, 0); else ME_NT256_OLD(false, 0); }
-            else if (epi == 1) { if (pp) ME_NT256_PP(false, 1); else ME_NT256_OLD(false, 1); }
-            else if (epi == 2) ME_NT256_OLD(false, 2);
-            else if (epi == 4) ME_NT256_OLD(false, 4);
-            else if (epi == 5) ME_NT256_OLD(false, 5);
-            else ME_NT256_OLD(false, 3);
-#undef ME_NT256_OLD
-#undef ME_NT256_PP
-#undef ME_NT256_4W
+#define ME_NT256(F32, E) gemm_nt256_kernel<T, F32, 2, 4, E><<<g256, 512, NT256_LDS, st>>>((const T*)A, lda, (const T*)B, ldb, C, ldc, bias, \
+                                                                                  (const T*)add, ldadd, (const T*)gate, ldgate, M, N, K, flags)
+            if (flags & ME_EPI_OUT_F32) { if (epi == 0) ME_NT256(true, 0); else ME_NT256(true, 3); }
+            else if (epi == 0) ME_NT256(false, 0);
+            else if (epi == 1) ME_NT256(false, 1);
+            else if (epi == 2) ME_NT256(false, 2);
+            else if (epi == 4) ME_NT256(false, 4);
+            else if (epi == 5) ME_NT256(false, 5);
+            else ME_NT256(false, 3);
+#undef ME_NT256
             return me_launch_status();
         }
     }
@@ -1781,7 +1373,7 @@ int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int 
 }
 
 // plan of a (grouped) 256-tile launch: token ranges so that tiles x ranges just fills the chip (one block per CU)
-struct tn_item_256 { const bf16_t* A; int lda; const bf16_t* B; int ldb; float* dW; int lddw; float* dbias; int N, K; };
+struct tn_item_256 { const void* A; int lda; const void* B; int ldb; float* dW; int lddw; float* dbias; int N, K; };
 static void tn256_plan(int Tn, int ntile, int* ns_out, int* tp_out, int* grid_out) {
     int ns = persistent_cus() / ntile;
     if (ns < 1) ns = 1;
@@ -1796,13 +1388,14 @@ static bool tn256_eligible(int Tn, int N, int K, int lda, int ldb) {
     const int n256 = ((N + 255) / 256) * 256;
     return !no256 && (N % 256 == 0 || lda >= n256) && K % 256 == 0 && Tn >= 2048 && off32;
 }
+template <typename T>
 static int tn256_group_launch(const tn_item_256* it, int n, int Tn, void* ws_caller, size_t ws_bytes, hipStream_t st) {
     static bool attr_set[16] = {false};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
     if (dev < 0 || dev >= 16 || !attr_set[dev]) {                       // the attribute is per device
-        (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, TN256_LDS);
-        (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, TN256_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, TN256_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, TN256_LDS);
         if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
     tn_group G;
@@ -1828,8 +1421,8 @@ static int tn256_group_launch(const tn_item_256* it, int n, int Tn, void* ws_cal
     }
     // whole slabs in every range is all the unpredicated feed needs (tp is a multiple of the slab; the last range may be shorter):
     // at T = 32768 and 5 ranges (103 / 103 / 103 / 103 / 100 slabs) round 3 took the predicated kernel for no reason
-    if (Tn % TN256_BT == 0) gemm_tn256_kernel<false><<<grid256, 512, TN256_LDS, st>>>(G, ws);
-    else gemm_tn256_kernel<true><<<grid256, 512, TN256_LDS, st>>>(G, ws);
+    if (Tn % TN256_BT == 0) gemm_tn256_kernel<T, false><<<grid256, 512, TN256_LDS, st>>>(G, ws);
+    else gemm_tn256_kernel<T, true><<<grid256, 512, TN256_LDS, st>>>(G, ws);
     if (ws) tn256_reduce_kernel<<<dim3(ntile, 32), 512, 0, st>>>(ws, G);
     return me_launch_status();
 }
@@ -1853,12 +1446,12 @@ int gemm_tn_launch(const void* A, int lda, const void* B, int ldb, float* dW, in
     dim3 grid(tn, tk, nsplit);
     if constexpr (sizeof(T) == 2) {
         if (tn256_eligible(Tn, N, K, lda, ldb)) {
-            tn_item_256 it = {(const bf16_t*)A, lda, (const bf16_t*)B, ldb, dW, lddw, dbias, N, K};
-            return tn256_group_launch(&it, 1, Tn, ws_caller, ws_bytes, st);
+            tn_item_256 it = {A, lda, B, ldb, dW, lddw, dbias, N, K};
+            return tn256_group_launch<T>(&it, 1, Tn, ws_caller, ws_bytes, st);
         }
         const int npairs8 = ((tn * nsplit + 7) / 8) * 8;
-        gemm_tn_bf16_kernel<<<npairs8 * tk, NTHREADS, 0, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, dW, lddw, dbias, Tn, N, K,
-                                                               t_per, tn, tk, nsplit);
+        gemm_tn16_kernel<T><<<npairs8 * tk, NTHREADS, 0, st>>>((const T*)A, lda, (const T*)B, ldb, dW, lddw, dbias, Tn, N, K, t_per, tn, tk,
+                                                               nsplit);
     } else
         gemm_tn_kernel<T><<<grid, NTHREADS, 0, st>>>((const T*)A, lda, (const T*)B, ldb, dW, lddw, dbias, Tn, N, K, t_per);
     return me_launch_status();
@@ -1877,6 +1470,7 @@ int me_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
     hipStream_t st = (hipStream_t)stream;
     if (dtype == ME_F32) return gemm_nt_launch<float>(A, lda, B, ldb, C, ldc, bias, add, ldadd, gate, ldgate, M, N, K, flags, st);
     if (dtype == ME_BF16) return gemm_nt_launch<bf16_t>(A, lda, B, ldb, C, ldc, bias, add, ldadd, gate, ldgate, M, N, K, flags, st);
+    if (dtype == ME_F16) return gemm_nt_launch<f16_t>(A, lda, B, ldb, C, ldc, bias, add, ldadd, gate, ldgate, M, N, K, flags, st);
     return ME_ERR_BAD_DTYPE;
 }
 
@@ -1885,9 +1479,14 @@ int me_gemm_nt_relu_mask(const void* A, int lda, const void* B, int ldb, void* C
     me_clear_error();
     if (!A || !B || !C || !mask) return ME_ERR_NULL;
     if (dir != 0 && dir != 1) return ME_ERR_BAD_SHAPE;
-    if (dtype != ME_BF16) return dtype == ME_F32 ? ME_ERR_BAD_SHAPE : ME_ERR_BAD_DTYPE;      // the f32 tier keeps the gate operand
-    return gemm_nt_launch<bf16_t>(A, lda, B, ldb, C, ldc, dir == 0 ? bias : nullptr, nullptr, 0, mask, 0, M, N, K,
-                                  dir == 0 ? ME_EPI_RELU : 0, (hipStream_t)stream, dir);
+    if (dtype == ME_F32) return ME_ERR_BAD_SHAPE;                                          // the f32 tier keeps the gate operand
+    if (dtype == ME_BF16)
+        return gemm_nt_launch<bf16_t>(A, lda, B, ldb, C, ldc, dir == 0 ? bias : nullptr, nullptr, 0, mask, 0, M, N, K,
+                                      dir == 0 ? ME_EPI_RELU : 0, (hipStream_t)stream, dir);
+    if (dtype == ME_F16)
+        return gemm_nt_launch<f16_t>(A, lda, B, ldb, C, ldc, dir == 0 ? bias : nullptr, nullptr, 0, mask, 0, M, N, K,
+                                     dir == 0 ? ME_EPI_RELU : 0, (hipStream_t)stream, dir);
+    return ME_ERR_BAD_DTYPE;
 }
 
 // bytes of partial-tile workspace a 256-tile launch over `ntile` tiles needs; 0 = no token split
@@ -1906,15 +1505,15 @@ static size_t tn_ws_bytes(int Tn, int N, int K) {
 
 size_t me_workspace_bytes(int op, int M, int N, int K, int dtype) {
     if (op == ME_WS_RELU_MASK)                                            // 64 bytes per 8 rows x 64 columns, rows rounded up to 256; 0 = use the gate operand
-        return (dtype == ME_BF16 && M > 0 && N > 0 && (N & 63) == 0 && nt256_shape_ok(M, N, K) &&
+        return (dtype != ME_F32 && M > 0 && N > 0 && (N & 63) == 0 && nt256_shape_ok(M, N, K) &&
                 (unsigned long long)M * K * 2ull < (1ull << 32) && (unsigned long long)N * K * 2ull < (1ull << 32))
                    ? (size_t)((M + 255) / 256) * 32 * (size_t)(N / 64) * 64 : 0;
-    if (op == ME_WS_GEMM_TN) return dtype == ME_BF16 ? tn_ws_bytes(M, N, K) : 0;
-    if (op == ME_WS_GEMM_TN_GROUP) return dtype == ME_BF16 ? tn_ws_bytes_tiles(M, N) : 0;      // N = total 256 x 256 tiles of the group
+    if (op == ME_WS_GEMM_TN) return dtype != ME_F32 ? tn_ws_bytes(M, N, K) : 0;
+    if (op == ME_WS_GEMM_TN_GROUP) return dtype != ME_F32 ? tn_ws_bytes_tiles(M, N) : 0;      // N = total 256 x 256 tiles of the group
     if (op == ME_WS_RGA_PT || op == ME_WS_RGA_DGT) {
         // 32 x 32 tiles of the compute type per (batch, head): M = B*H, N = Lp (multiple of 32), K = causal flag
         if (M <= 0 || N <= 0 || (N & 31)) return 0;
-        const size_t nq = (size_t)N / 32, es = dtype == ME_BF16 ? 2 : 4;
+        const size_t nq = (size_t)N / 32, es = dtype != ME_F32 ? 2 : 4;
         const size_t tiles = (op == ME_WS_RGA_DGT || K) ? nq * (nq + 1) / 2 : nq * nq;
         return (size_t)M * tiles * 1024 * es;
     }
@@ -1931,6 +1530,7 @@ int me_gemm_tn_acc(const void* A, int lda, const void* B, int ldb, float* dW, in
     hipStream_t st = (hipStream_t)stream;
     if (dtype == ME_F32) return gemm_tn_launch<float>(A, lda, B, ldb, dW, lddw, dbias, T, N, K, ws, ws_bytes, st);
     if (dtype == ME_BF16) return gemm_tn_launch<bf16_t>(A, lda, B, ldb, dW, lddw, dbias, T, N, K, ws, ws_bytes, st);
+    if (dtype == ME_F16) return gemm_tn_launch<f16_t>(A, lda, B, ldb, dW, lddw, dbias, T, N, K, ws, ws_bytes, st);
     return ME_ERR_BAD_DTYPE;
 }
 
@@ -1941,7 +1541,8 @@ int me_gemm_tn_acc_group(const me_tn_item* items, int n_items, int T, void* ws, 
     for (int i = 0; i < n_items; ++i)
         if (!items[i].A || !items[i].B || !items[i].dW) return ME_ERR_NULL;
     hipStream_t st = (hipStream_t)stream;
-    bool grouped = dtype == ME_BF16 && n_items > 1;
+    if (dtype != ME_F32 && dtype != ME_BF16 && dtype != ME_F16) return ME_ERR_BAD_DTYPE;
+    bool grouped = dtype != ME_F32 && n_items > 1;
     for (int i = 0; grouped && i < n_items; ++i) {
         const me_tn_item& m = items[i];
         grouped = m.N > 0 && m.K > 0 && m.lda % 8 == 0 && m.ldb % 8 == 0 && aligned16(m.A) && aligned16(m.B) &&
@@ -1950,9 +1551,9 @@ int me_gemm_tn_acc_group(const me_tn_item* items, int n_items, int T, void* ws, 
     if (grouped) {
         tn_item_256 it[ME_TN_MAX_GROUP];
         for (int i = 0; i < n_items; ++i)
-            it[i] = {(const bf16_t*)items[i].A, items[i].lda, (const bf16_t*)items[i].B, items[i].ldb, items[i].dW, items[i].lddw,
-                     items[i].dbias, items[i].N, items[i].K};
-        return tn256_group_launch(it, n_items, T, ws, ws_bytes, st);
+            it[i] = {items[i].A, items[i].lda, items[i].B, items[i].ldb, items[i].dW, items[i].lddw, items[i].dbias, items[i].N, items[i].K};
+        return dtype == ME_BF16 ? tn256_group_launch<bf16_t>(it, n_items, T, ws, ws_bytes, st)
+                                : tn256_group_launch<f16_t>(it, n_items, T, ws, ws_bytes, st);
     }
     // shapes / types the grouped kernel does not take: one launch per product (same results as me_gemm_tn_acc)
     for (int i = 0; i < n_items; ++i) {
@@ -1974,6 +1575,8 @@ int me_cast_transpose(const float* src, int rows, int cols, void* dst, int ld_ds
         cast_transpose_kernel<float><<<grid, 256, 0, st>>>(src, rows, cols, (float*)dst, ld_dst, (float*)dstT, ld_dstT);
     else if (dtype == ME_BF16)
         cast_transpose_kernel<bf16_t><<<grid, 256, 0, st>>>(src, rows, cols, (bf16_t*)dst, ld_dst, (bf16_t*)dstT, ld_dstT);
+    else if (dtype == ME_F16)
+        cast_transpose_kernel<f16_t><<<grid, 256, 0, st>>>(src, rows, cols, (f16_t*)dst, ld_dst, (f16_t*)dstT, ld_dstT);
     else
         return ME_ERR_BAD_DTYPE;
     return me_launch_status();
@@ -1988,6 +1591,7 @@ int me_cast_transpose_multi(const me_ct_desc* desc_dev, int n_tensors, int total
     const unsigned grid = (unsigned)(total_tiles < 2048 ? total_tiles : 2048);
     if (dtype == ME_F32) cast_transpose_multi_kernel<float><<<grid, 256, 0, st>>>(desc_dev, n_tensors);
     else if (dtype == ME_BF16) cast_transpose_multi_kernel<bf16_t><<<grid, 256, 0, st>>>(desc_dev, n_tensors);
+    else if (dtype == ME_F16) cast_transpose_multi_kernel<f16_t><<<grid, 256, 0, st>>>(desc_dev, n_tensors);
     else return ME_ERR_BAD_DTYPE;
     return me_launch_status();
 }

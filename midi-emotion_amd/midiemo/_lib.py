@@ -9,12 +9,14 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MIDIEMO_LIB") or os.path.join(HERE, "libmidiemo_hip.so")
 
-ME_F32, ME_BF16 = 0, 1
+ME_F32, ME_BF16, ME_F16 = 0, 1, 2
 ME_COND_NONE, ME_COND_CONCAT, ME_COND_TOKEN = 0, 1, 2
 ME_EPI_RELU, ME_EPI_OUT_F32, ME_EPI_RELU_BWD = 1, 2, 4
 ME_WS_GEMM_TN, ME_WS_RGA_PT, ME_WS_RGA_DGT, ME_WS_RGA_MT, ME_WS_GEMM_TN_GROUP, ME_WS_EMBED_BWD, ME_WS_SUMSQ, ME_WS_RELU_MASK = 1, 2, 3, 4, 5, 6, 7, 8
 ME_TN_MAX_GROUP = 5
-ABI_VERSION = 21
+ABI_VERSION = 22
+# words of the loss-scaler state (me_scaler_step; enum ME_SCALER_* of include/midiemo.h)
+ME_SCALER_SCALE, ME_SCALER_INV, ME_SCALER_TRACKER, ME_SCALER_STEP, ME_SCALER_FOUND_INF, ME_SCALER_SKIPPED, ME_SCALER_WORDS = 0, 1, 2, 3, 4, 5, 8
 
 ERRORS = {0: "ME_OK", -1: "ME_ERR_BAD_DTYPE", -2: "ME_ERR_BAD_SHAPE", -3: "ME_ERR_ALIGNMENT",
           -4: "ME_ERR_LAUNCH", -5: "ME_ERR_NULL", -6: "ME_ERR_WORKSPACE"}
@@ -42,17 +44,17 @@ SIGNATURES = {
     "me_resid_ln_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _f, _u64, _u32, _i, _p],
     "me_resid_ln_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _u64, _u32, _i, _p],
     "me_ce_fwd": [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p],
-    "me_ce_bwd": [_p, _i, _p, _p, _p, _i, _p, _f, _p, _i, _i, _i, _i, _i, _p],
+    "me_ce_bwd": [_p, _i, _p, _p, _p, _i, _p, _f, _p, _p, _i, _i, _i, _i, _i, _p],
     "me_sumsq": [_p, _i64, _p, _p, ctypes.c_size_t, _p],
-    "me_adamw_step": [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _p],
+    "me_adamw_step": [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _p, _p],
+    "me_scaler_step": [_p, _p, _f, _f, _i, _p],
     "me_dec_qkv": [_p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p],
     "me_dec_embed_qkv": [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p],
     "me_dec_embed_qkv_attn": [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p],
-    "me_dec_ln_qkv_attn": [_p, _p, _i, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p],
-    "me_dec_ffn": [_p, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "me_dec_ln_qkv_attn": [_p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p],
     "me_dec_attn": [_p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p],
     "me_dec_proj_resid": [_p, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p],
-    "me_dec_ln_proj": [_p, _p, _i, _p, _p, _p, _p, _f, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "me_dec_ln_proj": [_p, _p, _p, _f, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "me_greedy_pick": [_p, _i, _i, _p, _i, _p, _i, _p],
     "me_sample_topk_topp": [_p, _i, _i, _p, _i, _p, _i, _f, _p, _p, _p, _p, _p, _i, _p],
     "me_sample_step": [_p, _i, _i, _p, _i, _p, _p, _p, _f, _f, _f, _i, _f, _p, _i, _p, _i, _p, _p, _i, _p],

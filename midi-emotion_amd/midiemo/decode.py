@@ -62,15 +62,6 @@ class DecodeSession:
         # any other shape takes the separate me_dec_qkv + me_dec_attn launches)
         self.fused = os.environ.get("MIDIEMO_DEC_UNFUSED", "0") in ("", "0") and d <= 1024 and d % 8 == 0 and dh in (32, 48, 64) and \
             self.nsplit >= 2 and -(-m.max_seq // (self.nsplit - 1)) <= 2048
-        # fused feed-forward stage (me_dec_ffn, round 5): FFN_pre + FFN_suf in one launch, split over d_inner; the partial
-        # outputs [d_inner / 64][rows][d] are summed by the next launch's LayerNorm prologue (20 launches per token at 6 layers)
-        es = 2 if dt != f32 else 4
-        # MEASURED SLOWER (profiles/r05_decode.txt: 0.188 vs 0.160 ms per token; the 32-block launch takes 11.6 us against
-        # 5.1 + 4.9 us for the two it replaces and its consumers pay 2-5 us for the partial sums): opt-in, MIDIEMO_DEC_FFN_FUSED=1
-        self.ffn_fused = os.environ.get("MIDIEMO_DEC_FFN_FUSED", "0") not in ("", "0") and self.fused
-        self.ffn_fusable = self.fused and d % 16 == 0 and d // (16 // es) <= 128 and di % 64 == 0
-        self.ffn_fused = self.ffn_fused and self.ffn_fusable
-        self.ffn_part = e(di // 64, min(B, ROWS), d, dtype=f32) if self.ffn_fusable else None
         self.logits = e(B, V, dtype=f32)
         self.t = 0                      # next model position to be written
         self._pos_dev = None            # device-side position: set while a step is issued for graph capture / replay
@@ -96,7 +87,6 @@ class DecodeSession:
             Mr = r1 - r0
             part = self.part[r0 * H:r1 * H]
             fused0 = False
-            psum = None                                        # split-K form of the previous layer's pre-norm sum (me_dec_ffn)
             for i in range(m.num_layer):
                 W = m._prep["layers"][i]
                 p = f"enc_layers.{i}."
@@ -119,9 +109,9 @@ class DecodeSession:
                     # layers >= 1: LayerNorm2 of the previous layer -> q|k|v of a head -> cache append -> attention partials
                     # in ONE launch (me_dec_ln_qkv_attn): 27 instead of 32 launches per token at 6 layers
                     pp = f"enc_layers.{i - 1}."
-                    ops.dec_ln_qkv_attn(None if psum else self.s2[r0:r1], pv(pp + "layernorm2.weight"), pv(pp + "layernorm2.bias"), eps,
+                    ops.dec_ln_qkv_attn(self.s2[r0:r1], pv(pp + "layernorm2.weight"), pv(pp + "layernorm2.bias"), eps,
                                         W["Wqkv"], W["bqkv"], self.xres[r0:r1], self.kc[i][r0:r1], self.vc[i][r0:r1], W["E"],
-                                        None, 0, part, ns, Mr, d, H, dh, M, M, t, self._pos_dev, dt, psum=psum)
+                                        None, 0, part, ns, Mr, d, H, dh, M, M, t, self._pos_dev, dt)
                 else:
                     pp = f"enc_layers.{i - 1}."
                     ops.dec_qkv(self.s2[r0:r1], pv(pp + "layernorm2.weight"), pv(pp + "layernorm2.bias"), eps, None, None,
@@ -132,20 +122,13 @@ class DecodeSession:
                                  M, t, self._pos_dev, dt)
                 ops.dec_proj_resid(part, ns, H, dh, None, W["Wo"], pv(p + "rga.fc.bias"), self.xres[r0:r1], self.s1[r0:r1],
                                    Mr, d, d, dt)
-                if self.ffn_fused:
-                    fp = self.ffn_part.view(-1)[:self.ffn_part.shape[0] * Mr * d].view(-1, Mr, d)     # compact [slices][Mr][d]
-                    ops.dec_ffn(self.s1[r0:r1], pv(p + "layernorm1.weight"), pv(p + "layernorm1.bias"), eps, W["W1"],
-                                pv(p + "FFN_pre.bias"), W["W2"], self.o1res[r0:r1], fp, Mr, d, di, dt)
-                    psum = (fp, self.o1res[r0:r1], pv(p + "FFN_suf.bias"))
-                else:
-                    ops.dec_ln_proj(self.s1[r0:r1], pv(p + "layernorm1.weight"), pv(p + "layernorm1.bias"), eps, W["W1"],
-                                    pv(p + "FFN_pre.bias"), self.o1res[r0:r1], self.hid[r0:r1], Mr, di, d, ops.ME_EPI_RELU, dt)
-                    ops.dec_proj_resid(None, 0, 0, 0, self.hid[r0:r1], W["W2"], pv(p + "FFN_suf.bias"), self.o1res[r0:r1],
-                                       self.s2[r0:r1], Mr, d, di, dt)
+                ops.dec_ln_proj(self.s1[r0:r1], pv(p + "layernorm1.weight"), pv(p + "layernorm1.bias"), eps, W["W1"],
+                                pv(p + "FFN_pre.bias"), self.o1res[r0:r1], self.hid[r0:r1], Mr, di, d, ops.ME_EPI_RELU, dt)
+                ops.dec_proj_resid(None, 0, 0, 0, self.hid[r0:r1], W["W2"], pv(p + "FFN_suf.bias"), self.o1res[r0:r1],
+                                   self.s2[r0:r1], Mr, d, di, dt)
             pl = f"enc_layers.{m.num_layer - 1}."
-            ops.dec_ln_proj(None if psum else self.s2[r0:r1], pv(pl + "layernorm2.weight"), pv(pl + "layernorm2.bias"), eps,
-                            m._prep["head"]["Wf"], pv(m._HEAD_B), None, self.logits[r0:r1], Mr, V, d, ops.ME_EPI_OUT_F32, dt,
-                            psum=psum)
+            ops.dec_ln_proj(self.s2[r0:r1], pv(pl + "layernorm2.weight"), pv(pl + "layernorm2.bias"), eps,
+                            m._prep["head"]["Wf"], pv(m._HEAD_B), None, self.logits[r0:r1], Mr, V, d, ops.ME_EPI_OUT_F32, dt)
         if self._pos_dev is None:
             self.t += 1
         return self.logits
@@ -153,7 +136,7 @@ class DecodeSession:
     # -------------------------------------------------------------- public steps
     @property
     def launches_per_token(self):
-        return ((3 if self.ffn_fused else 4) if self.fused else 5) * self.m.num_layer + 2     # + head, + pick / commit
+        return (4 if self.fused else 5) * self.m.num_layer + 2     # + head, + pick / commit
 
     def prefill_condition_slots(self, cond):
         """continuous_token: model positions 0 and 1 are the two condition vectors

@@ -24,7 +24,10 @@ import torch.nn as nn
 
 from .. import ops
 
-_DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}
+# compute tiers: "bf16" (BASELINE's headline dtype), "fp16" (the reference's own autocast dtype, train.py:281 -- needs the loss
+# scale: optim.LossScaler), "fp32" (exact-f32 MFMA, the parity gate)
+_DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp16": torch.float16, "float16": torch.float16, "f16": torch.float16,
+           "fp32": torch.float32, "float32": torch.float32}
 
 
 def _round_up(x, m):
@@ -586,10 +589,12 @@ class MusicTransformerHIP(nn.Module):
         return _EngineFn.apply(self, tokens, cond, (B, Ltok, Lm), p_drop, self._next_seed(), *params)
 
     def loss_and_backward(self, x, condition, target, grad_scale=1.0, bucket_hook=None, backward=True,
-                          return_logits=False):
+                          return_logits=False, loss_scale=None):
         """Fused train-step front half: forward, CrossEntropyLoss(ignore_index=pad) (mean over
-        non-pad targets), backward into `flat_grads` (+=).  Returns the loss as a device scalar
-        (no host sync).  Replaces Runner.forward_pass + loss.backward() (train.py:276-292,317)."""
+        non-pad targets), backward into `flat_grads` (+=).  Returns the (unscaled) loss as a device scalar
+        (no host sync).  Replaces Runner.forward_pass + loss.backward() (train.py:276-292,317).
+        loss_scale: f32 device scalar multiplied into the backward (optim.LossScaler.scale_tensor -- the f16 tier's
+        `scaler.scale(loss).backward()`; the optimiser step divides it out again)."""
         tokens, cond, B, Ltok, Lm = self._check_inputs(x, condition)
         target = target.to(device=self._flat.device, dtype=torch.int64).contiguous().view(-1)
         T, V = B * Lm, self.head_size
@@ -604,7 +609,7 @@ class MusicTransformerHIP(nn.Module):
         if backward:
             fuse_db = ops.ce_bwd_fuses_dbias(ws.logits, ws.dlogits)     # bf16 tier: head bias gradient from the f32 dlogits
             ops.ce_bwd(ws.logits, target, ws.row_lse, ws.dlogits, ws.acc[1:2], grad_scale, T, V, self.pad_token,
-                       dbias=self._pview(self._gflat, self._HEAD_B) if fuse_db else None)
+                       dbias=self._pview(self._gflat, self._HEAD_B) if fuse_db else None, loss_scale=loss_scale)
             self._backward_impl(ws, tokens, cond, B, Ltok, Lm, p_drop, seed, self._gflat, bucket_hook, head_bias_done=fuse_db)
         if return_logits:                                   # f32 [B, Lm, V] copy of the workspace logits
             return loss, ws.logits[:, :V].float().view(B, Lm, V)
@@ -708,7 +713,7 @@ class MusicRegression(MusicTransformerHIP):
             self._forward_impl(tokens, cond, B, Ltok, Lm, False, p_drop, self._next_seed(), out)
             return torch.tanh(out.view(B, Lm, self.head_size)[:, 0, :]).clone()
 
-    def loss_and_backward(self, x, target, grad_scale=1.0, bucket_hook=None, backward=True):
+    def loss_and_backward(self, x, target, grad_scale=1.0, bucket_hook=None, backward=True, loss_scale=None):
         """L1Loss(tanh(head(x[:, 0])), target) (train.py:282-284: `self.l1_loss(output, condition)`, mean over B x
         output_size) and its backward into `flat_grads` (+=).  target: [B, output_size] (valence, arousal)."""
         tokens, cond, B, Ltok, Lm = self._check_inputs(x, None)
@@ -723,6 +728,8 @@ class MusicRegression(MusicTransformerHIP):
         loss = diff.abs().mean()
         if backward:
             dz = torch.sign(diff) * (1.0 - y * y) * (float(grad_scale) / diff.numel())
+            if loss_scale is not None:
+                dz = dz * loss_scale
             ws.dlogits.zero_()                                   # only position 0 of every sequence feeds the head
             ws.dlogits.view(B, Lm, ldv)[:, 0, :n_out] = dz.to(ws.dlogits.dtype)
             self._backward_impl(ws, tokens, cond, B, Ltok, Lm, p_drop, seed, self._gflat, bucket_hook)

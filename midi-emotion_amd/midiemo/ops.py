@@ -8,11 +8,11 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import (ME_BF16, ME_COND_CONCAT, ME_COND_NONE, ME_COND_TOKEN, ME_EPI_OUT_F32, ME_EPI_RELU,
+from ._lib import (ME_BF16, ME_F16, ME_COND_CONCAT, ME_COND_NONE, ME_COND_TOKEN, ME_EPI_OUT_F32, ME_EPI_RELU,
                    ME_EPI_RELU_BWD, ME_F32, ME_TN_MAX_GROUP, ME_WS_EMBED_BWD, ME_WS_SUMSQ, ME_WS_GEMM_TN, ME_WS_GEMM_TN_GROUP, ME_WS_RGA_DGT, ME_WS_RGA_MT,
                    ME_WS_RGA_PT, ME_WS_RELU_MASK, check)
 
-DTYPE_CODE = {torch.float32: ME_F32, torch.bfloat16: ME_BF16}
+DTYPE_CODE = {torch.float32: ME_F32, torch.bfloat16: ME_BF16, torch.float16: ME_F16}
 
 
 def lib():
@@ -35,7 +35,7 @@ def _code(dtype):
     try:
         return DTYPE_CODE[dtype]
     except KeyError:
-        raise RuntimeError("unsupported compute dtype %s (float32 or bfloat16)" % dtype)
+        raise RuntimeError("unsupported compute dtype %s (float32, bfloat16 or float16)" % dtype)
 
 
 def cast_transpose(src, dst, dstT, dtype):
@@ -205,7 +205,10 @@ def _side_stream(device):
 
 def rga_bwd(qkv, Epk, out, lse, dout, dqkv, dE, delta_ws, PT, MT, dGT, B, L, Lp, H, dh, M, causal=True, overlap=False):
     """overlap=True: the key-owned kernel (dK, dV) stays on the current stream, the E-row-owned kernel (dE) runs beside it on a
-    second stream (me_rga_bwd_phases; both only depend on the query-owned kernel); the current stream then waits for it."""
+    second stream (me_rga_bwd_phases; both only depend on the query-owned kernel); the current stream then waits for it.
+    Lifetime: the side stream reads dGT / qkv and accumulates into dE without the caching allocator knowing -- the caller keeps
+    those tensors alive until the current stream has passed this call (the model's workspaces and flat gradients are; a caller
+    that frees them right after the call must synchronise or record_stream() them first)."""
     es = PT.element_size()
     if (PT.numel() * es < workspace_bytes(ME_WS_RGA_PT, B * H, Lp, 1 if causal else 0, qkv.dtype) or
             MT.numel() * 4 < workspace_bytes(ME_WS_RGA_MT, B * H, Lp, 0, qkv.dtype) or
@@ -223,17 +226,6 @@ def rga_bwd(qkv, Epk, out, lse, dout, dqkv, dE, delta_ws, PT, MT, dGT, B, L, Lp,
         check(lib().me_rga_bwd_phases(_ptr(qkv), _ptr(Epk), _ptr(out), _ptr(lse), _ptr(dout), _ptr(dqkv), _ptr(dE), _ptr(delta_ws),
                                       _ptr(PT), _ptr(MT), _ptr(dGT), B, L, Lp, H, dh, M, 1 if causal else 0, bits, _code(qkv.dtype),
                                       ctypes.c_void_p(stream.cuda_stream)), "me_rga_bwd_phases")
-    if overlap == 2:
-        # delta first, then the key-owned kernel on the second stream beside the query-owned and the E-row-owned ones
-        phase(8, main)
-        ev_q.record(main)
-        side.wait_event(ev_q)
-        phase(2, side)
-        ev_e.record(side)
-        phase(1 | 16, main)
-        phase(4, main)
-        main.wait_event(ev_e)
-        return
     phase(1, main)
     ev_q.record(main)
     side.wait_event(ev_q)
@@ -260,14 +252,15 @@ def ce_fwd(logits, target, row_lse, loss_sum, n_valid, rows, V, ignore_index):
 
 
 def ce_bwd_fuses_dbias(logits, dlogits):
-    """can me_ce_bwd produce the head's bias gradient itself (f32 column sums before the bf16 rounding)?"""
-    return (logits.dtype == torch.bfloat16 and dlogits.dtype == torch.bfloat16 and logits.stride(0) % 8 == 0 and
+    """can me_ce_bwd produce the head's bias gradient itself (f32 column sums before the 16-bit rounding)?"""
+    return (logits.dtype in (torch.bfloat16, torch.float16) and dlogits.dtype == logits.dtype and logits.stride(0) % 8 == 0 and
             dlogits.stride(0) % 8 == 0 and logits.stride(0) >= dlogits.stride(0) and dlogits.stride(0) <= 2048)
 
 
-def ce_bwd(logits, target, row_lse, dlogits, n_valid, extra_scale, rows, V, ignore_index, dbias=None):
+def ce_bwd(logits, target, row_lse, dlogits, n_valid, extra_scale, rows, V, ignore_index, dbias=None, loss_scale=None):
+    """loss_scale: f32 device scalar (the f16 tier's dynamic loss scale, LossScaler.scale_tensor) multiplied into dlogits."""
     check(lib().me_ce_bwd(_ptr(logits), logits.stride(0), _ptr(target), _ptr(row_lse), _ptr(dlogits),
-                          dlogits.stride(0), _ptr(n_valid), float(extra_scale), _ptr(dbias), rows, V, ignore_index,
+                          dlogits.stride(0), _ptr(n_valid), float(extra_scale), _ptr(loss_scale), _ptr(dbias), rows, V, ignore_index,
                           _code(logits.dtype), _code(dlogits.dtype), _stream()), "me_ce_bwd")
 
 
@@ -282,28 +275,26 @@ def sumsq_ws(device):
     return torch.zeros(workspace_bytes(ME_WS_SUMSQ, 0, 0, 0, torch.float32), dtype=torch.uint8, device=device)
 
 
-def adamw_step(p, g, m, v, sumsq_t, clip, grad_scale, lr, beta1, beta2, eps, weight_decay, step, zero_grad):
-    bc1 = 1.0 - beta1 ** step
-    bc2 = 1.0 - beta2 ** step
+def scaler_step(state, sumsq_t, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+    """GradScaler.unscale_/step/update bookkeeping on the device (me_scaler_step): state f32 [ME_SCALER_WORDS]."""
+    check(lib().me_scaler_step(_ptr(state), _ptr(sumsq_t), float(growth_factor), float(backoff_factor), int(growth_interval),
+                               _stream()), "me_scaler_step")
+
+
+def adamw_step(p, g, m, v, sumsq_t, clip, grad_scale, lr, beta1, beta2, eps, weight_decay, step, zero_grad, scaler_state=None):
+    """scaler_state: the state me_scaler_step just updated (f16 tier): unscale, skip on inf / nan, device-side step count."""
+    bc1 = 1.0 - beta1 ** max(step, 1)
+    bc2 = 1.0 - beta2 ** max(step, 1)
     check(lib().me_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(sumsq_t), float(clip),
                               float(grad_scale), float(lr), float(beta1), float(beta2), float(eps),
-                              float(weight_decay), float(bc1), float(bc2), int(bool(zero_grad)), _stream()),
+                              float(weight_decay), float(bc1), float(bc2), int(bool(zero_grad)), _ptr(scaler_state), _stream()),
           "me_adamw_step")
 
 
-def _psum_args(psum):
-    """psum = None | (partials f32 [n][Mr][d], residual rows f32 [Mr][d], bias f32 [d]): the split-K form of a LayerNorm input row"""
-    if psum is None:
-        return None, 0, None, None
-    part, resid, bias = psum
-    return _ptr(part), int(part.shape[0]), _ptr(resid), _ptr(bias)
-
-
 def dec_ln_qkv_attn(s_in, gamma, beta, eps, Wqkv, bqkv, x_out, kcache, vcache, E, key_pad, ld_pad, part, nsplit, Mr, d, H, dh, M,
-                    Mc, t, t_dev, dtype, psum=None):
-    """fused LayerNorm -> q|k|v of one head -> cache append -> key-split attention partials (me_dec_ln_qkv_attn).
-    psum: see _psum_args (then s_in must be None)."""
-    check(lib().me_dec_ln_qkv_attn(_ptr(s_in), *_psum_args(psum), _ptr(gamma), _ptr(beta), float(eps), _ptr(Wqkv), _ptr(bqkv), _ptr(x_out),
+                    Mc, t, t_dev, dtype):
+    """fused LayerNorm -> q|k|v of one head -> cache append -> key-split attention partials (me_dec_ln_qkv_attn)."""
+    check(lib().me_dec_ln_qkv_attn(_ptr(s_in), _ptr(gamma), _ptr(beta), float(eps), _ptr(Wqkv), _ptr(bqkv), _ptr(x_out),
                                    _ptr(kcache), _ptr(vcache), _ptr(E), _ptr(key_pad), ld_pad, _ptr(part), nsplit, Mr, d, H, dh, M,
                                    Mc, int(t), _ptr(t_dev), _code(dtype), _stream()), "me_dec_ln_qkv_attn")
 
@@ -339,14 +330,8 @@ def dec_proj_resid(part, nsplit, H, dh, x_T, W, bias, resid, out, Mr, N, K, dtyp
           "me_dec_proj_resid")
 
 
-def dec_ffn(s_in, gamma, beta, eps, W1, b1, W2, x_out, part, Mr, d, d_inner, dtype):
-    """fused LayerNorm1 -> FFN_pre + ReLU -> FFN_suf split over d_inner (me_dec_ffn): part f32 [d_inner / 64][Mr][d]"""
-    check(lib().me_dec_ffn(_ptr(s_in), _ptr(gamma), _ptr(beta), float(eps), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(x_out), _ptr(part),
-                           Mr, d, d_inner, _code(dtype), _stream()), "me_dec_ffn")
-
-
-def dec_ln_proj(s_in, gamma, beta, eps, W, bias, x_out, y, Mr, N, K, flags, dtype, psum=None):
-    check(lib().me_dec_ln_proj(_ptr(s_in), *_psum_args(psum), _ptr(gamma), _ptr(beta), float(eps), _ptr(W), W.stride(0), _ptr(bias), _ptr(x_out),
+def dec_ln_proj(s_in, gamma, beta, eps, W, bias, x_out, y, Mr, N, K, flags, dtype):
+    check(lib().me_dec_ln_proj(_ptr(s_in), _ptr(gamma), _ptr(beta), float(eps), _ptr(W), W.stride(0), _ptr(bias), _ptr(x_out),
                                _ptr(y), y.stride(0), Mr, N, K, int(flags), _code(dtype), _stream()), "me_dec_ln_proj")
 
 

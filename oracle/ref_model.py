@@ -278,15 +278,17 @@ def adam_step(P, G, M1, M2, step: int, lr=2e-5, b1=0.9, b2=0.999, eps=1e-8,
     return total
 
 
-def loss_and_grads(cfg: Cfg, P: Dict[str, Tensor], tokens, cond, target, dropout: float = 0.0):
+def loss_and_grads(cfg: Cfg, P: Dict[str, Tensor], tokens, cond, target, dropout: float = 0.0, loss_scale: float = 1.0):
     """Forward + CE + backward through the restatement (torch autograd on the
     closed-form graph).  Embedding pad row receives no gradient
-    (padding_idx, music_multi.py:57-59)."""
+    (padding_idx, music_multi.py:57-59).  loss_scale: the reference's fp16 path backpropagates scaler.scale(loss) and
+    unscales the gradients before the clip (train.py:317,320: GradScaler.scale / unscale_); run under
+    torch.autocast(float16) this is the arithmetic of its --amp step."""
     Pg = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
     logits = forward(cfg, Pg, tokens, cond, dropout=dropout)
     loss = ce_loss(cfg, logits, target)
-    loss.backward()
-    G = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in Pg.items()}
+    (loss * loss_scale if loss_scale != 1.0 else loss).backward()
+    G = {k: ((v.grad / loss_scale if loss_scale != 1.0 else v.grad) if v.grad is not None else torch.zeros_like(v)) for k, v in Pg.items()}
     G["embedding.weight"][cfg.pad_token].zero_()
     return loss.detach(), logits.detach(), G
 

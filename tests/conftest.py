@@ -12,7 +12,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 # Collection order of the GPU suite: every comparison of a HIP kernel with the oracle / a golden fixture first, the
 # multi-process files last, so that a `pytest -x` stop in a launcher test still leaves the whole parity record.
-_ORDER = ["test_oracle_golden", "test_host_cpu", "test_data_cpu", "test_kernels_gpu", "test_model_gpu", "test_decode_gpu",
+_ORDER = ["test_oracle_golden", "test_host_cpu", "test_data_cpu", "test_kernels_gpu", "test_model_gpu", "test_fp16_tier_gpu", "test_decode_gpu",
           "test_c_abi_example", "test_train_cli_gpu", "test_ddp_gpu"]
 
 

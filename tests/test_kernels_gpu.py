@@ -24,7 +24,8 @@ def ops():
 
 
 DEV = "cuda"
-DTYPES = [torch.float32, torch.bfloat16]
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
+DT16 = [torch.bfloat16, torch.float16]        # the two 16-bit storage tiers: same kernels, different MFMA opcode / conversions
 
 
 def store_err(ref, dtype=torch.bfloat16):
@@ -45,7 +46,9 @@ def tol(dtype, f32, *stored):
     if dtype == torch.float32:
         return f32
     assert stored, "bf16 bound needs the exact value(s) of the stored tensor(s)"
-    return K_STORE * sum(store_err(t) for t in stored) + 1e-6
+    # + the f32 accumulation of the products: 16-bit x 16-bit products are exact in f32, their sums are not (f16's 22-bit products
+    # lose more per add than bf16's 16-bit ones: measured 2e-6 on a K = 512 projection with nothing stored in between)
+    return K_STORE * sum(store_err(t, dtype) for t in stored) + (1e-6 if dtype == torch.bfloat16 else 5e-6)
 
 
 def relerr(got, ref):
@@ -81,10 +84,10 @@ def test_gemm_nt_plain_and_bias(ops, dtype, M, N, K):
     assert torch.isnan(C32[:, N:]).all()
 
 
+@pytest.mark.parametrize("dtype", DT16)
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 1536, 512), (700, 1007, 512), (1024, 512, 2048), (260, 200, 128), (2050, 2048, 512)])
-def test_gemm_nt_256_tile_path(ops, M, N, K):
-    """bf16 shapes that take the 256x256 direct-to-LDS kernel (K % 64 == 0), incl. ragged M/N and all epilogues."""
-    dtype = torch.bfloat16
+def test_gemm_nt_256_tile_path(ops, dtype, M, N, K):
+    """16-bit shapes that take the 256x256 kernel (K % 64 == 0), incl. ragged M/N and all epilogues."""
     A = rnd(M, K, seed=31).to(dtype)
     B = rnd(N, K, seed=32).to(dtype)
     bias = rnd(N, seed=33).float()
@@ -95,12 +98,12 @@ def test_gemm_nt_256_tile_path(ops, M, N, K):
     ld = ((N + 15) // 16) * 16
     C = torch.full((M, ld), float("nan"), dtype=dtype, device=DEV)
     ops.gemm_nt(Ad, Bd, C, bias=bias.to(DEV), flags=ops.ME_EPI_RELU, N=N)
-    assert relerr(C[:, :N], torch.relu(base + bias.double())) < 6e-3
+    assert relerr(C[:, :N], torch.relu(base + bias.double())) < tol(dtype, 0, torch.relu(base + bias.double()))
     assert torch.isnan(C[:, N:]).all()
     addp = torch.zeros(M, ld, dtype=dtype, device=DEV)
     addp[:, :N] = add.to(DEV)
     ops.gemm_nt(Ad, Bd, C, add=addp, N=N)
-    assert relerr(C[:, :N], base + add.double()) < 6e-3
+    assert relerr(C[:, :N], base + add.double()) < tol(dtype, 0, base + add.double())
     assert torch.isnan(C[:, N:]).all()
     # round 4: a 16-byte aligned residual operand is read row-contiguously and transposed into the accumulators' layout through
     # the staging buffer; the sum is still formed in f32 before the one rounding, so the result must be BIT-identical to the
@@ -115,7 +118,7 @@ def test_gemm_nt_256_tile_path(ops, M, N, K):
     gatep = torch.zeros(M, ld, dtype=dtype, device=DEV)
     gatep[:, :N] = gate.to(DEV)
     ops.gemm_nt(Ad, Bd, C, gate=gatep, flags=ops.ME_EPI_RELU_BWD, N=N)
-    assert relerr(C[:, :N], base * (gate.double() > 0)) < 6e-3
+    assert relerr(C[:, :N], base * (gate.double() > 0)) < tol(dtype, 0, base * (gate.double() > 0))
     assert torch.isnan(C[:, N:]).all()
     # round 4: with 16-byte aligned gate rows and N % 8 == 0 the gate is applied to the staged (already rounded) rows, read
     # row-contiguously; a select commutes with the rounding, so the result must be BIT-identical to the element-wise path,
@@ -179,14 +182,15 @@ def test_gemm_tn_acc(ops, dtype, T, N, K):
     assert relerr(db, refb) < 2e-5, relerr(db, refb)
 
 
-def test_gemm_tn_acc_caller_workspace(ops):
+@pytest.mark.parametrize("dt16", DT16)
+def test_gemm_tn_acc_caller_workspace(ops, dt16):
     """SURVEY 8b ownership: the partial-tile workspace is the caller's (me_workspace_bytes).  With it the summation
     order is fixed -> bit-identical results across launches that reuse the buffer; without it the kernel falls back to
     f32 atomics (same value up to rounding order); a buffer that is too small is an error, not a silent fallback."""
     T, N, K = 8192, 512, 256
-    A = rnd(T, N, seed=21).to(torch.bfloat16).to(DEV)
-    B = rnd(T, K, seed=22).to(torch.bfloat16).to(DEV)
-    need = ops.workspace_bytes(ops.ME_WS_GEMM_TN, T, N, K, torch.bfloat16)
+    A = rnd(T, N, seed=21).to(dt16).to(DEV)
+    B = rnd(T, K, seed=22).to(dt16).to(DEV)
+    need = ops.workspace_bytes(ops.ME_WS_GEMM_TN, T, N, K, dt16)
     assert need > 0 and ops.workspace_bytes(ops.ME_WS_GEMM_TN, T, N, K, torch.float32) == 0
     ws = torch.empty(need, dtype=torch.uint8, device=DEV)
     got = [torch.zeros(N, K, device=DEV) for _ in range(3)]
@@ -232,7 +236,7 @@ def test_gemm_tn_acc_group(ops, dtype, T, shapes):
         assert relerr(dW, rW) < 2e-5, (N, K, relerr(dW, rW))
         if db is not None:
             assert relerr(db, rb) < 2e-5, (N, K, relerr(db, rb))
-    grouped = dtype == torch.bfloat16 and T >= 2048 and all(k % 256 == 0 and (n % 256 == 0 or n == 1007) for n, k in shapes)
+    grouped = dtype != torch.float32 and T >= 2048 and all(k % 256 == 0 and (n % 256 == 0 or n == 1007) for n, k in shapes)
     if ws is not None and grouped:                       # the grouped kernel: fixed summation order
         for a, b in zip(runs[0], runs[1]):
             assert torch.equal(a[2], b[2])
@@ -240,12 +244,12 @@ def test_gemm_tn_acc_group(ops, dtype, T, shapes):
                 assert torch.equal(a[3], b[3])               # the bias column sums go through the workspace as well
 
 
-def test_gemm_full_size_replication_property(ops):
+@pytest.mark.parametrize("dt", DT16)
+def test_gemm_full_size_replication_property(ops, dt):
     """The train step's GEMM shapes at FULL size (T = 32768 tokens, bf16) through a size-independent property: the token
     dimension is a 256-row block replicated 128 times.  NT: every 256-row block of C must be bit-identical to the 256-row
     product (tile walk, XCD renumbering, persistent-tile bookkeeping).  TN (grouped launch of a layer's four products):
     dW of the full problem = 128 x dW of one block up to f32 summation order, and two runs are bit-identical."""
-    dt = torch.bfloat16
     T0, R = 256, 128
     T = T0 * R
     shapes = [(1536, 512), (512, 512), (2048, 512), (512, 2048)]
@@ -279,24 +283,25 @@ def test_gemm_full_size_replication_property(ops):
         assert relerr(dW1, R * dWs) < 1e-5 and relerr(db1, R * dbs) < 1e-5, (N, K)
 
 
-def test_resid_ln_fwd_hi_lo_residual_stream(ops):
+@pytest.mark.parametrize("dt16", DT16)
+def test_resid_ln_fwd_hi_lo_residual_stream(ops, dt16):
     """bf16 tier: the residual stream travels as hi + lo (me_resid_ln_fwd x_lo / y_lo).  y must be exactly
     bf16(LN(x_hi + x_lo + a)) computed in f32, and y + y_lo must carry ~16 mantissa bits of it."""
     rows, d = 300, 512
     x = rnd(rows, d, seed=51).float() * 3
-    a = rnd(rows, d, seed=52).to(torch.bfloat16)
+    a = rnd(rows, d, seed=52).to(dt16)
     gamma, beta = rnd(d, seed=53).float(), rnd(d, seed=54).float()
-    x_hi = x.to(torch.bfloat16)
-    x_lo = (x - x_hi.float()).to(torch.bfloat16)
+    x_hi = x.to(dt16)
+    x_lo = (x - x_hi.float()).to(dt16)
     xs = x_hi.double() + x_lo.double() + a.double()
     ref = torch.nn.functional.layer_norm(xs, (d,), gamma.double(), beta.double(), 1e-6)
-    y = torch.empty(rows, d, dtype=torch.bfloat16, device=DEV)
+    y = torch.empty(rows, d, dtype=dt16, device=DEV)
     y_lo = torch.empty_like(y)
     ops.resid_ln_fwd(x_hi.to(DEV), a.to(DEV), gamma.to(DEV), beta.to(DEV), y, None, None, rows, d, 1e-6, 0.0, 0, 1,
                      x_lo=x_lo.to(DEV), y_lo=y_lo)
     assert relerr(y, ref) < 3e-3                                        # one bf16 rounding
     assert relerr(y.double() + y_lo.double(), ref) < 2e-5               # hi + lo: f32-class
-    assert (y.float().cpu() - ref.float().to(torch.bfloat16).float()).abs().max() <= 2.0 ** -6   # ulp-level agreement with bf16(ref)
+    assert (y.float().cpu() - ref.float().to(dt16).float()).abs().max() <= (2.0 ** -6 if dt16 == torch.bfloat16 else 2.0 ** -9)   # ulp-level agreement with T(ref)
     y2 = torch.empty_like(y)                                            # without lo the input rounding is visible
     ops.resid_ln_fwd(x_hi.to(DEV), a.to(DEV), gamma.to(DEV), beta.to(DEV), y2, None, None, rows, d, 1e-6, 0.0, 0, 1)
     ref_hi = torch.nn.functional.layer_norm(x_hi.double() + a.double(), (d,), gamma.double(), beta.double(), 1e-6)
@@ -536,18 +541,19 @@ def test_rowwise_kernels_full_size_replication_property(ops):
 
 
 @pytest.mark.parametrize("V,ld", [(1007, 1024), (1017, 1024), (97, 128), (2500, 2560)])
-def test_ce_bf16_logits(ops, V, ld):
+@pytest.mark.parametrize("dt16", DT16)
+def test_ce_bf16_logits(ops, V, ld, dt16):
     """bf16 tier: the head GEMM writes bf16 logits (me_ce_fwd / me_ce_bwd with logits_dtype = ME_BF16).  The kernels
     must give exactly the cross-entropy of those rounded logits (f32 arithmetic): compared with fp64 CE of the same
     bf16 values; padding columns [V, ld) hold garbage and must not leak in."""
     rows = 203
-    lg = rnd(rows, V, seed=31, scale=4.0).to(torch.bfloat16)
+    lg = rnd(rows, V, seed=31, scale=4.0).to(dt16)
     tgt = torch.randint(0, V, (rows,), generator=torch.Generator().manual_seed(32))
     tgt[::7] = 0
     l64 = lg.double().requires_grad_(True)
     loss = torch.nn.functional.cross_entropy(l64, tgt, ignore_index=0)
     loss.backward()
-    lgd = torch.full((rows, ld), 1e4, dtype=torch.bfloat16, device=DEV)        # huge padding: would dominate the lse
+    lgd = torch.full((rows, ld), 1e4, dtype=dt16, device=DEV)        # huge padding: would dominate the lse
     lgd[:, :V] = lg.to(DEV)
     row_lse = torch.empty(rows, device=DEV)
     acc = torch.zeros(2, device=DEV)
@@ -556,21 +562,24 @@ def test_ce_bf16_logits(ops, V, ld):
     assert abs(acc[1].item() - nvalid) < 1e-3
     assert abs(acc[0].item() / nvalid - loss.item()) < 2e-5 * abs(loss.item())
     assert relerr(row_lse, torch.logsumexp(lg.double(), -1)) < 1e-6
-    dl = torch.full((rows, ld), float("nan"), dtype=torch.bfloat16, device=DEV)
-    ops.ce_bwd(lgd, tgt.to(DEV), row_lse, dl, acc[1:2], 1.0, rows, V, 0)
-    assert relerr(dl[:, :V], l64.grad) < tol(torch.bfloat16, 0, l64.grad)
+    dl = torch.full((rows, ld), float("nan"), dtype=dt16, device=DEV)
+    # (x 4096 through the device-resident loss scale: f16 dlogits of a 1 / n_valid mean would sit in the subnormal range)
+    lsc = torch.full((1,), 4096.0, device=DEV)
+    ops.ce_bwd(lgd, tgt.to(DEV), row_lse, dl, acc[1:2], 1.0, rows, V, 0, loss_scale=lsc)
+    assert relerr(dl[:, :V], l64.grad * 4096.0) < tol(dt16, 0, l64.grad * 4096.0)
     assert (dl[:, V:] == 0).all()
     # fused head-bias gradient: f32 column sums of dlogits BEFORE the rounding to bf16 (accumulated into dbias)
     if ld <= 2048:
         assert ops.ce_bwd_fuses_dbias(lgd, dl)
         db = torch.zeros(V, device=DEV)
         dl2 = torch.full_like(dl, float("nan"))
-        ops.ce_bwd(lgd, tgt.to(DEV), row_lse, dl2, acc[1:2], 1.0, rows, V, 0, dbias=db)
+        ops.ce_bwd(lgd, tgt.to(DEV), row_lse, dl2, acc[1:2], 1.0, rows, V, 0, dbias=db, loss_scale=lsc)
         assert torch.equal(dl2, dl)
-        assert relerr(db, l64.grad.sum(0)) < 2e-5                                    # f32 exact, not the bf16 column sums
-        ops.ce_bwd(lgd, tgt.to(DEV), row_lse, dl2, acc[1:2], 1.0, rows, V, 0, dbias=db)   # accumulates (+=)
-        assert relerr(db, 2 * l64.grad.sum(0)) < 2e-5
-        assert relerr(dl[:, :V].double().sum(0).cpu(), l64.grad.sum(0)) > 1e-4       # ... which is what it replaces
+        assert relerr(db, 4096.0 * l64.grad.sum(0)) < 2e-5                           # f32 exact, not the 16-bit column sums
+        ops.ce_bwd(lgd, tgt.to(DEV), row_lse, dl2, acc[1:2], 1.0, rows, V, 0, dbias=db, loss_scale=lsc)   # accumulates (+=)
+        assert relerr(db, 2 * 4096.0 * l64.grad.sum(0)) < 2e-5
+        if dt16 == torch.bfloat16:
+            assert relerr(dl[:, :V].double().sum(0).cpu(), 4096.0 * l64.grad.sum(0)) > 1e-4   # ... which is what it replaces
     else:
         assert not ops.ce_bwd_fuses_dbias(lgd, dl)
         with pytest.raises(RuntimeError, match="ME_ERR_BAD_SHAPE"):
@@ -806,7 +815,7 @@ def attn_bounds(dtype, f32, q, k, v, E, dO, pad, causal=True, backward=True):
     ref = ref_attn(q, k, v, E, dO, pad, dtype, causal) if backward else None
     r = lambda t: t.to(dtype).float().requires_grad_(backward)
     q32, k32, v32, E32 = r(q), r(k), r(v), r(E)
-    with torch.autocast("cpu", dtype=torch.bfloat16):
+    with torch.autocast("cpu", dtype=dtype):
         o, lse = O.rga_attention_core(q32, k32, v32, E32, pad, causal)
     if backward:
         (o.float() * dO.to(dtype).float()).sum().backward()
@@ -991,7 +1000,7 @@ def test_dec_attn_pad_keys_and_fully_masked_row(ops):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("dh", [32, 48, 64])
 def test_rel_pack_layout_and_refresh_path(ops, dtype, dh):
     """me_rga_pack_rel against its definition (include/midiemo.h) and against the multi-tensor refresh (mode 1), bit-exact."""
@@ -1093,7 +1102,7 @@ def test_rga_bwd_bidirectional(ops, dtype, B, H, L, dh, M):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype,B,H,L,dh", [(torch.bfloat16, 4, 8, 1024, 64), (torch.bfloat16, 2, 2, 300, 64), (torch.float32, 2, 2, 200, 32)])
+@pytest.mark.parametrize("dtype,B,H,L,dh", [(torch.bfloat16, 4, 8, 1024, 64), (torch.float16, 2, 8, 1024, 64), (torch.bfloat16, 2, 2, 300, 64), (torch.float32, 2, 2, 200, 32)])
 def test_rga_bwd_phases_on_two_streams_equal_the_single_call(ops, dtype, B, H, L, dh):
     """me_rga_bwd_phases (round 5): the backward kernel by kernel.  (1) key-owned and E-row-owned kernels side by side on two
     streams, (2) delta as its own launch and the key-owned kernel beside the query-owned one -- dQ / dK / dV must be BIT-identical
@@ -1120,7 +1129,7 @@ def test_rga_bwd_phases_on_two_streams_equal_the_single_call(ops, dtype, B, H, L
         ops.rga_bwd(qkv, Epk, out, lse, dout, dqkv, dE, delta, PT, MT, dGT, B, L, Lp, H, dh, M, overlap=ov)
         torch.cuda.synchronize()
         res[ov] = (dqkv, dE, delta)
-    it = torch.int16 if dtype == torch.bfloat16 else torch.int32
+    it = torch.int16 if dtype != torch.float32 else torch.int32
     for ov in (True, 2):
         assert torch.equal(res[ov][0].view(it), res[False][0].view(it)), ov
         assert torch.equal(res[ov][2], res[False][2]), ov                      # delta: same lanes, same order of the multiply-adds
@@ -1130,11 +1139,11 @@ def test_rga_bwd_phases_on_two_streams_equal_the_single_call(ops, dtype, B, H, L
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (777, 1024, 512), (2050, 2048, 512), (1024, 192, 128), (32768, 2048, 512)])
-def test_gemm_nt_relu_mask_equals_the_gate_operand(ops, M, N, K):
+@pytest.mark.parametrize("dtype", DT16)
+def test_gemm_nt_relu_mask_equals_the_gate_operand(ops, M, N, K, dtype):
     """me_gemm_nt_relu_mask (round 5): the FFN_pre forward leaves the ReLU's sign pattern as a bit mask and the FFN_suf dgrad
     applies it -- both launches must agree BIT for bit with me_gemm_nt (ME_EPI_RELU / gate = the activations + ME_EPI_RELU_BWD),
     ragged M included; the padding columns of C stay untouched; shapes the 256-tile kernel does not serve answer 0 bytes."""
-    dtype = torch.bfloat16
     nbytes = ops.workspace_bytes(ops.ME_WS_RELU_MASK, M, N, K, dtype)
     if N % 64:
         assert nbytes == 0
@@ -1159,7 +1168,8 @@ def test_gemm_nt_relu_mask_equals_the_gate_operand(ops, M, N, K):
     d = torch.full((M, ld), float("nan"), dtype=dtype, device=DEV)
     ops.gemm_nt_relu_mask(dC, W2T, d, mask, N=N, backward=True)
     assert torch.equal(d[:, :N].view(torch.int16), d_ref[:, :N].view(torch.int16)) and torch.isnan(d[:, N:]).all()
-    assert relerr(d[:, :N], (dC.double() @ W2T.double().t()).cpu() * (hid_ref[:, :N] > 0).cpu().double()) < 6e-3
+    dref = (dC.double() @ W2T.double().t()).cpu() * (hid_ref[:, :N] > 0).cpu().double()
+    assert relerr(d[:, :N], dref) < tol(dtype, 0, dref)
 
 
 @pytest.mark.gpu
@@ -1173,17 +1183,3 @@ def test_gemm_nt_relu_mask_refuses_what_it_does_not_serve(ops):
     mask = torch.zeros(1 << 16, dtype=torch.uint8, device=DEV)
     with pytest.raises(RuntimeError):
         ops.gemm_nt_relu_mask(A, W, C, mask)
-
-
-@pytest.mark.gpu
-def test_gemm_nt_main_loops_bit_identical():
-    """The main loops of the 256-tile NT kernel (MIDIEMO_NT_MAINLOOP = 0 register-staged / 1 ping-pong + direct-to-LDS feed /
-    2 hand-scheduled 4-wave loop / 3 the mix of 0 and 2 by launch shape) accumulate every output element in the same k order: 66 cases (ragged M / N, persistent multi-tile walks, every write-out
-    path, f32 out) must agree bit for bit.  Each setting needs its own copy of the library (the switch is read once per load),
-    so the comparison runs in a subprocess (tools/ab_nt_mainloop.py)."""
-    import subprocess
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ab_nt_mainloop.py"), "--nobench"], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "ALL BIT-IDENTICAL" in r.stdout, r.stdout[-3000:]
-    assert r.stdout.count("bit-identical=True") == 66

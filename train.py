@@ -14,7 +14,10 @@ Data: the Lakh/Spotify pipeline (src/data, src/create_dataset) is outside the ac
 path and its dataset is not shipped; `--synthetic` (default) draws the synthetic batches
 defined in SURVEY 8d.  One process per GPU: launch with
     python -m torch.distributed.run --nproc-per-node N train.py ...
-Deviations from the reference, on purpose: bf16 (no GradScaler) instead of fp16 autocast;
+Deviations from the reference, on purpose: the default 16-bit tier is bf16 (no GradScaler; BASELINE.json's headline
+dtype) -- `--compute_dtype fp16` runs the reference's own autocast dtype with its GradScaler semantics on the device
+(midiemo.optim.LossScaler: init 65536, x2 every 2000 finite steps, x0.5 and a skipped step on inf / nan; `scaler.pt` in the
+checkpoint like train.py:403-404, `--reset_scaler` like train.py:207);
 `loss.item()` is only read every --log_step (the reference syncs every step, train.py:308);
 schedulers `cosine`/`inv_sqrt` are implemented (the reference never constructs them,
 train.py:129 tests for '--'); `cyclic` and `dev_perf` drive torch's own CyclicLR / ReduceLROnPlateau on a shadow
@@ -75,7 +78,9 @@ def parse_args(argv=None):
     p.add_argument("--debug", action="store_true", help="do not write files")
     p.add_argument("--max_step", type=int, default=1000000000)
     p.add_argument("--n_emotion_bins", type=int, default=5)
-    p.add_argument("--no_amp", action="store_true", help="exact-f32 engine tier instead of bf16")
+    p.add_argument("--no_amp", action="store_true", help="exact-f32 engine tier instead of a 16-bit one")
+    p.add_argument("--compute_dtype", default="bf16", choices=["bf16", "fp16"],
+                   help="16-bit tier used unless --no_amp: bf16 (default) or fp16 = the reference's autocast dtype, with loss scaling")
     p.add_argument("--overwrite_lr", action="store_true")
     p.add_argument("--regression", action="store_true")
     # ---- additions
@@ -104,7 +109,7 @@ def parse_args(argv=None):
     p.add_argument("--find_lr", action="store_true")
     # reference flags without a counterpart on this engine: accepted, answered with a notice
     p.add_argument("--no_cuda", action="store_true", help="(reference: run on the CPU) -- this engine has no CPU path")
-    p.add_argument("--reset_scaler", action="store_true", help="(reference: reset the fp16 GradScaler) -- bf16, no scaler here")
+    p.add_argument("--reset_scaler", action="store_true", help="on restart: do not load scaler.pt (train.py:207); fp16 tier only")
     p.add_argument("--regression_dir", type=str, default=None,
                    help="(reference: regress emotions of a folder of generated MIDI files, train.py:70-73) -- needs the "
                         "MIDI -> token direction, which is outside this build (DESIGN section 7)")
@@ -118,9 +123,10 @@ def parse_args(argv=None):
                          "pipeline (pretty_midi / pypianoroll), which this build does not contain; --regression on the "
                          "dataset (with --feature_file) is supported")
     for flag, msg in (("no_cuda", "there is no CPU path: training runs on the HIP engine (cuda:LOCAL_RANK)"),
-                      ("reset_scaler", "bf16 / f32 tiers use no GradScaler: nothing to reset"),
+                      ("reset_scaler", "" if (args.compute_dtype == "fp16" and not args.no_amp) else
+                       "bf16 / f32 tiers use no GradScaler: nothing to reset"),
                       ("find_lr", "the reference parses --find_lr and never runs a finder; ignored here too")):
-        if getattr(args, flag):
+        if getattr(args, flag) and msg:
             print(f"[train.py] --{flag}: {msg}")
     for flag, default in (("n_bars", -1), ("eval_tgt_len", -1), ("arousal_feature", "note_density")):
         if getattr(args, flag) != default:
@@ -247,7 +253,7 @@ def main(argv=None):
 
     from midiemo.ddp import GradAllReducer, broadcast_params
     from midiemo.models.build_model import build_model
-    from midiemo.optim import FusedAdamW
+    from midiemo.optim import FusedAdamW, LossScaler
     from midiemo.vocab import get_maps
 
     torch.manual_seed(args.seed if args.seed > 0 else 0)
@@ -297,7 +303,7 @@ def main(argv=None):
             maps["idx2tuple"][len(maps["idx2tuple"])] = "<CLS>"
     V = len(maps["tuple2idx"])
     pad_idx = maps["tuple2idx"]["<PAD>"]
-    config = dict(vars(args), vocab_size=V, compute_dtype="fp32" if args.no_amp else "bf16")
+    config = dict(vars(args), vocab_size=V, compute_dtype="fp32" if args.no_amp else args.compute_dtype)
     work_dir = os.path.join(args.work_dir, ("DEBUG_" if args.debug else "") + time.strftime("%Y%m%d-%H%M%S"))
     base_dir, n_try = work_dir, 0
     while os.path.exists(work_dir):                           # one-second names: never reuse (or restart into) an existing run
@@ -312,7 +318,14 @@ def main(argv=None):
         bad = {k: (config.get(k), v) for k, v in want.items() if k in config and config.get(k) != v}
         if bad:
             raise SystemExit("restart: model_config.pt disagrees with the command line (saved, requested): %s" % bad)
-        model, _ = build_model(vars(args), load_config_dict=config)    # train.py:175 (args carry --overwrite_dropout / --dropout)
+        # train.py:175.  build_model() reads ONLY the saved config once load_config_dict is given (the reference's own
+        # --overwrite_dropout therefore never fires: its flag is looked up in model_config.pt); here the command line's
+        # flag and rate are merged into the loaded config so that the documented behaviour is the actual one
+        if args.overwrite_dropout:
+            config = dict(config, overwrite_dropout=True, dropout=args.dropout)
+        if not args.no_amp and config.get("compute_dtype") in ("bf16", "fp16"):
+            config = dict(config, compute_dtype=args.compute_dtype)      # the 16-bit tier is a run-time choice, not a model property
+        model, _ = build_model(vars(args), load_config_dict=config)
         model.load_state_dict(torch.load(os.path.join(restart, "model.pt"), map_location="cpu"))
         # work_dir stays the fresh time-stamped directory (train.py:173-180 writes there, never into restart_dir)
     else:
@@ -321,7 +334,9 @@ def main(argv=None):
     broadcast_params(model.flat_params)
     model.mark_params_changed()
     model.seed_dropout((args.seed if args.seed > 0 else 0) * 1000 + rank)
-    opt = FusedAdamW(model, lr=args.lr, clip=args.clip, weight_decay=args.weight_decay)
+    # f16 tier: the reference's GradScaler (train.py:108), state and decisions on the device
+    scaler = LossScaler(device) if model.compute_dtype == torch.float16 else None
+    opt = FusedAdamW(model, lr=args.lr, clip=args.clip, weight_decay=args.weight_decay, scaler=scaler)
     stats = {"step": 0, "hour": 0.0, "epoch": 0, "sample": 0}
     if restart:
         # optimizer.pt and stats.pt are restored independently, each tolerating absence (train.py:187-211)
@@ -335,6 +350,12 @@ def main(argv=None):
             stats = dict(stats, **torch.load(os.path.join(restart, "stats.pt")))
         except Exception as e:
             print("stats.pt not restored (%s); step / hour / epoch start from zero" % type(e).__name__)
+        scaler_fp = os.path.join(restart, "scaler.pt")
+        if scaler is not None and os.path.exists(scaler_fp) and not args.reset_scaler:      # train.py:207-209
+            try:
+                scaler.load_state_dict(torch.load(scaler_fp))
+            except Exception as e:
+                print("scaler.pt not restored (%s); the loss scale starts from 65536" % type(e).__name__)
         if args.overwrite_lr:
             opt.param_groups[0]["lr"] = args.lr
         if rank == 0 and not args.debug and os.path.exists(os.path.join(restart, "performance.csv")):
@@ -479,10 +500,11 @@ def main(argv=None):
             last = (micro + 1) % args.accumulate_step == 0
             # every micro-batch contributes grad/accumulate_step (train.py:309); buckets are exchanged on the last one
             hook = reducer.hook if (last and world > 1) else None
+            ls = scaler.scale_tensor if scaler is not None else None     # scaler.scale(loss).backward(), train.py:317
             if args.regression:                                 # train.py:282-284: L1Loss(model(input), condition)
-                loss = model.loss_and_backward(x, c, grad_scale=1.0 / args.accumulate_step, bucket_hook=hook)
+                loss = model.loss_and_backward(x, c, grad_scale=1.0 / args.accumulate_step, bucket_hook=hook, loss_scale=ls)
             else:
-                loss = model.loss_and_backward(x, c, y, grad_scale=1.0 / args.accumulate_step, bucket_hook=hook)
+                loss = model.loss_and_backward(x, c, y, grad_scale=1.0 / args.accumulate_step, bucket_hook=hook, loss_scale=ls)
             loss_acc += loss.detach()
             n_acc += 1
             micro += 1
@@ -511,6 +533,8 @@ def main(argv=None):
                         stats.update(step=step, hour=stats["hour"] + el / 3600)
                         torch.save(model.state_dict(), os.path.join(work_dir, "model.pt"))
                         torch.save(opt.state_dict(), os.path.join(work_dir, "optimizer.pt"))
+                        if scaler is not None:                   # train.py:403-404
+                            torch.save(scaler.state_dict(), os.path.join(work_dir, "scaler.pt"))
                         torch.save(stats, os.path.join(work_dir, "stats.pt"))
                 loss_acc.zero_()
                 n_acc = 0
