@@ -266,21 +266,28 @@ def make_f4():
 
 
 # ---------------------------------------------------------------- F4h: the same at the HEADLINE geometry (BASELINE config 2 / 5 model)
-def make_f4h():
-    """Greedy ids of the reference's own generate() on the 6-layer d512 8-head (dh 64) d_inner 2048 continuous_concat model:
-    4 (valence, arousal) pairs x 128 tokens, no slide.  Weights = O.seeded_params(cfg, 43), regenerated by the test, not
-    stored.  Also stored: the top-1 / top-2 logit margin of every step (from a second pass through the reference model over
-    the generated sequences) -- the test's f32 criterion is bit-exact ids, and the margin says how much room that has."""
+def _make_f4h_variant(mode, gen_len, fname, seed=43):
+    """Greedy ids of the reference's own generate() on the 6-layer d512 8-head (dh 64) d_inner 2048 model of BASELINE configs
+    2 / 4 / 5: 4 (valence, arousal) pairs x gen_len tokens, no slide (max_input_len = gen_len).  Weights =
+    O.seeded_params(cfg, seed), regenerated by the test, not stored.  Also stored: the top-1 / top-2 logit margin of every step
+    (from a second pass through the reference model over the generated sequences) -- the test's f32 criterion is bit-exact
+    ids, and the margin says how much room that has."""
     conds = [[-0.8, -0.8], [-0.8, 0.8], [0.8, -0.8], [0.8, 0.8]]          # train.py:361-366
-    cfg = O.Cfg(1007, 6, 8, 512, 2048, d_condition=128, conditioning="continuous_concat")
-    params = O.seeded_params(cfg, seed=43)
-    args = dict(vocab_size=1007, n_layer=6, n_head=8, d_model=512, d_inner=2048, dropout=0.0, d_condition=128,
-                conditioning="continuous_concat")
+    V = 1017 if mode == "discrete_token" else 1007
+    dc = 128 if mode == "continuous_concat" else -1
+    cfg = O.Cfg(V, 6, 8, 512, 2048, d_condition=dc, conditioning=mode)
+    params = O.seeded_params(cfg, seed=seed)
+    args = dict(vocab_size=V, n_layer=6, n_head=8, d_model=512, d_inner=2048, dropout=0.0, d_condition=dc, conditioning=mode)
     model, _ = ref_build_model(args)
     model.load_state_dict(params, strict=True)
     model.eval()
-    maps = decode_maps("continuous_concat")
-    gen_len = 128
+    maps = decode_maps(mode)
+    disc, prefix = None, None
+    if mode == "discrete_token":
+        bins = np.linspace(-1 - 1e-12, 1 + 1e-12, 6)
+        disc = [[f"<V{np.searchsorted(bins, v, side='right') - 1 - 2}>",
+                 f"<A{np.searchsorted(bins, a, side='right') - 1 - 2}>"] for v, a in conds]
+        prefix = np.array([[maps["tuple2idx"][s_] for s_ in d] for d in disc]).T          # [2, B]
     captured = []
     orig = ref_generate.ind_tensor_to_str
 
@@ -289,16 +296,21 @@ def make_f4h():
         return _o(x, a, b)
     ref_generate.ind_tensor_to_str = spy
     try:
-        ref_generate.generate(model, maps, torch.device("cpu"), "/tmp/none", "continuous_concat", discrete_conditions=None,
-                              continuous_conditions=conds, max_input_len=gen_len, amp=False, gen_len=gen_len, top_k=1,
-                              debug=True, min_n_instruments=0, primers=[["<START>"]])
+        ref_generate.generate(model, maps, torch.device("cpu"), "/tmp/none", mode, discrete_conditions=disc,
+                              continuous_conditions=None if mode == "none" else conds, max_input_len=gen_len, amp=False,
+                              gen_len=gen_len, top_k=1, debug=True, min_n_instruments=0, primers=[["<START>"]])
     finally:
         ref_generate.ind_tensor_to_str = orig
     ids = np.stack(captured, axis=1)                        # [T, B], row 0 = <START>
     assert ids.shape == (gen_len, 4), ids.shape
     # margins: teacher-force the generated sequences through the reference model, mask what generate() masks
+    inp = ids.T[:, :-1]
+    if prefix is not None:                                  # discrete_token: the two bin tokens sit in front of every window (generate.py:105-107)
+        inp = np.concatenate([prefix.T, inp], axis=1)
     with torch.no_grad():
-        lg = model(torch.tensor(ids.T[:, :-1]), torch.tensor(conds, dtype=torch.float32)).double()     # [B, T-1, V]
+        lg = model(torch.tensor(inp), torch.tensor(conds, dtype=torch.float32)).double()     # [B, T-1 (+2), V]
+    if prefix is not None:
+        lg = lg[:, 2:]
     for tok in ("<PAD>", "<START>", "<END>"):
         if tok in maps["tuple2idx"]:
             lg[:, :, maps["tuple2idx"][tok]] = -float("inf")
@@ -306,9 +318,27 @@ def make_f4h():
     assert bool((top2.indices[:, :, 0].numpy().T == ids[1:]).all()), "teacher-forced argmax != generated ids"
     margin = (top2.values[:, :, 0] - top2.values[:, :, 1]).numpy().T            # [T-1, B]
     scale = float(lg[torch.isfinite(lg)].abs().max())
-    print("F4h ok: ids", ids[:6, 0], "min margin %.3e (logit scale %.2f)" % (margin.min(), scale))
-    np.savez_compressed(os.path.join(OUT, "f4h_decode_cfg2.npz"), ids=ids.astype(np.int16), conds=np.array(conds, dtype=np.float32),
-                        weight_seed=np.array(43), margin=margin.astype(np.float32), logit_scale=np.array(scale))
+    print(fname, "ok: ids", ids[:6, 0], "min margin %.3e (logit scale %.2f)" % (margin.min(), scale))
+    rec = dict(ids=ids.astype(np.int16), conds=np.array(conds, dtype=np.float32), weight_seed=np.array(seed),
+               margin=margin.astype(np.float32), logit_scale=np.array(scale))
+    if prefix is not None:
+        rec["prefix"] = prefix.astype(np.int16)
+    np.savez_compressed(os.path.join(OUT, fname), **rec)
+
+
+def make_f4h():
+    """round 5: continuous_concat, 4 x 128 tokens"""
+    _make_f4h_variant("continuous_concat", 128, "f4h_decode_cfg2.npz")
+
+
+def make_f4h512():
+    """round 6: continuous_concat, 4 x 512 tokens -- contexts past the first key-split chunk of the decode attention"""
+    _make_f4h_variant("continuous_concat", 512, "f4h_decode_cfg2_512.npz")
+
+
+def make_f4hd():
+    """round 6: the discrete_token headline model (V = 1017, BASELINE config 4's model), 4 x 256 tokens"""
+    _make_f4h_variant("discrete_token", 256, "f4h_decode_cfg4_256.npz", seed=44)
 
 
 # ---------------------------------------------------------------- F5: attention core in fp64 through the reference's skewing code

@@ -32,6 +32,7 @@ def test_scaler_step_follows_torch_gradscaler():
     p = torch.nn.Parameter(torch.zeros(4, device=DEV))
     sgd = torch.optim.SGD([p], lr=1.0)
     mine = LossScaler(DEV, init_scale=1024.0, growth_interval=4)
+    ref.scale(torch.zeros(1, device=DEV))                  # GradScaler creates its device state on the first scale()
     taken = 0
     for i, bad in enumerate(pattern):
         p.grad = torch.full((4,), float("inf") if bad else 1.0, device=DEV)

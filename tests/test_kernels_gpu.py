@@ -574,7 +574,12 @@ def test_ce_bf16_logits(ops, V, ld, dt16):
         db = torch.zeros(V, device=DEV)
         dl2 = torch.full_like(dl, float("nan"))
         ops.ce_bwd(lgd, tgt.to(DEV), row_lse, dl2, acc[1:2], 1.0, rows, V, 0, dbias=db, loss_scale=lsc)
-        assert torch.equal(dl2, dl)
+        if dt16 == torch.bfloat16:
+            assert torch.equal(dl2, dl)
+        else:      # f16: hipcc fuses (x * scale -> f16) into ONE rounding (v_fma_mixlo_f16) in the variant without the column sums and
+            # rounds twice (v_mul_f32, v_cvt_pk_f16_f32) in the one with them: neighbours at most, and only on double-rounding ties
+            assert int((dl2.view(torch.int16).int() - dl.view(torch.int16).int()).abs().max()) <= 1
+            assert float((dl2 != dl).float().mean()) < 1e-3
         assert relerr(db, 4096.0 * l64.grad.sum(0)) < 2e-5                           # f32 exact, not the 16-bit column sums
         ops.ce_bwd(lgd, tgt.to(DEV), row_lse, dl2, acc[1:2], 1.0, rows, V, 0, dbias=db, loss_scale=lsc)   # accumulates (+=)
         assert relerr(db, 2 * 4096.0 * l64.grad.sum(0)) < 2e-5

@@ -42,6 +42,43 @@ def test_train_cli_config1_and_checkpoints(tmp_path, capsys):
     assert "step       40" in out
 
 
+def test_train_cli_fp16_tier_scaler_checkpoint_and_overwrite_dropout(tmp_path, capsys):
+    """--compute_dtype fp16 = the reference's autocast dtype with its GradScaler (train.py:108,317-324): the loss decreases, the
+    checkpoint holds scaler.pt with GradScaler's keys (train.py:403-404), a restart loads it (train.py:207-209) unless
+    --reset_scaler, and --overwrite_dropout on a restart really changes the model's rate."""
+    import train
+    argv = ["--conditioning", "continuous_concat", "--n_layer", "2", "--d_model", "128", "--n_head", "2", "--d_inner", "256",
+            "--d_condition", "32", "--tgt_len", "128", "--batch_size", "4", "--lr", "1e-3", "--max_step", "30", "--log_step", "10",
+            "--eval_step", "1000", "--work_dir", str(tmp_path), "--dropout", "0.1", "--seed", "1", "--compute_dtype", "fp16",
+            "--accumulate_step", "2"]
+    train.main(argv)
+    out = capsys.readouterr().out
+    assert "dtype = fp16" in out
+    losses = [float(l.split("| loss")[1].split("|")[0]) for l in out.splitlines() if "| loss" in l]
+    assert len(losses) == 3 and losses[-1] < losses[0] - 0.05, losses
+    run = sorted(os.listdir(tmp_path))[0]
+    sd = torch.load(tmp_path / run / "scaler.pt")
+    assert set(sd) == {"scale", "growth_factor", "backoff_factor", "growth_interval", "_growth_tracker"}
+    assert sd["scale"] in (65536.0, 32768.0, 16384.0) and sd["growth_interval"] == 2000
+    assert torch.load(tmp_path / run / "optimizer.pt")["step"] == 30 - {65536.0: 0, 32768.0: 1, 16384.0: 2}[sd["scale"]]
+    # a hand-edited scale must come back on restart, and not with --reset_scaler
+    sd["scale"], sd["_growth_tracker"] = 4096.0, 7
+    torch.save(sd, tmp_path / run / "scaler.pt")
+    rest = ["--conditioning", "continuous_concat", "--n_layer", "2", "--d_model", "128", "--n_head", "2", "--d_inner", "256",
+            "--d_condition", "32", "--tgt_len", "128", "--batch_size", "4", "--lr", "1e-3", "--log_step", "5", "--eval_step", "1000",
+            "--work_dir", str(tmp_path), "--restart_dir", run, "--max_step", "35", "--compute_dtype", "fp16", "--seed", "1"]
+    train.main(rest + ["--dropout", "0.3", "--overwrite_dropout"])
+    out = capsys.readouterr().out
+    assert "Dropout rate changed to 0.3" in out and "step       35" in out
+    runs = sorted(os.listdir(tmp_path))
+    sd2 = torch.load(tmp_path / runs[-1] / "scaler.pt")
+    assert sd2["scale"] == 4096.0 and sd2["_growth_tracker"] == 7 + 5, sd2
+    train.main(rest + ["--reset_scaler"])
+    capsys.readouterr()
+    runs3 = [r for r in sorted(os.listdir(tmp_path)) if r not in runs]
+    assert torch.load(tmp_path / runs3[-1] / "scaler.pt")["scale"] == 65536.0
+
+
 def test_train_cli_grad_accumulation_matches_big_batch():
     """accumulate_step=2 with batch 2 == one step with the same 4 sequences (dropout 0, f32 tier)."""
     import train
