@@ -667,6 +667,7 @@ def main():
         # EVERY 256-tile launch take a second tile round -- measured on one GPU: qkv 59.6 -> 70.8 us, proj 27.1 -> 43.9 us
         # with 64 CUs reserved -- so none is applied automatically)
         out["ddp"] = {"policy": os.environ.get("MIDIEMO_DDP_POLICY", "window"), "policy_in_force": ddp_state[0],
+                      "compress": "bf16" if reducer is not None and reducer.compress else None,       # MIDIEMO_DDP_COMPRESS=bf16: 41.2 MB instead of 82.4 MB per step
                       "policy_decision": ddp_state[1],          # "auto": the two measured spans and the choice (midiemo/ddp.py)
                       "cu_reserve": int(os.environ.get("MIDIEMO_CU_RESERVE", "0") or 0), "world": world,
                       "backend": backend if dist_on else None}
@@ -676,7 +677,7 @@ def main():
             # a SCALE run: value(N) / (N value(1)) ~ 1 - exposed / step when nothing else changes.
             out["ddp"].update(exposed_wait_ms_per_step=round(exposed_mean, 4), exposed_wait_ms_p50=round(exposed_p50, 4),
                               exposed_frac_of_step=round(exposed_mean / (1000.0 * elapsed / args.steps), 4),
-                              grad_bytes_per_step=int(model.flat_grads.numel() * 4))
+                              grad_bytes_per_step=int(model.flat_grads.numel() * (2 if reducer.compress else 4)))
         if hbm_table is not None:
             out["hbm_kernels"] = hbm_table
         if world == 1 and not args.no_cpu_baseline:

@@ -33,11 +33,23 @@ class GradAllReducer:
                  runs from then on.  Measured on one MI355X: "window" costs 0.2 ms per step even with nothing to exchange
                  (RCCL's channels take CUs from the attention backward, profiles/r04_measurements.txt), so it only pays
                  when the exposed all-reduce of "end" is longer than that.  `decision` holds the numbers (bench.py prints
-                 them as ddp.policy_decision).  One host synchronisation, once, at the decision."""
+                 them as ddp.policy_decision).  One host synchronisation, once, at the decision.
+    compress (env MIDIEMO_DDP_COMPRESS=bf16, opt-in; SURVEY 8e "41.2 MB bf16-compressed"): a bucket travels as bf16 -- cast
+                 into a staging buffer, summed by the collective in bf16, cast back into the f32 flat gradient after the wait.
+                 Halves the payload (82.4 -> 41.2 MB per step at the headline model); costs two cast passes and bf16
+                 rounding of every reduced gradient element (the sum of `world` bf16 values rounded to bf16: ~2^-9 relative
+                 per element -- the global-norm clip and Adam then see those values on EVERY rank alike: a ring / tree
+                 all-reduce hands every rank the same bits, so the ranks stay bit-identical, asserted in the tests)."""
     AUTO_PROBE = 3
 
-    def __init__(self, flat_grads_fn, bucket_ranges, group=None, policy=None):
+    def __init__(self, flat_grads_fn, bucket_ranges, group=None, policy=None, compress=None):
         import os
+        compress = compress if compress is not None else os.environ.get("MIDIEMO_DDP_COMPRESS", "")
+        if compress not in ("", "0", "none", "bf16"):
+            raise ValueError("MIDIEMO_DDP_COMPRESS must be bf16 (or unset)")
+        self.compress = compress == "bf16"
+        self._cbuf = None
+        self._copy_back = []
         self._flat = flat_grads_fn
         self.ranges = list(bucket_ranges)
         self.group = group
@@ -66,9 +78,18 @@ class GradAllReducer:
         return 1.0 / self.world
 
     def _launch(self, lo, hi):
-        if hi > lo:
-            self._works.append(dist.all_reduce(self._flat()[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
-                                               async_op=True))
+        if hi <= lo:
+            return
+        flat = self._flat()
+        if self.compress:
+            if self._cbuf is None or self._cbuf.numel() != flat.numel() or self._cbuf.device != flat.device:
+                self._cbuf = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device)
+            buf = self._cbuf[lo:hi]
+            buf.copy_(flat[lo:hi])                              # on the compute stream; the collective waits for it
+            self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._copy_back.append((lo, hi))
+            return
+        self._works.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _flush(self):
         # adjacent parked buckets travel as one collective
@@ -115,6 +136,9 @@ class GradAllReducer:
             a.record()
         for w in self._works:
             w.wait()
+        for lo, hi in self._copy_back:                          # compressed buckets: bf16 sums back into the f32 gradients
+            self._flat()[lo:hi].copy_(self._cbuf[lo:hi])
+        self._copy_back.clear()
         if self.timing:
             b.record()
             self._wait_events.append((a, b))

@@ -127,7 +127,10 @@ class MusicTransformerHIP(nn.Module):
         self.resid_lo = os.environ.get("MIDIEMO_RESID_LO", "1") != "0"
         # attention backward: the key-owned (dK, dV) and the E-row-owned (dE) kernels side by side on two streams (both only
         # depend on the query-owned kernel; same results); measured -9 us (L = 1024) / -35 us (L = 2048) per layer
-        self.attn_bwd_overlap = os.environ.get("MIDIEMO_ATTN_BWD_OVERLAP", "1") != "0"
+        # Under an initialised process group (RCCL's own streams alive) the second stream measured no gain under the `window` /
+        # `eager` bucket policies and +0.1 ms per step under `end` (profiles/r06_ddp_overlap.txt): default = on for a single
+        # process, off once torch.distributed is initialised; MIDIEMO_ATTN_BWD_OVERLAP=0|1 forces either.
+        self._attn_bwd_overlap_env = os.environ.get("MIDIEMO_ATTN_BWD_OVERLAP")
 
         self.embedding = _Emb(vocab_size, embedding_dim - d_condition)
         if self.token_conditioning:
@@ -149,6 +152,17 @@ class MusicTransformerHIP(nn.Module):
         self._pe = None
         self._packing = False
         self._pack()
+
+    @property
+    def attn_bwd_overlap(self):
+        if self._attn_bwd_overlap_env is not None:
+            return self._attn_bwd_overlap_env != "0"
+        import torch.distributed as dist
+        return not (dist.is_available() and dist.is_initialized())
+
+    @attn_bwd_overlap.setter
+    def attn_bwd_overlap(self, on):
+        self._attn_bwd_overlap_env = "1" if on else "0"
 
     # ------------------------------------------------------------------ head (overridden by MusicRegression: Sequential(Linear, Tanh))
     _HEAD_W, _HEAD_B = "fc.weight", "fc.bias"
@@ -465,6 +479,17 @@ class MusicTransformerHIP(nn.Module):
         return ws
 
     # ------------------------------------------------------------------ engine: backward
+    @staticmethod
+    def backward_hook_sequence(num_layer):
+        """The bucket_hook arguments in the order _backward_impl issues them (bucket ids of bucket_ranges(): 0 = embedding,
+        i + 1 = layer i, num_layer + 1 = head; -1 = a comm window opens: the next layer's attention backward follows).  The
+        reducer tests replay exactly this sequence on the CPU; tests/test_ddp_gpu.py asserts the engine emits it."""
+        seq = [num_layer + 1]
+        for i in reversed(range(num_layer)):
+            seq += [-1, i + 1]
+        seq.append(0)
+        return seq
+
     def _backward_impl(self, ws, tokens, cond, B, Ltok, Lm, p_drop, seed, gflat, bucket_hook=None, head_bias_done=False):
         """dlogits in ws.dlogits (T, padded ld) -> accumulates every parameter gradient into gflat."""
         dt = self.compute_dtype

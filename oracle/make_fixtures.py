@@ -288,6 +288,8 @@ def _make_f4h_variant(mode, gen_len, fname, seed=43):
         disc = [[f"<V{np.searchsorted(bins, v, side='right') - 1 - 2}>",
                  f"<A{np.searchsorted(bins, a, side='right') - 1 - 2}>"] for v, a in conds]
         prefix = np.array([[maps["tuple2idx"][s_] for s_ in d] for d in disc]).T          # [2, B]
+    # generate() takes 2 off max_input_len for the token-conditioned modes (generate.py:76,81): + 2 keeps the window from sliding
+    mil = gen_len + (2 if mode in ("discrete_token", "continuous_token") else 0)
     captured = []
     orig = ref_generate.ind_tensor_to_str
 
@@ -297,7 +299,7 @@ def _make_f4h_variant(mode, gen_len, fname, seed=43):
     ref_generate.ind_tensor_to_str = spy
     try:
         ref_generate.generate(model, maps, torch.device("cpu"), "/tmp/none", mode, discrete_conditions=disc,
-                              continuous_conditions=None if mode == "none" else conds, max_input_len=gen_len, amp=False,
+                              continuous_conditions=None if mode == "none" else conds, max_input_len=mil, amp=False,
                               gen_len=gen_len, top_k=1, debug=True, min_n_instruments=0, primers=[["<START>"]])
     finally:
         ref_generate.ind_tensor_to_str = orig
@@ -311,16 +313,16 @@ def _make_f4h_variant(mode, gen_len, fname, seed=43):
         lg = model(torch.tensor(inp), torch.tensor(conds, dtype=torch.float32)).double()     # [B, T-1 (+2), V]
     if prefix is not None:
         lg = lg[:, 2:]
-    for tok in ("<PAD>", "<START>", "<END>"):
-        if tok in maps["tuple2idx"]:
-            lg[:, :, maps["tuple2idx"][tok]] = -float("inf")
+    for tok, idx in maps["tuple2idx"].items():             # generate.py:57,131-136: every symbol that starts with "<" is excluded
+        if isinstance(tok, str) and tok[:1] == "<":
+            lg[:, :, idx] = -float("inf")
     top2 = lg.topk(2, dim=-1)
     assert bool((top2.indices[:, :, 0].numpy().T == ids[1:]).all()), "teacher-forced argmax != generated ids"
     margin = (top2.values[:, :, 0] - top2.values[:, :, 1]).numpy().T            # [T-1, B]
     scale = float(lg[torch.isfinite(lg)].abs().max())
     print(fname, "ok: ids", ids[:6, 0], "min margin %.3e (logit scale %.2f)" % (margin.min(), scale))
     rec = dict(ids=ids.astype(np.int16), conds=np.array(conds, dtype=np.float32), weight_seed=np.array(seed),
-               margin=margin.astype(np.float32), logit_scale=np.array(scale))
+               margin=margin.astype(np.float32), logit_scale=np.array(scale), max_input_len=np.array(mil))
     if prefix is not None:
         rec["prefix"] = prefix.astype(np.int16)
     np.savez_compressed(os.path.join(OUT, fname), **rec)

@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--compute_dtype", default="fp32")
     ap.add_argument("--out", required=True)
     ap.add_argument("--big", action="store_true")
+    ap.add_argument("--compress", default="", help="bf16: bf16-compressed buckets (GradAllReducer compress)")
     ap.add_argument("--dump_prep", action="store_true", help="diagnosis: also save the prepared (cast) weights every step ran with")
     a = ap.parse_args()
     if a.big:
@@ -73,7 +74,14 @@ def main():
     broadcast_params(model.flat_params)
     model.mark_params_changed()
     opt = FusedAdamW(model, lr=2e-5, clip=1.0)          # same as the reference run in test_ddp_gpu.py
-    red = GradAllReducer(lambda: model.flat_grads, model.bucket_ranges(), policy=a.policy)
+    red = GradAllReducer(lambda: model.flat_grads, model.bucket_ranges(), policy=a.policy, compress=a.compress)
+    # the bucket_hook sequence the engine really emits must be the documented one (the CPU reducer test replays exactly it)
+    seen_hooks = []
+    red_hook = red.hook
+
+    def hook(b):
+        seen_hooks.append(b)
+        red_hook(b)
     g1 = None
     gs, pb, pa, preps = [], [], [], []
     for step in range(STEPS):
@@ -81,11 +89,13 @@ def main():
         for micro in range(a.accumulate):
             x, c, y = micro_batch(step, micro, rank, dev)
             last = micro + 1 == a.accumulate
-            model.loss_and_backward(x, c, y, grad_scale=1.0 / a.accumulate, bucket_hook=red.hook if last else None)
+            model.loss_and_backward(x, c, y, grad_scale=1.0 / a.accumulate, bucket_hook=hook if last else None)
             if a.dump_prep and micro == 0 and rank == 0:
                 preps.append([{k: v.detach().cpu().clone() for k, v in L.items() if torch.is_tensor(v)} for L in model._prep["layers"]] +
                              [{k: v.detach().cpu().clone() for k, v in model._prep["head"].items()}])
         red.finish()
+        assert seen_hooks == type(model).backward_hook_sequence(model.num_layer), seen_hooks
+        del seen_hooks[:]
         if step == 0:
             g1 = (model.flat_grads * red.grad_scale).clone()
         gs.append((model.flat_grads * red.grad_scale).cpu())         # averaged gradient as the optimiser sees it
