@@ -266,7 +266,7 @@ def make_f4():
 
 
 # ---------------------------------------------------------------- F4h: the same at the HEADLINE geometry (BASELINE config 2 / 5 model)
-def _make_f4h_variant(mode, gen_len, fname, seed=43):
+def _make_f4h_variant(mode, gen_len, fname, seed=43, min_margin=1e-4):
     """Greedy ids of the reference's own generate() on the 6-layer d512 8-head (dh 64) d_inner 2048 model of BASELINE configs
     2 / 4 / 5: 4 (valence, arousal) pairs x gen_len tokens, no slide (max_input_len = gen_len).  Weights =
     O.seeded_params(cfg, seed), regenerated by the test, not stored.  Also stored: the top-1 / top-2 logit margin of every step
@@ -316,16 +316,22 @@ def _make_f4h_variant(mode, gen_len, fname, seed=43):
     for tok, idx in maps["tuple2idx"].items():             # generate.py:57,131-136: every symbol that starts with "<" is excluded
         if isinstance(tok, str) and tok[:1] == "<":
             lg[:, :, idx] = -float("inf")
-    top2 = lg.topk(2, dim=-1)
-    assert bool((top2.indices[:, :, 0].numpy().T == ids[1:]).all()), "teacher-forced argmax != generated ids"
-    margin = (top2.values[:, :, 0] - top2.values[:, :, 1]).numpy().T            # [T-1, B]
+    # margin of the GENERATED id over the best other candidate (teacher-forced logits differ from the step-by-step ones by f32
+    # summation order, ~1e-6: a generated id that is not the teacher-forced arg-max sat on a tie and shows as a negative margin)
+    gen = torch.tensor(ids[1:].T.astype(np.int64))[:, :, None]                  # [B, T-1, 1]
+    chosen = lg.gather(2, gen)[:, :, 0]
+    others = lg.scatter(2, gen, -float("inf")).max(dim=-1).values
+    margin = (chosen - others).numpy().T                                        # [T-1, B]
     scale = float(lg[torch.isfinite(lg)].abs().max())
-    print(fname, "ok: ids", ids[:6, 0], "min margin %.3e (logit scale %.2f)" % (margin.min(), scale))
+    print(fname, "seed", seed, ": ids", ids[:6, 0], "min margin %.3e (logit scale %.2f)" % (margin.min(), scale))
+    if margin.min() < min_margin:
+        return False
     rec = dict(ids=ids.astype(np.int16), conds=np.array(conds, dtype=np.float32), weight_seed=np.array(seed),
                margin=margin.astype(np.float32), logit_scale=np.array(scale), max_input_len=np.array(mil))
     if prefix is not None:
         rec["prefix"] = prefix.astype(np.int16)
     np.savez_compressed(os.path.join(OUT, fname), **rec)
+    return True
 
 
 def make_f4h():
@@ -340,7 +346,11 @@ def make_f4h512():
 
 def make_f4hd():
     """round 6: the discrete_token headline model (V = 1017, BASELINE config 4's model), 4 x 256 tokens"""
-    _make_f4h_variant("discrete_token", 256, "f4h_decode_cfg4_256.npz", seed=44)
+    # the weight seed is the first of 44, 45, ... whose greedy stream has no near-tie (margin >= 1e-4 = 100 x the f32 noise between
+    # two evaluation orders of the same logits): a golden for BIT-exact ids must not hinge on a coin flip of the reference itself
+    for seed in range(44, 60):
+        if _make_f4h_variant("discrete_token", 256, "f4h_decode_cfg4_256.npz", seed=seed):
+            break
 
 
 # ---------------------------------------------------------------- F5: attention core in fp64 through the reference's skewing code

@@ -59,70 +59,99 @@ def test_greedy_ids_bit_exact_vs_reference(golden_dir, mode):
         assert np.array_equal(ids_nc, z[f"{mode}_{tag}_ids"]), (mode, tag, "no-cache")
 
 
-def test_headline_geometry_greedy_ids_vs_reference(golden_dir):
-    """BASELINE config 5's model against the REFERENCE at its own geometry (VERDICT r4 missing #5): 6 layers, d 512, 8 heads
-    of 64, d_inner 2048, continuous_concat; 4 (valence, arousal) pairs x 128 greedy tokens captured from the reference's
-    generate() (oracle/make_fixtures.py make_f4h -> tests/golden/f4h_decode_cfg2.npz; weights = O.seeded_params(cfg, 43),
-    regenerated here).  f32 tier: ids bit-exact through the cached decode (DecodeSession under generate()) AND through
-    the no-cache full recompute; the fixture's smallest top-2 margin (1.2e-3 on logits of scale 6.7) is > 100 x the tier's
-    logit error.  bf16 tier: the derived teacher-forcing criterion of test_bf16_decode_agrees_with_reference_mostly -- every
-    step whose f32 top-2 gap exceeds twice K_LOGITS x the oracle's own bf16-autocast error at that step picks the
-    reference's token; free-running agreement is printed."""
+F4H = {"cc128": ("f4h_decode_cfg2.npz", "continuous_concat"), "cc512": ("f4h_decode_cfg2_512.npz", "continuous_concat"),
+       "dt256": ("f4h_decode_cfg4_256.npz", "discrete_token")}
+
+
+@pytest.mark.parametrize("which", list(F4H))
+def test_headline_geometry_greedy_ids_vs_reference(golden_dir, which):
+    """The 6-layer d512 8-head (dh 64) d_inner 2048 model of BASELINE configs 2 / 4 / 5 against the REFERENCE at its own
+    geometry: greedy tokens captured from the reference's generate() for the 4 standard (valence, arousal) pairs
+    (oracle/make_fixtures.py make_f4h / make_f4h512 / make_f4hd; weights = O.seeded_params(cfg, seed), regenerated here):
+    continuous_concat 4 x 128 (round 5), continuous_concat 4 x 512 (round 6: contexts past the first chunk of every key split
+    of the decode attention, default nsplit) and the discrete_token headline model (V = 1017, two bin tokens in front) 4 x 256.
+    f32 tier: ids bit-exact through the cached decode (DecodeSession under generate()) AND through the no-cache full
+    recompute; the fixture's smallest margin is > 10 x the tier's logit error.  16-bit tiers (bf16, f16): the derived
+    teacher-forcing criterion -- every step whose f32 top-2 gap exceeds twice K_LOGITS x the oracle's own autocast error at that
+    step picks the reference's token; free-running agreement is printed (f16, the reference's own autocast dtype: expected far above bf16's)."""
     import generate as G
     from midiemo.decode import DecodeSession
     from midiemo.models.build_model import build_model
     from midiemo.vocab import get_maps
-    z = np.load(os.path.join(golden_dir, "f4h_decode_cfg2.npz"))
-    ref_ids = z["ids"].astype(np.int64)                      # [128, 4]
+    fname, mode = F4H[which]
+    z = np.load(os.path.join(golden_dir, fname))
+    ref_ids = z["ids"].astype(np.int64)                      # [T, 4]
     conds = z["conds"].tolist()
-    cfg = O.Cfg(1007, 6, 8, 512, 2048, d_condition=128, conditioning="continuous_concat")
+    V = 1017 if mode == "discrete_token" else 1007
+    dc = 128 if mode == "continuous_concat" else -1
+    cfg = O.Cfg(V, 6, 8, 512, 2048, d_condition=dc, conditioning=mode)
     P = O.seeded_params(cfg, int(z["weight_seed"]))
-    maps = get_maps(n_emotion_bins=0)
+    maps = get_maps(n_emotion_bins=5 if mode == "discrete_token" else 0)
+    disc, prefix = None, None
+    if mode == "discrete_token":
+        bins = np.linspace(-1 - 1e-12, 1 + 1e-12, 6)
+        disc = [[f"<V{np.searchsorted(bins, v, side='right') - 3}>", f"<A{np.searchsorted(bins, a, side='right') - 3}>"] for v, a in conds]
+        prefix = torch.tensor([[maps["tuple2idx"][s_] for s_ in d] for d in disc])      # [4, 2]
+        assert np.array_equal(prefix.numpy().T, z["prefix"])
     models = {}
-    for cd in ("fp32", "bf16"):
-        m, _ = build_model(dict(vocab_size=1007, n_layer=6, n_head=8, d_model=512, d_inner=2048, dropout=0.0, d_condition=128,
-                                conditioning="continuous_concat", compute_dtype=cd))
+    for cd in ("fp32", "bf16", "fp16"):
+        m, _ = build_model(dict(vocab_size=V, n_layer=6, n_head=8, d_model=512, d_inner=2048, dropout=0.0, d_condition=dc,
+                                conditioning=mode, compute_dtype=cd))
         m.load_state_dict(P)
         models[cd] = m.to("cuda").eval()
     n = ref_ids.shape[0]
-    ids = run(G, models["fp32"], maps, "continuous_concat", conds, None, n, n, use_cache=True)
+    mil = int(z["max_input_len"]) if "max_input_len" in z else n
+    ids = run(G, models["fp32"], maps, mode, conds, disc, n, mil, use_cache=True)
     assert np.array_equal(ids, ref_ids), ("cached decode", np.argwhere(ids != ref_ids)[:4])
-    ids_nc = run(G, models["fp32"], maps, "continuous_concat", conds, None, n, n, use_cache=False)
+    ids_nc = run(G, models["fp32"], maps, mode, conds, disc, n, mil, use_cache=False)
     assert np.array_equal(ids_nc, ref_ids), ("full recompute", np.argwhere(ids_nc != ref_ids)[:4])
-    # the f32 margin the bit-exactness rests on, measured on this run's own logits
+    # the f32 margin the bit-exactness rests on, measured on this run's own logits (teacher-forced through the cache)
     cond = torch.tensor(conds, dtype=torch.float32)
-    toks = torch.from_numpy(ref_ids.T.copy())                # [4, 128]
-    lg32 = O.forward(cfg, P, toks, cond)
-    sess = DecodeSession(models["fp32"], 4)
-    worst = 0.0
-    for t in range(n - 1):
-        lg = sess.step(toks[:, t].cuda(), cond.cuda()).float().cpu()
-        worst = max(worst, float((lg[:, 2:1007] - lg32[:, t, 2:1007]).abs().max()))
+    toks = torch.from_numpy(ref_ids.T.copy())                # [4, T]
+    feed = toks if prefix is None else torch.cat([prefix, toks], 1)      # discrete_token: the bin tokens occupy positions 0, 1
+    sh = 0 if prefix is None else 2
+    nv = 1007                                                # candidates: ids 2 .. 1006 (every "<...>" symbol is excluded, generate.py:57)
+    lg32 = O.forward(cfg, P, feed, cond if mode.startswith("continuous") else torch.full((4, 2), float("nan")))
+    c_dev = cond.cuda() if mode.startswith("continuous") else None
+
+    def cached_logits(model):
+        sess = DecodeSession(model, 4)
+        out = []
+        for t in range(feed.shape[1] - 1):
+            lg = sess.step(feed[:, t].cuda(), c_dev).float().cpu()
+            if t >= sh:
+                out.append(lg[:, 2:nv])
+        return out                                           # out[t] predicts toks[:, t + 1]
+    worst = max(float((lg - lg32[:, t + sh, 2:nv]).abs().max()) for t, lg in enumerate(cached_logits(models["fp32"])))
     assert worst < 0.1 * float(z["margin"].min()), (worst, float(z["margin"].min()))
-    print("headline-geometry decode, f32: 4 x %d greedy ids bit-exact vs the reference (cache and recompute); max |logit error| %.2e "
-          "against a smallest top-2 margin of %.2e" % (n, worst, float(z["margin"].min())))
-    # bf16: free-running agreement reported, teacher-forced criterion asserted
-    idb = run(G, models["bf16"], maps, "continuous_concat", conds, None, n, n, use_cache=True)
-    same = idb == ref_ids
+    print("headline-geometry decode %s, f32: 4 x %d greedy ids bit-exact vs the reference (cache and recompute); max |logit error| %.2e "
+          "against a smallest margin of %.2e" % (which, n, worst, float(z["margin"].min())))
     K_LOGITS = 1.25
-    with torch.autocast("cpu", dtype=torch.bfloat16):
-        lgac = O.forward(cfg, P, toks, cond).float()
-    sess = DecodeSession(models["bf16"], 4)
-    agree = stable = 0
-    for t in range(n - 1):
-        lg = sess.step(toks[:, t].cuda(), cond.cuda()).float().cpu()[:, 2:1007]
-        r32 = lg32[:, t, 2:1007]
-        err_bound = K_LOGITS * (lgac[:, t, 2:1007] - r32).abs().max(-1).values
-        top2 = r32.topk(2, dim=-1)
-        gap = top2.values[:, 0] - top2.values[:, 1]
-        pick, want = lg.argmax(-1), top2.indices[:, 0]
-        assert (want + 2 == toks[:, t + 1]).all()
-        must = gap > 2 * err_bound
-        assert (pick[must] == want[must]).all(), (t, pick, want, gap, err_bound)
-        agree += int((pick == want).sum())
-        stable += int(must.sum())
-    print("headline-geometry decode, bf16: %d / %d tokens equal free-running; teacher-forced %d / %d steps pick the reference "
-          "token, all %d steps with a gap above twice the derived bound agree" % (int(same.sum()), same.size, agree, 4 * (n - 1), stable))
+    for cd, acdt in (("bf16", torch.bfloat16), ("fp16", torch.float16)):
+        idb = run(G, models[cd], maps, mode, conds, disc, n, mil, use_cache=True)
+        same = idb == ref_ids
+        with torch.autocast("cpu", dtype=acdt):
+            lgac = O.forward(cfg, P, feed, cond if mode.startswith("continuous") else torch.full((4, 2), float("nan"))).float()
+        agree = stable = 0
+        for t, lg in enumerate(cached_logits(models[cd])):
+            r32 = lg32[:, t + sh, 2:nv]
+            err_bound = K_LOGITS * (lgac[:, t + sh, 2:nv] - r32).abs().max(-1).values
+            top2 = r32.topk(2, dim=-1)
+            gap = top2.values[:, 0] - top2.values[:, 1]
+            pick, want = lg.argmax(-1), top2.indices[:, 0]
+            assert (want + 2 == toks[:, t + 1]).all()
+            must = gap > 2 * err_bound
+            assert (pick[must] == want[must]).all(), (cd, t, pick, want, gap, err_bound)
+            agree += int((pick == want).sum())
+            stable += int(must.sum())
+        line = ("headline-geometry decode %s, %s: %d / %d tokens equal free-running; teacher-forced %d / %d steps pick the reference "
+                "token, all %d steps with a gap above twice the derived bound agree" % (which, cd, int(same.sum()), same.size, agree, 4 * (n - 1), stable))
+        print(line)
+        try:
+            with open(os.path.join(ROOT, "gpurun_out", "parity_report.txt"), "a") as f:
+                f.write(line + "\n")
+        except OSError:
+            pass
 
 
 @pytest.mark.parametrize("mode", ["continuous_concat", "discrete_token"])

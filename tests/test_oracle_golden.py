@@ -141,19 +141,33 @@ def test_f4_greedy_decode_ids(golden_dir, mode):
         assert np.array_equal(ids.numpy(), z[f"{mode}_{tag}_ids"]), (mode, tag)
 
 
-def test_f4h_headline_geometry_greedy_ids(golden_dir):
-    """The oracle against the reference's generate() at the headline geometry (6L d512 8H dh64, 4 pairs x 128 tokens):
-    teacher-forced with the reference's own ids, the oracle's arg-max (specials masked like generate.py:122-136) is the
-    reference's next token at every step, and its top-2 margins are the fixture's."""
-    z = load(golden_dir, "f4h_decode_cfg2.npz")
-    cfg = O.Cfg(1007, 6, 8, 512, 2048, d_condition=128, conditioning="continuous_concat")
+@pytest.mark.parametrize("fname,mode", [("f4h_decode_cfg2.npz", "continuous_concat"), ("f4h_decode_cfg2_512.npz", "continuous_concat"),
+                                        ("f4h_decode_cfg4_256.npz", "discrete_token")])
+def test_f4h_headline_geometry_greedy_ids(golden_dir, fname, mode):
+    """The oracle against the reference's generate() at the headline geometry (6L d512 8H dh64; continuous_concat 4 x 128 and
+    4 x 512 tokens, discrete_token V1017 4 x 256): teacher-forced with the reference's own ids, the oracle's arg-max (every
+    "<...>" symbol masked like generate.py:57,131-136) is the reference's next token at every step, and the margins of the
+    generated ids are the fixture's."""
+    z = load(golden_dir, fname)
+    V = 1017 if mode == "discrete_token" else 1007
+    cfg = O.Cfg(V, 6, 8, 512, 2048, d_condition=128 if mode == "continuous_concat" else -1, conditioning=mode)
     P = O.seeded_params(cfg, int(z["weight_seed"]))
-    ids = torch.from_numpy(z["ids"].astype(np.int64))            # [128, 4]
-    lg = O.forward(cfg, P, ids.t()[:, :-1].contiguous(), torch.from_numpy(z["conds"])).double()
+    ids = torch.from_numpy(z["ids"].astype(np.int64))            # [T, 4]
+    inp = ids.t()[:, :-1].contiguous()
+    sh = 0
+    if mode == "discrete_token":
+        inp = torch.cat([torch.from_numpy(z["prefix"].astype(np.int64)).t(), inp], 1)
+        sh = 2
+    cond = torch.from_numpy(z["conds"]) if mode.startswith("continuous") else torch.full((4, 2), float("nan"))
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    lg = O.forward(cfg, P, inp, cond).double()[:, sh:]
     lg[:, :, :2] = -float("inf")                                 # <PAD>, <START> (the 1007-symbol vocabulary has no <END>)
-    top2 = lg.topk(2, dim=-1)
-    assert torch.equal(top2.indices[:, :, 0].t(), ids[1:])
-    margin = (top2.values[:, :, 0] - top2.values[:, :, 1]).t()
+    lg[:, :, 1007:] = -float("inf")                              # discrete_token: the ten bin symbols
+    gen = ids[1:].t()[:, :, None]
+    chosen = lg.gather(2, gen)[:, :, 0]
+    others = lg.scatter(2, gen, -float("inf")).max(dim=-1).values
+    margin = (chosen - others).t()
+    assert float(margin.min()) > 0                                # the oracle's arg-max IS the reference's token at every step
     assert float((margin - torch.from_numpy(z["margin"]).double()).abs().max()) < 1e-4
 
 
