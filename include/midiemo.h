@@ -238,7 +238,7 @@ int me_rga_pack_rel(const void* E, void* Epk, int M, int dh, int dtype, void* st
  *         (ME_WS_RGA_DGT).
  * Neither S nor dS is stored or recomputed from Q.K^T: dS = P o (V dO^T - delta) / sqrt(dh) with P from PT / MT.
  * causal: as in me_rga_fwd (autograd of music_multi.py:211-235 for 1, of music_regression.py's mask = None attention for 0). */
-int me_rga_bwd(const void* qkv, const void* Epk, const uint8_t* key_pad, const void* out, const float* lse, const void* dout,
+int me_rga_bwd(const void* qkv, const void* Epk, const void* out, const float* lse, const void* dout,
                void* dqkv, float* dE, float* delta_ws, const void* PT, const float* MT, void* dGT,
                int B, int L, int Lp, int H, int dh, int M, int causal, int dtype, void* stream);
 
@@ -247,7 +247,7 @@ int me_rga_bwd(const void* qkv, const void* Epk, const uint8_t* key_pad, const v
  * call the selected kernels run in the order 0, 1, 2.  The kernels of bits 1 and 2 do not depend on each other: a caller
  * that owns two streams may enqueue them side by side (its own events order them; the library never synchronises).
  * phases = 7 on one stream is me_rga_bwd. */
-int me_rga_bwd_phases(const void* qkv, const void* Epk, const uint8_t* key_pad, const void* out, const float* lse, const void* dout,
+int me_rga_bwd_phases(const void* qkv, const void* Epk, const void* out, const float* lse, const void* dout,
                       void* dqkv, float* dE, float* delta_ws, const void* PT, const float* MT, void* dGT,
                       int B, int L, int Lp, int H, int dh, int M, int causal, int phases, int dtype, void* stream);
 

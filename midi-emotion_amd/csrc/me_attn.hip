@@ -292,17 +292,11 @@ template <typename T> struct PHalf { typedef typename V16<T>::x8 type; static co
 template <> struct PHalf<float> { typedef f32x4_t type; static constexpr int N = 4; };
 
 // (186 registers, two waves per SIMD; a cap of 168 for three spills 152 bytes per lane: 411 vs 388 us per backward)
-// RECOMP (round 6, VERDICT r5 next-3: the FlashAttention-2 shape): the probability tile is NOT read back from PT / MT but rebuilt
-// from q, the key tile, the relative blocks and the row's final lse -- S^T = K Q^T (KA atoms), the new relative block G^T = E Q^T
-// (KA atoms) through the forward's f32 ring skew, P = exp2((s + g) c2 - lse log2e): the forward's arithmetic (same MFMA order,
-// same ring), normalised directly by the FINAL lse instead of a running maximum.  The 35 KB of f32 rings take the place of the
-// E^T image ring (those fragments then come straight from global memory, as in the f32 tier): 75 KB, still two blocks per CU.
-template <typename T, int DH, bool CAUSAL = true, bool RECOMP = false>
+template <typename T, int DH, bool CAUSAL = true>
 __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
     const T* __restrict__ qkv, const T* __restrict__ Epk, const T* __restrict__ out, const float* __restrict__ lse,
     const T* __restrict__ dout, T* __restrict__ dqkv, float* __restrict__ delta_ws, const T* __restrict__ PT,
-    const float* __restrict__ MT, T* __restrict__ dGT, const uint8_t* __restrict__ key_pad, int B, int L, int Lp, int H, int M,
-    float scale) {
+    const float* __restrict__ MT, T* __restrict__ dGT, int B, int L, int Lp, int H, int M, float scale) {
     using C = ACfg<T, DH>;
     using PH = typename PHalf<T>::type;
     constexpr int PE = PHalf<T>::N, PN = 16 / PE;        // elements per piece, pieces per lane and tile
@@ -315,11 +309,9 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
     // (one 16-byte chunk per thread, two steps ahead, like the key tiles) instead of once per wave: 16 KB -> 4 KB of L1
     // requests per step.  (round 3's per-phase s_memtime sums showed the waves stalling at the ISSUE of their loads: the CU's L1 miss
     // queue, not the latency of any single load, bounds this kernel.)  5 slots: 4 in use + the one being written.
-    constexpr bool ERING = sizeof(T) == 2 && !RECOMP;
+    constexpr bool ERING = sizeof(T) == 2;
     constexpr int EIMG = 2 * C::DB * 512, ENCH = EIMG * (int)sizeof(T) / 16, ENPT = (ENCH + 255) / 256, ESLOTS = 5;
     __shared__ __attribute__((aligned(16))) T Es[ERING ? ESLOTS * EIMG : 8];
-    __shared__ __attribute__((aligned(16))) float Gs[RECOMP ? 4 : 1][RECOMP ? 32 * LDG2 : 4];     // RECOMP: per wave [q][64-column ring] of G (forward's layout)
-    __shared__ uint32_t Ps[2][RECOMP ? 32 : 1];                                                     // RECOMP: pad flags of the key tile
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, a = lane & 31, h = lane >> 5;
     const int nqb = (L + 127) / 128;
@@ -355,46 +347,17 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
     for (int i = lane; i < 32 * LDR; i += 64) Ds[wid][i] = ET<T>::from_f(0.f);
 
     chunk16 rk[TileT<T, 32, DH>::NPT], rv[TileT<T, 32, DH>::NPT];
-    uint32_t rp = 0, rpm = 0;                                             // RECOMP: pad flag of key kt * 32 + tid % 32 (always loaded: a valid dummy row without a mask)
-    const uint8_t* kp_ = (RECOMP && key_pad) ? key_pad + (size_t)b * L : reinterpret_cast<const uint8_t*>(qkv);
-    const uint32_t kp_on = (RECOMP && key_pad) ? 0xffu : 0u;
     auto gload = [&](int kt) __attribute__((always_inline)) {
         tile_gload<T, 32, DH>(rk, kb_ + (size_t)kt * 32 * ldq, ldq, L - kt * 32, tid);
         tile_gload<T, 32, DH>(rv, vb_ + (size_t)kt * 32 * ldq, ldq, L - kt * 32, tid);
-        if constexpr (RECOMP) {
-            rp = kp_[min(kt * 32 + (tid & 31), L - 1)];
-            rpm = kt * 32 + (tid & 31) < L ? kp_on : 0u;
-        }
     };
     auto gload_full = [&](int kt) __attribute__((always_inline)) {       // tile kt entirely below L
         tile_gload_full<T, 32, DH>(rk, kb_ + (size_t)kt * 32 * ldq, ldq, tid);
         tile_gload_full<T, 32, DH>(rv, vb_ + (size_t)kt * 32 * ldq, ldq, tid);
-        if constexpr (RECOMP) {
-            rp = kp_[kt * 32 + (tid & 31)];
-            rpm = kp_on;
-        }
     };
     auto sstore = [&](int buf) __attribute__((always_inline)) {
         tile_sstore<T, 32, DH, C::LDV>(rk, Ks[buf], tid);
         tile_sstore<T, 32, DH, C::LDN>(rv, Vs[buf], tid);
-        if constexpr (RECOMP) { if (tid < 32) Ps[buf][tid] = rp & rpm; }
-    };
-    // ---- RECOMP: the forward's relative-block machinery (rga_fwd_kernel): G^T[m][q] = E[32 eb + m] . Q[q] into ring slot eb & 1
-    Frag<T> qf[RECOMP ? C::KA : 1], ef[RECOMP ? C::KA : 1];
-    auto e_frags = [&](Frag<T>* f, int eb) __attribute__((always_inline)) {
-#pragma unroll
-        for (int kk = 0; kk < C::KA; ++kk) frag_load(f[kk], Epk + (size_t)eb * C::PK + (kk * 64 + lane) * 8);
-    };
-    auto g_block = [&](const Frag<T>* f, int eb) __attribute__((always_inline)) {
-        f32x16_t g; acc_zero(g);
-#pragma unroll
-        for (int kk = 0; kk < C::KA; ++kk) mma32(g, f[kk], qf[kk]);
-        float* gs = &Gs[wid][a * LDG2 + (eb & 1) * 32];
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq)
-            *reinterpret_cast<f32x4_t*>(gs + 8 * gq + 4 * h) = (f32x4_t){g[4 * gq], g[4 * gq + 1], g[4 * gq + 2], g[4 * gq + 3]};
-        float* hs = &Gs[wid][a * LDG2] + (((eb & 1) | h) ? (eb & 1) * 32 + 4 * h : 64);      // halo: columns 64..66 mirror 0..2
-        *reinterpret_cast<f32x4_t*>(hs) = (f32x4_t){g[0], g[1], g[2], g[3]};
     };
     // E^T of block eb (packed relative table): A operand of dQ^T[d][q] += E^T[d][e] dG^T[e][q]
     auto et_frags = [&](Frag<T> (*f)[2], int eb) __attribute__((always_inline)) {
@@ -417,7 +380,6 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
     float mtn[UNR];
     auto load_p = [&](int kt, auto u_tag) __attribute__((always_inline)) {
         constexpr int U = decltype(u_tag)::value;
-        if constexpr (RECOMP) return;
         const int ktc = min(kt, kt_hi);
         const T* tp = ptb + pt_tile(ktc, qt, nq32, CAUSAL) * 1024;
 #pragma unroll
@@ -427,21 +389,11 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
     chunk16 rk0[TileT<T, 32, DH>::NPT], rv0[TileT<T, 32, DH>::NPT];          // key tile 0 (start-up only); rk / rv receive tile 1
     tile_gload<T, 32, DH>(rk0, kb_, ldq, L, tid);
     tile_gload<T, 32, DH>(rv0, vb_, ldq, L, tid);
-    uint32_t rp0 = 0;
-    if constexpr (RECOMP) rp0 = (tid & 31) < L ? (kp_[min(tid & 31, L - 1)] & kp_on) : 0u;      // pad flags of key tile 0
     if (nkt > 1) gload(1);
     load_p(0, std::integral_constant<int, 0>{});
     load_p(1, std::integral_constant<int, 1>{});
     const int eb0 = (M - 32 - q0) >> 5;
     const int ebB = (M - 32 - qb * 128) >> 5, eb_max = (M >> 5) - 1;     // wave 0's block at step 0 (>= 3); last block of the table
-    if constexpr (RECOMP) {
-        row_frags<T, DH>(qf, qb_ + (size_t)q * ldq, row_on, h);
-        if (wave_on) {
-            e_frags(ef, eb0);
-            g_block(ef, eb0);                                            // the first lo block
-            if (my_last_kt > 0) e_frags(ef, eb0 + 1);
-        }
-    }
     chunk16 re[ENPT], re0[4][ENPT];
     auto eload = [&](chunk16* r, int eb) __attribute__((always_inline)) {     // images of block eb (clamped: steps past the table never use them)
         const T* src = Epk + (size_t)min(max(eb, 0), eb_max) * C::PK + C::PK_B;
@@ -467,7 +419,6 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
     if (delta_ws && row_on && h == 0) delta_ws[((size_t)b * H + head) * L + q] = delta;
     tile_sstore<T, 32, DH, C::LDV>(rk0, Ks[0], tid);
     tile_sstore<T, 32, DH, C::LDN>(rv0, Vs[0], tid);
-    if constexpr (RECOMP) { if (tid < 32) Ps[0][tid] = rp0; }
     if constexpr (ERING) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) estore(re0[j], ebB - 3 + j);
@@ -486,58 +437,8 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
             // (Fetching the E^T images a step ahead as well costs 32 registers and was not faster, rounds 2 and 3.)
             Frag<T> etf[C::DB][2];
             if constexpr (!ERING) { if (!upper) et_frags(etf, eb_lo); }  // f32 tier: straight from global memory, in flight during dP / dS
+            const float fac = row_on ? fast_exp2(fmaf(mtn[U], c2, -lse2)) : 0.f;
             f32x16_t s, dp; acc_zero(dp);
-            if constexpr (RECOMP) {
-                // ---- P^T[key][q] rebuilt: the new relative block first (its ring write is consumed by this tile's band read),
-                //      then S^T = K Q^T from the key tile (read with 16-byte fragments from the transpose-read stride tile)
-                const bool diag = !MAIN && kt == my_last_kt;
-                if constexpr (MAIN) {
-                    g_block(ef, eb_lo + 1);
-                    e_frags(ef, min(eb_lo + 2, eb_max));
-                } else if (!diag && !upper) {
-                    g_block(ef, eb_lo + 1);
-                    if (kt + 1 < my_last_kt) e_frags(ef, min(eb_lo + 2, eb_max));
-                }
-                acc_zero(s);
-#pragma unroll
-                for (int kk = 0; kk < C::KA; ++kk) {
-                    Frag<T> kf; frag_load(kf, &Ks[buf][a * C::LDV + kk * 16 + h * 8]);
-                    mma32(s, kf, qf[kk]);
-                }
-                uint32_t pbits = 0;
-                if (key_pad) pbits = __builtin_amdgcn_readfirstlane((uint32_t)__ballot(lane < 32 && Ps[buf][a] != 0));
-                const float* grow = &Gs[wid][a * LDG2];
-                const int g0 = (eb_lo & 1) * 32 + 31 - a + 4 * h;
-                const bool plain = !diag && !upper && pbits == 0u && k0 + 32 <= L;
-#pragma unroll
-                for (int r0 = 0; r0 < 16; r0 += 8) {
-                    float gv[8];
-#pragma unroll
-                    for (int gq = 0; gq < 2; ++gq) {
-                        const float* gp = grow + ((g0 + 2 * r0 + 8 * gq) & 63);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) gv[4 * gq + i] = gp[i];
-                    }
-                    if (plain) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) s[r0 + j] = fast_exp2(fmaf(s[r0 + j] + gv[j], c2, -lse2));
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const int r = r0 + j;
-                            const int bk = (r & 3) + 8 * (r >> 2) + 4 * h, key = k0 + bk;
-                            const bool masked = (CAUSAL && key > q) || key >= L || ((pbits >> bk) & 1u);
-                            const float g = (CAUSAL || (!upper && key <= q)) ? gv[j] : 0.f;
-                            s[r] = masked ? 0.f : fast_exp2(fmaf(s[r] + g, c2, -lse2));
-                        }
-                    }
-                }
-                if (!row_on) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s[r] = 0.f;
-                }
-            }
-            const float fac = (!RECOMP && row_on) ? fast_exp2(fmaf(mtn[U], c2, -lse2)) : 0.f;
 #pragma unroll
             for (int kk = 0; kk < C::KA; ++kk) {
                 Frag<T> vf;
@@ -545,13 +446,8 @@ __global__ __launch_bounds__(256, 2) void rga_bwd_q_kernel(
                 mma32(dp, vf, dof[kk]);        // dP^T[key][q] = V[key] . dO[q]
             }
             const float nds = -delta * scale;
-            if constexpr (RECOMP) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[r] = s[r] * fmaf(dp[r], scale, nds);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[r] = (ET<T>::to_f(pp[U][r / PE][r % PE]) * fac) * fmaf(dp[r], scale, nds);
-            }
+            for (int r = 0; r < 16; ++r) s[r] = (ET<T>::to_f(pp[U][r / PE][r % PE]) * fac) * fmaf(dp[r], scale, nds);
             // the tile after next into the registers just consumed.  The asm pins the order: without it the compiler
             // hoists the loads above the last use of the old tile and keeps the old tile alive in copies whose v_movs
             // then wait for the newest loads (the prefetch distance collapses to one step).
@@ -1015,7 +911,7 @@ int fwd_launch(const void* qkv, const void* Epk, const uint8_t* key_pad, void* o
 template <typename T, int DH>
 int bwd_launch(const void* qkv, const void* Epk, const void* out, const float* lse, const void* dout, void* dqkv, float* dE,
                float* delta_ws, const void* PT, const float* MT, void* dGT, int B, int L, int Lp, int H, int M, int causal,
-               hipStream_t st, int phases = 7, const uint8_t* key_pad = nullptr) {
+               hipStream_t st, int phases = 7) {
     // phases (me_rga_bwd_phases): bit 0 = query-owned kernel (dQ, delta, dG^T), bit 1 = key-owned kernel (dK, dV; needs delta),
     // bit 2 = E-row-owned kernel (dE; needs dG^T).  The kernels of bits 1 and 2 are independent of each other: a caller with
     // two streams may run them side by side (ops.rga_bwd).
@@ -1028,14 +924,12 @@ int bwd_launch(const void* qkv, const void* Epk, const void* out, const float* l
     int rc = 0;
     float* const delta_q = delta_ws;
     if (phases & 1) {
-    // recompute mode of the query-owned kernel: the caller passed no probability tiles to THIS phase (me_rga_bwd_phases with
-    // phases = 1 and PT = MT = NULL; the key-owned kernel still needs them)
-    const bool recomp = PT == nullptr;
-#define ME_BQ(CA, RC) rga_bwd_q_kernel<T, DH, CA, RC><<<B * H * nqb, 256, 0, st>>>((const T*)qkv, (const T*)Epk, (const T*)out, lse, (const T*)dout, \
-                                                                                   (T*)dqkv, delta_q, (const T*)PT, MT, (T*)dGT, key_pad, B, L, Lp, H, M, scale)
-    if (causal) { if (recomp) ME_BQ(true, true); else ME_BQ(true, false); }
-    else { if (recomp) ME_BQ(false, true); else ME_BQ(false, false); }
-#undef ME_BQ
+    if (causal)
+        rga_bwd_q_kernel<T, DH, true><<<B * H * nqb, 256, 0, st>>>((const T*)qkv, (const T*)Epk, (const T*)out, lse, (const T*)dout,
+                                                                  (T*)dqkv, delta_q, (const T*)PT, MT, (T*)dGT, B, L, Lp, H, M, scale);
+    else
+        rga_bwd_q_kernel<T, DH, false><<<B * H * nqb, 256, 0, st>>>((const T*)qkv, (const T*)Epk, (const T*)out, lse, (const T*)dout,
+                                                                   (T*)dqkv, delta_q, (const T*)PT, MT, (T*)dGT, B, L, Lp, H, M, scale);
     rc = me_launch_status();
     if (rc) return rc;
     }
@@ -1099,8 +993,8 @@ int me_rga_fwd(const void* qkv, const void* Epk, const uint8_t* key_pad, void* o
     ME_ATTN_DISPATCH((fwd_launch<T, DH>(qkv, Epk, key_pad, out, lse, PT, MT, B, L, H, M, causal, st)))
 }
 
-int me_rga_bwd(const void* qkv, const void* Epk, const uint8_t* key_pad, const void* out, const float* lse, const void* dout, void* dqkv,
-               float* dE, float* delta_ws, const void* PT, const float* MT, void* dGT, int B, int L, int Lp, int H, int dh, int M,
+int me_rga_bwd(const void* qkv, const void* Epk, const void* out, const float* lse, const void* dout, void* dqkv, float* dE,
+               float* delta_ws, const void* PT, const float* MT, void* dGT, int B, int L, int Lp, int H, int dh, int M,
                int causal, int dtype, void* stream) {
     me_clear_error();
     if (!qkv || !Epk || !out || !lse || !dout || !dqkv || !dE || !delta_ws || !PT || !MT || !dGT) return ME_ERR_NULL;
@@ -1109,21 +1003,20 @@ int me_rga_bwd(const void* qkv, const void* Epk, const uint8_t* key_pad, const v
         !aligned16(PT) || !aligned16(dGT))
         return ME_ERR_ALIGNMENT;
     hipStream_t st = (hipStream_t)stream;
-    ME_ATTN_DISPATCH((bwd_launch<T, DH>(qkv, Epk, out, lse, dout, dqkv, dE, delta_ws, PT, MT, dGT, B, L, Lp, H, M, causal, st, 7, key_pad)))
+    ME_ATTN_DISPATCH((bwd_launch<T, DH>(qkv, Epk, out, lse, dout, dqkv, dE, delta_ws, PT, MT, dGT, B, L, Lp, H, M, causal, st)))
 }
 
-int me_rga_bwd_phases(const void* qkv, const void* Epk, const uint8_t* key_pad, const void* out, const float* lse, const void* dout,
-                      void* dqkv, float* dE, float* delta_ws, const void* PT, const float* MT, void* dGT, int B, int L, int Lp, int H,
-                      int dh, int M, int causal, int phases, int dtype, void* stream) {
+int me_rga_bwd_phases(const void* qkv, const void* Epk, const void* out, const float* lse, const void* dout, void* dqkv, float* dE,
+                      float* delta_ws, const void* PT, const float* MT, void* dGT, int B, int L, int Lp, int H, int dh, int M,
+                      int causal, int phases, int dtype, void* stream) {
     me_clear_error();
-    if (!qkv || !Epk || !out || !lse || !dout || !dqkv || !dE || !delta_ws || !dGT) return ME_ERR_NULL;
-    if ((PT == nullptr) != (MT == nullptr) || ((phases & 2) && !PT)) return ME_ERR_NULL;       // only the query-owned kernel can do without the tiles
+    if (!qkv || !Epk || !out || !lse || !dout || !dqkv || !dE || !delta_ws || !PT || !MT || !dGT) return ME_ERR_NULL;
     if (B <= 0 || L <= 0 || H <= 0 || L > M || (M & 31) || Lp != ((L + 31) / 32) * 32 || Lp > M || phases < 1 || phases > 7) return ME_ERR_BAD_SHAPE;
     if (!aligned16(qkv) || !aligned16(Epk) || !aligned16(out) || !aligned16(dout) || !aligned16(dqkv) ||
         !aligned16(PT) || !aligned16(dGT))
         return ME_ERR_ALIGNMENT;
     hipStream_t st = (hipStream_t)stream;
-    ME_ATTN_DISPATCH((bwd_launch<T, DH>(qkv, Epk, out, lse, dout, dqkv, dE, delta_ws, PT, MT, dGT, B, L, Lp, H, M, causal, st, phases, key_pad)))
+    ME_ATTN_DISPATCH((bwd_launch<T, DH>(qkv, Epk, out, lse, dout, dqkv, dE, delta_ws, PT, MT, dGT, B, L, Lp, H, M, causal, st, phases)))
 }
 
 }  // extern "C"

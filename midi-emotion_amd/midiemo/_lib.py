@@ -39,8 +39,8 @@ SIGNATURES = {
     "me_gemm_tn_acc_group": [_p, _i, _i, _p, ctypes.c_size_t, _i, _p],
     "me_rga_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "me_rga_pack_rel": [_p, _p, _i, _i, _i, _p],
-    "me_rga_bwd": [_p] * 12 + [_i, _i, _i, _i, _i, _i, _i, _i, _p],
-    "me_rga_bwd_phases": [_p] * 12 + [_i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "me_rga_bwd": [_p] * 11 + [_i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "me_rga_bwd_phases": [_p] * 11 + [_i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "me_resid_ln_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _f, _u64, _u32, _i, _p],
     "me_resid_ln_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _u64, _u32, _i, _p],
     "me_ce_fwd": [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p],

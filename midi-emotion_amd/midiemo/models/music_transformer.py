@@ -131,9 +131,6 @@ class MusicTransformerHIP(nn.Module):
         # `eager` bucket policies and +0.1 ms per step under `end` (profiles/r06_ddp_overlap.txt): default = on for a single
         # process, off once torch.distributed is initialised; MIDIEMO_ATTN_BWD_OVERLAP=0|1 forces either.
         self._attn_bwd_overlap_env = os.environ.get("MIDIEMO_ATTN_BWD_OVERLAP")
-        # query-owned attention backward kernel rebuilding P from q / k / E / lse instead of reading the saved tiles back
-        # (round 6, measured slower: profiles/r06_attn_recompute.txt); A/B switch, off by default
-        self.attn_bwd_recomp_q = os.environ.get("MIDIEMO_ATTN_RECOMP_Q", "0") not in ("", "0")
 
         self.embedding = _Emb(vocab_size, embedding_dim - d_condition)
         if self.token_conditioning:
@@ -554,8 +551,7 @@ class MusicTransformerHIP(nn.Module):
             if bucket_hook:
                 bucket_hook(-1)            # comm window: ~0.5 ms of attention-backward kernels follow (ddp.GradAllReducer)
             ops.rga_bwd(Lw.qkv, W["Epk"], Lw.att, Lw.lse, ws.dA, ws.dqkv, gv(p + "rga.E"), ws.delta, Lw.PT, Lw.MT, ws.dGT,
-                        B, Lm, ws.Lp, H, dh, M, causal=self.causal, overlap=self.attn_bwd_overlap,
-                        key_pad=ws.key_pad if self.causal else None, recomp_q=self.attn_bwd_recomp_q)
+                        B, Lm, ws.Lp, H, dh, M, causal=self.causal, overlap=self.attn_bwd_overlap)
             o, _, _ = self._slices[p + "rga.Wq.weight"]
             ob, _, _ = self._slices[p + "rga.Wq.bias"]
             wgrad(ws.dqkv, x, gflat[o:o + 3 * d * d].view(3 * d, d), gflat[ob:ob + 3 * d], N=3 * d, K=d)

@@ -203,8 +203,7 @@ def _side_stream(device):
     return _side[key]
 
 
-def rga_bwd(qkv, Epk, out, lse, dout, dqkv, dE, delta_ws, PT, MT, dGT, B, L, Lp, H, dh, M, causal=True, overlap=False, key_pad=None,
-            recomp_q=False):
+def rga_bwd(qkv, Epk, out, lse, dout, dqkv, dE, delta_ws, PT, MT, dGT, B, L, Lp, H, dh, M, causal=True, overlap=False):
     """overlap=True: the key-owned kernel (dK, dV) stays on the current stream, the E-row-owned kernel (dE) runs beside it on a
     second stream (me_rga_bwd_phases; both only depend on the query-owned kernel); the current stream then waits for it.
     Lifetime: the side stream reads dGT / qkv and accumulates into dE without the caching allocator knowing -- the caller keeps
@@ -215,8 +214,8 @@ def rga_bwd(qkv, Epk, out, lse, dout, dqkv, dE, delta_ws, PT, MT, dGT, B, L, Lp,
             MT.numel() * 4 < workspace_bytes(ME_WS_RGA_MT, B * H, Lp, 0, qkv.dtype) or
             dGT.numel() * es < workspace_bytes(ME_WS_RGA_DGT, B * H, Lp, 0, qkv.dtype)):
         raise RuntimeError("rga_bwd: PT / MT / dGT smaller than me_workspace_bytes")
-    if not overlap and not recomp_q:
-        check(lib().me_rga_bwd(_ptr(qkv), _ptr(Epk), _ptr(key_pad), _ptr(out), _ptr(lse), _ptr(dout), _ptr(dqkv), _ptr(dE), _ptr(delta_ws),
+    if not overlap:
+        check(lib().me_rga_bwd(_ptr(qkv), _ptr(Epk), _ptr(out), _ptr(lse), _ptr(dout), _ptr(dqkv), _ptr(dE), _ptr(delta_ws),
                                _ptr(PT), _ptr(MT), _ptr(dGT), B, L, Lp, H, dh, M, 1 if causal else 0, _code(qkv.dtype), _stream()),
               "me_rga_bwd")
         return
@@ -224,16 +223,9 @@ def rga_bwd(qkv, Epk, out, lse, dout, dqkv, dE, delta_ws, PT, MT, dGT, B, L, Lp,
     main = torch.cuda.current_stream(qkv.device)
 
     def phase(bits, stream):
-        # recomp_q: the query-owned kernel gets NO probability tiles and rebuilds them from q / k / E / lse (me_rga_bwd_phases)
-        nop = recomp_q and bits == 1
-        check(lib().me_rga_bwd_phases(_ptr(qkv), _ptr(Epk), _ptr(key_pad), _ptr(out), _ptr(lse), _ptr(dout), _ptr(dqkv), _ptr(dE), _ptr(delta_ws),
-                                      None if nop else _ptr(PT), None if nop else _ptr(MT), _ptr(dGT), B, L, Lp, H, dh, M, 1 if causal else 0,
-                                      bits, _code(qkv.dtype), ctypes.c_void_p(stream.cuda_stream)), "me_rga_bwd_phases")
-    if not overlap:
-        phase(1, main)
-        phase(2, main)
-        phase(4, main)
-        return
+        check(lib().me_rga_bwd_phases(_ptr(qkv), _ptr(Epk), _ptr(out), _ptr(lse), _ptr(dout), _ptr(dqkv), _ptr(dE), _ptr(delta_ws),
+                                      _ptr(PT), _ptr(MT), _ptr(dGT), B, L, Lp, H, dh, M, 1 if causal else 0, bits, _code(qkv.dtype),
+                                      ctypes.c_void_p(stream.cuda_stream)), "me_rga_bwd_phases")
     phase(1, main)
     ev_q.record(main)
     side.wait_event(ev_q)

@@ -792,7 +792,7 @@ def run_attn(ops, dtype, q, k, v, E, dO, pad, backward=True, causal=True):
         delta = torch.empty(B, H, L, dtype=torch.float32, device=DEV)
         dGT = ops.rga_bwd_workspace(B, H, L, dtype, DEV)
         dGT.fill_(float("nan"))
-        ops.rga_bwd(qkv, Epk, out, lse, dout, dqkv, dE, delta, PT, MT, dGT, B, L, Lp, H, dh, M, causal=causal, key_pad=kp)
+        ops.rga_bwd(qkv, Epk, out, lse, dout, dqkv, dE, delta, PT, MT, dGT, B, L, Lp, H, dh, M, causal=causal)
         g = dqkv.float().cpu().permute(2, 0, 3, 1, 4)   # [3,B,H,L,dh]
         res.update(dq=g[0], dk=g[1], dv=g[2], dE=dE.cpu())
     return res
