@@ -356,9 +356,10 @@ class OpProbe:
 
 class GemmProbe:
     """HIP-event timing of every NT-GEMM launch (me_gemm_nt and me_gemm_nt_relu_mask; events recorded on the launch stream).
-    At the bench shapes all of them run the 256 x 256 tile kernel (gemm_nt256_kernel<T, ...>).  Every launch is followed by an
-    EMPTY event pair (e1 -> e2, nothing between): what the two event packets themselves add to elapsed(e0, e1) at that place
-    of the live stream; summary() subtracts it."""
+    At the bench shapes all of them run the 256 x 256 tile kernel (gemm_nt256_kernel<T, ...>).  What an event pair adds to the
+    kernel it brackets is calibrated by replay(): the same launches timed with per-launch pairs and with ONE pair around the whole
+    back-to-back sequence; the difference per launch (~2 us: most of an event packet's latency hides under the kernel it follows;
+    an EMPTY pair costs 6 us and over-corrects -- round 6 tried it: 56.6 us against rocprofv3's 60.7) is subtracted from the in-step figure."""
 
     def __init__(self, ops, steps=0, pool=720):
         self.ops, self.rec, self.calls, self.steps = ops, [], [], steps
@@ -378,12 +379,11 @@ class GemmProbe:
                 m = A.shape[0] if kw.get("M") is None else kw["M"]
                 k = A.shape[1] if kw.get("K") is None else kw["K"]
                 n = B.shape[0] if kw.get("N") is None else kw["N"]
-                e0, e1, e2 = self._ev(), self._ev(), self._ev()
+                e0, e1 = self._ev(), self._ev()
                 e0.record()
                 fn(A, B, C, *rest, **kw)
                 e1.record()
-                e2.record()
-                self.rec.append((2.0 * m * n * k, e0, e1, (m * k + n * k) * A.element_size() + m * n * C.element_size(), e2))
+                self.rec.append((2.0 * m * n * k, e0, e1, (m * k + n * k) * A.element_size() + m * n * C.element_size()))
                 self.calls.append((fn, (A, B, C) + tuple(rest), dict(kw)))
             return nt
         for name in self.orig:
@@ -398,7 +398,6 @@ class GemmProbe:
         torch.cuda.synchronize()
         flops = sum(r[0] for r in self.rec)
         ms = sum(r[1].elapsed_time(r[2]) for r in self.rec)
-        self.empty_pair_ms = sum(r[2].elapsed_time(r[4]) for r in self.rec)       # cost of the event packets themselves, in situ
         self.alg_bytes = sum(r[3] for r in self.rec) / max(1, len(self.rec))
         return flops, ms, len(self.rec)
 
@@ -409,7 +408,7 @@ class GemmProbe:
         step's activation operands do not -- reported as `warm_replay_*` only, never as roofline.achieved.
         Returns (sum of per-call average ms over one step's calls, calls)."""
         calls = self.calls[:len(self.calls) // max(1, self.steps)] if self.steps else self.calls
-        total = 0.0
+        total, over = 0.0, []
         for (fn, a, kw) in calls:
             best = None
             for _ in range(rounds):
@@ -422,6 +421,16 @@ class GemmProbe:
                 t = e0.elapsed_time(e1) / reps
                 best = t if best is None else min(best, t)
             total += best
+            # the same launches with one event pair EACH (what the in-step probe does): the excess per launch is the pair's cost
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+            for e0, e1 in evs:
+                e0.record()
+                fn(*a, **kw)
+                e1.record()
+            torch.cuda.synchronize()
+            pair = sorted(e0.elapsed_time(e1) for e0, e1 in evs)[reps // 2]
+            over.append(pair - best)
+        self.pair_overhead_ms = max(0.0, sorted(over)[len(over) // 2])            # median over the step's calls
         return total, len(calls)
 
 
@@ -630,10 +639,10 @@ def main():
                     nl = sum(k["launches"] for k in ks)
                     traffic = int(round(sum((k["read_MB"] + k["write_MB"]) * k["launches"] for k in ks) / nl * 1e6))
                     traffic_note = "HBM bytes per launch, mean over the family's %d traced launches (rocprofv3 PMC passes FETCH_SIZE x2 + WRITE_SIZE, %s)" % (nl, tjd.get("_profile", "profiles/"))
-            # achieved = algorithmic FLOPs of the launches of 3 LIVE steps / (their HIP-event durations - the empty event pairs
-            # recorded right behind each of them): the kernel as the timed region runs it (cold activation operands)
+            # achieved = algorithmic FLOPs of the launches of 3 LIVE steps / (their HIP-event durations - the calibrated cost of the
+            # event pair around each of them): the kernel as the timed region runs it (cold activation operands)
             peak = PEAK_BF16_TFLOPS if args.compute_dtype != "fp32" else 157.3
-            ms_live = ms - gp.empty_pair_ms
+            ms_live = ms - n * gp.pair_overhead_ms
             ach = flops / (ms_live * 1e-3) / 1e12
             kname = {"bf16": "gemm_nt256_kernel<bf16>", "fp16": "gemm_nt256_kernel<f16>", "fp32": "gemm_nt_kernel<float>"}[args.compute_dtype]
             out["roofline"] = {"bound": "mfma", "kernel": kname,
@@ -643,7 +652,8 @@ def main():
                                "avg_launch_us": round(1000.0 * ms_live / n, 2),
                                "gemm_nt_ms_per_step": round(ms_live / 3, 3),
                                "timing": "HIP events on the launch stream around every NT launch of 3 live train steps (%d launches), minus the "
-                                         "empty event pair recorded behind each launch (%.2f us per pair)" % (n, 1000.0 * gp.empty_pair_ms / n),
+                                         "calibrated cost of an event pair around a launch (%.2f us: per-launch pairs vs one pair around the same "
+                                         "back-to-back launches)" % (n, 1000.0 * gp.pair_overhead_ms),
                                "raw_event_avg_launch_us": round(1000.0 * ms / n, 2),
                                "instrumented_step_ms": round(gp.instrumented_step_ms, 3),     # must stay device-bound: ~ ms_per_step + the event packets
                                "warm_replay_avg_launch_us": round(1000.0 * replay_ms / replay_calls, 2),

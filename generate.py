@@ -255,7 +255,9 @@ def main():
     parser.add_argument('--topp', type=float, default=0.7)
     parser.add_argument('--debug', action='store_true')
     parser.add_argument('--seed', type=int, default=0)
-    parser.add_argument('--no_amp', action='store_true', help="run the exact-f32 tier instead of bf16")
+    parser.add_argument('--no_amp', action='store_true', help="run the exact-f32 tier instead of a 16-bit one")
+    parser.add_argument('--compute_dtype', default=None, choices=["bf16", "fp16"],
+                        help="16-bit tier (default: the one the checkpoint was trained in; fp16 = the reference's autocast dtype, generate.py:116)")
     parser.add_argument("--conditioning", type=str, required=True,
                         choices=["none", "discrete_token", "continuous_token", "continuous_concat"])
     parser.add_argument('--penalty_coeff', type=float, default=0.5)
@@ -292,7 +294,7 @@ def main():
     maps = torch.load(mappings_fp) if os.path.exists(mappings_fp) else get_maps(
         n_emotion_bins=5 if args.conditioning == "discrete_token" else 0)
     config = torch.load(os.path.join(model_root, "model_config.pt"))
-    config["compute_dtype"] = "fp32" if args.no_amp else config.get("compute_dtype", "bf16")
+    config["compute_dtype"] = "fp32" if args.no_amp else (args.compute_dtype or config.get("compute_dtype", "bf16"))
     model, _ = build_model(None, load_config_dict=config)
     model_fp = os.path.join(model_root, "model.pt")
     if not os.path.exists(model_fp):
