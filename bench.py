@@ -554,6 +554,12 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    # MIDIEMO_DDP_POLICY=auto: its probe phases (2 x AUTO_PROBE steps, one host sync at the decision) must not fall into the timed
+    # region whatever --warmup says: keep stepping, untimed, until the reducer has decided
+    extra_warm = 0
+    while dist_on and getattr(reducer, "_auto", None) is not None and extra_warm < 64:
+        step(args.warmup + extra_warm)
+        extra_warm += 1
     fence()
     reducer.timing = dist_on               # two event records per step around the bucket waits (exposed communication)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -30,7 +30,7 @@ class GradAllReducer:
                  next AUTO_PROBE under "window"; each step's span from its first bucket hook (start of the backward) to the
                  end of the waits in finish() is timed with device events, the first step of each phase is dropped, the
                  means are MAX-reduced over the ranks (every rank decides from the same two numbers) and the cheaper policy
-                 runs from then on.  Measured on one MI355X: "window" costs 0.2 ms per step even with nothing to exchange
+                 runs from then on (MEDIAN of the kept spans since round 6, AUTO_PROBE = 5: four samples per policy).  Measured on one MI355X: "window" costs 0.2 ms per step even with nothing to exchange
                  (RCCL's channels take CUs from the attention backward, profiles/r04_measurements.txt), so it only pays
                  when the exposed all-reduce of "end" is longer than that.  `decision` holds the numbers (bench.py prints
                  them as ddp.policy_decision).  One host synchronisation, once, at the decision.
@@ -40,7 +40,7 @@ class GradAllReducer:
                  rounding of every reduced gradient element (the sum of `world` bf16 values rounded to bf16: ~2^-9 relative
                  per element -- the global-norm clip and Adam then see those values on EVERY rank alike: a ring / tree
                  all-reduce hands every rank the same bits, so the ranks stay bit-identical, asserted in the tests)."""
-    AUTO_PROBE = 3
+    AUTO_PROBE = 5
 
     def __init__(self, flat_grads_fn, bucket_ranges, group=None, policy=None, compress=None):
         import os
@@ -175,8 +175,8 @@ class GradAllReducer:
                 torch.cuda.synchronize()
             mean = {}
             for pol, sp in st["spans"].items():
-                ms = [self._span_ms(a, b) for a, b in sp[1:]] or [self._span_ms(a, b) for a, b in sp]
-                mean[pol] = sum(ms) / max(1, len(ms))
+                ms = sorted([self._span_ms(a, b) for a, b in sp[1:]] or [self._span_ms(a, b) for a, b in sp])
+                mean[pol] = ms[len(ms) // 2]
             t = torch.tensor([mean["end"], mean["window"]], dtype=torch.float64, device=self._flat().device)
             if dist.is_initialized() and self.world > 1:
                 dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)

@@ -93,8 +93,12 @@ def parse_args(argv=None):
     p.add_argument("--full_dataset", action="store_true", help="also train on songs without emotion labels")
     p.add_argument("--always_use_discrete_condition", action="store_true")
     p.add_argument("--num_workers", type=int, default=8)
-    # reference flags the loaders honour (data/loader.py:24-31 defaults; the reference parses them, config.py:92-103, and then
-    # constructs its loaders without them, train.py:61-68 -- here they reach the loader, defaults unchanged)
+    # reference flags of the loaders (data/loader.py:24-31 defaults).  The reference parses them (config.py:92-103) and then
+    # constructs its Loader WITHOUT them (train.py:64-68: only regression / always_use_discrete_condition are passed; only
+    # LoaderExhaustive gets max_samples = --n_samples, train.py:61-63).  DELIBERATE DEVIATION: here --overfit / --no_pad /
+    # --bar_start_prob / --max_transpose / a positive --n_samples reach the train and test Loader (defaults unchanged, so a
+    # default command line draws the reference's samples: tests/test_data_cpu.py); the exhaustive evaluation mirrors the
+    # reference exactly, including its max_samples = -1 default, i.e. data[:-1]: the LAST test song is not evaluated
     p.add_argument("--overfit", action="store_true", help="work on a single sample (debug data folder, no workers)")
     p.add_argument("--bar_start_prob", type=float, default=0.5, help="probability of a training sample starting at a bar")
     p.add_argument("--max_transpose", type=int, default=3, help="maximum transposition in semitones")
@@ -125,9 +129,11 @@ def parse_args(argv=None):
     for flag, msg in (("no_cuda", "there is no CPU path: training runs on the HIP engine (cuda:LOCAL_RANK)"),
                       ("reset_scaler", "" if (args.compute_dtype == "fp16" and not args.no_amp) else
                        "bf16 / f32 tiers use no GradScaler: nothing to reset"),
-                      ("find_lr", "the reference parses --find_lr and never runs a finder; ignored here too")):
+                      ("find_lr", "the reference parses --find_lr, never runs a finder and only sets debug = True (config.py:135-136); same here")):
         if getattr(args, flag) and msg:
             print(f"[train.py] --{flag}: {msg}")
+    if args.find_lr:
+        args.debug = True                                      # config.py:135-136
     for flag, default in (("n_bars", -1), ("eval_tgt_len", -1), ("arousal_feature", "note_density")):
         if getattr(args, flag) != default:
             print(f"[train.py] --{flag}: parsed and unused by the reference (config.py), unused here")
@@ -272,9 +278,9 @@ def main(argv=None):
                                                       use_labeled_only=not args.full_dataset)
         kw = dict(always_use_discrete_condition=args.always_use_discrete_condition, regression=args.regression,
                   pad=not args.no_pad, overfit=args.overfit, max_samples=args.n_samples if args.n_samples > 0 else None)
-        if args.exhaustive_eval:                               # train.py:58-63
+        if args.exhaustive_eval:                               # train.py:58-63: max_samples=args.n_samples as is (-1 -> data[:-1])
             from midiemo.data import LoaderExhaustive
-            test_ds = LoaderExhaustive(args.data_folder, test_feats, args.tgt_len, args.conditioning, **kw)
+            test_ds = LoaderExhaustive(args.data_folder, test_feats, args.tgt_len, args.conditioning, **dict(kw, max_samples=args.n_samples))
             train_ds = test_ds                                 # never iterated: the run evaluates and exits
         else:
             kw.update(bar_start_prob=args.bar_start_prob, max_transpose=args.max_transpose)
