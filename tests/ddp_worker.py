@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--big", action="store_true")
     ap.add_argument("--compress", default="", help="bf16: bf16-compressed buckets (GradAllReducer compress)")
+    ap.add_argument("--inject_inf_step", type=int, default=-1,
+                    help="f16 tier: rank 1 alone writes an inf into its local gradient at this step -- every rank must skip that update together")
     ap.add_argument("--dump_prep", action="store_true", help="diagnosis: also save the prepared (cast) weights every step ran with")
     a = ap.parse_args()
     if a.big:
@@ -65,15 +67,16 @@ def main():
     else:
         dist.init_process_group(a.backend)
     from midiemo.ddp import GradAllReducer, broadcast_params
-    from midiemo.optim import FusedAdamW
+    from midiemo.optim import FusedAdamW, LossScaler
     model = build(a.compute_dtype, dev)
+    scaler = LossScaler(dev) if a.compute_dtype == "fp16" else None
     if rank != 0:
         with torch.no_grad():
             model.flat_params.add_(0.01 * rank)             # the broadcast has to repair this
         model.mark_params_changed()
     broadcast_params(model.flat_params)
     model.mark_params_changed()
-    opt = FusedAdamW(model, lr=2e-5, clip=1.0)          # same as the reference run in test_ddp_gpu.py
+    opt = FusedAdamW(model, lr=2e-5, clip=1.0, scaler=scaler)          # same as the reference run in test_ddp_gpu.py
     red = GradAllReducer(lambda: model.flat_grads, model.bucket_ranges(), policy=a.policy, compress=a.compress)
     # the bucket_hook sequence the engine really emits must be the documented one (the CPU reducer test replays exactly it)
     seen_hooks = []
@@ -89,7 +92,10 @@ def main():
         for micro in range(a.accumulate):
             x, c, y = micro_batch(step, micro, rank, dev)
             last = micro + 1 == a.accumulate
-            model.loss_and_backward(x, c, y, grad_scale=1.0 / a.accumulate, bucket_hook=hook if last else None)
+            if last and step == a.inject_inf_step and rank == 1:
+                model.flat_grads[777] = float("inf")         # a local overflow on ONE rank: the all-reduce spreads it, all ranks skip
+            model.loss_and_backward(x, c, y, grad_scale=1.0 / a.accumulate, bucket_hook=hook if last else None,
+                                    loss_scale=scaler.scale_tensor if scaler is not None else None)
             if a.dump_prep and micro == 0 and rank == 0:
                 preps.append([{k: v.detach().cpu().clone() for k, v in L.items() if torch.is_tensor(v)} for L in model._prep["layers"]] +
                              [{k: v.detach().cpu().clone() for k, v in model._prep["head"].items()}])
@@ -105,14 +111,18 @@ def main():
     # the invariant data-parallel training rests on (SURVEY 8e "identical optimizer state evolution on every rank"): every
     # rank holds BIT-identical parameters and Adam moments after every update -- same reduced gradients, and an optimiser
     # whose clip coefficient does not depend on block arrival order (me_sumsq's ordered block sums)
-    for name, t in (("params", model.flat_params.detach()), ("m", opt.m), ("v", opt.v)):
+    checks = [("params", model.flat_params.detach()), ("m", opt.m), ("v", opt.v)]
+    if scaler is not None:
+        checks.append(("scaler state", scaler.state))       # scale, tracker, steps taken / skipped: decided identically everywhere
+    for name, t in checks:
         ref = t.clone()
         dist.broadcast(ref, src=0)
         ndiff = int((ref != t).sum())
         assert ndiff == 0, "rank %d: %d entries of %s differ from rank 0 after %d steps" % (rank, ndiff, name, STEPS)
     if rank == 0:
         torch.save({"g1": g1.cpu(), "params": model.flat_params.detach().cpu().clone(), "grads": gs, "params_before": pb,
-                    "params_steps": pa, "m": opt.m.cpu(), "v": opt.v.cpu(), "preps": preps}, a.out)
+                    "params_steps": pa, "m": opt.m.cpu(), "v": opt.v.cpu(), "preps": preps,
+                    "scaler": scaler.state.cpu() if scaler is not None else None}, a.out)
     dist.barrier()
     dist.destroy_process_group()
     print("rank", rank, "done")

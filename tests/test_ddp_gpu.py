@@ -143,14 +143,14 @@ def rel(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm())
 
 
-def run_workers(tmp_path, policy, accumulate, backend, compute_dtype, port, nproc=2, big=False, compress=""):
+def run_workers(tmp_path, policy, accumulate, backend, compute_dtype, port, nproc=2, big=False, compress="", extra=()):
     out = str(tmp_path / f"ddp_{policy}_{accumulate}_{backend}_{nproc}_{int(big)}{compress}.pt")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", MIDIEMO_DDP_FORCE="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
                         "--master-addr", "127.0.0.1", "--master-port", str(port),
                         os.path.join(ROOT, "tests", "ddp_worker.py"), "--policy", policy, "--accumulate", str(accumulate),
                         "--backend", backend, "--compute_dtype", compute_dtype, "--out", out] + (["--big"] if big else []) +
-                       (["--compress", compress] if compress else []),
+                       (["--compress", compress] if compress else []) + list(extra),
                        capture_output=True, text=True, env=env, timeout=600)
     return r, out
 
@@ -188,6 +188,22 @@ def test_two_ranks_bf16_compressed_buckets(tmp_path):
     print("bf16-compressed buckets: step-1 reduced gradient vs the f32 exchange rel-L2 %.2e" % e)
     assert 1e-5 < e < 2.0 ** -8, e
     assert bool((b["grads"][0] == b["grads"][0].to(torch.bfloat16).float()).all())          # what arrived IS bf16-valued
+
+
+def test_two_ranks_f16_tier_skip_an_overflow_together(tmp_path):
+    """The f16 tier under data parallelism: the loss scale and its decisions live on every rank's device and must evolve
+    identically (the worker asserts parameters, both Adam moments AND the scaler state bit-identical across ranks).  At step 1
+    rank 1 alone overflows (an inf in its local gradient): the all-reduce spreads it, BOTH ranks skip that update, halve the scale
+    and carry on -- parameters after the skipped step equal the parameters before it, 2 of 3 steps taken."""
+    from midiemo import _lib
+    r, out = run_workers(tmp_path, "window", 1, "gloo", "fp16", 29567, extra=["--inject_inf_step", "1"])
+    assert r.returncode == 0 and r.stdout.count("done") == 2, r.stdout[-3000:] + r.stderr[-3000:]
+    got = torch.load(out)
+    st = got["scaler"].tolist()
+    assert st[_lib.ME_SCALER_STEP] == 2 and st[_lib.ME_SCALER_SKIPPED] == 1 and st[_lib.ME_SCALER_SCALE] == 32768.0, st
+    assert torch.equal(got["params_steps"][1], got["params_before"][1])            # the skipped update changed nothing
+    assert not torch.equal(got["params_steps"][0], got["params_before"][0]) and not torch.equal(got["params_steps"][2], got["params_before"][2])
+    assert bool(torch.isfinite(got["params"]).all())
 
 
 def test_two_ranks_bf16_headline_model_accumulate(tmp_path):
