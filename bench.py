@@ -361,7 +361,7 @@ class GemmProbe:
     back-to-back sequence; the difference per launch (~2 us: most of an event packet's latency hides under the kernel it follows;
     an EMPTY pair costs 6 us and over-corrects -- round 6 tried it: 56.6 us against rocprofv3's 60.7) is subtracted from the in-step figure."""
 
-    def __init__(self, ops, steps=0, pool=720):
+    def __init__(self, ops, steps=0, pool=1200):
         self.ops, self.rec, self.calls, self.steps = ops, [], [], steps
         self.orig = {"gemm_nt": ops.gemm_nt, "gemm_nt_relu_mask": ops.gemm_nt_relu_mask}
         # events are created BEFORE the instrumented steps: hipEventCreate inside the loop (three per launch) made the host the
@@ -395,11 +395,18 @@ class GemmProbe:
             setattr(self.ops, name, fn)
 
     def summary(self):
+        """(FLOPs, ms, launches) of ONE step: the first instrumented step is dropped (the stream restarts after the timed region's
+        synchronisation), every launch position of the step takes the MEDIAN of its durations over the remaining steps."""
         torch.cuda.synchronize()
-        flops = sum(r[0] for r in self.rec)
-        ms = sum(r[1].elapsed_time(r[2]) for r in self.rec)
-        self.alg_bytes = sum(r[3] for r in self.rec) / max(1, len(self.rec))
-        return flops, ms, len(self.rec)
+        per = len(self.rec) // max(1, self.steps)
+        keep = range(1, self.steps) if self.steps > 1 else range(self.steps)
+        flops = sum(r[0] for r in self.rec[:per])
+        ms = 0.0
+        for j in range(per):
+            d = sorted(self.rec[st * per + j][1].elapsed_time(self.rec[st * per + j][2]) for st in keep)
+            ms += d[len(d) // 2]
+        self.alg_bytes = sum(r[3] for r in self.rec[:per]) / max(1, per)
+        return flops, ms, per
 
     def replay(self, reps=24, rounds=3):
         """Duration of every distinct NT call of ONE step from a back-to-back replay: `reps` launches of the call (same
@@ -593,20 +600,21 @@ def main():
     if not args.no_probe:
         # every rank runs the instrumented steps (they contain the gradient all-reduce); only rank 0 times its GEMMs
         if rank == 0:
-            with GemmProbe(ops, steps=3) as gp:
+            NPROBE = 7
+            with GemmProbe(ops, steps=NPROBE) as gp:
                 torch.cuda.synchronize()
                 t_i = time.perf_counter()
-                for i in range(3):
+                for i in range(NPROBE):
                     step(i)
                 probe = gp.summary()
-                gp.instrumented_step_ms = 1e3 * (time.perf_counter() - t_i) / 3
+                gp.instrumented_step_ms = 1e3 * (time.perf_counter() - t_i) / NPROBE
             replay_ms, replay_calls = gp.replay()          # the workspace buffers of the last step are still alive
             with OpProbe(ops, model, B, L) as op_probe:
                 for i in range(3):
                     step(i)
                 hbm_table = op_probe.table()
         else:
-            for i in range(3):
+            for i in range(7):
                 step(i)
             for i in range(3):
                 step(i)
@@ -648,22 +656,22 @@ def main():
             # achieved = algorithmic FLOPs of the launches of 3 LIVE steps / (their HIP-event durations - the calibrated cost of the
             # event pair around each of them): the kernel as the timed region runs it (cold activation operands)
             peak = PEAK_BF16_TFLOPS if args.compute_dtype != "fp32" else 157.3
-            ms_live = ms - n * gp.pair_overhead_ms
+            ms_live = ms - n * gp.pair_overhead_ms               # one step: `n` launches, medians over the instrumented steps
             ach = flops / (ms_live * 1e-3) / 1e12
             kname = {"bf16": "gemm_nt256_kernel<bf16>", "fp16": "gemm_nt256_kernel<f16>", "fp32": "gemm_nt_kernel<float>"}[args.compute_dtype]
             out["roofline"] = {"bound": "mfma", "kernel": kname,
                                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                                "traffic": traffic, "traffic_unit": traffic_note,
-                               "algorithmic_bytes_per_launch": int(gp.alg_bytes), "launches_per_step": n // 3,
+                               "algorithmic_bytes_per_launch": int(gp.alg_bytes), "launches_per_step": n,
                                "avg_launch_us": round(1000.0 * ms_live / n, 2),
-                               "gemm_nt_ms_per_step": round(ms_live / 3, 3),
-                               "timing": "HIP events on the launch stream around every NT launch of 3 live train steps (%d launches), minus the "
-                                         "calibrated cost of an event pair around a launch (%.2f us: per-launch pairs vs one pair around the same "
-                                         "back-to-back launches)" % (n, 1000.0 * gp.pair_overhead_ms),
+                               "gemm_nt_ms_per_step": round(ms_live, 3),
+                               "timing": "HIP events on the launch stream around every NT launch of %d live train steps after one discarded (%d launches per "
+                                         "step, median per launch position), minus the calibrated cost of an event pair around a launch (%.2f us: per-launch "
+                                         "pairs vs one pair around the same back-to-back launches)" % (gp.steps - 1, n, 1000.0 * gp.pair_overhead_ms),
                                "raw_event_avg_launch_us": round(1000.0 * ms / n, 2),
                                "instrumented_step_ms": round(gp.instrumented_step_ms, 3),     # must stay device-bound: ~ ms_per_step + the event packets
                                "warm_replay_avg_launch_us": round(1000.0 * replay_ms / replay_calls, 2),
-                               "warm_replay_frac": round(flops / 3.0 / (replay_ms * 1e-3) / 1e12 / peak, 4),
+                               "warm_replay_frac": round(flops / (replay_ms * 1e-3) / 1e12 / peak, 4),
                                "warm_replay_note": "24 back-to-back launches of each call on L2 / Infinity-Cache-warm operands, best of 3: an upper bound, not the step",
                                "step_frac_of_peak": round(tps * fpt / 1e12 / world / PEAK_BF16_TFLOPS, 4)}
             # the committed rocprofv3 kernel trace of the train steps alone (tools/round_profiles.sh -> profiles/step_trace.json),
@@ -675,7 +683,7 @@ def main():
                     fam = sjd["families"]["gemm_nt"]
                     out["roofline"]["rocprof_step_trace"] = {
                         "avg_launch_us": fam["avg_us"], "ms_per_step": fam["ms_per_step"], "launches_per_step": fam["launches_per_step"],
-                        "frac": round(flops / 3.0 / (fam["ms_per_step"] * 1e-3) / 1e12 / peak, 4), "profile": sjd.get("_profile")}
+                        "frac": round(flops / (fam["ms_per_step"] * 1e-3) / 1e12 / peak, 4), "profile": sjd.get("_profile")}
                 else:
                     out["roofline"]["rocprof_step_trace"] = "profiles/step_trace.json was measured on other kernel sources (hash mismatch): not quoted"
         # multi-GPU knobs of this run (SCALE runs are only interpretable with them): the overlap policy of the bucket
