@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 22
+#define ME_ABI_VERSION 23
 #define ME_DEC_PART_REC(dh) ((dh) + 4)      /* floats per attention partial of the decode step (me_dec_attn) */
 #define ME_SUMSQ_WS_BYTES 1040   /* me_sumsq workspace: ticket counter + 256 block sums + padding */
 
@@ -166,7 +166,8 @@ enum {
     ME_WS_GEMM_TN_GROUP = 5, /* me_gemm_tn_acc_group: (M, N, K) = (T, sum over the items of ceil(N/256) * (K/256), unused) */
     ME_WS_EMBED_BWD = 6,     /* me_embed_bwd frequent-token list: 1024 bytes, zero before the first use */
     ME_WS_SUMSQ = 7,         /* me_sumsq ordered block sums: ME_SUMSQ_WS_BYTES, zero before the first use */
-    ME_WS_RELU_MASK = 8      /* me_gemm_nt_relu_mask sign mask: (M, N, K) = the product's; 0 = shape / dtype not served, use the gate */
+    ME_WS_RELU_MASK = 8,     /* me_gemm_nt_relu_mask sign mask: (M, N, K) = the product's; 0 = shape / dtype not served, use the gate */
+    ME_WS_DEC_TOKEN = 9      /* me_dec_token exchange records: (M, N, K) = (Mr, d_inner, d); zero before the first use */
 };
 size_t me_workspace_bytes(int op, int M, int N, int K, int dtype);
 
@@ -399,6 +400,42 @@ int me_dec_proj_resid(const float* part, int nsplit, int H, int dh, const void* 
 int me_dec_ln_proj(const float* s_in, const float* gamma, const float* beta, float eps, const void* W, int ldw,
                    const float* bias, float* x_out, void* y, int ldy, int Mr, int N, int K, int flags, int dtype,
                    void* stream);
+
+/* ---- One decode token as ONE persistent launch (round 6) ---------------------------------------------------------
+ * me_dec_token runs what the launch chain {me_dec_embed_qkv_attn | me_dec_ln_qkv_attn, me_dec_proj_resid, me_dec_ln_proj,
+ * me_dec_proj_resid} x n_layer + me_dec_ln_proj (head) runs -- the model call of generate.py:116-119 for one new position --
+ * inside a single kernel of one block per CU.  The stages keep their all-to-all seams, but a seam is no longer a kernel
+ * boundary + a cold weight round trip (1.7 + ~2.5 us): every value that crosses a seam travels as an 8-byte record
+ * {payload, tag} written and polled with agent-scope atomic stores / loads (no counter, no fence, no L2 write-back: the
+ * record validates itself), ~2.2 us per exchange between 256 blocks (tools/ubench_ll_exchange.hip), and each block requests
+ * its stage's weight rows and cache rows BEFORE it polls.  Arithmetic, rounding points and summation orders are those of the
+ * per-stage launches (csrc/me_decode_common.h); tests compare the two paths bit for bit.
+ *
+ * layers: DEVICE array of n_layer <= ME_DEC_MAX_LAYERS entries (the kernel walks it; every pointer inside 16-byte aligned,
+ *     none NULL -- the library cannot check device memory).
+ * ws: caller-owned, me_workspace_bytes(ME_WS_DEC_TOKEN, Mr, d_inner, d, dtype) bytes, 256-byte aligned, ZERO before the first
+ *     use and private to one stream (it holds the exchange records, the launch epoch the tags are derived from and an
+ *     error word: the uint32 at byte offset 8 is non-zero after a poll ran into its bound (~0.3 s) -- the results of that token
+ *     and of every later one are undefined; a caller checks it when it next synchronises).
+ * nsplit in {2, 4, 8}, dh % nsplit == 0, (dh / nsplit) even, Mr * H * nsplit <= blocks; Mr <= 4; d <= 1024; d % 8 == 0;
+ * d_cond as me_dec_embed_qkv.  logits: f32 [Mr][ld_logits].  blocks: 0 = one per CU. */
+#define ME_DEC_MAX_LAYERS 16
+typedef struct me_dec_layer {
+    const void* Wqkv;  const float* bqkv;      /* T [3d][d], f32 [3d]          (music_multi.py:196-209) */
+    const void* Wo;    const float* bo;        /* T [d][d], f32 [d]            (:233-237) */
+    const void* W1;    const float* b1;        /* T [d_inner][d], f32 [d_inner] (FFN_pre, :129-131) */
+    const void* W2;    const float* b2;        /* T [d][d_inner], f32 [d]      (FFN_suf, :132-133) */
+    const float* ln1_g; const float* ln1_b;    /* f32 [d]                      (:128) */
+    const float* ln2_g; const float* ln2_b;    /* f32 [d]                      (:133-134) */
+    const void* E;                             /* T [M][dh] natural layout     (:185, 240-243) */
+    void* kcache;      void* vcache;           /* T [Mr][H][Mc][dh] */
+} me_dec_layer;
+int me_dec_token(const int64_t* tokens, const float* cond, const float* emb, const float* cw, const float* cb, const float* pe,
+                 int d_cond, const me_dec_layer* layers, int n_layer, const void* Wf, int ldwf, const float* bf, int V,
+                 float* logits, int ld_logits, void* ws, size_t ws_bytes, int nsplit, int Mr, int d, int d_inner, int H, int dh,
+                 int M, int Mc, int t, const int32_t* t_dev, float eps, int blocks, int dtype, void* stream);
+/* Largest number of co-resident blocks the device gives me_dec_token for this dtype / dh (0: shape not served). */
+int me_dec_token_blocks(int dh, int d, int d_inner, int dtype);
 
 /* Greedy pick for generate(top_k=1): logits f32 [B, ld]; NaN -> 0, ids in
  * special[0..n_special) -> -inf, argmax -> out_ids[B] (generate.py:122-136,166-183). */

@@ -244,6 +244,14 @@ ME_DEV bool me_keep(uint64_t seed, uint32_t site, uint64_t idx, uint32_t thr16) 
     return u >= thr16;
 }
 
+// me_dec_token's workspace (me_workspace_bytes(ME_WS_DEC_TOKEN)): a 256-byte control block (launch epoch, blocks done, error
+// word) followed by the 8-byte exchange records of ME_DEC_TOKEN_ROWS sequences: s2, s1, att [rows][d]; qkv [rows][3d]; hid [rows][d_inner];
+// attention partials [rows * H][nsplit <= 8][dh + 2] <= rows * 8 * (d + d / 16 + 2) (dh >= 32)
+#define ME_DEC_TOKEN_ROWS 4
+static inline size_t me_dec_token_ws_bytes(int d, int d_inner) {
+    return 256 + 8 * ((size_t)ME_DEC_TOKEN_ROWS * d * 6 + (size_t)ME_DEC_TOKEN_ROWS * d_inner + (size_t)ME_DEC_TOKEN_ROWS * 8 * (d + d / 16 + 2));
+}
+
 // status helpers for the C-ABI launchers.  hipGetLastError() is sticky per thread: other users
 // of the runtime (PyTorch) routinely leave benign non-success codes behind, so every entry point
 // clears the state first and only reports errors raised by its own launches.

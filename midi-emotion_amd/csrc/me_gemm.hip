@@ -1519,6 +1519,7 @@ size_t me_workspace_bytes(int op, int M, int N, int K, int dtype) {
     }
     if (op == ME_WS_RGA_MT) return (M > 0 && N > 0 && !(N & 31)) ? (size_t)M * (N / 32) * N * sizeof(float) : 0;
     if (op == ME_WS_SUMSQ) return ME_SUMSQ_WS_BYTES;                      // ordered block sums of me_sumsq (zero before the first use)
+    if (op == ME_WS_DEC_TOKEN) return (M > 0 && M <= ME_DEC_TOKEN_ROWS && N > 0 && K > 0) ? me_dec_token_ws_bytes(K, N) : 0;   // (M, N, K) = (Mr, d_inner, d)
     if (op == ME_WS_EMBED_BWD) return 1024;                               // frequent-token list of me_embed_bwd (zero before the first use)
     return 0;
 }

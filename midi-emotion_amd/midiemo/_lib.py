@@ -12,9 +12,10 @@ LIB_PATH = os.environ.get("MIDIEMO_LIB") or os.path.join(HERE, "libmidiemo_hip.s
 ME_F32, ME_BF16, ME_F16 = 0, 1, 2
 ME_COND_NONE, ME_COND_CONCAT, ME_COND_TOKEN = 0, 1, 2
 ME_EPI_RELU, ME_EPI_OUT_F32, ME_EPI_RELU_BWD = 1, 2, 4
-ME_WS_GEMM_TN, ME_WS_RGA_PT, ME_WS_RGA_DGT, ME_WS_RGA_MT, ME_WS_GEMM_TN_GROUP, ME_WS_EMBED_BWD, ME_WS_SUMSQ, ME_WS_RELU_MASK = 1, 2, 3, 4, 5, 6, 7, 8
+ME_WS_GEMM_TN, ME_WS_RGA_PT, ME_WS_RGA_DGT, ME_WS_RGA_MT, ME_WS_GEMM_TN_GROUP, ME_WS_EMBED_BWD, ME_WS_SUMSQ, ME_WS_RELU_MASK, ME_WS_DEC_TOKEN = 1, 2, 3, 4, 5, 6, 7, 8, 9
 ME_TN_MAX_GROUP = 5
-ABI_VERSION = 22
+ABI_VERSION = 23
+ME_DEC_MAX_LAYERS, ME_DEC_TOKEN_ROWS = 16, 4
 # words of the loss-scaler state (me_scaler_step; enum ME_SCALER_* of include/midiemo.h)
 ME_SCALER_SCALE, ME_SCALER_INV, ME_SCALER_TRACKER, ME_SCALER_STEP, ME_SCALER_FOUND_INF, ME_SCALER_SKIPPED, ME_SCALER_WORDS = 0, 1, 2, 3, 4, 5, 8
 
@@ -55,6 +56,8 @@ SIGNATURES = {
     "me_dec_attn": [_p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p],
     "me_dec_proj_resid": [_p, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p],
     "me_dec_ln_proj": [_p, _p, _p, _f, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "me_dec_token": [_p, _p, _p, _p, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, ctypes.c_size_t, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _f, _i, _i, _p],
+    "me_dec_token_blocks": [_i, _i, _i, _i],
     "me_greedy_pick": [_p, _i, _i, _p, _i, _p, _i, _p],
     "me_sample_topk_topp": [_p, _i, _i, _p, _i, _p, _i, _f, _p, _p, _p, _p, _p, _i, _p],
     "me_sample_step": [_p, _i, _i, _p, _i, _p, _p, _p, _f, _f, _f, _i, _f, _p, _i, _p, _i, _p, _p, _i, _p],
@@ -67,6 +70,11 @@ SIGNATURES = {
 class TnItem(ctypes.Structure):
     """struct me_tn_item of include/midiemo.h (one weight gradient of a grouped launch)."""
     _fields_ = [("A", _p), ("lda", _i), ("B", _p), ("ldb", _i), ("dW", _p), ("lddw", _i), ("dbias", _p), ("N", _i), ("K", _i)]
+
+
+class DecLayer(ctypes.Structure):
+    """struct me_dec_layer of include/midiemo.h (one layer's pointers for me_dec_token; the table lives in DEVICE memory)."""
+    _fields_ = [(n, _p) for n in ("Wqkv", "bqkv", "Wo", "bo", "W1", "b1", "W2", "b2", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "E", "kcache", "vcache")]
 
 
 _lib = None

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 INCLUDE = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include")
 LIB = os.path.join(HERE, "libmidiemo_hip.so")
-SOURCES = ["me_gemm.hip", "me_elem.hip", "me_attn.hip", "me_attn64.hip", "me_decode.hip"]
+SOURCES = ["me_gemm.hip", "me_elem.hip", "me_attn.hip", "me_attn64.hip", "me_decode.hip", "me_decode_token.hip"]
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs.  Without it hipcc parks the accumulators of loops whose
 # MFMAs sit under a wave-uniform branch in AGPRs and copies all of them (v_accvgpr_read/write) around every
 # iteration: 128 of ~250 VALU instructions per step in rga_bwd_kv, 96 of ~230 in rga_bwd_e.
@@ -33,7 +33,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     hipcc = _hipcc()
-    common = [os.path.join(CSRC, "me_common.h"), os.path.join(CSRC, "me_attn_common.h"), os.path.join(INCLUDE, "midiemo.h")]
+    common = [os.path.join(CSRC, "me_common.h"), os.path.join(CSRC, "me_attn_common.h"), os.path.join(CSRC, "me_decode_common.h"), os.path.join(INCLUDE, "midiemo.h")]
     objs = []
     procs = []
     for s in SOURCES:

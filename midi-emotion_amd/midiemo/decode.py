@@ -63,6 +63,23 @@ class DecodeSession:
         self.fused = os.environ.get("MIDIEMO_DEC_UNFUSED", "0") in ("", "0") and d <= 1024 and d % 8 == 0 and dh in (32, 48, 64) and \
             self.nsplit >= 2 and -(-m.max_seq // (self.nsplit - 1)) <= 2048
         self.logits = e(B, V, dtype=f32)
+        # One persistent launch per token (me_dec_token, round 6) instead of 4 per layer + head: the stages exchange self-validating
+        # records, no kernel boundaries.  Serves token-fed steps of up to 4 sequences; nsplit a power of two.  Bit-identical to the
+        # per-stage launches (tests) but not faster on this part (0.163 vs 0.154 ms per token, profiles/r06_decode_token.txt:
+        # six exchanges of ~2.2 us per layer against four kernel boundaries): opt-in, MIDIEMO_DEC_TOKEN=1.
+        self.token_kernel = False
+        self._tok_table = None
+        if self.fused and os.environ.get("MIDIEMO_DEC_TOKEN", "0") not in ("", "0") and B <= ops._lib.ME_DEC_TOKEN_ROWS and \
+                m.num_layer <= ops._lib.ME_DEC_MAX_LAYERS and di % 8 == 0 and (m.d_condition <= 0 or (m.d_condition % 4 == 0 and m.d_condition < d)):
+            ns = 8 if self.nsplit >= 8 else (4 if self.nsplit >= 4 else 2)
+            blocks = ops.dec_token_blocks(dh, d, di, dt)
+            if dh % ns == 0 and (dh // ns) % 2 == 0 and B * H * ns <= blocks and -(-m.max_seq // (ns - 1)) <= 2048:
+                if ns != self.nsplit:
+                    self.nsplit = ns
+                    self.part = e(B * H, self.nsplit, dh + 4, dtype=f32)
+                nbytes = ops.workspace_bytes(ops.ME_WS_DEC_TOKEN, B, di, d, dt)
+                self._tok_ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)      # zero before the first use (epoch, records)
+                self.token_kernel = nbytes > 0 and self._tok_ws.data_ptr() % 256 == 0
         self.t = 0                      # next model position to be written
         self._pos_dev = None            # device-side position: set while a step is issued for graph capture / replay
         self._graph = None
@@ -82,6 +99,22 @@ class DecodeSession:
             cw, cb = pv("fc_condition.weight"), pv("fc_condition.bias")
         else:
             cw = cb = None
+        if tokens is not None and self.token_kernel:
+            key = (id(m._prep), f.data_ptr())
+            if self._tok_table is None or self._tok_key != key:
+                rows = []
+                for i in range(m.num_layer):
+                    W, p = m._prep["layers"][i], f"enc_layers.{i}."
+                    rows.append(dict(Wqkv=W["Wqkv"], bqkv=W["bqkv"], Wo=W["Wo"], bo=pv(p + "rga.fc.bias"), W1=W["W1"], b1=pv(p + "FFN_pre.bias"),
+                                     W2=W["W2"], b2=pv(p + "FFN_suf.bias"), ln1_g=pv(p + "layernorm1.weight"), ln1_b=pv(p + "layernorm1.bias"),
+                                     ln2_g=pv(p + "layernorm2.weight"), ln2_b=pv(p + "layernorm2.bias"), E=W["E"], kcache=self.kc[i], vcache=self.vc[i]))
+                self._tok_table, self._tok_key = ops.dec_token_table(rows, f.device), key
+            ops.dec_token(tokens, cond if cw is not None else None, pv("embedding.weight"), cw, cb, m._pe, m.d_condition, self._tok_table,
+                          m.num_layer, m._prep["head"]["Wf"], pv(m._HEAD_B), V, self.logits, self._tok_ws, ns, B, d, di, H, dh, M, M, t,
+                          self._pos_dev, eps, 0, dt)
+            if self._pos_dev is None:
+                self.t += 1
+            return self.logits
         for r0 in range(0, B, ROWS):                          # row chunks (Mr <= 8 per kernel call)
             r1 = min(B, r0 + ROWS)
             Mr = r1 - r0
@@ -136,7 +169,14 @@ class DecodeSession:
     # -------------------------------------------------------------- public steps
     @property
     def launches_per_token(self):
+        if self.token_kernel:
+            return 2                                                # the token + pick / commit
         return (4 if self.fused else 5) * self.m.num_layer + 2     # + head, + pick / commit
+
+    def check_token_status(self):
+        """me_dec_token's error word (a poll ran into its bound: results undefined).  Synchronises; call at a sync point."""
+        if self.token_kernel and int(self._tok_ws[8:12].view(torch.int32).item()) != 0:
+            raise RuntimeError("me_dec_token: a block gave up polling its inputs (error word set); decode results are undefined")
 
     def prefill_condition_slots(self, cond):
         """continuous_token: model positions 0 and 1 are the two condition vectors

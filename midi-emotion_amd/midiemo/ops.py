@@ -10,7 +10,7 @@ import torch
 from . import _lib
 from ._lib import (ME_BF16, ME_F16, ME_COND_CONCAT, ME_COND_NONE, ME_COND_TOKEN, ME_EPI_OUT_F32, ME_EPI_RELU,
                    ME_EPI_RELU_BWD, ME_F32, ME_TN_MAX_GROUP, ME_WS_EMBED_BWD, ME_WS_SUMSQ, ME_WS_GEMM_TN, ME_WS_GEMM_TN_GROUP, ME_WS_RGA_DGT, ME_WS_RGA_MT,
-                   ME_WS_RGA_PT, ME_WS_RELU_MASK, check)
+                   ME_WS_RGA_PT, ME_WS_RELU_MASK, ME_WS_DEC_TOKEN, check)
 
 DTYPE_CODE = {torch.float32: ME_F32, torch.bfloat16: ME_BF16, torch.float16: ME_F16}
 
@@ -333,6 +333,32 @@ def dec_proj_resid(part, nsplit, H, dh, x_T, W, bias, resid, out, Mr, N, K, dtyp
 def dec_ln_proj(s_in, gamma, beta, eps, W, bias, x_out, y, Mr, N, K, flags, dtype):
     check(lib().me_dec_ln_proj(_ptr(s_in), _ptr(gamma), _ptr(beta), float(eps), _ptr(W), W.stride(0), _ptr(bias), _ptr(x_out),
                                _ptr(y), y.stride(0), Mr, N, K, int(flags), _code(dtype), _stream()), "me_dec_ln_proj")
+
+def dec_token_blocks(dh, d, d_inner, dtype):
+    """co-resident blocks me_dec_token gets on this device (0: shape / type not served)."""
+    return int(lib().me_dec_token_blocks(int(dh), int(d), int(d_inner), _code(dtype)))
+
+
+def dec_token_table(layers, device):
+    """device copy of an array of me_dec_layer built from dicts of tensors (keys = the struct's fields)."""
+    import numpy as np
+    from ._lib import DecLayer
+    arr = (DecLayer * len(layers))()
+    for i, L in enumerate(layers):
+        for name, _ in DecLayer._fields_:
+            setattr(arr[i], name, L[name].data_ptr())
+    raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+    return torch.from_numpy(raw).to(device)
+
+
+def dec_token(tokens, cond, emb, cw, cb, pe, d_cond, table, n_layer, Wf, bf, V, logits, ws, nsplit, Mr, d, d_inner, H, dh, M, Mc, t,
+              t_dev, eps, blocks, dtype):
+    """one decode position through all layers and the head in ONE persistent launch (me_dec_token)."""
+    check(lib().me_dec_token(_ptr(tokens), _ptr(cond), _ptr(emb), _ptr(cw), _ptr(cb), _ptr(pe), int(d_cond), _ptr(table), int(n_layer),
+                             _ptr(Wf), Wf.stride(0), _ptr(bf), int(V), _ptr(logits), logits.stride(0), _ptr(ws), ws.numel() * ws.element_size(),
+                             int(nsplit), int(Mr), int(d), int(d_inner), int(H), int(dh), int(M), int(Mc), int(t), _ptr(t_dev), float(eps),
+                             int(blocks), _code(dtype), _stream()), "me_dec_token")
+
 
 
 def sample_topk_topp(logits, V, special, temp, top_k, top_p, u, out_ids, n_choices=None, dbg_p=None, dbg_i=None):

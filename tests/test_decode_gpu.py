@@ -333,6 +333,53 @@ def test_fused_decode_stages_equal_the_separate_launches(conditioning, cd):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cd", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("conditioning,geom", [("continuous_concat", (3, 2, 128, 256, 32)), ("none", (2, 4, 128, 512, -1)),
+                                               ("discrete_token", (2, 8, 512, 2048, -1))])
+def test_token_kernel_equals_the_launch_chain_bit_for_bit(conditioning, geom, cd, monkeypatch):
+    """me_dec_token (one persistent launch per token: the stages exchange self-validating 8-byte records instead of ending a
+    kernel; opt-in, MIDIEMO_DEC_TOKEN=1) against the per-stage launch chain it restates: SAME arithmetic, rounding points and
+    summation orders (csrc/me_decode_common.h), so logits of every step and the K / V caches must be EQUAL, not close -- over
+    positions that cross several key-split chunks, with sequences at different tokens, for head dims 64 / 32 / 64, B = 3 and 4
+    (rows beyond the batch), and through the graph-replayed greedy loop.  The error word of the workspace stays clear."""
+    import torch
+    from midiemo.decode import DecodeSession
+    from midiemo.models.build_model import build_model
+    n_layer, n_head, d, di, dc = geom
+    torch.manual_seed(5)
+    V = 1017 if conditioning == "discrete_token" else 1007
+    model, _ = build_model(dict(vocab_size=V, n_layer=n_layer, n_head=n_head, d_model=d, d_inner=di, dropout=0.0, d_condition=dc,
+                                conditioning=conditioning, compute_dtype=cd))
+    model = model.cuda().eval()
+    for B, n in ((4, 150), (3, 40)):
+        cond = torch.rand(B, 2, device="cuda") * 2 - 1
+        toks = torch.randint(2, 1007, (n, B), device="cuda")
+        with torch.no_grad():
+            monkeypatch.setenv("MIDIEMO_DEC_TOKEN", "0")
+            a = DecodeSession(model, B)
+            monkeypatch.setenv("MIDIEMO_DEC_TOKEN", "1")
+            b = DecodeSession(model, B)
+            assert not a.token_kernel and b.token_kernel and b.launches_per_token == 2
+            if a.nsplit != b.nsplit:                          # the chain with the token kernel's (power of two) key split
+                monkeypatch.setenv("MIDIEMO_DEC_NSPLIT", str(b.nsplit))
+                monkeypatch.setenv("MIDIEMO_DEC_TOKEN", "0")
+                a = DecodeSession(model, B)
+                monkeypatch.delenv("MIDIEMO_DEC_NSPLIT")
+            for i in range(n):
+                la, lb = a.step(toks[i], cond).clone(), b.step(toks[i], cond).clone()
+                assert torch.equal(la, lb), (B, i, float((la - lb).abs().max()))
+            for l in range(n_layer):
+                assert torch.equal(a.kc[l], b.kc[l]) and torch.equal(a.vc[l], b.vc[l]), (B, l)
+            b.check_token_status()
+            # graph-replayed greedy loop from a fresh position 0
+            a.reset(); b.reset()
+            ia = a.greedy_run(toks[0], 64, cond=cond).clone()
+            ib = b.greedy_run(toks[0], 64, cond=cond).clone()
+            assert torch.equal(ia, ib)
+            b.check_token_status()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("top_k,top_p,V", [(-1, 0.7, 1007), (20, 1.0, 1007), (50, 0.9, 1007), (-1, 1.0, 1007), (3, 0.5, 1007),
                                              (-1, 0.8, 1500), (40, 1.0, 2048), (-1, 0.9, 3000), (-1, 1.0, 4096)])
 def test_fused_sampling_tail_matches_torch_path(top_k, top_p, V):

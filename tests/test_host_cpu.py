@@ -48,6 +48,9 @@ def test_workspace_sizes_are_host_side_arithmetic():
     nq = 1024 // 32
     assert ws(_lib.ME_WS_RGA_PT, 256, 1024, 1, _lib.ME_BF16) == 256 * (nq * (nq + 1) // 2) * 1024 * 2
     assert ws(_lib.ME_WS_RGA_DGT, 256, 1024, 0, _lib.ME_BF16) == 256 * (nq * (nq + 1) // 2) * 1024 * 2
+    # me_dec_token (round 6): control block + 8-byte records of 4 rows: s2, s1, att [d], qkv [3d], hid [d_inner], partials
+    assert ws(_lib.ME_WS_DEC_TOKEN, 4, 2048, 512, _lib.ME_BF16) == 256 + 8 * (4 * 512 * 6 + 4 * 2048 + 4 * 8 * (512 + 32 + 2))
+    assert ws(_lib.ME_WS_DEC_TOKEN, 5, 2048, 512, _lib.ME_BF16) == 0                         # at most ME_DEC_TOKEN_ROWS sequences
 
 
 @pytest.mark.parametrize("mode", ["none", "discrete_token", "continuous_token", "continuous_concat"])
