@@ -17,6 +17,57 @@ __device__ __forceinline__ void st_rec(unsigned long long* p, float v, unsigned 
 __device__ __forceinline__ unsigned long long ld_rec(const unsigned long long* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ void st_rec_sys(unsigned long long* p, float v, unsigned tag) {
+    const unsigned long long w = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+    __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ unsigned long long ld_rec_sys(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// variant 3: system-scope stores and loads;  variant 4: only wave 0 polls (RPT * 4 records per lane), the block meets at a barrier
+template <int RPT>
+__global__ __launch_bounds__(256) void k_ll2(unsigned long long* buf, int rounds, float* out, unsigned* err, int variant) {
+    const int NV = 256 * RPT, G = gridDim.x, own = NV / G;
+    float acc = 0.f;
+    __shared__ float red[2][4];
+    for (int i = 0; i < rounds; ++i) {
+        unsigned long long* v = buf + (size_t)(i & 1) * NV;
+        if ((int)threadIdx.x < own) {
+            if (variant == 3) st_rec_sys(&v[blockIdx.x * own + threadIdx.x], acc * 1e-6f + (float)(i & 7), (unsigned)(i + 1));
+            else st_rec(&v[blockIdx.x * own + threadIdx.x], acc * 1e-6f + (float)(i & 7), (unsigned)(i + 1));
+        }
+        float s = 0.f;
+        if (variant == 3) {
+            unsigned long long w[RPT];
+            unsigned pending = (1u << RPT) - 1u;
+            int spins = 0;
+            while (pending) {
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) if (pending >> r & 1) w[r] = ld_rec_sys(&v[r * 256 + threadIdx.x]);
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) if ((pending >> r & 1) && (unsigned)(w[r] >> 32) == (unsigned)(i + 1)) { pending &= ~(1u << r); s += __uint_as_float((unsigned)w[r]); }
+                if (pending && ++spins > (1 << 22)) { atomicAdd(err, 1u); pending = 0; }
+            }
+        } else if (threadIdx.x < 64) {
+            constexpr int R4 = RPT * 4;
+            unsigned long long w[R4];
+            unsigned pending = R4 >= 32 ? 0xffffffffu : (1u << R4) - 1u;
+            int spins = 0;
+            while (pending) {
+#pragma unroll
+                for (int r = 0; r < R4; ++r) if (pending >> r & 1) w[r] = ld_rec(&v[r * 64 + threadIdx.x]);
+#pragma unroll
+                for (int r = 0; r < R4; ++r) if ((pending >> r & 1) && (unsigned)(w[r] >> 32) == (unsigned)(i + 1)) { pending &= ~(1u << r); s += __uint_as_float((unsigned)w[r]); }
+                if (pending && ++spins > (1 << 22)) { atomicAdd(err, 1u); pending = 0; }
+            }
+        }
+        for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+        if ((threadIdx.x & 63) == 0) red[i & 1][threadIdx.x >> 6] = s;
+        __syncthreads();
+        acc = red[i & 1][0] + red[i & 1][1] + red[i & 1][2] + red[i & 1][3];
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = acc;
+}
 
 // NV records per round, block b owns NV / grid of them; every thread of every block reads NV / 256 records per round
 template <int RPT>                                         // records per thread on the read side (NV = 256 * RPT)
@@ -81,12 +132,13 @@ template <int RPT>
 static int run(int grid, hipStream_t st, unsigned long long* buf, float* out, unsigned* err) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int R = 500;
-    for (int variant = 0; variant < 3; ++variant) {
+    for (int variant = 0; variant < 5; ++variant) {
         std::vector<float> t;
         for (int rep = 0; rep < 7; ++rep) {
             CK(hipMemsetAsync(buf, 0, 1 << 20, st)); CK(hipMemsetAsync(err, 0, 4, st));
             CK(hipEventRecord(e0, st));
             if (variant < 2) k_ll<RPT><<<grid, 256, 0, st>>>(buf, R, out, err, variant);
+            else if (variant >= 3) k_ll2<RPT><<<grid, 256, 0, st>>>(buf, R, out, err, variant);
             else k_flag<RPT><<<grid, 256, 0, st>>>((float*)buf, (unsigned*)(buf + 65536), R, out, err);
             CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); t.push_back(ms);
@@ -95,7 +147,7 @@ static int run(int grid, hipStream_t st, unsigned long long* buf, float* out, un
         unsigned h_err = 0; float h0 = 0, h1 = 0; CK(hipMemcpy(&h_err, err, 4, hipMemcpyDeviceToHost));
         CK(hipMemcpy(&h0, out, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&h1, out + grid - 1, 4, hipMemcpyDeviceToHost));
         printf("grid %3d  %5d values  %-28s %.3f us per exchange (median of 7 x %d; min %.3f)  timeouts %u  acc %g %g\n", grid, 256 * RPT,
-               variant == 0 ? "tagged records" : variant == 1 ? "tagged records + s_sleep" : "flags then payload", t[3] * 1e3 / R, R, t[0] * 1e3 / R, h_err, h0, h1);
+               variant == 0 ? "tagged records" : variant == 1 ? "tagged records + s_sleep" : variant == 2 ? "flags then payload" : variant == 3 ? "tagged, system scope" : "tagged, wave 0 polls", t[3] * 1e3 / R, R, t[0] * 1e3 / R, h_err, h0, h1);
     }
     return 0;
 }
@@ -107,7 +159,6 @@ int main() {
     for (int grid : {32, 64, 128, 256}) {
         if (run<2>(grid, st, buf, out, err)) return 1;      //  512 values (a [4][128] slice)
         if (run<8>(grid, st, buf, out, err)) return 1;      // 2048 values ([4][512] residual rows)
-        if (run<32>(grid, st, buf, out, err)) return 1;     // 8192 values ([4][2048] hidden rows)
     }
     return 0;
 }
