@@ -591,90 +591,6 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_nt256_kernel(
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// 256x256 tile, FOUR waves (2 x 2, 128 x 128 per wave: one wave per SIMD, the 256 accumulators in AGPRs), 16-bit types,
-// K % 128 == 0, K >= 256 -- the hand-scheduled main loop of round 5 (the vendor kernel's wave tile: a third fewer LDS bytes per
-// FLOP than 128 x 64 waves; 1 110 TF/s on warm operands, but 68.4 -> 81.4 us inside the live step, where the activation operand
-// comes from HBM and ONE register stage covered 1.3 us of load latency) rebuilt in round 6 with a SECOND register stage
-// (VERDICT r5 item 4): the slab loop is one inline-asm body generated by tools/gen_nt4w.py (me_gemm_nt4w.inc) -- 64 MFMAs per
-// slab and wave with exactly ONE memory instruction in each of the 64 gaps (the 8 fragment reads of the next k-phase in the order
-// the MFMAs consume them; 16 ds_write_b128 of slab + 1 from the register set loaded two slabs ago; 16 global_load_dwordx4 of
-// slab + 3 into that set), one s_barrier per slab, every s_waitcnt counted from the periodic instruction stream: 32 loads in flight
-// per wave, 2.6 us of cover.  Same slab images and swizzle, same k order per accumulator element as gemm_nt256_kernel: results are
-// bit-identical (tests).  The tile loop and the write-out stay C++ (nt256_write_tile with the 2 x 2 wave grid); no state crosses
-// the write-out.  Opt-in (MIDIEMO_NT_MAINLOOP=2: launches of at most one tile per CU; 3: wherever legal).
-// LDS: [A even 32 KB][A odd][B even][B odd][write-out staging 32 KB].
-// ---------------------------------------------------------------------------------------------
-#include "me_gemm_nt4w.inc"
-template <typename T, bool OUT_F32, int EPI>
-__global__ __launch_bounds__(256) void gemm_nt4w_kernel(
-    const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc,
-    const float* __restrict__ bias, const T* __restrict__ add, int ldadd, const T* __restrict__ gate,
-    int ldgate, int M, int N, int K, int flags) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wid >> 1, wc = wid & 1;
-    const int ntn = (N + 255) / 256, ntiles = ntn * ((M + 255) / 256);
-    const bool relu = flags & ME_EPI_RELU;
-    const bool vec_c = (ldc % (OUT_F32 ? 4 : 8)) == 0 && (reinterpret_cast<uintptr_t>(Cv) & 15) == 0;
-    const int nloop = K / 128 - 2;
-    // operand feed: every wave stages 8 pieces of the A slab (rows 64 wid ..) and 8 of the B slab
-    const uint32_t lda2 = (uint32_t)lda * 2u, ldb2 = (uint32_t)ldb * 2u;
-    const uint32_t lwr = (uint32_t)wid * 8192u + (uint32_t)lane * 16u;
-    const int frow = lane & 31, h = lane >> 5;
-    uint32_t lra, lrb;
-    { const int r = wr * 128 + frow; lra = r * 128 + ((h ^ ((r ^ (r >> 3)) & 7)) << 4); }
-    { const int r = wc * 128 + frow; lrb = 65536 + r * 128 + ((h ^ ((r ^ (r >> 3)) & 7)) << 4); }
-    f32x16_t acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc_zero(acc[i][j]);
-    auto tile_origin = [&](int it, int& m0, int& n0) __attribute__((always_inline)) {
-        int t = it;
-        if ((ntiles & 7) == 0) t = (t & 7) * (ntiles >> 3) + (t >> 3);      // contiguous tile range per XCD
-        m0 = (t / ntn) * 256;
-        n0 = (t % ntn) * 256;
-    };
-    for (int it = blockIdx.x; it < ntiles; it += gridDim.x) {
-        int m0, n0;
-        tile_origin(it, m0, n0);
-        const char* sbase = reinterpret_cast<const char*>(A) + (size_t)(uint32_t)m0 * lda2;
-        const char* sbaseb = reinterpret_cast<const char*>(B) + (size_t)(uint32_t)n0 * ldb2;
-        uint32_t vo[16];
-        int lf = lane;                                                    // opaque per tile: the sixteen offsets are recomputed here, not
-        asm volatile("" : "+v"(lf));                                      // hoisted out of the tile loop and spilled around the asm body
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int r = (wid * 8 + p) * 8 + (lf >> 3);                   // row inside the slab; rows past the matrix are clamped
-            const uint32_t sw = (uint32_t)(((lf & 7) ^ ((r ^ (r >> 3)) & 7)) << 4);
-            vo[p] = (uint32_t)(min(m0 + r, M - 1) - m0) * lda2 + sw;
-            vo[8 + p] = (uint32_t)(min(n0 + r, N - 1) - n0) * ldb2 + sw;
-        }
-        // the offsets travel through the wave's write-out staging area (idle during the main loop; LDS operations of a wave
-        // complete in order, the body's reads follow these stores): 4 x 16 bytes per lane
-        const uint32_t vstg = 2u * 65536u + (uint32_t)wid * 8192u + (uint32_t)lf * 16u;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<u32x4_t*>(smem + vstg + q * 1024) = (u32x4_t){vo[4 * q], vo[4 * q + 1], vo[4 * q + 2], vo[4 * q + 3]};
-#define ME_NT4W_OPERANDS                                                                                                          \
-                     : [c0] "+a"(acc[0][0]), [c1] "+a"(acc[0][1]), [c2] "+a"(acc[0][2]), [c3] "+a"(acc[0][3]),                    \
-                       [c4] "+a"(acc[1][0]), [c5] "+a"(acc[1][1]), [c6] "+a"(acc[1][2]), [c7] "+a"(acc[1][3]),                    \
-                       [c8] "+a"(acc[2][0]), [c9] "+a"(acc[2][1]), [c10] "+a"(acc[2][2]), [c11] "+a"(acc[2][3]),                  \
-                       [c12] "+a"(acc[3][0]), [c13] "+a"(acc[3][1]), [c14] "+a"(acc[3][2]), [c15] "+a"(acc[3][3])                 \
-                     : [vstg] "v"(vstg), [lwr] "v"(lwr), [lra] "v"(lra), [lrb] "v"(lrb), [sbase] "s"(sbase), [sbaseb] "s"(sbaseb), [nloop] "s"(nloop)
-        if constexpr (std::is_same<T, bf16_t>::value) asm volatile(ME_NT4W_BF16_BODY ME_NT4W_OPERANDS : ME_NT4W_BF16_CLOBBERS);
-        else asm volatile(ME_NT4W_F16_BODY ME_NT4W_OPERANDS : ME_NT4W_F16_CLOBBERS);
-#undef ME_NT4W_OPERANDS
-        int ln = lane;                                                    // opaque: nothing of the write-out's address arithmetic
-        asm volatile("" : "+v"(ln));                                      // is hoisted out of the tile loop and held (spilled) across the asm body
-        nt256_write_tile<T, OUT_F32, 2, 2, EPI>(acc, smem, m0, n0, wid, ln, Cv, ldc, bias, add, ldadd, gate, ldgate, M, N, relu, vec_c);
-        // (no barrier: the staging area is private to the wave, the next prologue writes LDS buffer 0, which the last slab only
-        // touched with its never-consumed reads of "slab nk", and buffer 1 is written behind the prologue's own barrier)
-    }
-}
-
 // C = A.B^T.  128x128 block tile, 4 waves (2x2) x 64x64.  K-slab BKT (64 bf16 / 32 f32) is
 // double buffered in LDS: one barrier per slab, the slab after next is in flight in registers
 // while the current one is multiplied.  The 32x32 blocks are accumulated TRANSPOSED (mfma(B, A)):
@@ -1432,33 +1348,6 @@ int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, void* C, int 
             } else if (!add && !gate) epi = 0;
             else if (!(flags & ME_EPI_OUT_F32) && gate && !add && !bias && !(flags & ME_EPI_RELU) && vec_c && (ldgate & 7) == 0 && aligned16(gate)) epi = 1;
             else if (!(flags & ME_EPI_OUT_F32) && add && !gate && vec_c && (ldadd & 7) == 0 && aligned16(add)) epi = 2;
-            // MIDIEMO_NT_MAINLOOP: 0 (default) the 8-wave loop; 2 the hand-scheduled 4-wave loop for launches of at most one tile per
-            // CU (the long-K products: FFN_suf forward, FFN_pre dgrad); 3 wherever it is legal (K % 128 == 0, K >= 256, write-outs 0-3)
-            const char* ml_env = getenv("MIDIEMO_NT_MAINLOOP");                 // (read per launch while the variants are being compared)
-            const int mainloop = ml_env ? atoi(ml_env) : 0;
-            const unsigned tiles256 = (unsigned)(((N + 255) / 256) * ((M + 255) / 256));
-            if (mainloop >= 2 && epi <= 3 && K % 128 == 0 && K >= 256 && (mainloop == 3 || tiles256 <= ncu) &&
-                (mainloop != 4 || (K >= 2048 && epi == 0))) {
-                static bool attr4[16] = {false};
-                if (dev < 0 || dev >= 16 || !attr4[dev]) {
-                    (void)hipFuncSetAttribute((const void*)gemm_nt4w_kernel<T, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
-                    (void)hipFuncSetAttribute((const void*)gemm_nt4w_kernel<T, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
-                    (void)hipFuncSetAttribute((const void*)gemm_nt4w_kernel<T, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
-                    (void)hipFuncSetAttribute((const void*)gemm_nt4w_kernel<T, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
-                    (void)hipFuncSetAttribute((const void*)gemm_nt4w_kernel<T, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
-                    (void)hipFuncSetAttribute((const void*)gemm_nt4w_kernel<T, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
-                    if (dev >= 0 && dev < 16) attr4[dev] = true;
-                }
-#define ME_NT4W(F32, E) gemm_nt4w_kernel<T, F32, E><<<g256, 256, NT256_LDS, st>>>((const T*)A, lda, (const T*)B, ldb, C, ldc, bias, \
-                                                                             (const T*)add, ldadd, (const T*)gate, ldgate, M, N, K, flags)
-                if (flags & ME_EPI_OUT_F32) { if (epi == 0) ME_NT4W(true, 0); else ME_NT4W(true, 3); }
-                else if (epi == 0) ME_NT4W(false, 0);
-                else if (epi == 1) ME_NT4W(false, 1);
-                else if (epi == 2) ME_NT4W(false, 2);
-                else ME_NT4W(false, 3);
-#undef ME_NT4W
-                return me_launch_status();
-            }
 #define ME_NT256(F32, E) gemm_nt256_kernel<T, F32, 2, 4, E><<<g256, 512, NT256_LDS, st>>>((const T*)A, lda, (const T*)B, ldb, C, ldc, bias, \
                                                                                   (const T*)add, ldadd, (const T*)gate, ldgate, M, N, K, flags)
             if (flags & ME_EPI_OUT_F32) { if (epi == 0) ME_NT256(true, 0); else ME_NT256(true, 3); }

@@ -33,7 +33,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     hipcc = _hipcc()
-    common = [os.path.join(CSRC, "me_common.h"), os.path.join(CSRC, "me_attn_common.h"), os.path.join(CSRC, "me_decode_common.h"), os.path.join(CSRC, "me_gemm_nt4w.inc"), os.path.join(INCLUDE, "midiemo.h")]
+    common = [os.path.join(CSRC, "me_common.h"), os.path.join(CSRC, "me_attn_common.h"), os.path.join(CSRC, "me_decode_common.h"), os.path.join(INCLUDE, "midiemo.h")]
     objs = []
     procs = []
     for s in SOURCES:

@@ -1,4 +1,5 @@
-"""4-wave NT main loop (MIDIEMO_NT_MAINLOOP=3) against the 8-wave kernel: the switch is read when the library loads, so run this twice --
+"""(Kept for the record, see profiles/r06_nt_4wave.txt: needs the commit that holds gemm_nt4w_kernel.)
+4-wave NT main loop (MIDIEMO_NT_MAINLOOP=3) against the 8-wave kernel: the switch is read when the library loads, so run this twice --
    MIDIEMO_NT_MAINLOOP=0 python tools/check_nt4w.py save   then   MIDIEMO_NT_MAINLOOP=3 python tools/check_nt4w.py compare
 outputs of a set of shapes / write-outs must be bit-identical (same slab images, same k order per accumulator element)."""
 import os, sys

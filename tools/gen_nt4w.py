@@ -1,4 +1,6 @@
-"""Generator of the hand-scheduled main loop of the 4-wave NT GEMM (round 6: round 5's loop, deleted with the kernel it belonged to,
+"""(Kept for the record: the kernel it feeds, gemm_nt4w_kernel, is NOT in the library -- profiles/r06_nt_4wave.txt; `git log -S gemm_nt4w_kernel`
+finds the commit that holds it.)
+Generator of the hand-scheduled main loop of the 4-wave NT GEMM (round 6: round 5's loop, deleted with the kernel it belonged to,
 with a SECOND register stage in the operand feed -- VERDICT r5 item 4): emits midi-emotion_amd/csrc/me_gemm_nt4w.inc, ONE inline-asm
 body for gfx950 -- 256 x 256 tile, 4 waves (2 x 2) of 128 x 128, one wave per SIMD, the 256 accumulators as "+a" operands,
 64-deep slabs, fragments double-buffered over the four k-phases of a slab.
