@@ -728,6 +728,18 @@ def main():
             if not args.no_cpu_baseline:
                 dec["cpu_baseline"] = decode_cpu_baseline()
             dec["slide"] = decode_slide_bench("bf16")
+            # the opt-in per-token persistent kernel (me_dec_token, MIDIEMO_DEC_TOKEN=1): same token stream, measured beside the default
+            prev = os.environ.get("MIDIEMO_DEC_TOKEN")
+            os.environ["MIDIEMO_DEC_TOKEN"] = "1"
+            try:
+                tk = decode_bench("bf16")
+                dec["token_kernel"] = {k: tk[k] for k in ("tokens_per_s", "step_ms_p50", "step_ms_p90", "launches_per_step", "ids_checksum")}
+                dec["token_kernel"]["note"] = "one persistent launch per token (stages exchange tagged records); bit-identical to the launch chain, opt-in"
+            finally:
+                if prev is None:
+                    os.environ.pop("MIDIEMO_DEC_TOKEN", None)
+                else:
+                    os.environ["MIDIEMO_DEC_TOKEN"] = prev
             out["decode"] = dec
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -32,6 +32,7 @@
  *   MIDIEMO_NO_TN256=1     likewise for the weight-gradient (TN) GEMMs
  *   MIDIEMO_DEC_CW=1|2|4, MIDIEMO_DEC_KS=0|1   column / K-split geometry of the decode GEMV kernels
  *   MIDIEMO_DEBUG=1        print the HIP error string when a launch fails
+ * (host side, midiemo/decode.py: MIDIEMO_DEC_TOKEN=1 runs a decode token as ONE launch, me_dec_token, instead of 4 per layer)
  */
 #ifndef MIDIEMO_H
 #define MIDIEMO_H
