@@ -735,6 +735,8 @@ def main():
                 tk = decode_bench("bf16")
                 dec["token_kernel"] = {k: tk[k] for k in ("tokens_per_s", "step_ms_p50", "step_ms_p90", "launches_per_step", "ids_checksum")}
                 dec["token_kernel"]["note"] = "one persistent launch per token (stages exchange tagged records); bit-identical to the launch chain, opt-in"
+            except Exception as e:                               # an extra: its failure must not take the bench line with it
+                dec["token_kernel"] = {"error": repr(e)[:300]}
             finally:
                 if prev is None:
                     os.environ.pop("MIDIEMO_DEC_TOKEN", None)
