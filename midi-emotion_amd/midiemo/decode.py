@@ -268,6 +268,7 @@ class DecodeSession:
                 ev.record()
                 step_events.append(ev)
         self.t = t0 + n_steps
+        self.check_token_status()                           # (opt-in token kernel only: reads its error word, synchronises)
         return self._hist[:, t0:t0 + n_steps]
 
     def sample_run(self, tokens, n_steps, cond, special, is_timeshift, repeat_counts, temp_note, temp_rest,
@@ -339,6 +340,7 @@ class DecodeSession:
             else:
                 one_step()
         self.t = t0 + n_steps
+        self.check_token_status()
         repeat_counts.copy_(self._s_rc.to(repeat_counts.device))
         return self._hist[:, t0:t0 + n_steps]
 
