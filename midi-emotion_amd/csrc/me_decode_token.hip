@@ -144,7 +144,7 @@ ME_DEV void gemv_prefetch(int tid, chunk16 (&wp)[2][CW], const T* Wall, int ldw,
     }
 }
 template <typename T, int MR, int CW, bool KS>
-ME_DEV float gemv_run(int tid, chunk16 (&wp)[2][CW], const T* Wall, int ldw, int N, int K, int vb, float* xs) {
+ME_DEV float gemv_run(int tid, chunk16 (&wp)[2][CW], const T* Wall, int ldw, int N, int K, int vb, float* xs, float* ks = nullptr) {
     constexpr int CH = ET<T>::CH, PF = 2, NV = CW * MR;
     const int lane = tid & 63, wid = tid >> 6;
     const int nch_all = K / CH, kq = KS ? (nch_all + 3) / 4 : 0, ch_lo = KS ? wid * kq : 0;
@@ -186,9 +186,8 @@ ME_DEV float gemv_run(int tid, chunk16 (&wp)[2][CW], const T* Wall, int ldw, int
     float mine = 0.f;
 #pragma unroll
     for (int i = 0; i < NV / 4; ++i) if ((lane & 15) == i) mine = red[i];
-    if constexpr (KS) {                                     // the four K quarters meet in LDS (xs is dead after the barrier)
-        __syncthreads();
-        float* ks = xs;
+    if constexpr (KS) {                                     // the four K quarters meet in LDS: [4 waves][NV] floats at ks (NOT in xs as in
+        __syncthreads();                                    // dec_gemv_kernel: a block may walk several column groups over the same rows)
         if ((lane & 15) < NV / 4) ks[wid * NV + (lane & 15) + (NV / 4) * (lane >> 4)] = mine;
         __syncthreads();
         if (wid == 0 && (lane & 15) < NV / 4) {
@@ -657,13 +656,13 @@ __global__ __launch_bounds__(256, 1) void dec_token_kernel(const TokArgs a) {
                 constexpr bool KS = decltype(ks_tag)::value;
                 for (int vb = bid; vb < nvb_2; vb += G) {
                     if (vb != bid) {
-                        __syncthreads();                                    // KS: the previous pass parked its quarters in xs
+                        __syncthreads();                                    // KS: the previous pass's quarters (in ost) have been summed
                         gemv_prefetch<T, 2, KS>(tid, wp2, W2, di, d, di, vb);
                         own2 = gemv_owner<MR, 2, KS>(tid, d, Mr, vb, n2_, m2_);
                         bias2 = own2 ? Lc.b2[n2_] : 0.f;
                         res_v = own2 ? xo[m2_ * d + n2_] : 0.f;
                     }
-                    const float mine = gemv_run<T, MR, 2, KS>(tid, wp2, W2, di, d, di, vb, xs);
+                    const float mine = gemv_run<T, MR, 2, KS>(tid, wp2, W2, di, d, di, vb, xs, ost);
                     if (own2) st_rec(a.x_s2 + m2_ * d + n2_, f2u(res_v + (mine + bias2)), tag0 + 5u);
                 }
             };

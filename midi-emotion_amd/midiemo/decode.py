@@ -73,6 +73,9 @@ class DecodeSession:
                 m.num_layer <= ops._lib.ME_DEC_MAX_LAYERS and di % 8 == 0 and (m.d_condition <= 0 or (m.d_condition % 4 == 0 and m.d_condition < d)):
             ns = 8 if self.nsplit >= 8 else (4 if self.nsplit >= 4 else 2)
             blocks = ops.dec_token_blocks(dh, d, di, dt)
+            self._tok_blocks = int(os.environ.get("MIDIEMO_DEC_TOKEN_BLOCKS", "0"))       # 0 = one block per CU (tests: fewer)
+            if self._tok_blocks > 0:
+                blocks = min(blocks, self._tok_blocks)
             if dh % ns == 0 and (dh // ns) % 2 == 0 and B * H * ns <= blocks and -(-m.max_seq // (ns - 1)) <= 2048:
                 if ns != self.nsplit:
                     self.nsplit = ns
@@ -111,7 +114,7 @@ class DecodeSession:
                 self._tok_table, self._tok_key = ops.dec_token_table(rows, f.device), key
             ops.dec_token(tokens, cond if cw is not None else None, pv("embedding.weight"), cw, cb, m._pe, m.d_condition, self._tok_table,
                           m.num_layer, m._prep["head"]["Wf"], pv(m._HEAD_B), V, self.logits, self._tok_ws, ns, B, d, di, H, dh, M, M, t,
-                          self._pos_dev, eps, 0, dt)
+                          self._pos_dev, eps, getattr(self, "_tok_blocks", 0), dt)
             if self._pos_dev is None:
                 self.t += 1
             return self.logits

@@ -380,6 +380,37 @@ def test_token_kernel_equals_the_launch_chain_bit_for_bit(conditioning, geom, cd
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cd", ["bf16", "fp32"])
+def test_token_kernel_with_fewer_blocks_than_projection_tiles(cd, monkeypatch):
+    """me_dec_token on HALF the chip (128 blocks, 4 key splits): the q | k | v, FFN_pre and FFN_suf stages then have more column groups
+    (192 / 256 / 256) than blocks and every block walks several of them -- the path a smaller part would take.  Still equal to the chain."""
+    import torch
+    from midiemo.decode import DecodeSession
+    from midiemo.models.build_model import build_model
+    torch.manual_seed(9)
+    model, _ = build_model(dict(vocab_size=1007, n_layer=2, n_head=8, d_model=512, d_inner=2048, dropout=0.0, d_condition=128,
+                                conditioning="continuous_concat", compute_dtype=cd))
+    model = model.cuda().eval()
+    B, n = 4, 90
+    cond = torch.rand(B, 2, device="cuda") * 2 - 1
+    toks = torch.randint(2, 1007, (n, B), device="cuda")
+    monkeypatch.setenv("MIDIEMO_DEC_NSPLIT", "4")
+    with torch.no_grad():
+        monkeypatch.setenv("MIDIEMO_DEC_TOKEN", "0")
+        a = DecodeSession(model, B)
+        monkeypatch.setenv("MIDIEMO_DEC_TOKEN", "1")
+        monkeypatch.setenv("MIDIEMO_DEC_TOKEN_BLOCKS", "128")
+        b = DecodeSession(model, B)
+        assert b.token_kernel and a.nsplit == b.nsplit == 4 and b._tok_blocks == 128
+        for i in range(n):
+            la, lb = a.step(toks[i], cond).clone(), b.step(toks[i], cond).clone()
+            assert torch.equal(la, lb), (i, float((la - lb).abs().max()))
+        for l in range(2):
+            assert torch.equal(a.kc[l], b.kc[l]) and torch.equal(a.vc[l], b.vc[l]), l
+        b.check_token_status()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("top_k,top_p,V", [(-1, 0.7, 1007), (20, 1.0, 1007), (50, 0.9, 1007), (-1, 1.0, 1007), (3, 0.5, 1007),
                                              (-1, 0.8, 1500), (40, 1.0, 2048), (-1, 0.9, 3000), (-1, 1.0, 4096)])
 def test_fused_sampling_tail_matches_torch_path(top_k, top_p, V):
