@@ -411,6 +411,22 @@ def test_token_kernel_with_fewer_blocks_than_projection_tiles(cd, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_reference_goldens_and_long_contexts_under_the_token_kernel():
+    """The decode tests that pin the build to the REFERENCE (greedy ids of its generate(): toy models in all four modes, the headline
+    geometry at 128 / 512 / 256 tokens) and the long-context self-consistency tests (cache == full recompute at t = 2046, 2048-token
+    graph loop == eager steps, sampled loops, more than eight sequences) once more in a child process with MIDIEMO_DEC_TOKEN=1: every
+    eligible DecodeSession then runs me_dec_token instead of the launch chain."""
+    import subprocess
+    env = dict(os.environ, MIDIEMO_DEC_TOKEN="1")
+    k = "greedy_ids_bit_exact or headline_geometry or config5 or device_resident or bf16_decode_agrees or sampling_path"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k", k, "-p", "no:cacheprovider"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    tail = r.stdout[-1500:]
+    assert r.returncode == 0, tail
+    assert " passed" in tail and "failed" not in tail, tail
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("top_k,top_p,V", [(-1, 0.7, 1007), (20, 1.0, 1007), (50, 0.9, 1007), (-1, 1.0, 1007), (3, 0.5, 1007),
                                              (-1, 0.8, 1500), (40, 1.0, 2048), (-1, 0.9, 3000), (-1, 1.0, 4096)])
 def test_fused_sampling_tail_matches_torch_path(top_k, top_p, V):
