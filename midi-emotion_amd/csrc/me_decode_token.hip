@@ -12,16 +12,20 @@
 // 2048 values between 256 blocks (tools/ubench_ll_exchange.hip), and since the consumer block already exists it requests
 // its weight rows / cache rows BEFORE it polls -- the round trip that was serial is now under the exchange.
 //
-// Stage order per layer (tags 5 l + 0..4) and who needs what:
-//   S1  every block: rows x = LayerNorm2(s2 of layer l-1) (or the embedding), kept in LDS rounded (projection operand) and
-//       unrounded (residual of S2).  Role blocks (sequence m, head h): splits 0..ns-2 = cached keys [j0, j1) of [0, t):
-//       q of the head, scores, (max, sum, P.V) -> partial records; split ns-1 = the new key: q, k_t, v_t (cache append),
-//       (s_t, 1, v_t) -> partial records.                                                     exchange: part (group-local)
+// Stage order per layer (tags 6 l + 0..5) and who needs what:
+//   S0  every block: rows x = LayerNorm2(s2 of layer l-1) (or the embedding), kept in LDS rounded (projection operand) and
+//       unrounded (residual of S2); q | k | v projection, 8 columns per block.  (A first version computed q inside the attention
+//       stage like dec_ln_qkv_attn_kernel does: every block of a (sequence, head) group fetched the head's 64 KB of q rows --
+//       16 MB per layer through L2, 8-12 us; profiles/r06_decode_token.txt.)                   exchange: qkv (a head's slice per reader)
+//   S1  role blocks (sequence m, head h): splits 0..ns-2 = cached keys [j0, j1) of [0, t): scores, (max, sum, P.V) -> partial
+//       records; split ns-1 = the new key: k_t, v_t appended to the cache, (s_t, 1, v_t).      exchange: part (group-local)
 //   S1b the ns blocks of a (m, h) group poll the group's partials, each combines dh / ns of the head's outputs. exchange: att
 //   S2  Wo + bias + residual(x)                                                                exchange: s1
 //   S3  LayerNorm1 -> FFN_pre + bias + ReLU                                                    exchange: hid
 //   S4  FFN_suf + bias + residual(LayerNorm1 output)                                           exchange: s2
 // then LayerNorm2 of the last layer -> head -> logits (plain stores; the pick / sampling kernel is the next launch).
+// Request order inside a layer: the block's q | k | v rows before the first poll; the split's K | E | V rows right behind it;
+// its Wo / FFN rows after it has published q | k | v (loads return in order per wave: a poll issued behind cold rows waits for them).
 // A buffer is rewritten one layer later; its writer has by then passed at least one all-to-all poll that every block only
 // answers after its own read of the previous generation, so single buffers suffice.  Across launches the kernel boundary
 // orders everything; the epoch (advanced by the last block to finish) keeps stale records of earlier tokens invalid.
