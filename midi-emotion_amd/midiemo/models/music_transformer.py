@@ -125,6 +125,9 @@ class MusicTransformerHIP(nn.Module):
         self.compute_dtype = _DTYPES[compute_dtype] if isinstance(compute_dtype, str) else compute_dtype
         # residual stream carried as bf16 hi + lo (f32-class precision, like autocast's fp32 stream); 0 = round it to bf16
         self.resid_lo = os.environ.get("MIDIEMO_RESID_LO", "1") != "0"
+        # 1 (default): both residual arrays of a layer (the layer stream h and LayerNorm1's output o1) carry a low half;
+        # 2 / 3 (probes, tools/probe_f16_nolo.py): only h / only o1
+        self._resid_lo_mode = int(os.environ.get("MIDIEMO_RESID_LO", "1") or 1)
         # attention backward: the key-owned (dK, dV) and the E-row-owned (dE) kernels side by side on two streams (both only
         # depend on the query-owned kernel; same results); measured -9 us (L = 1024) / -35 us (L = 2048) per layer
         # Under an initialised process group (RCCL's own streams alive) the second stream measured no gain under the `window` /
@@ -450,8 +453,10 @@ class MusicTransformerHIP(nn.Module):
         ops.key_pad_mask(ws.key_pad, tokens, B, Ltok, shift, self.pad_token)
         cw0, cb0, cw1, cb1 = self._cond_params(f)
         ops.embed_fwd(ws.h[0], tokens, cond, self._pview(f, "embedding.weight"), cw0, cb0, cw1, cb1, self._pe,
-                      self._mode(), B, Ltok, d, self.d_condition, p_drop, seed, out_lo=ws.hlo[0])
+                      self._mode(), B, Ltok, d, self.d_condition, p_drop, seed, out_lo=ws.hlo[0] if self._resid_lo_mode != 3 else None)
         nh = len(ws.h)
+        hlo_h = ws.hlo[0] if self._resid_lo_mode != 3 else None           # low half of the layer stream
+        hlo_o = ws.hlo[1] if self._resid_lo_mode != 2 else None           # low half of LayerNorm1's output
         for i in range(N):
             W = self._prep["layers"][i]
             Lw = ws.layers[i if save else 0]
@@ -463,7 +468,7 @@ class MusicTransformerHIP(nn.Module):
                         causal=self.causal, PT=Lw.PT, MT=Lw.MT)   # bidirectional (mask=None in the reference): no pad mask either
             ops.gemm_nt(Lw.att, W["Wo"], ws.tmp, bias=self._pview(f, p + "rga.fc.bias"), M=T, N=d, K=d, dtype=dt)
             ops.resid_ln_fwd(x, ws.tmp, self._pview(f, p + "layernorm1.weight"), self._pview(f, p + "layernorm1.bias"),
-                             Lw.o1, Lw.s1, Lw.st1, T, d, self.LN_EPS, p_drop, seed, 1 + 2 * i, x_lo=ws.hlo[0], y_lo=ws.hlo[1])
+                             Lw.o1, Lw.s1, Lw.st1, T, d, self.LN_EPS, p_drop, seed, 1 + 2 * i, x_lo=hlo_h, y_lo=hlo_o)
             if Lw.rmask is not None:
                 ops.gemm_nt_relu_mask(Lw.o1, W["W1"], Lw.hid, Lw.rmask, bias=self._pview(f, p + "FFN_pre.bias"), M=T, N=di, K=d, dtype=dt)
             else:
@@ -471,7 +476,7 @@ class MusicTransformerHIP(nn.Module):
                             flags=ops.ME_EPI_RELU, dtype=dt)
             ops.gemm_nt(Lw.hid, W["W2"], ws.tmp, bias=self._pview(f, p + "FFN_suf.bias"), M=T, N=d, K=di, dtype=dt)
             ops.resid_ln_fwd(Lw.o1, ws.tmp, self._pview(f, p + "layernorm2.weight"), self._pview(f, p + "layernorm2.bias"),
-                             y, Lw.s2, Lw.st2, T, d, self.LN_EPS, p_drop, seed, 2 + 2 * i, x_lo=ws.hlo[1], y_lo=ws.hlo[0])
+                             y, Lw.s2, Lw.st2, T, d, self.LN_EPS, p_drop, seed, 2 + 2 * i, x_lo=hlo_o, y_lo=hlo_h)
         hN = ws.h[N % nh if not save else N]
         out = logits_out if logits_out is not None else ws.logits
         ops.gemm_nt(hN, self._prep["head"]["Wf"], out, bias=self._pview(f, self._HEAD_B), M=T, N=V, K=d,
