@@ -38,7 +38,44 @@ inline uint32_t thr_of(float p) {
 }
 
 // ------------------------------------------------------------------ embedding prologue
-template <typename T>
+// ---- 8-bit low half of a 16-bit residual value (round 6: the residual stream's low halves are 0.22 ms of the step as two 16-bit
+// arrays, profiles / DESIGN): q = round((v - hi) / (ulp(hi) / 256)) in [-127, 127], one byte per element.  hi has MB stored mantissa bits
+// (bf16 7, f16 10), so hi + q * ulp / 256 carries MB + 8 of them: 15 for bf16 (the 16-bit low half gave ~16), 18 for f16.  Values whose
+// exponent is too small for the step to be a normal float (|hi| < 2^-111) keep no low half.
+template <typename T> struct LoMant { static constexpr uint32_t MB = 7; };
+template <> struct LoMant<f16_t> { static constexpr uint32_t MB = 10; };
+template <typename T> ME_DEV uint32_t lo8_enc(float v, float hf) {
+    constexpr uint32_t SH = LoMant<T>::MB + 8;
+    const uint32_t e = (__builtin_bit_cast(uint32_t, hf) >> 23) & 0xffu;
+    if (e <= SH) return 0u;
+    const float inv = __builtin_bit_cast(float, (254u + SH - e) << 23);
+    const float q = fminf(fmaxf(rintf((v - hf) * inv), -127.f), 127.f);
+    return (uint32_t)(int)q & 0xffu;
+}
+template <typename T> ME_DEV float lo8_dec(float hf, uint32_t byte) {
+    constexpr uint32_t SH = LoMant<T>::MB + 8;
+    const uint32_t e = (__builtin_bit_cast(uint32_t, hf) >> 23) & 0xffu;
+    if (e <= SH) return 0.f;
+    const float step = __builtin_bit_cast(float, (e - SH) << 23);
+    return (float)(int)(int8_t)byte * step;
+}
+// CH = 8 values of a lane <-> 8 bytes
+template <typename T> ME_DEV uint2 lo8_pack(const float (&v)[8], const float (&hf)[8]) {
+    uint2 r = {0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r.x |= lo8_enc<T>(v[i], hf[i]) << (8 * i); r.y |= lo8_enc<T>(v[4 + i], hf[4 + i]) << (8 * i); }
+    return r;
+}
+template <typename T> ME_DEV void lo8_add(float (&xv)[8], uint2 q) {          // xv (the high halves as floats) += low halves
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float l0 = lo8_dec<T>(xv[i], (q.x >> (8 * i)) & 0xffu), l1 = lo8_dec<T>(xv[4 + i], (q.y >> (8 * i)) & 0xffu);
+        xv[i] += l0;
+        xv[4 + i] += l1;
+    }
+}
+
+template <typename T, bool LO8 = false>
 __global__ __launch_bounds__(256) void embed_fwd_kernel(T* __restrict__ out, T* __restrict__ out_lo, const int64_t* __restrict__ tokens,
                                                         const float* __restrict__ cond, const float* __restrict__ emb,
                                                         const float* __restrict__ cw0, const float* __restrict__ cb0,
@@ -114,9 +151,13 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(T* __restrict__ out, T* 
         if (out_lo) {                                   // low-order part of the residual stream: v - float(T(v))
             float hf[CH];
             chunk_to_f<T>(hi, hf);
+            if constexpr (LO8 && CH == 8) {
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(out_lo) + row * d + col) = lo8_pack<T>(v, hf);
+            } else {
 #pragma unroll
-            for (int i = 0; i < CH; ++i) hf[i] = v[i] - hf[i];
-            st_chunk(out_lo + row * d + col, f_to_chunk<T>(hf));
+                for (int i = 0; i < CH; ++i) hf[i] = v[i] - hf[i];
+                st_chunk(out_lo + row * d + col, f_to_chunk<T>(hf));
+            }
         }
     }
 }
@@ -570,7 +611,7 @@ __global__ void key_pad_kernel(uint8_t* __restrict__ kp, const int64_t* __restri
 }
 
 // ------------------------------------------------------------------ residual + dropout + LayerNorm
-template <typename T>
+template <typename T, bool LO8 = false>
 __global__ __launch_bounds__(256) void resid_ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ x_lo, const T* __restrict__ a,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            T* __restrict__ y, T* __restrict__ y_lo, T* __restrict__ s_out, float* __restrict__ stats,
@@ -589,10 +630,14 @@ __global__ __launch_bounds__(256) void resid_ln_fwd_kernel(const T* __restrict__
                 chunk_to_f<T>(ld_chunk(x + row * d + col), xv);
                 chunk_to_f<T>(ld_chunk(a + row * d + col), av);
                 if (x_lo) {                             // residual stream = hi + lo (the reference keeps it in fp32 under autocast)
-                    float lv[CH];
-                    chunk_to_f<T>(ld_chunk(x_lo + row * d + col), lv);
+                    if constexpr (LO8 && CH == 8) {
+                        lo8_add<T>(xv, *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(x_lo) + row * d + col));
+                    } else {
+                        float lv[CH];
+                        chunk_to_f<T>(ld_chunk(x_lo + row * d + col), lv);
 #pragma unroll
-                    for (int i = 0; i < CH; ++i) xv[i] += lv[i];
+                        for (int i = 0; i < CH; ++i) xv[i] += lv[i];
+                    }
                 }
                 if (thr16) {
                     float mult[CH];
@@ -631,9 +676,13 @@ __global__ __launch_bounds__(256) void resid_ln_fwd_kernel(const T* __restrict__
                 if (y_lo) {
                     float hf[CH];
                     chunk_to_f<T>(hi, hf);
+                    if constexpr (LO8 && CH == 8) {
+                        *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(y_lo) + row * d + col) = lo8_pack<T>(o, hf);
+                    } else {
 #pragma unroll
-                    for (int i = 0; i < CH; ++i) hf[i] = o[i] - hf[i];
-                    st_chunk(y_lo + row * d + col, f_to_chunk<T>(hf));
+                        for (int i = 0; i < CH; ++i) hf[i] = o[i] - hf[i];
+                        st_chunk(y_lo + row * d + col, f_to_chunk<T>(hf));
+                    }
                 }
                 if (s_out) st_chunk(s_out + row * d + col, f_to_chunk<T>(s[c]));
             }
@@ -644,7 +693,7 @@ __global__ __launch_bounds__(256) void resid_ln_fwd_kernel(const T* __restrict__
 // d == 64 CH (one 16-byte chunk per lane and row: 512 bf16 / 256 f32): R rows per wave in flight, the next R rows are
 // requested before the current ones are reduced (a wave that loads, reduces and stores one row at a time leaves the
 // memory pipe idle during its two dependent reductions).  Loads are unconditional (clamped to the last row).
-template <typename T, int R>
+template <typename T, int R, bool LO8 = false>
 __global__ __launch_bounds__(256) void resid_ln_fwd1_kernel(const T* __restrict__ x, const T* __restrict__ x_lo, const T* __restrict__ a,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             T* __restrict__ y, T* __restrict__ y_lo, T* __restrict__ s_out, float* __restrict__ stats,
@@ -660,13 +709,17 @@ __global__ __launch_bounds__(256) void resid_ln_fwd1_kernel(const T* __restrict_
     const int64_t stride = (int64_t)gridDim.x * 4 * R;
     int64_t row0 = ((int64_t)blockIdx.x * 4 + wid) * R;
     chunk16 nx[R], na[R], nl[R];
+    uint2 nq[R];
     auto fetch = [&](int64_t r0) {
 #pragma unroll
         for (int u = 0; u < R; ++u) {
             const int64_t r = min(r0 + u, (int64_t)rows - 1);
             nx[u] = ld_chunk(x + r * d + col);
             na[u] = ld_chunk(a + r * d + col);
-            if (x_lo) nl[u] = ld_chunk(x_lo + r * d + col);
+            if (x_lo) {
+                if constexpr (LO8 && CH == 8) nq[u] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(x_lo) + r * d + col);
+                else nl[u] = ld_chunk(x_lo + r * d + col);
+            }
         }
     };
     fetch(row0);
@@ -679,10 +732,14 @@ __global__ __launch_bounds__(256) void resid_ln_fwd1_kernel(const T* __restrict_
             chunk_to_f<T>(nx[u], xv);
             chunk_to_f<T>(na[u], av);
             if (x_lo) {
-                float lv[CH];
-                chunk_to_f<T>(nl[u], lv);
+                if constexpr (LO8 && CH == 8) {
+                    lo8_add<T>(xv, nq[u]);
+                } else {
+                    float lv[CH];
+                    chunk_to_f<T>(nl[u], lv);
 #pragma unroll
-                for (int i = 0; i < CH; ++i) xv[i] += lv[i];
+                    for (int i = 0; i < CH; ++i) xv[i] += lv[i];
+                }
             }
             if (thr16) {
                 float mult[CH];
@@ -720,9 +777,13 @@ __global__ __launch_bounds__(256) void resid_ln_fwd1_kernel(const T* __restrict_
                 if (y_lo) {
                     float hf[CH];
                     chunk_to_f<T>(hi, hf);
+                    if constexpr (LO8 && CH == 8) {
+                        *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(y_lo) + row * d + col) = lo8_pack<T>(o, hf);
+                    } else {
 #pragma unroll
-                    for (int i = 0; i < CH; ++i) hf[i] = o[i] - hf[i];
-                    st_chunk(y_lo + row * d + col, f_to_chunk<T>(hf));
+                        for (int i = 0; i < CH; ++i) hf[i] = o[i] - hf[i];
+                        st_chunk(y_lo + row * d + col, f_to_chunk<T>(hf));
+                    }
                 }
                 if (s_out) st_chunk(s_out + row * d + col, f_to_chunk<T>(s[u]));
             }
@@ -1537,6 +1598,9 @@ int me_embed_fwd(void* out, void* out_lo, int dtype, const int64_t* tokens, cons
                  const float* cb0, const float* cw1, const float* cb1, const float* pe, const int32_t* pos_dev, int mode, int B, int Ltok,
                  int d, int dc, float p, uint64_t seed, void* stream) {
     me_clear_error();
+    const bool lo8 = (dtype & ME_LO8) != 0;
+    dtype &= ~ME_LO8;
+    if (lo8 && dtype == ME_F32) return ME_ERR_BAD_DTYPE;
     if (!out || !tokens || !emb || !pe) return ME_ERR_NULL;
     if (mode == ME_COND_CONCAT && (!cond || !cw0 || !cb0 || dc <= 0 || dc >= d)) return ME_ERR_NULL;
     if (mode == ME_COND_TOKEN && (!cond || !cw0 || !cb0 || !cw1 || !cb1)) return ME_ERR_NULL;
@@ -1549,6 +1613,11 @@ int me_embed_fwd(void* out, void* out_lo, int dtype, const int64_t* tokens, cons
     const uint32_t thr = thr_of(p);
     const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
     hipStream_t st = (hipStream_t)stream;
+    if (lo8) {
+        ME_DISPATCH(dtype, (embed_fwd_kernel<T, true><<<(unsigned)((rows + 3) / 4), 256, 0, st>>>(
+                               (T*)out, (T*)out_lo, tokens, cond, emb, cw0, cb0, cw1, cb1, pe, pos_dev, mode, B, Ltok, d, dc, thr, inv_keep, seed)));
+        return me_launch_status();
+    }
     ME_DISPATCH(dtype, (embed_fwd_kernel<T><<<(unsigned)((rows + 3) / 4), 256, 0, st>>>(
                            (T*)out, (T*)out_lo, tokens, cond, emb, cw0, cb0, cw1, cb1, pe, pos_dev, mode, B, Ltok, d, dc, thr, inv_keep, seed)));
     return me_launch_status();
@@ -1634,6 +1703,9 @@ int me_resid_ln_fwd(const void* x, const void* x_lo, const void* a, const float*
                     void* y_lo, void* s_out, float* stats, int rows, int d, float eps, float p, uint64_t seed,
                     uint32_t site, int dtype, void* stream) {
     me_clear_error();
+    const bool lo8 = (dtype & ME_LO8) != 0;
+    dtype &= ~ME_LO8;
+    if (lo8 && dtype == ME_F32) return ME_ERR_BAD_DTYPE;
     if (!x || !a || !gamma || !beta || !y) return ME_ERR_NULL;
     if (rows <= 0) return ME_OK;
     const int ch = dtype == ME_F32 ? 4 : 8;
@@ -1648,8 +1720,20 @@ int me_resid_ln_fwd(const void* x, const void* x_lo, const void* a, const float*
         // one chunk per lane and row (d = 512 bf16): two rows per wave in flight, next pair prefetched -- 42.8 -> 37.9 us at
         // T = 32768 (5.3 TB/s of its 201 MB; rows per wave 1 / 2 / 4: 38.8 / 37.9 / 40.4, grid 512 .. 8192 flat within 1.5 us;
         // non-temporal loads / stores: 39.9)
+        if (lo8) {
+            ME_DISPATCH(dtype, (resid_ln_fwd1_kernel<T, 2, true><<<row_grid((rows + 1) / 2, 4096), 256, 0, st>>>(
+                                   (const T*)x, (const T*)x_lo, (const T*)a, gamma, beta, (T*)y, (T*)y_lo, (T*)s_out, stats, rows, eps, thr,
+                                   inv_keep, seed, site)));
+            return me_launch_status();
+        }
         ME_DISPATCH(dtype, (resid_ln_fwd1_kernel<T, 2><<<row_grid((rows + 1) / 2, 4096), 256, 0, st>>>(
                                (const T*)x, (const T*)x_lo, (const T*)a, gamma, beta, (T*)y, (T*)y_lo, (T*)s_out, stats, rows, eps, thr,
+                               inv_keep, seed, site)));
+        return me_launch_status();
+    }
+    if (lo8) {
+        ME_DISPATCH(dtype, (resid_ln_fwd_kernel<T, true><<<row_grid(rows, 8192), 256, 0, st>>>(
+                               (const T*)x, (const T*)x_lo, (const T*)a, gamma, beta, (T*)y, (T*)y_lo, (T*)s_out, stats, rows, d, eps, thr,
                                inv_keep, seed, site)));
         return me_launch_status();
     }

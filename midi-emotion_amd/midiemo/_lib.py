@@ -14,7 +14,8 @@ ME_COND_NONE, ME_COND_CONCAT, ME_COND_TOKEN = 0, 1, 2
 ME_EPI_RELU, ME_EPI_OUT_F32, ME_EPI_RELU_BWD = 1, 2, 4
 ME_WS_GEMM_TN, ME_WS_RGA_PT, ME_WS_RGA_DGT, ME_WS_RGA_MT, ME_WS_GEMM_TN_GROUP, ME_WS_EMBED_BWD, ME_WS_SUMSQ, ME_WS_RELU_MASK, ME_WS_DEC_TOKEN = 1, 2, 3, 4, 5, 6, 7, 8, 9
 ME_TN_MAX_GROUP = 5
-ABI_VERSION = 23
+ABI_VERSION = 24
+ME_LO8 = 0x100             # OR-ed into the dtype of me_resid_ln_fwd / me_embed_fwd: 8-bit low halves of the residual stream
 ME_DEC_MAX_LAYERS, ME_DEC_TOKEN_ROWS = 16, 4
 # words of the loss-scaler state (me_scaler_step; enum ME_SCALER_* of include/midiemo.h)
 ME_SCALER_SCALE, ME_SCALER_INV, ME_SCALER_TRACKER, ME_SCALER_STEP, ME_SCALER_FOUND_INF, ME_SCALER_SKIPPED, ME_SCALER_WORDS = 0, 1, 2, 3, 4, 5, 8

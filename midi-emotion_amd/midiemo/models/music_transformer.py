@@ -128,6 +128,11 @@ class MusicTransformerHIP(nn.Module):
         # 1 (default): both residual arrays of a layer (the layer stream h and LayerNorm1's output o1) carry a low half;
         # 2 / 3 (probes, tools/probe_f16_nolo.py): only h / only o1
         self._resid_lo_mode = int(os.environ.get("MIDIEMO_RESID_LO", "1") or 1)
+        # the low halves as one BYTE per element (ME_LO8: 15 mantissa bits of the bf16 stream in 3 bytes) or as a second 16-bit array.
+        # bf16 tier: 8 bits since round 6 (-0.06 ms per step same-process; logits 3.476e-3 against 3.487e-3, every derived bound holds);
+        # f16 tier: 16 bits (with 8, the condition projection's bias gradient sits at 2.12 x the oracle's fp16-autocast error, bound 2.0).
+        # MIDIEMO_RESID_LO_BITS=8|16 overrides both.
+        self._resid_lo_bits_env = int(os.environ.get("MIDIEMO_RESID_LO_BITS", "0"))
         # attention backward: the key-owned (dK, dV) and the E-row-owned (dE) kernels side by side on two streams (both only
         # depend on the query-owned kernel; same results); measured -9 us (L = 1024) / -35 us (L = 2048) per layer
         # Under an initialised process group (RCCL's own streams alive) the second stream measured no gain under the `window` /
@@ -374,7 +379,7 @@ class MusicTransformerHIP(nn.Module):
         # bf16 tier: low-order half of the residual stream (h, o1), so that the stream itself is ~f32 like the
         # reference's under autocast while the GEMMs still read the bf16 "hi" tensors (me_resid_ln_fwd x_lo / y_lo)
         lo = self.resid_lo and dt != torch.float32
-        ws.hlo = [e(T, d) if lo else None for _ in range(2)]
+        ws.hlo = [(e(T, d, dtype=torch.uint8) if self.resid_lo_bits == 8 else e(T, d)) if lo else None for _ in range(2)]
         ws.layers = []
         for _ in range(nl):
             L = _Workspace()
@@ -439,6 +444,18 @@ class MusicTransformerHIP(nn.Module):
             cond = torch.full((B, 2), float("nan"))
         cond = cond.to(device=self._flat.device, dtype=torch.float32).contiguous()
         return tokens, cond, B, Ltok, Ltok + shift
+
+    @property
+    def resid_lo_bits(self):
+        if getattr(self, "_resid_lo_bits_set", 0):
+            return self._resid_lo_bits_set
+        if self._resid_lo_bits_env in (8, 16):
+            return self._resid_lo_bits_env
+        return 8 if self.compute_dtype == torch.bfloat16 else 16
+
+    @resid_lo_bits.setter
+    def resid_lo_bits(self, bits):                      # (tools/ab_step.py flips it between arms; drop the workspaces afterwards)
+        self._resid_lo_bits_set = int(bits)
 
     def _forward_impl(self, tokens, cond, B, Ltok, Lm, save, p_drop, seed, logits_out):
         dt = self.compute_dtype

@@ -70,8 +70,18 @@ def make_ct_desc(items, device):
     return t, len(items), tiles
 
 
+def _lo_flag(*los):
+    """ME_LO8 when the low halves are byte arrays (uint8 [rows, d]), 0 for the 16-bit form."""
+    los = [t for t in los if t is not None]
+    if any(t.dtype == torch.uint8 for t in los):
+        if not all(t.dtype == torch.uint8 for t in los):
+            raise RuntimeError("low halves of the residual stream: 8-bit and 16-bit arrays mixed in one call")
+        return _lib.ME_LO8
+    return 0
+
+
 def embed_fwd(out, tokens, cond, emb, cw0, cb0, cw1, cb1, pe, mode, B, Ltok, d, dc, p, seed, pos_dev=None, out_lo=None):
-    check(lib().me_embed_fwd(_ptr(out), _ptr(out_lo), _code(out.dtype), _ptr(tokens), _ptr(cond), _ptr(emb), _ptr(cw0), _ptr(cb0),
+    check(lib().me_embed_fwd(_ptr(out), _ptr(out_lo), _code(out.dtype) | _lo_flag(out_lo), _ptr(tokens), _ptr(cond), _ptr(emb), _ptr(cw0), _ptr(cb0),
                              _ptr(cw1), _ptr(cb1), _ptr(pe), _ptr(pos_dev), mode, B, Ltok, d, dc, float(p), int(seed), _stream()),
           "me_embed_fwd")
 
@@ -237,7 +247,7 @@ def rga_bwd(qkv, Epk, out, lse, dout, dqkv, dE, delta_ws, PT, MT, dGT, B, L, Lp,
 
 def resid_ln_fwd(x, a, gamma, beta, y, s_out, stats, rows, d, eps, p, seed, site, x_lo=None, y_lo=None):
     check(lib().me_resid_ln_fwd(_ptr(x), _ptr(x_lo), _ptr(a), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(y_lo), _ptr(s_out), _ptr(stats), rows, d,
-                                float(eps), float(p), int(seed), int(site), _code(x.dtype), _stream()), "me_resid_ln_fwd")
+                                float(eps), float(p), int(seed), int(site), _code(x.dtype) | _lo_flag(x_lo, y_lo), _stream()), "me_resid_ln_fwd")
 
 
 def resid_ln_bwd(dy, s, stats, gamma, dx, da, dgamma, dbeta, rows, d, p, seed, site):

@@ -1188,3 +1188,67 @@ def test_gemm_nt_relu_mask_refuses_what_it_does_not_serve(ops):
     mask = torch.zeros(1 << 16, dtype=torch.uint8, device=DEV)
     with pytest.raises(RuntimeError):
         ops.gemm_nt_relu_mask(A, W, C, mask)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cd", ["bf16", "fp16"])
+@pytest.mark.parametrize("d", [512, 768])
+def test_resid_ln_and_embed_with_8_bit_low_halves(cd, d):
+    """ME_LO8: the residual stream's low half as ONE byte per element, q = round((v - hi) / (ulp(hi) / 256)).  The high halves, the
+    pre-norm sums and the statistics must EQUAL those of the 16-bit form wherever the inputs agree, and hi + decode(q) must carry the
+    stream to 2^-(MB + 8) of its magnitude (MB = 7 / 10 stored mantissa bits): checked against an f64 LayerNorm on the decoded stream,
+    for the one-chunk-per-lane kernel (d = 512) and the generic one (d = 768), and for the embedding prologue."""
+    import torch
+    from midiemo import ops
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[cd]
+    mb = {"bf16": 7, "fp16": 10}[cd]
+    torch.manual_seed(3)
+    rows = 777
+    dev = "cuda"
+
+    def decode(hi, q):                                  # the kernel's lo8_dec in torch: step = 2^(exponent(hi) - MB - 8)
+        e = torch.floor(torch.log2(hi.double().abs().clamp_min(1e-300)))
+        return hi.double() + (q.view(torch.int8).double() * torch.pow(2.0, e - mb - 8)) * (hi != 0)
+
+    xf = torch.randn(rows, d, device=dev, dtype=torch.float64) * 1.7
+    x_hi = xf.to(dt)
+    # the exact 8-bit low half of xf
+    e = torch.floor(torch.log2(x_hi.double().abs().clamp_min(1e-300)))
+    q = torch.round((xf - x_hi.double()) / torch.pow(2.0, e - mb - 8)).clamp(-127, 127).to(torch.int8).view(torch.uint8)
+    x_dec = decode(x_hi, q)
+    a = (torch.randn(rows, d, device=dev) * 0.8).to(dt)
+    gamma, beta = torch.rand(d, device=dev) + 0.5, torch.randn(d, device=dev) * 0.1
+    y, s_out, st = torch.empty(rows, d, device=dev, dtype=dt), torch.empty(rows, d, device=dev, dtype=dt), torch.empty(rows, 2, device=dev)
+    y_q = torch.zeros(rows, d, device=dev, dtype=torch.uint8)
+    ops.resid_ln_fwd(x_hi, a, gamma, beta, y, s_out, st, rows, d, 1e-6, 0.0, 0, 1, x_lo=q, y_lo=y_q)
+    s_ref = x_dec + a.double()
+    mu, var = s_ref.mean(-1, keepdim=True), s_ref.var(-1, unbiased=False, keepdim=True)
+    y_ref = (s_ref - mu) / torch.sqrt(var + 1e-6) * gamma.double() + beta.double()
+    y_dec = decode(y, y_q)
+    ulp = 2.0 ** -(mb + 8)
+    # the decoded output stream follows the f64 LayerNorm to the f32 arithmetic of the kernel + one step of the 8-bit code
+    err = ((y_dec - y_ref).abs() / y_ref.abs().clamp_min(0.25)).max().item()
+    assert err < 4 * ulp + 3e-6, (err, ulp)
+    # and the hi half alone is the rounding of that stream (what the next GEMM reads)
+    assert ((y.double() - y_ref).abs() / y_ref.abs().clamp_min(0.25)).max().item() < 2.0 ** -(mb + 1) * 1.01 + 3e-6
+    # same call with 16-bit low halves holding the SAME stream (x_lo16 = the decoded low half, exactly representable): equal hi / sums / statistics
+    # (bf16 only: a code step 2^(E - 18) of small f16 values lies below f16's own denormal step)
+    if cd == "bf16":
+        x_lo16 = (x_dec - x_hi.double()).to(dt)
+        assert torch.equal((x_hi.double() + x_lo16.double()), x_dec)
+        y2, s2, st2, ylo2 = torch.empty_like(y), torch.empty_like(s_out), torch.empty_like(st), torch.empty_like(y)
+        ops.resid_ln_fwd(x_hi, a, gamma, beta, y2, s2, st2, rows, d, 1e-6, 0.0, 0, 1, x_lo=x_lo16, y_lo=ylo2)
+        assert torch.equal(y, y2) and torch.equal(s_out, s2) and torch.equal(st, st2)
+    if d == 512:
+        # embedding prologue: hi equal to the 16-bit form, decoded stream within one code step of hi + lo16
+        B, L, V = 3, 37, 1007
+        tok = torch.randint(1, V, (B, L), device=dev)
+        emb = (torch.rand(V, d, device=dev) - 0.5) * 0.2
+        pe = torch.randn(64, d, device=dev)
+        o8, o16, q8, l16 = torch.empty(B * L, d, device=dev, dtype=dt), torch.empty(B * L, d, device=dev, dtype=dt), \
+            torch.zeros(B * L, d, device=dev, dtype=torch.uint8), torch.empty(B * L, d, device=dev, dtype=dt)
+        ops.embed_fwd(o8, tok, None, emb, None, None, None, None, pe, ops.ME_COND_NONE, B, L, d, 0, 0.0, 0, out_lo=q8)
+        ops.embed_fwd(o16, tok, None, emb, None, None, None, None, pe, ops.ME_COND_NONE, B, L, d, 0, 0.0, 0, out_lo=l16)
+        assert torch.equal(o8, o16)
+        full = o16.double() + l16.double()
+        assert ((decode(o8, q8) - full).abs() / full.abs().clamp_min(0.25)).max().item() < 2 * ulp

@@ -1,4 +1,4 @@
-"""AB_WHAT=relu_mask (default) | attn_overlap.  Same-process, interleaved A/B of the whole train step (bench.py's workload) with and without the ReLU sign mask
+"""AB_WHAT=relu_mask (default) | attn_overlap | resid_lo.  Same-process, interleaved A/B of the whole train step (bench.py's workload) with and without the ReLU sign mask
 (MIDIEMO_NO_RELU_MASK is read when a workspace is created: the workspace cache is dropped between the arms).
 Median of per-step device times, ROUNDS rounds x STEPS steps per arm."""
 import os, sys
@@ -23,7 +23,7 @@ def step(i):
     return loss
 ROUNDS, STEPS = 6, 12
 WHAT = os.environ.get("AB_WHAT", "relu_mask")
-ARMS = ("gate", "mask") if WHAT == "relu_mask" else ("serial", "overlap")
+ARMS = ("gate", "mask") if WHAT == "relu_mask" else (("serial", "overlap") if WHAT == "attn_overlap" else ("lo16", "lo8"))
 res = {a: [] for a in ARMS}
 for r in range(ROUNDS):
     for arm in ARMS:
@@ -31,8 +31,11 @@ for r in range(ROUNDS):
             if arm == "gate": os.environ["MIDIEMO_NO_RELU_MASK"] = "1"
             else: os.environ.pop("MIDIEMO_NO_RELU_MASK", None)
             model._ws.clear()
-        else:
+        elif WHAT == "attn_overlap":
             model.attn_bwd_overlap = arm == "overlap"
+        else:                                                   # AB_WHAT=resid_lo: the residual stream's low halves as 16-bit / 8-bit arrays
+            model.resid_lo_bits = 8 if arm == "lo8" else 16
+            model._ws.clear()
         for i in range(3): step(i)
         torch.cuda.synchronize()
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(STEPS + 1)]

@@ -7,6 +7,10 @@ sys.path.insert(0, os.path.join(HERE, "..")); sys.path.insert(0, os.path.join(HE
 import torch
 import bench
 for lo in (sys.argv[1:] or ["1", "0"]):
+    if lo.startswith("b"):
+        os.environ["MIDIEMO_RESID_LO_BITS"] = lo[1:]; lo = "1"
+    else:
+        os.environ["MIDIEMO_RESID_LO_BITS"] = "16"
     os.environ["MIDIEMO_RESID_LO"] = lo
     par = bench.tier_parity_sample()
     t16 = bench.tier_bench("fp16", bench.BATCH, bench.SEQ, steps=30, warmup=8)
